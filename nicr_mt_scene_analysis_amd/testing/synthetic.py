@@ -1,0 +1,188 @@
+"""
+Deterministic synthetic inputs of the shapes in SURVEY.md §8d.
+
+Everything is generated with numpy (PCG64) in float64 using only + - * / and
+one `exp` per heatmap pixel, then rounded once to float32, so that the same
+seed gives bit-identical arrays in the build container and on the GPU box
+(`input_digest` lets a test verify that before trusting a committed golden).
+
+Layouts/dtypes follow what the reference's decoders/targets produce:
+  semantic logits  [B,C,H,W] f32          (model/decoder: raw, pre-softmax)
+  instance center  [B,1,H,W] f32 in [0,1] (sigmoid head; targets are Gaussians,
+                                            data/preprocessing/instance.py:143-150)
+  instance offset  [B,2,H,W] f32, (dy,dx) normalised by (H,W)
+                                           (data/preprocessing/instance.py:252-256)
+  orientation      [B,2,H,W] f32 unit biternion (cos, sin)
+"""
+import hashlib
+from typing import Dict
+
+import numpy as np
+
+
+def _bilinear_up(coarse: np.ndarray, H: int, W: int) -> np.ndarray:
+    """align_corners=False bilinear upsample of [..., h, w] -> [..., H, W] (f64)."""
+    h, w = coarse.shape[-2:]
+    ys = (np.arange(H, dtype=np.float64) + 0.5) * (h / H) - 0.5
+    xs = (np.arange(W, dtype=np.float64) + 0.5) * (w / W) - 0.5
+    ys = np.clip(ys, 0, h - 1)
+    xs = np.clip(xs, 0, w - 1)
+    y0 = np.floor(ys).astype(np.int64)
+    x0 = np.floor(xs).astype(np.int64)
+    y1 = np.minimum(y0 + 1, h - 1)
+    x1 = np.minimum(x0 + 1, w - 1)
+    wy = (ys - y0)[:, None]
+    wx = (xs - x0)[None, :]
+    a = coarse[..., y0[:, None], x0[None, :]]
+    b = coarse[..., y0[:, None], x1[None, :]]
+    c = coarse[..., y1[:, None], x0[None, :]]
+    d = coarse[..., y1[:, None], x1[None, :]]
+    return (a * (1 - wx) + b * wx) * (1 - wy) + (c * (1 - wx) + d * wx) * wy
+
+
+def make_panoptic_inputs(
+    batch_size: int,
+    n_classes: int = 40,
+    height: int = 480,
+    width: int = 640,
+    n_centers: int = 24,
+    seed: int = 0,
+    quantize_offsets: bool = True,
+    sigma: float = 8.0,
+    offset_noise_px: float = 2.0,
+    with_orientation: bool = False,
+) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed)
+    B, Cn, H, W = batch_size, n_classes, height, width
+    gh, gw = max(H // 32, 2), max(W // 32, 2)
+
+    logits = np.empty((B, Cn, H, W), np.float32)
+    center = np.empty((B, 1, H, W), np.float32)
+    offset = np.empty((B, 2, H, W), np.float32)
+    planted = np.empty((B, n_centers, 2), np.int32)
+    orientation = np.empty((B, 2, H, W), np.float32) if with_orientation else None
+
+    yy = np.arange(H, dtype=np.float64)[:, None]
+    xx = np.arange(W, dtype=np.float64)[None, :]
+    border = int(min(8, H // 4, W // 4))
+
+    for b in range(B):
+        coarse = rng.standard_normal((Cn, gh, gw))
+        logits[b] = (4.0 * _bilinear_up(coarse, H, W)).astype(np.float32)
+
+        cy = rng.integers(border, H - border, size=n_centers)
+        cx = rng.integers(border, W - border, size=n_centers)
+        planted[b, :, 0] = cy
+        planted[b, :, 1] = cx
+
+        heat = np.zeros((H, W), np.float64)
+        best_d2 = np.full((H, W), np.inf)
+        near_y = np.zeros((H, W), np.float64)
+        near_x = np.zeros((H, W), np.float64)
+        for k in range(n_centers):
+            dy = cy[k] - yy
+            dx = cx[k] - xx
+            d2 = dy * dy + dx * dx
+            heat = np.maximum(heat, np.exp(-d2 / (2.0 * sigma * sigma)))
+            closer = d2 < best_d2
+            best_d2 = np.where(closer, d2, best_d2)
+            near_y = np.where(closer, dy, near_y)
+            near_x = np.where(closer, dx, near_x)
+        center[b, 0] = heat.astype(np.float32)
+
+        oy = near_y + offset_noise_px * rng.standard_normal((H, W))
+        ox = near_x + offset_noise_px * rng.standard_normal((H, W))
+        if quantize_offsets:
+            oy = np.round(oy * 2.0) / 2.0
+            ox = np.round(ox * 2.0) / 2.0
+        offset[b, 0] = (oy / H).astype(np.float32)
+        offset[b, 1] = (ox / W).astype(np.float32)
+
+        if with_orientation:
+            # smooth angle field -> unit biternion (cos, sin) via rational
+            # parametrisation (no trig: keeps generation platform-stable)
+            t = _bilinear_up(rng.standard_normal((1, gh, gw)), H, W)[0] * 2.0
+            den = 1.0 + t * t
+            orientation[b, 0] = ((1.0 - t * t) / den).astype(np.float32)
+            orientation[b, 1] = ((2.0 * t) / den).astype(np.float32)
+
+    is_thing = tuple(bool(c >= Cn // 2) for c in range(Cn))
+    out = {
+        'semantic_logits': logits,
+        'instance_center': center,
+        'instance_offset': offset,
+        'planted_centers': planted,
+        'semantic_classes_is_thing': np.array(is_thing, dtype=bool),
+    }
+    if with_orientation:
+        out['instance_orientation'] = orientation
+    return out
+
+
+def make_metric_inputs(
+    pred_panoptic: np.ndarray,
+    n_classes_with_void: int,
+    seed: int = 0,
+    shift_px: int = 3,
+) -> Dict[str, np.ndarray]:
+    """GT for the metric accumulators: target_pan = roll(pred_pan, shift_px)
+    with a void band, target_sem uniform in [0, C]."""
+    rng = np.random.default_rng(seed + 1000)
+    target_pan = np.roll(pred_panoptic, shift=(shift_px, shift_px), axis=(-2, -1)).copy()
+    target_pan[..., :shift_px, :] = 0          # void band
+    target_sem = rng.integers(0, n_classes_with_void, size=pred_panoptic.shape,
+                              dtype=np.int64).astype(np.uint8)
+    return {'panoptic_target': target_pan.astype(np.int64),
+            'semantic_target': target_sem}
+
+
+def make_loss_inputs(
+    batch_size: int,
+    n_classes: int = 40,
+    height: int = 480,
+    width: int = 640,
+    seed: int = 0,
+    embedding_dim: int = 0,
+    n_lut: int = 64,
+) -> Dict[str, np.ndarray]:
+    rng = np.random.default_rng(seed + 2000)
+    B, Cn, H, W = batch_size, n_classes, height, width
+    base = make_panoptic_inputs(B, Cn, H, W, seed=seed, with_orientation=True)
+    out = {
+        'semantic_logits': base['semantic_logits'],
+        'semantic_target': rng.integers(0, Cn + 1, size=(B, H, W)).astype(np.uint8),
+        'class_weights': (rng.random(Cn) + 0.5).astype(np.float32),
+        # predictions: noisy versions of the targets
+        'center_target': base['instance_center'][:, 0].copy(),
+        'center_pred': np.clip(base['instance_center'][:, 0]
+                               + 0.1 * rng.standard_normal((B, H, W)), 0, 1).astype(np.float32),
+        'center_mask': rng.random((B, H, W)) < 0.7,
+        'offset_target': base['instance_offset'],
+        'offset_pred': (base['instance_offset']
+                        + 0.01 * rng.standard_normal((B, 2, H, W))).astype(np.float32),
+        'offset_mask': rng.random((B, H, W)) < 0.5,
+        'orientation_target': base['instance_orientation'],
+        'orientation_mask': rng.random((B, H, W)) < 0.3,
+    }
+    # unit-length noisy orientation prediction (normalised with sqrt only)
+    op = base['instance_orientation'].astype(np.float64) + 0.3 * rng.standard_normal((B, 2, H, W))
+    op = op / (np.sqrt((op * op).sum(axis=1, keepdims=True)) + 1e-7)
+    out['orientation_pred'] = op.astype(np.float32)
+    if embedding_dim:
+        D = embedding_dim
+        lut = rng.standard_normal((B, n_lut, D))
+        lut = lut / np.sqrt((lut * lut).sum(axis=-1, keepdims=True))
+        out['embedding_lut'] = lut.astype(np.float32)
+        out['embedding_indices'] = rng.integers(0, n_lut + 1, size=(B, H, W)).astype(np.int32)
+        out['embedding_pred'] = rng.standard_normal((B, D, H, W)).astype(np.float32)
+    return out
+
+
+def input_digest(*arrays: np.ndarray) -> str:
+    h = hashlib.sha256()
+    for a in arrays:
+        a = np.ascontiguousarray(a)
+        h.update(str(a.dtype).encode())
+        h.update(str(a.shape).encode())
+        h.update(a.tobytes())
+    return h.hexdigest()

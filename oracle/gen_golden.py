@@ -1,0 +1,569 @@
+"""
+TEST INFRASTRUCTURE — golden-vector generator.  Runs ONLY in the build
+container (needs the read-only reference mount); its outputs (small .npz data
+files: inputs + the reference's outputs) are committed under tests/golden/.
+
+    python oracle/gen_golden.py            # (re)generate everything
+    python oracle/gen_golden.py norm       # only check the norm formula
+
+Every case calls the reference's own, unmodified Python (loaded by
+oracle/ref_loader.py) on seeded inputs.
+"""
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+from oracle.ref_loader import load_reference          # noqa: E402
+from nicr_mt_scene_analysis_amd.testing import synthetic as syn   # noqa: E402
+
+GOLDEN = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                      'tests', 'golden')
+os.makedirs(GOLDEN, exist_ok=True)
+torch.set_num_threads(8)
+
+
+def save(name, **arrays):
+    path = os.path.join(GOLDEN, name + '.npz')
+    np.savez_compressed(path, **arrays)
+    print(f'  wrote {name}.npz  ({os.path.getsize(path) / 1024:.1f} KiB)')
+
+
+def jdump(obj) -> np.ndarray:
+    return np.frombuffer(json.dumps(obj).encode(), dtype=np.uint8)
+
+
+def make_batch(ref, B, H, W, extra=None):
+    batch = {
+        'rgb_fullres': torch.zeros((B, 3, H, W)),
+        ref.APPLIED_PREPROCESSING_KEY: [[{
+            'type': 'Resize',
+            'valid_region_slice_y': slice(0, H),
+            'valid_region_slice_x': slice(0, W),
+        }]] * B,
+    }
+    if extra:
+        batch.update(extra)
+    return batch
+
+
+def meta_to_arrays(meta_list, cap=320):
+    """list[dict[id -> {center_yx, area, score}]] -> dense arrays."""
+    B = len(meta_list)
+    n = np.zeros((B,), np.int32)
+    cyx = np.zeros((B, cap, 2), np.int32)
+    area = np.zeros((B, cap), np.int64)
+    score = np.zeros((B, cap), np.float32)
+    for b, meta in enumerate(meta_list):
+        n[b] = len(meta)
+        for i, m in meta.items():
+            cyx[b, i - 1] = m['center_yx']
+            area[b, i - 1] = m['area']
+            score[b, i - 1] = m['score']
+    return n, cyx, area, score
+
+
+def ids_to_arrays(dicts, cap=320):
+    B = len(dicts)
+    n = np.zeros((B,), np.int32)
+    k = np.zeros((B, cap), np.int64)
+    v = np.zeros((B, cap), np.int64)
+    for b, d in enumerate(dicts):
+        n[b] = len(d)
+        for i, (pk, pv) in enumerate(d.items()):    # insertion order matters
+            k[b, i] = pk
+            v[b, i] = pv
+    return n, k, v
+
+
+# ---------------------------------------------------------------------------
+def check_norm_formula(ref):
+    """torch.norm(int32 centers - f32 loc, dim=-1) == sqrtf(fmaf(dx,dx,dy*dy))."""
+    g = torch.Generator().manual_seed(0)
+    n, P = 64, 200000
+    centers = torch.stack([torch.randint(0, 480, (n,), generator=g),
+                           torch.randint(0, 640, (n,), generator=g)], 1).int()
+    loc = torch.stack([torch.rand(P, generator=g) * 480,
+                       torch.rand(P, generator=g) * 640], 1).float()
+    d = centers.unsqueeze(1) - loc.unsqueeze(0)
+    r = torch.norm(d, dim=-1).numpy()
+    dy = d[..., 0].numpy()
+    dx = d[..., 1].numpy()
+    emu = np.sqrt((dx.astype(np.float64) ** 2
+                   + (dy * dy).astype(np.float64)).astype(np.float32))
+    mism = int((emu != r).sum())
+    print(f'norm formula sqrt(fma(dx,dx,dy*dy)): {mism} mismatches / {r.size}')
+    assert mism == 0
+
+
+# ---------------------------------------------------------------------------
+def run_panoptic(ref, inp, heatmap_kwargs=None, with_orientation=False):
+    is_thing = tuple(bool(x) for x in inp['semantic_classes_is_thing'])
+    sem_post = ref.post_semantic.SemanticPostprocessing()
+    ins_post = ref.post_instance.InstancePostprocessing(**(heatmap_kwargs or {}))
+    post = ref.post_panoptic.PanopticPostprocessing(
+        semantic_postprocessing=sem_post, instance_postprocessing=ins_post,
+        semantic_classes_is_thing=is_thing,
+        semantic_class_has_orientation=is_thing)
+    logits = torch.from_numpy(inp['semantic_logits'])
+    center = torch.from_numpy(inp['instance_center'])
+    offset = torch.from_numpy(inp['instance_offset'])
+    B, _, H, W = logits.shape
+    i_out = (center, offset)
+    if with_orientation:
+        i_out = i_out + (torch.from_numpy(inp['instance_orientation']),)
+    data = ((logits, i_out), (None, None))
+    batch = make_batch(ref, B, H, W)
+    return post.postprocess(data, batch, is_training=False)
+
+
+def panoptic_outputs(r, with_orientation=False, score_stride=1):
+    n, cyx, area, score = meta_to_arrays(r['panoptic_segmentation_deeplab_instance_meta'])
+    idn, idk, idv = ids_to_arrays(r['panoptic_segmentation_deeplab_ids'])
+    out = dict(
+        semantic_idx=r['semantic_segmentation_idx'].numpy().astype(np.uint8),
+        semantic_score=r['semantic_segmentation_score'].numpy()[:, ::score_stride, ::score_stride],
+        semantic_score_stride=np.int32(score_stride),
+        foreground=r['panoptic_foreground_mask'].numpy(),
+        instance=r['panoptic_segmentation_deeplab_instance_idx'].numpy(),
+        panoptic=r['panoptic_segmentation_deeplab'].numpy(),
+        panoptic_semantic=r['panoptic_segmentation_deeplab_semantic_idx'].numpy().astype(np.uint8),
+        meta_n=n, meta_center_yx=cyx, meta_area=area, meta_score=score,
+        ids_n=idn, ids_pan=idk, ids_ins=idv,
+    )
+    if with_orientation:
+        ori = r['orientations_panoptic_segmentation_deeplab_instance']
+        arr = np.full((len(ori), 256), np.nan, np.float32)
+        for b, d in enumerate(ori):
+            for k, v in d.items():
+                arr[b, k] = v
+        out['orientation'] = arr
+    return out
+
+
+def gen_panoptic(ref):
+    print('panoptic pipeline (reference PanopticPostprocessing.postprocess)')
+    # small: inputs stored
+    inp = syn.make_panoptic_inputs(2, n_classes=8, height=96, width=128,
+                                   n_centers=6, seed=3, with_orientation=True)
+    r = run_panoptic(ref, inp, with_orientation=True)
+    save('panoptic_small', **{f'in_{k}': v for k, v in inp.items()},
+         **panoptic_outputs(r, with_orientation=True))
+
+    # small, unrounded offsets + distance threshold + fg-masked heatmap
+    inp = syn.make_panoptic_inputs(3, n_classes=5, height=64, width=96,
+                                   n_centers=5, seed=4, quantize_offsets=False)
+    kw = dict(heatmap_threshold=0.2, heatmap_nms_kernel_size=5,
+              heatmap_apply_foreground_mask=True, top_k_instances=3,
+              offset_distance_threshold=20)
+    r = run_panoptic(ref, inp, heatmap_kwargs=kw)
+    save('panoptic_small_kwargs', kwargs=jdump(kw),
+         **{f'in_{k}': v for k, v in inp.items()}, **panoptic_outputs(r))
+
+    # cfg1: B=4, C=40, 480x640, 24 centers, quantised offsets (digest only)
+    for name, B, seed, quant in (('panoptic_cfg1_q', 4, 0, True),
+                                 ('panoptic_cfg1_r', 2, 1, False)):
+        inp = syn.make_panoptic_inputs(B, seed=seed, quantize_offsets=quant)
+        r = run_panoptic(ref, inp)
+        digest = syn.input_digest(inp['semantic_logits'], inp['instance_center'],
+                                  inp['instance_offset'])
+        save(name, params=jdump(dict(batch_size=B, seed=seed, quantize_offsets=quant)),
+             digest=jdump(digest), **panoptic_outputs(r, score_stride=8))
+
+
+def gen_centers(ref):
+    print('center NMS / top-k adversarial cases (reference _get_instance_centers)')
+    rng = np.random.default_rng(7)
+    cases = {}
+    H, W = 24, 40
+
+    def add(name, heat, fg=None, **kw):
+        cases[name] = (heat.astype(np.float32), fg, kw)
+
+    # 1) random noise, many candidates, small top-k -> exercises kth selection
+    add('noise_k4', rng.random((3, 1, H, W)), top_k_instances=4)
+    add('noise_k64', rng.random((2, 1, H, W)), top_k_instances=64)
+    # 2) quantised heatmap -> many ties (plateaus, equal peaks)
+    q = np.round(rng.random((3, 1, H, W)) * 4) / 4
+    add('quant_ties_k3', q, top_k_instances=3)
+    add('quant_ties_ks1', q, top_k_instances=5, heatmap_nms_kernel_size=1)
+    add('quant_ties_ks5', q, top_k_instances=5, heatmap_nms_kernel_size=5)
+    # 3) peaks on/next to the border (never centers with ks=3)
+    b = np.zeros((1, 1, H, W))
+    b[0, 0, 0, 0] = 1.0
+    b[0, 0, 0, 7] = 0.9
+    b[0, 0, 1, 1] = 0.8
+    b[0, 0, H - 1, W - 1] = 0.7
+    b[0, 0, H - 2, W - 2] = 0.6
+    b[0, 0, 12, 0] = 0.95
+    b[0, 0, 12, 20] = 0.5
+    add('border', b)
+    add('border_ks1', b, heatmap_nms_kernel_size=1)
+    # 4) fewer than k survivors / none at all / all below threshold
+    add('empty', np.zeros((2, 1, H, W)))
+    add('below_thr', np.full((1, 1, H, W), 0.05))
+    # 5) foreground-masked heatmap
+    fg = rng.random((3, H, W)) < 0.5
+    add('noise_fg', rng.random((3, 1, H, W)), fg=fg, top_k_instances=6,
+        heatmap_apply_foreground_mask=True)
+    # 6) equal isolated peaks, more than k (all kept by the >= kth rule)
+    e = np.zeros((1, 1, H, W))
+    e[0, 0, 2:H - 2:3, 2:W - 2:3] = 1.0
+    add('equal_peaks_k5', e, top_k_instances=5)
+    # 7) NaN / inf in the heatmap
+    nn = rng.random((2, 1, H, W))
+    nn[0, 0, 5, 5] = np.nan
+    nn[0, 0, 10, 30] = np.inf
+    nn[1, 0, 3, 3] = -np.inf
+    add('nonfinite', nn, top_k_instances=8)
+    # 8) negative threshold, zero-valued heatmap corner (pixel-0 corner case)
+    z = rng.random((1, 1, H, W)) - 0.5
+    z[0, 0, 0, 0] = 0.0
+    add('neg_threshold', z, heatmap_threshold=-0.25, top_k_instances=10)
+
+    out = {}
+    for name, (heat, fg, kw) in cases.items():
+        post = ref.post_instance.InstancePostprocessing(**kw)
+        mask, clist = post._get_instance_centers(
+            torch.from_numpy(heat.copy()),
+            None if fg is None else torch.from_numpy(fg))
+        B = heat.shape[0]
+        cap = max(max(len(c) for c in clist), 1)
+        cyx = np.zeros((B, cap, 2), np.int32)
+        n = np.zeros((B,), np.int32)
+        for bi, c in enumerate(clist):
+            n[bi] = len(c)
+            cyx[bi, :len(c)] = c.numpy()
+        out[f'{name}__heat'] = heat
+        if fg is not None:
+            out[f'{name}__fg'] = fg
+        out[f'{name}__kwargs'] = jdump(kw)
+        out[f'{name}__mask'] = mask.numpy()
+        out[f'{name}__n'] = n
+        out[f'{name}__centers'] = cyx
+    out['names'] = jdump(list(cases.keys()))
+    save('centers_adversarial', **out)
+
+
+def gen_grouping(ref):
+    print('offset grouping adversarial cases (reference _get_instance_segmentation)')
+    rng = np.random.default_rng(11)
+    out = {}
+    names = []
+
+    def run(name, heat, offset, fg, **kw):
+        post = ref.post_instance.InstancePostprocessing(normalized_offset=False, **kw)
+        seg, meta = post._get_instance_segmentation(
+            torch.from_numpy(heat.copy()), torch.from_numpy(offset.copy()),
+            torch.from_numpy(fg))
+        n, cyx, area, score = meta_to_arrays(meta, cap=400)
+        out.update({f'{name}__heat': heat, f'{name}__offset': offset,
+                    f'{name}__fg': fg, f'{name}__kwargs': jdump(kw),
+                    f'{name}__inst': seg.numpy(), f'{name}__meta_n': n,
+                    f'{name}__meta_center_yx': cyx, f'{name}__meta_area': area,
+                    f'{name}__meta_score': score})
+        names.append(name)
+
+    # exact ties: zero offsets, symmetric centers -> lowest center index wins
+    H, W = 33, 49
+    heat = np.zeros((1, 1, H, W), np.float32)
+    for (y, x) in ((8, 8), (8, 40), (24, 8), (24, 40), (16, 24)):
+        heat[0, 0, y, x] = 1.0
+    off = np.zeros((1, 2, H, W), np.float32)
+    fg = np.ones((1, H, W), bool)
+    run('ties_zero_offset', heat, off, fg)
+    # with a distance threshold (int, like the reference kwarg)
+    run('ties_thr10', heat, off, fg, offset_distance_threshold=10)
+    # random offsets, random fg, continuous values
+    off = (rng.standard_normal((1, 2, H, W)) * 6).astype(np.float32)
+    fg = rng.random((1, H, W)) < 0.6
+    run('random_offsets', heat, off, fg)
+    run('random_offsets_thr', heat, off, fg, offset_distance_threshold=7)
+    # NaN / inf offsets
+    offn = off.copy()
+    offn[0, 0, 3, 3] = np.nan
+    offn[0, 1, 4, 4] = np.inf
+    offn[0, 0, 5, 5] = -np.inf
+    run('nonfinite_offsets', heat, offn, np.ones((1, H, W), bool))
+    # no centers at all / empty foreground
+    run('no_centers', np.zeros((2, 1, H, W), np.float32),
+        np.zeros((2, 2, H, W), np.float32), np.ones((2, H, W), bool))
+    run('empty_fg', heat, off, np.zeros((1, H, W), bool))
+
+    # > 255 centers: uint8 id wrap (instance.py:236); 300 equal isolated peaks
+    H, W = 64, 96
+    heat = np.zeros((1, 1, H, W), np.float32)
+    ys, xs = np.meshgrid(np.arange(2, H - 2, 3), np.arange(2, W - 2, 3), indexing='ij')
+    pts = np.stack([ys.ravel(), xs.ravel()], 1)[:300]
+    heat[0, 0, pts[:, 0], pts[:, 1]] = 1.0
+    off = (rng.standard_normal((1, 2, H, W)) * 2).astype(np.float32)
+    fg = rng.random((1, H, W)) < 0.8
+    run('wrap_300_centers', heat, off, fg, top_k_instances=254)
+
+    out['names'] = jdump(names)
+    save('grouping_adversarial', **out)
+
+
+def gen_merge(ref):
+    print('merge (reference deeplab_merge_batch + numpy twins + naive)')
+    pm = ref.panoptic_merge
+    rng = np.random.default_rng(13)
+    H, W = 40, 56
+    out = {}
+    names = []
+
+    def blobs(n_vals, B, lo=0):
+        coarse = rng.integers(lo, n_vals, size=(B, H // 8, W // 8))
+        return np.repeat(np.repeat(coarse, 8, axis=1), 8, axis=2)
+
+    def run(name, sem, ins, thing, max_inst, thing_ids, void):
+        pan, dicts = pm.deeplab_merge_batch(
+            torch.from_numpy(sem), torch.from_numpy(ins), torch.from_numpy(thing),
+            max_inst, thing_ids, void)
+        n, k, v = ids_to_arrays(dicts, cap=512)
+        out.update({f'{name}__sem': sem, f'{name}__ins': ins, f'{name}__thing': thing,
+                    f'{name}__params': jdump(dict(max_inst=max_inst,
+                                                  thing_ids=[int(t) for t in thing_ids],
+                                                  void=void)),
+                    f'{name}__pan': pan.numpy(), f'{name}__ids_n': n,
+                    f'{name}__ids_pan': k, f'{name}__ids_ins': v})
+        names.append(name)
+        return pan.numpy(), dicts
+
+    # prediction-style: sem 1..C (no void), instance blobs cut across classes,
+    # instances only inside things
+    C = 6
+    sem = blobs(C, 3, lo=0).astype(np.int64) + 1
+    thing_ids = [4, 5, 6]
+    thing = np.isin(sem, thing_ids)
+    ins = (np.roll(blobs(9, 3), 3, axis=2) * thing).astype(np.uint8)
+    run('pred_style', sem, ins, thing, 1 << 16, thing_ids, 0)
+    # GT-style with void (0) in sem, int32 instance ids, thing mask = ins != 0,
+    # ids spanning void-majority regions and tie votes
+    sem = blobs(C + 1, 3).astype(np.int64)
+    ins = blobs(12, 3).astype(np.int32)
+    ins[:, ::2, :] = np.roll(ins, 5, axis=2)[:, ::2, :]
+    thing = ins != 0
+    run('gt_style_void', sem, ins, thing, 1 << 16, [3, 4], 0)
+    # thing mask disagreeing with ins>0, small max_inst, non-zero void label
+    thing2 = rng.random(sem.shape) < 0.5
+    run('mask_mismatch', sem, ins, thing2, 256, [1, 2, 6], 0)
+    run('void_label_7', sem, ins, thing, 100, [3, 4], 7)
+    # everything stuff / everything void
+    run('all_stuff', sem, np.zeros_like(ins), np.zeros_like(thing), 1 << 16, [], 0)
+    run('all_void', np.zeros_like(sem), ins, thing, 1 << 16, [1], 0)
+
+    # numpy twins + naive on consistent GT-style maps (instances never span
+    # classes: the invariant of reference tests/test_merge.py:97-102)
+    B = 2
+    ins_u16 = blobs(10, B).astype(np.uint16)
+    cls_of_ins = np.array([0, 3, 4, 3, 4, 4, 3, 3, 4, 3])
+    stuff = blobs(3, B).astype(np.uint8)          # 0,1,2 (0 = void)
+    sem_u8 = np.where(ins_u16 > 0, cls_of_ins[ins_u16], stuff).astype(np.uint8)
+    naive_p, deeplab_p, torch_p = [], [], []
+    for b in range(B):
+        n_p, n_d = pm.naive_merge_semantic_and_instance_np(
+            sem_u8[b], ins_u16[b], 1 << 16, [3, 4], 0)
+        d_p, d_d = pm.deeplab_merge_semantic_and_instance_np(
+            sem_u8[b], ins_u16[b], ins_u16[b] != 0, 1 << 16, [3, 4], 0)
+        t_p, t_d = pm.deeplab_merge_semantic_and_instance(
+            torch.from_numpy(sem_u8[b].astype(np.int64)),
+            torch.from_numpy(ins_u16[b].astype(np.int32)),
+            torch.from_numpy(ins_u16[b] != 0), 1 << 16, [3, 4], 0)
+        assert (n_p == d_p).all() and (n_p == t_p.numpy()).all()
+        assert n_d == d_d == t_d
+        naive_p.append(n_p)
+    n, k, v = ids_to_arrays([n_d], cap=64)
+    out.update(consistent__sem=sem_u8, consistent__ins=ins_u16,
+               consistent__pan=np.stack(naive_p).astype(np.int64),
+               consistent__last_ids_n=n, consistent__last_ids_pan=k,
+               consistent__last_ids_ins=v)
+    # naive on an inconsistent map (instances split by class)
+    sem_b = blobs(5, 1).astype(np.uint8)
+    n_p, n_d = pm.naive_merge_semantic_and_instance_np(
+        sem_b[0], ins_u16[0], 1 << 16, [3, 4], 0)
+    n, k, v = ids_to_arrays([n_d], cap=128)
+    out.update(naive_split__sem=sem_b, naive_split__ins=ins_u16[:1],
+               naive_split__pan=n_p[None].astype(np.int64), naive_split__ids_n=n,
+               naive_split__ids_pan=k, naive_split__ids_ins=v)
+    out['names'] = jdump(names)
+    save('merge_cases', **out)
+
+
+def gen_metrics(ref):
+    print('metrics (reference MeanIntersectionOverUnion / compare_and_accumulate)')
+    rng = np.random.default_rng(17)
+    out = {}
+    # mIoU: n in (5, 41, 101), with/without void, incl. absent classes
+    for n in (5, 41, 101):
+        pred = rng.integers(0, n, size=(4, 50, 60))
+        tgt = rng.integers(0, n, size=(4, 50, 60))
+        tgt[tgt == 3] = 2                        # class 3 has no GT
+        for ign in (False, True):
+            m = ref.metric_miou.MeanIntersectionOverUnion(n, ignore_first_class=ign)
+            m.update(torch.from_numpy(pred[:2]), torch.from_numpy(tgt[:2]))
+            m.update(torch.from_numpy(pred[2:]), torch.from_numpy(tgt[2:]))
+            miou, ious = m.compute(return_ious=True)
+            out[f'miou_{n}_{int(ign)}__confmat'] = m.confmat.numpy()
+            out[f'miou_{n}_{int(ign)}__miou'] = np.float32(miou.item())
+            out[f'miou_{n}_{int(ign)}__ious'] = ious.numpy()
+        out[f'miou_{n}__pred'] = pred.astype(np.uint8)
+        out[f'miou_{n}__target'] = tgt.astype(np.uint8)
+
+    # PQ on blobby random panoptic maps (class*65536 + inst), offset 256**3
+    H, W = 48, 64
+
+    def pan_map(B, n_cls, seed):
+        r = np.random.default_rng(seed)
+        cls = np.repeat(np.repeat(r.integers(0, n_cls, (B, H // 8, W // 8)), 8, 1), 8, 2)
+        ins = np.repeat(np.repeat(r.integers(0, 4, (B, H // 4, W // 4)), 4, 1), 4, 2)
+        thing = cls >= n_cls // 2
+        return (cls.astype(np.int64) * 65536 + ins * thing).astype(np.int64)
+
+    n_cls = 9
+    pred = pan_map(3, n_cls, 1)
+    tgt = np.roll(pred, 2, axis=2)
+    tgt[:, :6] = 0
+    tgt2 = pan_map(3, n_cls, 2)
+    states = []
+    all_matches = []
+    for name, (p, t) in (('shift', (pred, tgt)), ('indep', (pred, tgt2))):
+        st = [np.zeros(n_cls) for _ in range(4)]
+        per_image = []
+        for b in range(p.shape[0]):
+            iou, tp, fn, fp, matched = ref.metric_pq.compare_and_accumulate(
+                torch.from_numpy(p[b]), torch.from_numpy(t[b]),
+                n_cls, 0, 65536, 256 ** 3, 0)
+            for s, x in zip(st, (iou, tp, fn, fp)):
+                s += x.numpy()
+            per_image.append(sorted(matched))
+        out[f'pq_{name}__pred'] = p
+        out[f'pq_{name}__target'] = t
+        out[f'pq_{name}__state'] = np.stack(st)
+        out[f'pq_{name}__matches'] = jdump(per_image)
+    out['pq_params'] = jdump(dict(num_categories=n_cls, ignored_label=0,
+                                  max_instances_per_category=65536, offset=256 ** 3))
+    save('metric_cases', **out)
+
+
+def gen_losses(ref):
+    print('losses (reference loss classes + task-helper masking, with autograd grads)')
+    B, Cn, H, W, D = 2, 7, 24, 32, 16
+    inp = syn.make_loss_inputs(B, Cn, H, W, seed=5, embedding_dim=D, n_lut=9)
+    out = {f'in_{k}': v for k, v in inp.items()}
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)) for k, v in inp.items()}
+
+    # --- CE (ce.py) : plain / weighted / label smoothing / weighted reduction
+    for name, kw in (('plain', {}),
+                     ('weighted', dict(weights=t['class_weights'])),
+                     ('smooth', dict(weights=t['class_weights'], label_smoothing=0.25)),
+                     ('smooth_nw', dict(label_smoothing=0.5)),
+                     ('wred', dict(weights=t['class_weights'], weighted_reduction=True))):
+        x = t['semantic_logits'].clone().requires_grad_(True)
+        fn = ref.loss_ce.CrossEntropyLossSemantic(**kw)
+        (loss, n), = fn([x], [t['semantic_target']])
+        loss.backward()
+        out[f'ce_{name}__loss'] = np.float32(loss.item())
+        out[f'ce_{name}__n'] = np.int64(n)
+        out[f'ce_{name}__grad'] = x.grad.numpy()
+
+    # --- center (mse / l1), masking of task_helper/instance.py:129-139
+    for kind, cls in (('mse', ref.loss_mse.MSELoss), ('l1', ref.loss_l1.L1Loss)):
+        x = t['center_pred'].clone().requires_grad_(True)
+        mask = t['center_mask']
+        (loss, n), = cls(reduction='sum')([x * mask], [t['center_target']])
+        loss.backward()
+        out[f'center_{kind}__loss'] = np.float32(loss.item())
+        out[f'center_{kind}__n_loss'] = np.int64(n)
+        out[f'center_{kind}__n_mask'] = np.int64(mask.sum().item())
+        out[f'center_{kind}__grad'] = x.grad.numpy()
+    # --- offset (l1), task_helper/instance.py:154-167
+    x = t['offset_pred'].clone().requires_grad_(True)
+    mask = t['offset_mask']
+    (loss, n), = ref.loss_l1.L1Loss(reduction='sum')(
+        [x * mask.unsqueeze(1).expand_as(x)], [t['offset_target']])
+    loss.backward()
+    out['offset_l1__loss'] = np.float32(loss.item())
+    out['offset_l1__n_loss'] = np.int64(n)
+    out['offset_l1__n_mask'] = np.int64(mask.sum().item())
+    out['offset_l1__grad'] = x.grad.numpy()
+    # --- orientation (von Mises), task_helper/instance.py:186-216
+    x = t['orientation_pred'].clone().requires_grad_(True)
+    mask = t['orientation_mask'].flatten()
+    p2 = x.permute(0, 2, 3, 1).reshape(-1, 2)[mask, :]
+    y2 = t['orientation_target'].permute(0, 2, 3, 1).reshape(-1, 2)[mask, :]
+    for kappa in (1.0, 2.5):
+        x.grad = None
+        (loss, n), = ref.loss_vonmises.VonMisesLossBiternion(kappa=kappa)([p2], [y2])
+        loss.backward(retain_graph=True)
+        out[f'vonmises_{kappa}__loss'] = np.float32(loss.item())
+        out[f'vonmises_{kappa}__n'] = np.int64(n)
+        out[f'vonmises_{kappa}__grad'] = x.grad.numpy().copy()
+    # --- cosine embedding, task_helper/dense_visual_embedding.py:110-171
+    x = t['embedding_pred'].clone().requires_grad_(True)
+    idx = t['embedding_indices']
+    valid = idx != 0
+    pm_ = x.permute(0, 2, 3, 1)[valid]
+    keep = (idx - 1)[valid].long()
+    bidx = torch.where(valid)[0]
+    tg = torch.cat([t['embedding_lut'][b][keep[bidx == b]] for b in range(B)], 0)
+    (loss, n), = ref.loss_cos_emb.CosineEmbeddingLoss()([pm_], [tg])
+    loss.backward()
+    out['cos_emb__loss'] = np.float32(loss.item())
+    out['cos_emb__n'] = np.int64(n)
+    out['cos_emb__grad'] = x.grad.numpy()
+    save('loss_cases', **out)
+
+
+def gen_orientation(ref):
+    print('instance orientation (reference _get_instance_orientation)')
+    inp = syn.make_panoptic_inputs(2, n_classes=6, height=48, width=64, n_centers=5,
+                                   seed=9, with_orientation=True)
+    rng = np.random.default_rng(19)
+    inst = np.repeat(np.repeat(rng.integers(0, 5, (2, 6, 8)), 8, 1), 8, 2).astype(np.uint8)
+    mask = rng.random((2, 48, 64)) < 0.7
+    post = ref.post_instance.InstancePostprocessing()
+    res = {}
+    for name, m in (('masked', mask), ('nomask', None)):
+        r = post._get_instance_orientation(
+            torch.from_numpy(inp['instance_orientation']), torch.from_numpy(inst),
+            None if m is None else torch.from_numpy(m))
+        arr = np.full((2, 256), np.nan, np.float32)
+        for b, d in enumerate(r):
+            for k, v in d.items():
+                arr[b, k] = v
+        res[f'{name}__angle'] = arr
+    save('orientation_cases', orientation=inp['instance_orientation'], inst=inst,
+         mask=mask, **res)
+
+
+def main():
+    ref = load_reference()
+    only = set(sys.argv[1:])
+
+    def want(k):
+        return not only or k in only
+    if want('norm'):
+        check_norm_formula(ref)
+    if want('panoptic'):
+        gen_panoptic(ref)
+    if want('centers'):
+        gen_centers(ref)
+    if want('grouping'):
+        gen_grouping(ref)
+    if want('merge'):
+        gen_merge(ref)
+    if want('metrics'):
+        gen_metrics(ref)
+    if want('losses'):
+        gen_losses(ref)
+    if want('orientation'):
+        gen_orientation(ref)
+
+
+if __name__ == '__main__':
+    main()

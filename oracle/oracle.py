@@ -1,0 +1,277 @@
+"""
+TEST INFRASTRUCTURE — numpy front-end of the C oracle (oracle/nmsa_oracle.c).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
+this module; the product package never does.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB_PATH = os.path.join(_HERE, 'libnmsa_oracle.so')
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, 'nmsa_oracle.c')
+    if (force or not os.path.exists(_LIB_PATH)
+            or os.path.getmtime(_LIB_PATH) < os.path.getmtime(src)):
+        subprocess.check_call(['make', '-C', _HERE, '-B', 'libnmsa_oracle.so'],
+                              stdout=subprocess.DEVNULL)
+    return _LIB_PATH
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(_LIB_PATH)
+        _lib.orc_miou_compute.restype = C.c_float
+    return _lib
+
+
+def _p(a, t):
+    if a is None:
+        return None
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def _c(a, dtype):
+    return np.ascontiguousarray(a, dtype=dtype)
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise OracleError(f'{what}: oracle error {rc}')
+
+
+# -- a1 -----------------------------------------------------------------------
+def semantic_argmax(logits):
+    logits = _c(logits, np.float32)
+    B, Cn, H, W = logits.shape
+    idx = np.empty((B, H, W), np.int64)
+    score = np.empty((B, H, W), np.float32)
+    _chk(lib().orc_semantic_argmax(_p(logits, C.c_float), B, Cn, H, W,
+                                   _p(idx, C.c_int64), _p(score, C.c_float)),
+         'semantic_argmax')
+    return idx, score
+
+
+# -- a2 -----------------------------------------------------------------------
+def center_nms_topk(center, fg=None, threshold=0.1, ksize=3, topk=64,
+                    apply_fg=False, max_centers=256):
+    center = _c(center, np.float32)
+    if center.ndim == 4:
+        center = center[:, 0]
+    center = np.ascontiguousarray(center)
+    B, H, W = center.shape
+    fg_ = None if fg is None else _c(fg, np.uint8)
+    cyx = np.zeros((B, max_centers, 2), np.int32)
+    n = np.zeros((B,), np.int32)
+    scores = np.zeros((B, max_centers), np.float32)
+    mask = np.zeros((B, H, W), np.uint8)
+    rc = lib().orc_center_nms_topk(
+        _p(center, C.c_float), _p(fg_, C.c_uint8), B, H, W,
+        C.c_float(threshold), ksize, topk, int(bool(apply_fg)), max_centers,
+        _p(cyx, C.c_int32), _p(n, C.c_int32), _p(scores, C.c_float),
+        _p(mask, C.c_uint8))
+    _chk(rc, 'center_nms_topk')
+    return cyx, n, scores, mask.astype(bool)
+
+
+# -- a3 -----------------------------------------------------------------------
+def group_offsets(offset, fg, centers_yx, n_centers, scale_y=1.0, scale_x=1.0,
+                  dist_thr=None):
+    offset = _c(offset, np.float32)
+    B, two, H, W = offset.shape
+    assert two == 2
+    fg = _c(fg, np.uint8)
+    centers_yx = _c(centers_yx, np.int32)
+    n_centers = _c(n_centers, np.int32)
+    max_centers = centers_yx.shape[1]
+    inst = np.zeros((B, H, W), np.uint8)
+    area = np.zeros((B, 256), np.int32)
+    rc = lib().orc_group_offsets(
+        _p(offset, C.c_float), _p(fg, C.c_uint8), _p(centers_yx, C.c_int32),
+        _p(n_centers, C.c_int32), B, H, W, max_centers,
+        C.c_float(scale_y), C.c_float(scale_x),
+        0 if dist_thr is None else 1,
+        C.c_float(0.0 if dist_thr is None else dist_thr),
+        _p(inst, C.c_uint8), _p(area, C.c_int32))
+    _chk(rc, 'group_offsets')
+    return inst, area
+
+
+# -- a5 -----------------------------------------------------------------------
+def _merge(fn, sem, ins, thing_seg, max_inst, thing_ids, void_label, cap=1024):
+    sem = _c(sem, np.int64)
+    ins = _c(ins, np.int64)
+    B, H, W = sem.shape
+    thing_ids = _c(list(thing_ids), np.int64)
+    pan = np.empty((B, H, W), np.int64)
+    id_pan = np.zeros((B, cap), np.int64)
+    id_ins = np.zeros((B, cap), np.int64)
+    n_ids = np.zeros((B,), np.int32)
+    if thing_seg is not None:
+        thing_seg = _c(thing_seg, np.uint8)
+        rc = fn(_p(sem, C.c_int64), _p(ins, C.c_int64), _p(thing_seg, C.c_uint8),
+                B, H, W, C.c_int64(max_inst), _p(thing_ids, C.c_int64),
+                len(thing_ids), C.c_int64(void_label), _p(pan, C.c_int64), cap,
+                _p(id_pan, C.c_int64), _p(id_ins, C.c_int64), _p(n_ids, C.c_int32))
+    else:
+        rc = fn(_p(sem, C.c_int64), _p(ins, C.c_int64),
+                B, H, W, C.c_int64(max_inst), _p(thing_ids, C.c_int64),
+                len(thing_ids), C.c_int64(void_label), _p(pan, C.c_int64), cap,
+                _p(id_pan, C.c_int64), _p(id_ins, C.c_int64), _p(n_ids, C.c_int32))
+    _chk(rc, 'merge')
+    dicts = [{int(id_pan[b, i]): int(id_ins[b, i]) for i in range(n_ids[b])}
+             for b in range(B)]
+    return pan, dicts
+
+
+def deeplab_merge(sem, ins, thing_seg, max_inst, thing_ids, void_label=0):
+    return _merge(lib().orc_deeplab_merge, sem, ins, thing_seg, max_inst,
+                  thing_ids, void_label)
+
+
+def naive_merge(sem, ins, max_inst, thing_ids, void_label=0):
+    return _merge(lib().orc_naive_merge, sem, ins, None, max_inst,
+                  thing_ids, void_label)
+
+
+# -- orientation ----------------------------------------------------------------
+def instance_orientation(orientation, inst, mask=None):
+    orientation = _c(orientation, np.float32)
+    inst = _c(inst, np.uint8)
+    B, H, W = inst.shape
+    mask_ = None if mask is None else _c(mask, np.uint8)
+    angle = np.zeros((B, 256), np.float32)
+    present = np.zeros((B, 256), np.uint8)
+    _chk(lib().orc_instance_orientation(
+        _p(orientation, C.c_float), _p(inst, C.c_uint8), _p(mask_, C.c_uint8),
+        B, H, W, _p(angle, C.c_float), _p(present, C.c_uint8)), 'orientation')
+    return [{i: float(angle[b, i]) for i in range(256) if present[b, i]}
+            for b in range(B)]
+
+
+# -- a11 ----------------------------------------------------------------------
+def confmat_update(preds, target, n_classes, confmat=None):
+    preds = _c(preds, np.int64).reshape(-1)
+    target = _c(target, np.int64).reshape(-1)
+    if confmat is None:
+        confmat = np.zeros((n_classes, n_classes), np.int64)
+    _chk(lib().orc_confmat_update(_p(preds, C.c_int64), _p(target, C.c_int64),
+                                  C.c_int64(preds.size), n_classes,
+                                  _p(confmat, C.c_int64)), 'confmat_update')
+    return confmat
+
+
+def miou_compute(confmat, ignore_first_class=False):
+    confmat = _c(confmat, np.int64)
+    n = confmat.shape[0]
+    ious = np.empty((n,), np.float32)
+    miou = lib().orc_miou_compute(_p(confmat, C.c_int64), n,
+                                  int(bool(ignore_first_class)), _p(ious, C.c_float))
+    return float(miou), ious
+
+
+# -- a12 ----------------------------------------------------------------------
+def pq_compare_and_accumulate(pred, target, num_categories, ignored_label,
+                              max_instances_per_category, offset,
+                              void_segment_id=None, state=None, match_cap=4096):
+    """pred/target: one image [H,W] int64.  Returns (iou, tp, fn, fp, matches)."""
+    pred = _c(pred, np.int64).reshape(-1)
+    target = _c(target, np.int64).reshape(-1)
+    if void_segment_id is None:
+        void_segment_id = ignored_label * max_instances_per_category
+    if state is None:
+        state = [np.zeros((num_categories,), np.float64) for _ in range(4)]
+    matches = np.zeros((match_cap, 2), np.int64)
+    nm = C.c_int32(0)
+    _chk(lib().orc_pq_compare_and_accumulate(
+        _p(pred, C.c_int64), _p(target, C.c_int64), C.c_int64(pred.size),
+        num_categories, C.c_int64(ignored_label),
+        C.c_int64(max_instances_per_category), C.c_int64(offset),
+        C.c_int64(void_segment_id),
+        _p(state[0], C.c_double), _p(state[1], C.c_double),
+        _p(state[2], C.c_double), _p(state[3], C.c_double),
+        match_cap, _p(matches, C.c_int64), C.byref(nm)), 'pq')
+    m = [(int(a), int(b)) for a, b in matches[:nm.value]]
+    return state[0], state[1], state[2], state[3], m
+
+
+# -- losses ---------------------------------------------------------------------
+def loss_ce(logits, target, weights=None, label_smoothing=0.0, want_grad=False):
+    logits = _c(logits, np.float32)
+    target = _c(target, np.uint8)
+    B, Cn, H, W = logits.shape
+    w = None if weights is None else _c(weights, np.float32)
+    s = C.c_double(0)
+    n = C.c_int64(0)
+    wd = C.c_double(0)
+    grad = np.empty_like(logits) if want_grad else None
+    _chk(lib().orc_loss_ce(_p(logits, C.c_float), _p(target, C.c_uint8),
+                           _p(w, C.c_float), B, Cn, H, W,
+                           C.c_float(label_smoothing), C.byref(s), C.byref(n),
+                           C.byref(wd), _p(grad, C.c_float)), 'loss_ce')
+    return s.value, n.value, wd.value, grad
+
+
+def loss_masked_elementwise(pred, target, mask, kind, want_grad=False):
+    """kind: 'mse' | 'l1'.  pred/target [B,H,W] or [B,C,H,W]; mask [B,H,W]|None."""
+    pred = _c(pred, np.float32)
+    target = _c(target, np.float32)
+    if pred.ndim == 3:
+        B, H, W = pred.shape
+        Cn = 1
+    else:
+        B, Cn, H, W = pred.shape
+    m = None if mask is None else _c(mask, np.uint8)
+    s = C.c_double(0)
+    n = C.c_int64(0)
+    grad = np.empty_like(pred) if want_grad else None
+    _chk(lib().orc_loss_masked_elementwise(
+        _p(pred, C.c_float), _p(target, C.c_float), _p(m, C.c_uint8),
+        B, Cn, H, W, 0 if kind == 'mse' else 1, C.byref(s), C.byref(n),
+        _p(grad, C.c_float)), 'loss_elementwise')
+    return s.value, n.value, grad
+
+
+def loss_vonmises(pred, target, mask, kappa=1.0, want_grad=False):
+    pred = _c(pred, np.float32)
+    target = _c(target, np.float32)
+    B, two, H, W = pred.shape
+    m = None if mask is None else _c(mask, np.uint8)
+    s = C.c_double(0)
+    n = C.c_int64(0)
+    grad = np.empty_like(pred) if want_grad else None
+    _chk(lib().orc_loss_vonmises(_p(pred, C.c_float), _p(target, C.c_float),
+                                 _p(m, C.c_uint8), B, H, W, C.c_float(kappa),
+                                 C.byref(s), C.byref(n), _p(grad, C.c_float)),
+         'loss_vonmises')
+    return s.value, n.value, grad
+
+
+def loss_cosine_embedding(pred, indices, lut, want_grad=False):
+    pred = _c(pred, np.float32)
+    indices = _c(indices, np.int32)
+    lut = _c(lut, np.float32)
+    B, D, H, W = pred.shape
+    L = lut.shape[1]
+    s = C.c_double(0)
+    n = C.c_int64(0)
+    grad = np.empty_like(pred) if want_grad else None
+    _chk(lib().orc_loss_cosine_embedding(
+        _p(pred, C.c_float), _p(indices, C.c_int32), _p(lut, C.c_float),
+        B, D, H, W, L, C.byref(s), C.byref(n), _p(grad, C.c_float)),
+        'loss_cos_emb')
+    return s.value, n.value, grad

@@ -1,0 +1,229 @@
+"""
+CPU tier: pins the C oracle (oracle/nmsa_oracle.c) against the golden vectors
+produced by the reference's own Python (oracle/gen_golden.py) and against the
+reference's known-answer PQ tables (reference tests/test_metrics.py:76-446).
+"""
+import numpy as np
+import pytest
+
+from _golden import load, jload, meta_from_arrays, ids_from_arrays
+from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+
+
+# ---------------------------------------------------------------------------
+# full panoptic pipeline a1..a5
+def _run_pipeline_oracle(oracle, logits, center, offset, is_thing, kw=None):
+    kw = dict(kw or {})
+    B, C, H, W = logits.shape
+    idx, score = oracle.semantic_argmax(logits)
+    fg = is_thing[idx]
+    cyx, n, scores, _ = oracle.center_nms_topk(
+        center, fg=fg,
+        threshold=kw.get('heatmap_threshold', 0.1),
+        ksize=kw.get('heatmap_nms_kernel_size', 3),
+        topk=kw.get('top_k_instances', 64),
+        apply_fg=kw.get('heatmap_apply_foreground_mask', False),
+        max_centers=512)
+    inst, area = oracle.group_offsets(offset, fg, cyx, n, scale_y=H, scale_x=W,
+                                      dist_thr=kw.get('offset_distance_threshold'))
+    thing_ids = np.where(is_thing)[0] + 1
+    pan, ids = oracle.deeplab_merge(idx + 1, inst, fg, 1 << 16, thing_ids, 0)
+    return dict(idx=idx, score=score, fg=fg, cyx=cyx, n=n, scores=scores,
+                inst=inst, area=area, pan=pan, ids=ids)
+
+
+def _check_pipeline(g, r):
+    assert (r['idx'] == g['semantic_idx']).all()
+    st = int(g['semantic_score_stride']) if 'semantic_score_stride' in g else 1
+    np.testing.assert_allclose(r['score'][:, ::st, ::st], g['semantic_score'],
+                               rtol=1e-5, atol=1e-7)
+    assert (r['fg'] == g['foreground']).all()
+    assert (r['n'] == g['meta_n']).all()
+    for b in range(len(r['n'])):
+        nb = int(r['n'][b])
+        assert (r['cyx'][b, :nb] == g['meta_center_yx'][b, :nb]).all()
+        assert (r['scores'][b, :nb] == g['meta_score'][b, :nb]).all()
+        assert (r['area'][b, 1:min(nb, 255) + 1] == g['meta_area'][b, :min(nb, 255)]).all()
+    assert (r['inst'] == g['instance']).all()
+    assert (r['pan'] == g['panoptic']).all()
+    assert r['ids'] == ids_from_arrays(g['ids_n'], g['ids_pan'], g['ids_ins'])
+    for rd, gd in zip(r['ids'], ids_from_arrays(g['ids_n'], g['ids_pan'], g['ids_ins'])):
+        assert list(rd.items()) == list(gd.items())      # insertion order too
+
+
+@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_small_kwargs'])
+def test_pipeline_small(oracle, name):
+    g = load(name)
+    kw = jload(g['kwargs']) if 'kwargs' in g else None
+    r = _run_pipeline_oracle(oracle, g['in_semantic_logits'], g['in_instance_center'],
+                             g['in_instance_offset'], g['in_semantic_classes_is_thing'], kw)
+    _check_pipeline(g, r)
+
+
+@pytest.mark.parametrize('name', ['panoptic_cfg1_q', 'panoptic_cfg1_r'])
+def test_pipeline_cfg1(oracle, name):
+    g = load(name)
+    p = jload(g['params'])
+    inp = syn.make_panoptic_inputs(p['batch_size'], seed=p['seed'],
+                                   quantize_offsets=p['quantize_offsets'])
+    digest = syn.input_digest(inp['semantic_logits'], inp['instance_center'],
+                              inp['instance_offset'])
+    if digest != jload(g['digest']):
+        pytest.skip('synthetic inputs differ bit-wise on this host (numpy/libm)')
+    r = _run_pipeline_oracle(oracle, inp['semantic_logits'], inp['instance_center'],
+                             inp['instance_offset'], inp['semantic_classes_is_thing'])
+    _check_pipeline(g, r)
+
+
+# ---------------------------------------------------------------------------
+def test_centers_adversarial(oracle):
+    g = load('centers_adversarial')
+    for name in jload(g['names']):
+        kw = jload(g[f'{name}__kwargs'])
+        heat = g[f'{name}__heat']
+        fg = g[f'{name}__fg'] if f'{name}__fg' in g else None
+        cyx, n, _, mask = oracle.center_nms_topk(
+            heat, fg=fg,
+            threshold=kw.get('heatmap_threshold', 0.1),
+            ksize=kw.get('heatmap_nms_kernel_size', 3),
+            topk=kw.get('top_k_instances', 64),
+            apply_fg=kw.get('heatmap_apply_foreground_mask', False),
+            max_centers=1024)
+        assert (n == g[f'{name}__n']).all(), name
+        assert (mask == g[f'{name}__mask']).all(), name
+        for b in range(len(n)):
+            assert (cyx[b, :n[b]] == g[f'{name}__centers'][b, :n[b]]).all(), name
+
+
+def test_grouping_adversarial(oracle):
+    g = load('grouping_adversarial')
+    for name in jload(g['names']):
+        kw = jload(g[f'{name}__kwargs'])
+        heat, offset, fg = g[f'{name}__heat'], g[f'{name}__offset'], g[f'{name}__fg']
+        cyx, n, scores, _ = oracle.center_nms_topk(
+            heat, topk=kw.get('top_k_instances', 64), max_centers=512)
+        inst, area = oracle.group_offsets(offset, fg, cyx, n,
+                                          dist_thr=kw.get('offset_distance_threshold'))
+        assert (inst == g[f'{name}__inst']).all(), name
+        assert (n == g[f'{name}__meta_n']).all(), name
+        for b in range(len(n)):
+            nb = int(n[b])
+            assert (cyx[b, :nb] == g[f'{name}__meta_center_yx'][b, :nb]).all(), name
+            assert (scores[b, :nb] == g[f'{name}__meta_score'][b, :nb]).all(), name
+            # reference: bincount(uint8 ids, minlength=n+1)[i], i = 1..n
+            ref_area = g[f'{name}__meta_area'][b, :nb]
+            got = np.array([area[b, i] if i <= 255 else 0 for i in range(1, nb + 1)])
+            assert (got == ref_area).all(), name
+
+
+def test_merge_cases(oracle):
+    g = load('merge_cases')
+    for name in jload(g['names']):
+        p = jload(g[f'{name}__params'])
+        pan, ids = oracle.deeplab_merge(g[f'{name}__sem'], g[f'{name}__ins'],
+                                        g[f'{name}__thing'], p['max_inst'],
+                                        p['thing_ids'], p['void'])
+        assert (pan == g[f'{name}__pan']).all(), name
+        want = ids_from_arrays(g[f'{name}__ids_n'], g[f'{name}__ids_pan'], g[f'{name}__ids_ins'])
+        for a, b in zip(ids, want):
+            assert list(a.items()) == list(b.items()), name
+    # numpy twins + naive on consistent GT-style maps
+    sem, ins = g['consistent__sem'], g['consistent__ins']
+    pan_d, ids_d = oracle.deeplab_merge(sem, ins, ins != 0, 1 << 16, [3, 4], 0)
+    pan_n, ids_n = oracle.naive_merge(sem, ins, 1 << 16, [3, 4], 0)
+    assert (pan_d == g['consistent__pan']).all()
+    assert (pan_n == g['consistent__pan']).all()
+    want = ids_from_arrays(g['consistent__last_ids_n'], g['consistent__last_ids_pan'],
+                           g['consistent__last_ids_ins'])[0]
+    assert list(ids_d[-1].items()) == list(want.items())
+    assert list(ids_n[-1].items()) == list(want.items())
+    pan_s, ids_s = oracle.naive_merge(g['naive_split__sem'], g['naive_split__ins'],
+                                      1 << 16, [3, 4], 0)
+    assert (pan_s == g['naive_split__pan']).all()
+    want = ids_from_arrays(g['naive_split__ids_n'], g['naive_split__ids_pan'],
+                           g['naive_split__ids_ins'])[0]
+    assert list(ids_s[0].items()) == list(want.items())
+
+
+def test_orientation_cases(oracle):
+    g = load('orientation_cases')
+    for name, mask in (('masked', g['mask']), ('nomask', None)):
+        res = oracle.instance_orientation(g['orientation'], g['inst'], mask)
+        want = g[f'{name}__angle']
+        for b, d in enumerate(res):
+            present = ~np.isnan(want[b])
+            assert sorted(d.keys()) == list(np.where(present)[0])
+            for k, v in d.items():
+                assert abs(v - want[b, k]) < 1e-5
+
+
+# ---------------------------------------------------------------------------
+def test_miou(oracle):
+    g = load('metric_cases')
+    for n in (5, 41, 101):
+        pred, tgt = g[f'miou_{n}__pred'], g[f'miou_{n}__target']
+        cm = oracle.confmat_update(pred[:2], tgt[:2], n)
+        cm = oracle.confmat_update(pred[2:], tgt[2:], n, cm)
+        for ign in (0, 1):
+            assert (cm == g[f'miou_{n}_{ign}__confmat']).all()
+            miou, ious = oracle.miou_compute(cm, bool(ign))
+            np.testing.assert_allclose(miou, g[f'miou_{n}_{ign}__miou'], rtol=1e-5)
+            np.testing.assert_allclose(ious, g[f'miou_{n}_{ign}__ious'], rtol=1e-5,
+                                       equal_nan=True)
+
+
+def test_pq_random(oracle):
+    g = load('metric_cases')
+    p = jload(g['pq_params'])
+    for name in ('shift', 'indep'):
+        pred, tgt = g[f'pq_{name}__pred'], g[f'pq_{name}__target']
+        state = None
+        all_m = []
+        for b in range(pred.shape[0]):
+            *state, m = oracle.pq_compare_and_accumulate(
+                pred[b], tgt[b], p['num_categories'], p['ignored_label'],
+                p['max_instances_per_category'], p['offset'], state=state)
+            all_m.append(sorted(m))
+        # counts exact, IoU sums bit-exact (same fp64 op order as the reference)
+        assert (np.stack(state) == g[f'pq_{name}__state']).all()
+        assert all_m == [[tuple(x) for x in im] for im in jload(g[f'pq_{name}__matches'])]
+
+
+# ---------------------------------------------------------------------------
+def test_losses(oracle):
+    g = load('loss_cases')
+    logits, tgt, w = g['in_semantic_logits'], g['in_semantic_target'], g['in_class_weights']
+    for name, kw in (('plain', {}), ('weighted', dict(weights=w)),
+                     ('smooth', dict(weights=w, label_smoothing=0.25)),
+                     ('smooth_nw', dict(label_smoothing=0.5))):
+        s, n, _, grad = oracle.loss_ce(logits, tgt, want_grad=True, **kw)
+        np.testing.assert_allclose(s, g[f'ce_{name}__loss'], rtol=1e-5)
+        assert n == g[f'ce_{name}__n']
+        np.testing.assert_allclose(grad, g[f'ce_{name}__grad'], rtol=1e-4, atol=1e-6)
+    s, n, wd, _ = oracle.loss_ce(logits, tgt, weights=w)
+    np.testing.assert_allclose(s / wd, g['ce_wred__loss'], rtol=1e-5)
+
+    for kind in ('mse', 'l1'):
+        s, n, grad = oracle.loss_masked_elementwise(
+            g['in_center_pred'], g['in_center_target'], g['in_center_mask'], kind, True)
+        np.testing.assert_allclose(s, g[f'center_{kind}__loss'], rtol=1e-5)
+        assert n == g[f'center_{kind}__n_mask']
+        np.testing.assert_allclose(grad, g[f'center_{kind}__grad'], rtol=1e-5, atol=1e-7)
+    s, n, grad = oracle.loss_masked_elementwise(
+        g['in_offset_pred'], g['in_offset_target'], g['in_offset_mask'], 'l1', True)
+    np.testing.assert_allclose(s, g['offset_l1__loss'], rtol=1e-5)
+    assert n == g['offset_l1__n_mask']
+    np.testing.assert_allclose(grad, g['offset_l1__grad'], rtol=1e-5, atol=1e-7)
+
+    for kappa in (1.0, 2.5):
+        s, n, grad = oracle.loss_vonmises(g['in_orientation_pred'], g['in_orientation_target'],
+                                          g['in_orientation_mask'], kappa, True)
+        np.testing.assert_allclose(s, g[f'vonmises_{kappa}__loss'], rtol=1e-5)
+        assert n == g[f'vonmises_{kappa}__n']
+        np.testing.assert_allclose(grad, g[f'vonmises_{kappa}__grad'], rtol=1e-5, atol=1e-7)
+
+    s, n, grad = oracle.loss_cosine_embedding(g['in_embedding_pred'], g['in_embedding_indices'],
+                                              g['in_embedding_lut'], True)
+    np.testing.assert_allclose(s, g['cos_emb__loss'], rtol=1e-5)
+    assert n == g['cos_emb__n']
+    np.testing.assert_allclose(grad, g['cos_emb__grad'], rtol=1e-4, atol=1e-6)
