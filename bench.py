@@ -1,0 +1,196 @@
+#!/usr/bin/env python3
+"""
+bench.py — Mpix/s of the panoptic hot path on synthetic 640x480 maps.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
+        --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch that is already resident
+in HBM: center-NMS/top-k -> fused semantic-argmax + offset grouping + class
+votes -> per-instance class/rank -> panoptic paint (BASELINE.json configs[1]:
+B=32 per GPU, C=40, 640x480), followed — when the metric accumulators are
+enabled — by the mIoU confusion-matrix + PQ updates of configs[3].  Images are
+independent units, so ranks shard the batch (weak scaling: 32 images per GPU)
+with no data-path collective; only the few-KB metric accumulators are
+all-reduced (RCCL) inside the timed region.
+
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np   # noqa: E402
+import torch         # noqa: E402
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E spec peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=50)
+    ap.add_argument('--warmup', type=int, default=10)
+    ap.add_argument('--batch-per-gpu', type=int, default=32)
+    ap.add_argument('--classes', type=int, default=40)
+    ap.add_argument('--height', type=int, default=480)
+    ap.add_argument('--width', type=int, default=640)
+    ap.add_argument('--centers', type=int, default=24)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-metrics', action='store_true')
+    ap.add_argument('--cpu-sample-images', type=int, default=4)
+    return ap.parse_args()
+
+
+def cpu_baseline(inp_dev, n_images, C, H, W):
+    """The C oracle ("port" of the reference's CPU path) timed on the host, single
+    thread, on the first `n_images` images of the very batch the GPU processes."""
+    from oracle import oracle as orc
+    orc.build()
+    n = min(n_images, inp_dev['semantic_logits'].shape[0])
+    logits = inp_dev['semantic_logits'][:n].float().cpu().numpy()
+    center = inp_dev['instance_center'][:n].cpu().numpy()
+    offset = inp_dev['instance_offset'][:n].cpu().numpy()
+    is_thing = inp_dev['semantic_classes_is_thing'].cpu().numpy().astype(bool)
+    t0 = time.perf_counter()
+    idx, _ = orc.semantic_argmax(logits)
+    fg = is_thing[idx]
+    cyx, nc, _, _ = orc.center_nms_topk(center, max_centers=256)
+    inst, _ = orc.group_offsets(offset, fg, cyx, nc, scale_y=H, scale_x=W)
+    pan, _ = orc.deeplab_merge(idx + 1, inst, fg, 1 << 16, np.where(is_thing)[0] + 1, 0)
+    dt = time.perf_counter() - t0
+    return {'value': n * H * W / dt / 1e6, 'unit': 'Mpix/s', 'cores': 1, 'kind': 'port',
+            'sample': f'{n} images {W}x{H}x{C} of the bench batch, C oracle '
+                      f'(argmax+NMS+grouping+merge), {dt:.2f} s'}, (idx, inst, pan)
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if args.gpus != world and world > 1:
+        raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
+    if args.gpus > 1 and world == 1:
+        raise SystemExit('launch N>1 with torch.distributed.run (one rank per GPU)')
+
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_
+        dist = dist_
+        dist.init_process_group('nccl', rank=rank, world_size=world,
+                                device_id=dev)
+
+    B, C, H, W = args.batch_per_gpu, args.classes, args.height, args.width
+    inp = syn.make_panoptic_inputs_torch(B, C, H, W, n_centers=args.centers,
+                                         seed=1234 + rank, device=dev)
+    logits, center, offset = inp['semantic_logits'], inp['instance_center'], inp['instance_offset']
+    is_thing = inp['semantic_classes_is_thing']
+    torch.cuda.synchronize()
+
+    metrics = None
+    if not args.no_metrics:
+        try:
+            from nicr_mt_scene_analysis_amd.metric import bench_support
+            metrics = bench_support.MetricAccumulators(C + 1, dev, inp, rank)
+        except ImportError:
+            metrics = None
+
+    events = []
+
+    def step(record):
+        r = ops.panoptic_pipeline(logits, center, offset, is_thing,
+                                  fused_kernel_events=events if record else None)
+        if metrics is not None:
+            metrics.update(r['panoptic'])
+            metrics.all_reduce(dist)
+        return r
+
+    for _ in range(args.warmup):
+        r = step(False)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        r = step(True)
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_px_step = B * H * W * world
+    ms_per_step = elapsed / args.steps * 1e3
+    value = n_px_step / (elapsed / args.steps) / 1e6
+
+    # ---- roofline of the dominant kernel (fused argmax + grouping + votes) ----------
+    # algorithmic bytes per launch: logits 4C + offsets 8 read, instance u8 1 written,
+    # per pixel (DESIGN.md "Kernels"); the intermediate sem u8 (1 B/px) is NOT counted
+    fused_ms = float(np.mean([a.elapsed_time(b) for a, b in events]))
+    esize = logits.element_size()
+    fused_bytes_px = esize * C + 8 + 1
+    fused_bytes = fused_bytes_px * B * H * W
+    achieved = fused_bytes / (fused_ms * 1e-3) / 1e9
+    pipeline_bytes_px = esize * C + 4 + 8 + 8 + 1           # 181 B/px at f32, C=40
+    roofline = {
+        'bound': 'hbm', 'kernel': 'k_panoptic_fused',
+        'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+        'kernel_ms': round(fused_ms, 4), 'algorithmic_bytes_per_px': fused_bytes_px,
+        'pipeline_algorithmic_bytes_per_px': pipeline_bytes_px,
+        'pipeline_frac': round(pipeline_bytes_px * B * H * W / (ms_per_step * 1e-3) / 1e9
+                               / HBM_PEAK_GBS, 4),
+    }
+
+    out = {
+        'metric': 'Mpix/s panoptic merge+metrics, 640x480xB',
+        'value': round(value, 1), 'unit': 'Mpix/s', 'n_gpus': world,
+        'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': 'configs[1]: center-NMS + offset grouping + panoptic merge'
+                               + (' + mIoU/PQ accumulators (configs[3])' if metrics else ''),
+                   'batch_per_gpu': B, 'global_batch': B * world, 'classes': C,
+                   'height': H, 'width': W, 'centers_per_image': args.centers,
+                   'parallelism': f'dp{world} (images sharded, accumulators all-reduced)'},
+        'roofline': roofline,
+    }
+
+    if rank == 0 and not args.no_cpu_baseline:
+        cb, (idx, inst, pan) = cpu_baseline(inp, args.cpu_sample_images, C, H, W)
+        n = idx.shape[0]
+        ok = bool((r['semantic_idx_u8'][:n].cpu().numpy() == idx).all()
+                  and (r['instance'][:n].cpu().numpy() == inst).all()
+                  and (r['panoptic'][:n].cpu().numpy() == pan).all())
+        cb['gpu_matches_oracle_bit_exact'] = ok
+        out['cpu_baseline'] = cb
+    elif rank == 0:
+        out['cpu_baseline'] = None
+
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

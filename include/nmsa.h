@@ -1,0 +1,191 @@
+/*
+ * nmsa.h — C ABI of libnmsa_hip.so: the MI355X (gfx950) implementation of the
+ * dense-prediction hot path of nicr-mt-scene-analysis.
+ *
+ * The reference is pure Python (no FFI of its own); each entry point below names
+ * the reference Python symbol whose ATen-op chain it replaces
+ * (paths relative to src/nicr_mt_scene_analysis/ of the reference).  The Python
+ * mirror of the reference API (package nicr_mt_scene_analysis_amd) binds these
+ * with ctypes; INTEGRATION.md shows the binding a reference maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer owned by the caller (contiguous, NCHW /
+ *    row-major as noted), unless the parameter name ends in _host;
+ *  - all work is enqueued on `stream` (a hipStream_t); nothing synchronises,
+ *    nothing allocates; scratch is passed in by the caller and sized with the
+ *    matching *_workspace_bytes() query;
+ *  - return value: NMSA_OK (0) or a negative NMSA_ERR_* code; nothing throws.
+ *  - "bool" tensors are uint8 (torch.bool storage), 0 / non-0.
+ */
+#ifndef NMSA_H
+#define NMSA_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* nmsa_stream_t; /* hipStream_t */
+
+enum {
+    NMSA_OK = 0,
+    NMSA_ERR_ARG = -1,         /* invalid argument (shape, null pointer, range)      */
+    NMSA_ERR_LAUNCH = -2,      /* HIP launch / runtime error (see nmsa_last_hip_error) */
+    NMSA_ERR_WORKSPACE = -3,   /* workspace too small                                  */
+    NMSA_ERR_UNSUPPORTED = -4  /* valid in the reference, not implemented here        */
+};
+
+/* floating-point element types of prediction tensors */
+enum { NMSA_F32 = 0, NMSA_BF16 = 1, NMSA_F16 = 2 };
+/* integer element types of label / id tensors */
+enum { NMSA_U8 = 0, NMSA_I16 = 1, NMSA_I32 = 2, NMSA_I64 = 3 };
+
+#define NMSA_MAX_INSTANCE_IDS 256 /* instance ids are uint8 in the reference (instance.py:236) */
+
+int nmsa_version(void);
+const char* nmsa_strerror(int code);
+int nmsa_last_hip_error(void); /* last hipError_t seen by this library (thread-local) */
+
+/* ---------------------------------------------------------------------------
+ * a2  InstancePostprocessing._get_instance_centers
+ *     model/postprocessing/instance.py:79-168
+ * threshold -> k x k max-pool NMS (first maximum in the window wins, border of
+ * (k-1)/2 px never a center) -> per-image top-k value (before the optional
+ * foreground mask) -> keep >= kth (ties kept) -> raster-ordered coordinates.
+ *   center        f32 [B,H,W]           (the [B,1,H,W] head output)
+ *   fg            u8  [B,H,W] or NULL   (required iff apply_fg)
+ *   centers_yx    i32 [B,max_centers,2] (y,x) raster order, first n_centers[b] valid
+ *   n_centers     i32 [B]  TRUE count (may exceed max_centers: caller re-runs larger)
+ *   scores        f32 [B,max_centers]   raw heatmap value at each center (meta 'score')
+ *   center_mask   u8  [B,H,W] or NULL   the boolean map the reference also returns
+ * ------------------------------------------------------------------------- */
+size_t nmsa_center_nms_workspace_bytes(int B, int H, int W);
+int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
+                         int B, int H, int W,
+                         float threshold, int ksize, int topk, int apply_fg,
+                         int max_centers,
+                         int32_t* centers_yx, int32_t* n_centers, float* scores,
+                         uint8_t* center_mask,
+                         void* workspace, size_t workspace_bytes,
+                         nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a3  InstancePostprocessing._get_instance_segmentation (grouping part)
+ *     model/postprocessing/instance.py:187-253
+ * For every foreground pixel: loc = (y,x) + offset*(scale_y,scale_x); id =
+ * 1 + argmin_i ||center_i - loc||_2 (fp32, lowest index on ties, uint8 wrap);
+ * optional `min_dist > dist_thr -> 0`.
+ *   offset  f32 [B,2,H,W] (dy,dx); scale = (H,W) for normalized offsets, else 1
+ *   inst    u8  [B,H,W]   (0 outside fg)
+ *   area    i32 [B,256]   bincount of ids over fg (meta 'area'); may be NULL
+ * ------------------------------------------------------------------------- */
+int nmsa_group_offsets(const float* offset, const uint8_t* fg,
+                       const int32_t* centers_yx, const int32_t* n_centers,
+                       int B, int H, int W, int max_centers,
+                       float scale_y, float scale_x,
+                       int use_dist_thr, float dist_thr,
+                       uint8_t* inst, int32_t* area,
+                       nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a1  SemanticPostprocessing._postprocess_inference (argmax + score)
+ *     model/postprocessing/semantic.py:52-53
+ *   logits  f32|bf16|f16 [B,C,H,W];  any of the outputs may be NULL
+ *   idx_u8 [B,H,W] (C <= 256), idx_i64 [B,H,W], score f32 [B,H,W] = max softmax
+ * ------------------------------------------------------------------------- */
+int nmsa_semantic_argmax(const void* logits, int logits_dtype,
+                         int B, int C, int H, int W,
+                         uint8_t* idx_u8, int64_t* idx_i64, float* score,
+                         nmsa_stream_t stream);
+
+/* softmax over C (semantic.py:52 'semantic_softmax_scores'), f32 out [B,C,H,W] */
+int nmsa_semantic_softmax(const void* logits, int logits_dtype,
+                          int B, int C, int H, int W, float* probs,
+                          nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a1+a3+a4+a5  PanopticPostprocessing._postprocess_inference (core)
+ *     model/postprocessing/panoptic.py:77-168 with
+ *     utils/panoptic_merge.py:172-225 (deeplab_merge_semantic_and_instance)
+ *
+ * nmsa_panoptic_fused: one pass over the logits: per-pixel argmax (a1),
+ * foreground = is_thing[class] (panoptic.py:123-127), offset grouping (a3) and
+ * the per-instance class-vote histogram of the merge (panoptic_merge.py:201).
+ *   is_thing   u8 [C]
+ *   sem_u8     u8 [B,H,W]   class index 0..C-1 (required: paint reads it)
+ *   inst       u8 [B,H,W]
+ *   fg_out     u8 [B,H,W] or NULL ('panoptic_foreground_mask')
+ *   score      f32 [B,H,W] or NULL
+ *   votes      u32 [B,256,C+1]  zeroed by this call; votes[b,id,c] = #px of
+ *              instance id whose (class+1) == c
+ *   vote_rows_hint  expected #instance ids + 1 (e.g. top_k_instances + 1): rows
+ *              privatised in LDS; larger ids still count (global atomics). 0 = auto
+ * nmsa_panoptic_assign: per instance: class = mode (smallest on ties), running
+ * per-class counter in ascending id order -> panoptic id (panoptic_merge.py:
+ * 192-210).
+ *   pan_of_inst i64 [B,256]  (void_label where the instance is dropped)
+ *   area        i32 [B,256]  row sums of votes (meta 'area'; index 0 unused)
+ *   ids_pan/ids_ins i64 [B,256], n_ids i32 [B]: the id dict in insertion order
+ * nmsa_panoptic_paint: pan[p] = inst ? pan_of_inst[inst] :
+ *                               (is_thing[sem] ? void : (sem+1)*max_inst)
+ *   pan i64 [B,H,W]; pan_sem i64 [B,H,W] or NULL (= pan // max_inst, panoptic.py:160)
+ * ------------------------------------------------------------------------- */
+int nmsa_panoptic_fused(const void* logits, int logits_dtype, const float* offset,
+                        const int32_t* centers_yx, const int32_t* n_centers,
+                        const uint8_t* is_thing,
+                        int B, int C, int H, int W, int max_centers,
+                        float scale_y, float scale_x,
+                        int use_dist_thr, float dist_thr,
+                        uint8_t* sem_u8, uint8_t* inst, uint8_t* fg_out, float* score,
+                        uint32_t* votes, int vote_rows_hint,
+                        nmsa_stream_t stream);
+
+int nmsa_panoptic_assign(const uint32_t* votes, int B, int n_vote_classes,
+                         int64_t max_instances_per_category, int64_t void_label,
+                         int64_t* pan_of_inst, int32_t* area,
+                         int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
+                         nmsa_stream_t stream);
+
+int nmsa_panoptic_paint(const uint8_t* sem_u8, const uint8_t* inst,
+                        const int64_t* pan_of_inst, const uint8_t* is_thing,
+                        int B, int C, int H, int W,
+                        int64_t max_instances_per_category, int64_t void_label,
+                        int64_t* pan, int64_t* pan_sem,
+                        nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a5  deeplab_merge_batch   utils/panoptic_merge.py:18-40,172-225
+ * Generic entry (GT path / InstanceTaskHelper): arbitrary integer dtypes.
+ *   sem        [B,H,W] sem_dtype, class values 0..n_classes-1 (0 = void)
+ *   ins        [B,H,W] ins_dtype, instance ids 0..255
+ *   thing_seg  u8 [B,H,W]
+ *   is_thing_class u8 [n_classes]  (class value c is in thing_ids)
+ *   votes      u32 [B,256,n_classes] scratch, zeroed by this call
+ * Outputs as for assign + paint.
+ * ------------------------------------------------------------------------- */
+int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* ins, int ins_dtype,
+                        const uint8_t* thing_seg, const uint8_t* is_thing_class,
+                        int B, int n_classes, int H, int W,
+                        int64_t max_instances_per_category, int64_t void_label,
+                        uint32_t* votes, int64_t* pan_of_inst,
+                        int64_t* pan, int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
+                        nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * next-1  InstancePostprocessing._get_instance_orientation
+ *     model/postprocessing/instance.py:271-319
+ *   orientation f32 [B,2,H,W]; inst u8; mask u8 or NULL
+ *   sums f64 [B,256,2] (sum of channel 0 / 1 per id), count i32 [B,256]; both
+ *   zeroed by this call
+ *   (angle = atan2(sum1, sum0) is taken on the host over <= 255 entries)
+ * ------------------------------------------------------------------------- */
+int nmsa_instance_orientation(const float* orientation, const uint8_t* inst,
+                              const uint8_t* mask, int B, int H, int W,
+                              double* sums, int32_t* count, nmsa_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* NMSA_H */

@@ -1,0 +1,291 @@
+// center_nms.hip — instance-center NMS + per-image top-k + ordered compaction.
+//
+// Replaces the ATen chain of InstancePostprocessing._get_instance_centers
+// (reference model/postprocessing/instance.py:79-168):
+//   F.threshold -> max_pool2d(return_indices) -> pad -> index test -> equality
+//   test -> topk(k)[..., -1] -> clamp(min=0) -> [fg mask] -> >= kth -> nonzero()
+//
+// Two kernels, both HBM/L2-latency bound integer + compare work (no MFMA):
+//   k_nms_candidates : LDS-staged (TH+2p)x(TW+2p) tile of the thresholded map,
+//                      window scan per pixel, survivors with value >= 0 set a
+//                      bit in a per-image bitmask (4 B/px read, ~0 written).
+//   k_select_compact : one 1024-thread workgroup per image: 3-level radix
+//                      select (11/11/10 bits) of the k-th largest candidate
+//                      key, then an ORDER-PRESERVING compaction (block prefix
+//                      sum over the bitmask) so that center index == raster
+//                      order, exactly as `nonzero()` yields it.
+//
+// Why "value >= 0 candidates only": everything kept must pass `>= clamp(kth, 0)`,
+// so negative survivors never matter, and for v >= 0 the IEEE bit pattern is a
+// monotone unsigned key (with -0.0 mapped to key 0).
+#include "nmsa_common.hpp"
+
+namespace nmsa {
+
+constexpr int NMS_TW = 64;
+constexpr int NMS_TH = 16;
+constexpr int NMS_PAD_MAX = 4;  // LDS path for ksize <= 9, direct-global path beyond
+
+__device__ __forceinline__ float threshold_m1(float x, float thr)
+{
+    // F.threshold(x, thr, -1): ATen evaluates `x <= thr ? -1 : x` (NaN is kept)
+    return (x <= thr) ? -1.0f : x;
+}
+
+template <bool USE_LDS>
+__global__ __launch_bounds__(256) void k_nms_candidates(
+    const float* __restrict__ center, uint32_t* __restrict__ cand_bits,
+    int H, int W, int words_per_image, float thr, int pad)
+{
+    __shared__ float tile[USE_LDS ? (NMS_TH + 2 * NMS_PAD_MAX) * (NMS_TW + 2 * NMS_PAD_MAX) : 1];
+    const int b = blockIdx.z;
+    const int x0 = blockIdx.x * NMS_TW, y0 = blockIdx.y * NMS_TH;
+    const float* img = center + (size_t)b * H * W;
+    const int tw = NMS_TW + 2 * pad, th = NMS_TH + 2 * pad;
+
+    if (USE_LDS) {
+        for (int i = threadIdx.x; i < tw * th; i += blockDim.x) {
+            const int ty = i / tw, tx = i - ty * tw;
+            const int gy = y0 + ty - pad, gx = x0 + tx - pad;
+            float v = -1.0f;
+            if (gy >= 0 && gy < H && gx >= 0 && gx < W) v = threshold_m1(img[(size_t)gy * W + gx], thr);
+            tile[i] = v;
+        }
+        __syncthreads();
+    }
+    auto at = [&](int gy, int gx) -> float {
+        if (USE_LDS) return tile[(gy - y0 + pad) * tw + (gx - x0 + pad)];
+        return threshold_m1(img[(size_t)gy * W + gx], thr);
+    };
+
+    uint32_t* bits = cand_bits + (size_t)b * words_per_image;
+    for (int i = threadIdx.x; i < NMS_TW * NMS_TH; i += blockDim.x) {
+        const int ly = i / NMS_TW, lx = i - ly * NMS_TW;
+        const int y = y0 + ly, x = x0 + lx;
+        if (y >= H || x >= W) continue;
+        const int self = y * W + x;
+        const float h = at(y, x);
+        bool survive;
+        if (y < pad || y >= H - pad || x < pad || x >= W - pad) {
+            // zero-padded pooled value / index (instance.py:104-109): only pixel 0
+            // can pass the index test, and only with value exactly 0
+            survive = (self == 0) && (h == 0.0f);
+        } else {
+            // ATen max_pool2d window scan: row-major, take on (v > max) || isnan(v)
+            float pooled = -INFINITY;
+            int pidx = (y - pad) * W + (x - pad);
+            for (int dy = -pad; dy <= pad; ++dy)
+                for (int dx = -pad; dx <= pad; ++dx) {
+                    const float v = at(y + dy, x + dx);
+                    if (v > pooled || v != v) { pooled = v; pidx = (y + dy) * W + (x + dx); }
+                }
+            survive = (pidx == self) && (h == pooled);
+        }
+        if (survive && h >= 0.0f) atomicOr(&bits[self >> 5], 1u << (self & 31));
+    }
+}
+
+// ---- block-wide helpers (1024 threads = 16 waves) ---------------------------
+__device__ __forceinline__ int wave_inclusive_scan(int v)
+{
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(v, o);
+        if (lane_id() >= o) v += t;
+    }
+    return v;
+}
+
+// inclusive prefix sum over the block; `scratch` holds >= 17 ints; returns the
+// inclusive prefix for this thread and writes the block total to *total.
+__device__ __forceinline__ int block_inclusive_scan(int v, int* scratch, int* total)
+{
+    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    const int incl = wave_inclusive_scan(v);
+    __syncthreads();
+    if (lane_id() == 63) scratch[w] = incl;
+    __syncthreads();
+    if (w == 0) {
+        int s = (lane_id() < nw) ? scratch[lane_id()] : 0;
+        s = wave_inclusive_scan(s);
+        if (lane_id() < nw) scratch[lane_id()] = s;
+    }
+    __syncthreads();
+    const int base = (w == 0) ? 0 : scratch[w - 1];
+    *total = scratch[nw - 1];
+    return incl + base;
+}
+
+__device__ __forceinline__ uint32_t cand_key(float v)
+{
+    return (v == 0.0f) ? 0u : __float_as_uint(v);   // v >= 0 here
+}
+
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_BINS = 2048;
+
+__global__ __launch_bounds__(SEL_THREADS) void k_select_compact(
+    const float* __restrict__ center, const uint8_t* __restrict__ fg,
+    const uint32_t* __restrict__ cand_bits,
+    int H, int W, int words_per_image, int topk, int apply_fg, int max_centers,
+    int32_t* __restrict__ centers_yx, int32_t* __restrict__ n_centers,
+    float* __restrict__ scores, uint8_t* __restrict__ center_mask)
+{
+    __shared__ int hist[SEL_BINS];
+    __shared__ int scratch[32];
+    __shared__ uint32_t s_prefix;
+    __shared__ int s_krem;
+
+    const int b = blockIdx.x;
+    const int P = H * W;
+    const float* img = center + (size_t)b * P;
+    const uint32_t* bits = cand_bits + (size_t)b * words_per_image;
+    const uint8_t* fgb = fg ? fg + (size_t)b * P : nullptr;
+
+    // contiguous word range per thread (keeps raster order for the compaction)
+    const int wpt = (words_per_image + SEL_THREADS - 1) / SEL_THREADS;
+    const int w_begin = min((int)threadIdx.x * wpt, words_per_image);
+    const int w_end = min(w_begin + wpt, words_per_image);
+
+    // ---- number of candidates ------------------------------------------------
+    int cnt = 0;
+    for (int w = w_begin; w < w_end; ++w) cnt += __popc(bits[w]);
+    int total;
+    block_inclusive_scan(cnt, scratch, &total);
+
+    // ---- k-th largest candidate key (torch.topk(...)[..., -1], clamp(min=0)) --
+    uint32_t key_kth = 0;
+    if (total >= topk) {
+        if (threadIdx.x == 0) { s_prefix = 0; s_krem = topk; }
+        const int shifts[3] = {21, 10, 0};
+        const int nbits[3] = {11, 11, 10};
+        for (int pass = 0; pass < 3; ++pass) {
+            const int shift = shifts[pass];
+            const int nb = 1 << nbits[pass];
+            for (int i = threadIdx.x; i < SEL_BINS; i += SEL_THREADS) hist[i] = 0;
+            __syncthreads();
+            const uint32_t prefix = s_prefix;
+            // bits above (shift + nbits) must equal the prefix found so far
+            const int hi_shift = shift + nbits[pass];
+            for (int w = w_begin; w < w_end; ++w) {
+                uint32_t m = bits[w];
+                while (m) {
+                    const int bit = __ffs((int)m) - 1;
+                    m &= m - 1;
+                    const uint32_t k = cand_key(img[(w << 5) + bit]);
+                    const bool match = (hi_shift >= 32) || ((k >> hi_shift) == (prefix >> hi_shift));
+                    if (match) atomicAdd(&hist[(k >> shift) & (nb - 1)], 1);
+                }
+            }
+            __syncthreads();
+            // suffix sums: thread t owns bins 2t, 2t+1 (reversed so that an
+            // inclusive prefix scan yields "count of keys in bins >= mine")
+            const int t = threadIdx.x;
+            const int hi_bin = SEL_BINS - 1 - 2 * t, lo_bin = hi_bin - 1;
+            const int c_hi = hist[hi_bin], c_lo = hist[lo_bin];
+            int dummy;
+            const int incl = block_inclusive_scan(c_hi + c_lo, scratch, &dummy);
+            const int above = incl - (c_hi + c_lo);     // keys in bins > hi_bin
+            const int krem = s_krem;
+            __syncthreads();
+            if (above < krem && krem <= incl) {
+                int sel, new_k;
+                if (above + c_hi >= krem) { sel = hi_bin; new_k = krem - above; }
+                else { sel = lo_bin; new_k = krem - above - c_hi; }
+                s_prefix = prefix | ((uint32_t)sel << shift);
+                s_krem = new_k;
+            }
+            __syncthreads();
+        }
+        key_kth = s_prefix;
+    }
+
+    // ---- ordered compaction ----------------------------------------------------
+    auto kept = [&](int p) -> bool {
+        if (apply_fg && !fgb[p]) return false;
+        return cand_key(img[p]) >= key_kth;
+    };
+    int mine = 0;
+    for (int w = w_begin; w < w_end; ++w) {
+        uint32_t m = bits[w];
+        while (m) {
+            const int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            mine += kept((w << 5) + bit) ? 1 : 0;
+        }
+    }
+    int n_total;
+    const int incl = block_inclusive_scan(mine, scratch, &n_total);
+    int pos = incl - mine;
+    for (int w = w_begin; w < w_end; ++w) {
+        uint32_t m = bits[w];
+        while (m) {
+            const int bit = __ffs((int)m) - 1;
+            m &= m - 1;
+            const int p = (w << 5) + bit;
+            if (!kept(p)) continue;
+            if (pos < max_centers) {
+                const int y = p / W;
+                centers_yx[((size_t)b * max_centers + pos) * 2 + 0] = y;
+                centers_yx[((size_t)b * max_centers + pos) * 2 + 1] = p - y * W;
+                scores[(size_t)b * max_centers + pos] = img[p];
+            }
+            if (center_mask) center_mask[(size_t)b * P + p] = 1;
+            ++pos;
+        }
+    }
+    if (threadIdx.x == 0) n_centers[b] = n_total;
+}
+
+}  // namespace nmsa
+
+using namespace nmsa;
+
+extern "C" size_t nmsa_center_nms_workspace_bytes(int B, int H, int W)
+{
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t words = ((size_t)H * W + 31) / 32;
+    return (size_t)B * words * sizeof(uint32_t);
+}
+
+extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
+                                    int B, int H, int W,
+                                    float threshold, int ksize, int topk, int apply_fg,
+                                    int max_centers,
+                                    int32_t* centers_yx, int32_t* n_centers, float* scores,
+                                    uint8_t* center_mask,
+                                    void* workspace, size_t workspace_bytes,
+                                    nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!center || !centers_yx || !n_centers || !scores || !workspace) return NMSA_ERR_ARG;
+    if (B <= 0 || H <= 0 || W <= 0 || max_centers <= 0) return NMSA_ERR_ARG;
+    if (ksize < 1 || (ksize & 1) == 0 || topk < 1) return NMSA_ERR_ARG;
+    if ((int64_t)H * W > (int64_t)1 << 30) return NMSA_ERR_ARG;
+    if ((int64_t)H * W < topk) return NMSA_ERR_ARG;            // torch.topk would raise
+    if (apply_fg && !fg) return NMSA_ERR_ARG;
+    if (workspace_bytes < nmsa_center_nms_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
+
+    const int words = (int)(((size_t)H * W + 31) / 32);
+    uint32_t* bits = (uint32_t*)workspace;
+    int rc = check_hip(hipMemsetAsync(bits, 0, (size_t)B * words * sizeof(uint32_t), stream));
+    if (rc) return rc;
+    if (center_mask) {
+        rc = check_hip(hipMemsetAsync(center_mask, 0, (size_t)B * H * W, stream));
+        if (rc) return rc;
+    }
+    const int pad = (ksize - 1) / 2;
+    dim3 grid((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH, B);
+    if (pad <= NMS_PAD_MAX)
+        hipLaunchKernelGGL(k_nms_candidates<true>, grid, dim3(256), 0, stream,
+                           center, bits, H, W, words, threshold, pad);
+    else
+        hipLaunchKernelGGL(k_nms_candidates<false>, grid, dim3(256), 0, stream,
+                           center, bits, H, W, words, threshold, pad);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_select_compact, dim3(B), dim3(SEL_THREADS), 0, stream,
+                       center, apply_fg ? fg : nullptr, bits, H, W, words, topk, apply_fg,
+                       max_centers, centers_yx, n_centers, scores, center_mask);
+    return check_launch();
+}

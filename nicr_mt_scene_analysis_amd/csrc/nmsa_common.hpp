@@ -1,0 +1,69 @@
+// nmsa_common.hpp — shared device/host helpers of libnmsa_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/nmsa.h"
+
+namespace nmsa {
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+extern thread_local int g_last_hip_error;
+
+inline int check_launch()
+{
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return NMSA_ERR_LAUNCH; }
+    return NMSA_OK;
+}
+
+inline int check_hip(hipError_t e)
+{
+    if (e != hipSuccess) { g_last_hip_error = (int)e; return NMSA_ERR_LAUNCH; }
+    return NMSA_OK;
+}
+
+__device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
+
+__device__ __forceinline__ float bf16_to_f32(uint16_t v)
+{
+    return __uint_as_float(((uint32_t)v) << 16);
+}
+
+__device__ __forceinline__ float f16_to_f32(uint16_t v)
+{
+    return (float)__builtin_bit_cast(_Float16, v);
+}
+
+// Wave-aggregated histogram increment: lanes holding the same key are counted
+// with one ballot + popcount and ONE atomic by the group's leader.  Keys are
+// spatially coherent on this path (neighbouring pixels share instance/class),
+// so the loop runs 1-3 times per wave.  key < 0 = lane does not contribute.
+template <typename AddFn>
+__device__ __forceinline__ void wave_aggregate_add(int key, AddFn add)
+{
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long same = __ballot(key == k) & todo;
+        if (lane_id() == leader) add(k, (uint32_t)__popcll(same));
+        todo &= ~same;
+    }
+}
+
+__device__ __forceinline__ float wave_reduce_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+__device__ __forceinline__ double wave_reduce_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+}  // namespace nmsa

@@ -1,0 +1,909 @@
+// panoptic.hip — semantic argmax + offset grouping + panoptic merge for gfx950.
+//
+// Replaces, behind the C ABI of include/nmsa.h, the ATen chains of
+//   SemanticPostprocessing._postprocess_inference    (semantic.py:52-53)
+//   InstancePostprocessing._get_instance_segmentation (instance.py:187-253)
+//   PanopticPostprocessing._postprocess_inference     (panoptic.py:105-160)
+//   deeplab_merge_semantic_and_instance               (panoptic_merge.py:172-225)
+//
+// Data flow (B images, P = H*W pixels each, C classes):
+//   k_panoptic_fused  reads  logits 4C B/px (f32) + offset 8 B/px
+//                     writes sem u8 1 B/px + inst u8 1 B/px (+ votes, tiny)
+//   k_assign          256 threads / image over the [256 x (C+1)] vote table
+//   k_paint           reads sem+inst 2 B/px, writes panoptic i64 8 B/px
+// All three are HBM-bound streaming kernels: 16-B loads per lane, >= 8 loads
+// in flight per lane, no LDS staging of the big tensors (each byte is used
+// once), LDS only for the center list and the privatised vote histogram.
+//
+// Exactness (ids must be bit-identical to the reference CPU path):
+//  * loc = float(y) + off*scale  : explicit __fmul_rn / __fadd_rn (no FMA);
+//  * distance^2 s = fma(dx,dx, dy*dy) — the exact rounding sequence of ATen's
+//    norm (verified in oracle/gen_golden.py::check_norm_formula);
+//  * the reference compares d = sqrt_rn(s) and takes the lowest index among
+//    equal d.  sqrt_rn is monotone, so argmin is found WITHOUT a per-center
+//    sqrt: pass 1 takes s_min = min_i s_i; d_min = sqrt_rn(s_min); U = largest
+//    float with sqrt_rn(U) == d_min (from the exact fp64 square of the
+//    rounding midpoint); pass 2 (descending i) takes the lowest i with
+//    s_i <= U.  Both passes are branch-free compare/select.
+#include "nmsa_common.hpp"
+
+namespace nmsa {
+
+constexpr int FUSED_THREADS = 256;
+constexpr int PX_PER_THREAD = 4;
+constexpr int PX_PER_ITER = FUSED_THREADS * PX_PER_THREAD;   // 1024
+
+// ---- typed 4-pixel loads -------------------------------------------------------
+template <int DTYPE, bool VEC>
+__device__ __forceinline__ float4 load_px4(const void* base, size_t elem_off, int nvalid)
+{
+    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (DTYPE == NMSA_F32) {
+        const float* p = (const float*)base + elem_off;
+        if (VEC) return *(const float4*)p;
+        if (nvalid > 0) r.x = p[0];
+        if (nvalid > 1) r.y = p[1];
+        if (nvalid > 2) r.z = p[2];
+        if (nvalid > 3) r.w = p[3];
+        return r;
+    } else {
+        const uint16_t* p = (const uint16_t*)base + elem_off;
+        uint16_t h[4] = {0, 0, 0, 0};
+        if (VEC) {
+            const ushort4 u = *(const ushort4*)p;
+            h[0] = u.x; h[1] = u.y; h[2] = u.z; h[3] = u.w;
+        } else {
+            for (int j = 0; j < 4; ++j) if (j < nvalid) h[j] = p[j];
+        }
+        if (DTYPE == NMSA_BF16) {
+            r.x = bf16_to_f32(h[0]); r.y = bf16_to_f32(h[1]);
+            r.z = bf16_to_f32(h[2]); r.w = bf16_to_f32(h[3]);
+        } else {
+            r.x = f16_to_f32(h[0]); r.y = f16_to_f32(h[1]);
+            r.z = f16_to_f32(h[2]); r.w = f16_to_f32(h[3]);
+        }
+        return r;
+    }
+}
+
+// ---- per-pixel class argmax state ---------------------------------------------
+struct ArgmaxState {
+    float m[4];
+    int am[4];
+    float se[4];     // running sum of exp(x - m) (only when WITH_SCORE)
+    bool bad[4];
+};
+
+template <bool WITH_SCORE>
+__device__ __forceinline__ void argmax_step(ArgmaxState& s, int j, float v, int c)
+{
+    s.bad[j] = s.bad[j] || (v != v);
+    if (WITH_SCORE) {
+        // online softmax denominator: one exp per class
+        const float e = __expf(-fabsf(v - s.m[j]));
+        s.se[j] = (v > s.m[j]) ? fmaf(s.se[j], e, 1.0f) : (s.se[j] + e);
+    }
+    if (v > s.m[j]) { s.m[j] = v; s.am[j] = c; }
+}
+
+// ---- exact nearest-center search for 4 pixels -----------------------------------
+__device__ __forceinline__ float sqdist(float cy, float cx, float ly, float lx)
+{
+    const float dy = __fsub_rn(cy, ly);
+    const float dx = __fsub_rn(cx, lx);
+    return __fmaf_rn(dx, dx, __fmul_rn(dy, dy));
+}
+
+// largest float U with sqrt_rn(U) == d   (d = sqrt_rn(s) >= 0, or inf / NaN)
+__device__ __forceinline__ float sqrt_tie_upper(float d)
+{
+    if (!(d < INFINITY)) return d;                        // inf -> inf, NaN -> NaN
+    const float dn = __uint_as_float(__float_as_uint(d) + 1u);   // next float up
+    const double m = 0.5 * ((double)d + (double)dn);      // rounding midpoint (exact)
+    const double m2 = m * m;                              // exact (<= 50 bits)
+    float u = (float)m2;
+    if ((double)u >= m2) u = __uint_as_float(__float_as_uint(u) - 1u);   // largest float < m2
+    return u;
+}
+
+__device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
+                                       const float ly[4], const float lx[4],
+                                       const bool act[4], int use_thr, float thr,
+                                       uint32_t id[4])
+{
+    float smin[4];
+    {
+        const float2 c0 = cen[0];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) smin[j] = sqdist(c0.x, c0.y, ly[j], lx[j]);
+    }
+    for (int i = 1; i < n; ++i) {
+        const float2 c = cen[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) smin[j] = fminf(smin[j], sqdist(c.x, c.y, ly[j], lx[j]));
+    }
+    float U[4], dmin[4];
+    int best[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        dmin[j] = sqrtf(smin[j]);          // correctly rounded (no fast-math)
+        U[j] = sqrt_tie_upper(dmin[j]);
+        best[j] = 0;
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const float2 c = cen[i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (sqdist(c.x, c.y, ly[j], lx[j]) <= U[j]) best[j] = i;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        uint32_t v = (uint32_t)(best[j] + 1) & 0xFFu;               // uint8 wrap (instance.py:236)
+        if (use_thr && dmin[j] > thr) v = 0;                        // instance.py:246-247
+        id[j] = act[j] ? v : 0u;
+    }
+}
+
+// =================================================================================
+// fused: argmax + fg + grouping + class votes
+// dynamic LDS: float2 centers[max_centers] | u32 hist[lds_rows * NC] | u8 thing[256]
+// =================================================================================
+template <int DTYPE, bool VEC, bool WITH_SCORE>
+__global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
+    const void* __restrict__ logits, const float* __restrict__ offset,
+    const int32_t* __restrict__ centers_yx, const int32_t* __restrict__ n_centers,
+    const uint8_t* __restrict__ is_thing,
+    int C, int H, int W, int max_centers, int iters,
+    float scale_y, float scale_x, int use_thr, float thr,
+    uint8_t* __restrict__ sem_u8, uint8_t* __restrict__ inst, uint8_t* __restrict__ fg_out,
+    float* __restrict__ score, uint32_t* __restrict__ votes, int lds_rows)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2* cen = (float2*)smem;
+    uint32_t* hist = (uint32_t*)(cen + max_centers);
+    const int NC = C + 1;
+    uint8_t* thing = (uint8_t*)(hist + lds_rows * NC);
+
+    const int b = blockIdx.y;
+    const int P = H * W;
+    const int n = min(n_centers[b], max_centers);
+
+    for (int i = threadIdx.x; i < n; i += FUSED_THREADS) {
+        const int32_t cy = centers_yx[((size_t)b * max_centers + i) * 2 + 0];
+        const int32_t cx = centers_yx[((size_t)b * max_centers + i) * 2 + 1];
+        cen[i] = make_float2((float)cy, (float)cx);
+    }
+    for (int i = threadIdx.x; i < lds_rows * NC; i += FUSED_THREADS) hist[i] = 0;
+    for (int i = threadIdx.x; i < 256; i += FUSED_THREADS) thing[i] = (i < C) ? is_thing[i] : 0;
+    __syncthreads();
+
+    const size_t img_logits = (size_t)b * C * P;
+    const float* offy = offset + (size_t)b * 2 * P;
+    const float* offx = offy + P;
+    uint32_t* votes_b = votes + (size_t)b * 256 * NC;
+
+    const int chunk_start = blockIdx.x * iters * PX_PER_ITER;
+    for (int it = 0; it < iters; ++it) {
+        const int p0 = chunk_start + it * PX_PER_ITER + threadIdx.x * PX_PER_THREAD;
+        if (p0 >= P) break;                     // whole-thread out of range (tail chunk)
+        const int nvalid = min(4, P - p0);
+
+        // ---- a1: argmax over classes (first index of the maximum) --------------------
+        ArgmaxState st;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { st.m[j] = -INFINITY; st.am[j] = 0; st.se[j] = 0.f; st.bad[j] = false; }
+        int c = 0;
+        for (; c + 8 <= C; c += 8) {
+            float4 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = load_px4<DTYPE, VEC>(logits, img_logits + (size_t)(c + u) * P + p0, nvalid);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                argmax_step<WITH_SCORE>(st, 0, v[u].x, c + u);
+                argmax_step<WITH_SCORE>(st, 1, v[u].y, c + u);
+                argmax_step<WITH_SCORE>(st, 2, v[u].z, c + u);
+                argmax_step<WITH_SCORE>(st, 3, v[u].w, c + u);
+            }
+        }
+        for (; c < C; ++c) {
+            const float4 v = load_px4<DTYPE, VEC>(logits, img_logits + (size_t)c * P + p0, nvalid);
+            argmax_step<WITH_SCORE>(st, 0, v.x, c);
+            argmax_step<WITH_SCORE>(st, 1, v.y, c);
+            argmax_step<WITH_SCORE>(st, 2, v.z, c);
+            argmax_step<WITH_SCORE>(st, 3, v.w, c);
+        }
+        int cls[4];
+        bool fg[4];
+        bool any_fg = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // softmax of a column with a NaN / +inf / all -inf is all-NaN and
+            // torch.max then returns index 0 (semantic.py:52-53)
+            const bool degenerate = st.bad[j] || !(fabsf(st.m[j]) < INFINITY);
+            cls[j] = degenerate ? 0 : st.am[j];
+            if (WITH_SCORE) st.se[j] = degenerate ? __int_as_float(0x7fc00000) : (1.0f / st.se[j]);
+            fg[j] = (j < nvalid) && (thing[cls[j]] != 0);               // panoptic.py:123-127
+            any_fg = any_fg || fg[j];
+        }
+
+        // ---- a3: offset grouping ------------------------------------------------------
+        uint32_t id[4] = {0u, 0u, 0u, 0u};
+        if (any_fg && n > 0) {
+            const float4 oy = load_px4<NMSA_F32, VEC>(offy, (size_t)p0, nvalid);
+            const float4 ox = load_px4<NMSA_F32, VEC>(offx, (size_t)p0, nvalid);
+            const float oyv[4] = {oy.x, oy.y, oy.z, oy.w};
+            const float oxv[4] = {ox.x, ox.y, ox.z, ox.w};
+            float ly[4], lx[4];
+            int y = p0 / W, x = p0 - y * W;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // de-normalise (panoptic.py:108-109) then add the int grid (instance.py:194):
+                // two separate roundings, never an FMA
+                ly[j] = __fadd_rn((float)y, __fmul_rn(oyv[j], scale_y));
+                lx[j] = __fadd_rn((float)x, __fmul_rn(oxv[j], scale_x));
+                if (++x == W) { x = 0; ++y; }
+            }
+            group4(cen, n, ly, lx, fg, use_thr, thr, id);
+        }
+
+        // ---- stores --------------------------------------------------------------------
+        if (VEC) {
+            *(uchar4*)(sem_u8 + (size_t)b * P + p0) =
+                make_uchar4((uint8_t)cls[0], (uint8_t)cls[1], (uint8_t)cls[2], (uint8_t)cls[3]);
+            *(uchar4*)(inst + (size_t)b * P + p0) =
+                make_uchar4((uint8_t)id[0], (uint8_t)id[1], (uint8_t)id[2], (uint8_t)id[3]);
+            if (fg_out)
+                *(uchar4*)(fg_out + (size_t)b * P + p0) =
+                    make_uchar4(fg[0], fg[1], fg[2], fg[3]);
+            if (WITH_SCORE)
+                *(float4*)(score + (size_t)b * P + p0) =
+                    make_float4(st.se[0], st.se[1], st.se[2], st.se[3]);
+        } else {
+            for (int j = 0; j < nvalid; ++j) {
+                sem_u8[(size_t)b * P + p0 + j] = (uint8_t)cls[j];
+                inst[(size_t)b * P + p0 + j] = (uint8_t)id[j];
+                if (fg_out) fg_out[(size_t)b * P + p0 + j] = fg[j];
+                if (WITH_SCORE) score[(size_t)b * P + p0 + j] = st.se[j];
+            }
+        }
+
+        // ---- a5 (votes): hist[id][class+1] += 1, wave-aggregated ----------------------------
+        const bool wave_has_inst = __any((id[0] | id[1] | id[2] | id[3]) != 0u);
+        if (wave_has_inst) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int key = (id[j] != 0u) ? (int)(id[j] * NC + cls[j] + 1) : -1;
+                wave_aggregate_add(key, [&](int k, uint32_t cnt) {
+                    if (k < lds_rows * NC) atomicAdd(&hist[k], cnt);
+                    else atomicAdd(&votes_b[k], cnt);
+                });
+            }
+        }
+    }
+
+    __syncthreads();
+    for (int i = threadIdx.x; i < lds_rows * NC; i += FUSED_THREADS) {
+        const uint32_t v = hist[i];
+        if (v) atomicAdd(&votes_b[i], v);
+    }
+}
+
+// =================================================================================
+// standalone a1: argmax / score without grouping (SemanticPostprocessing only)
+// =================================================================================
+template <int DTYPE, bool VEC, bool WITH_SCORE>
+__global__ __launch_bounds__(FUSED_THREADS) void k_semantic_argmax(
+    const void* __restrict__ logits, int C, int P,
+    uint8_t* __restrict__ idx_u8, int64_t* __restrict__ idx_i64, float* __restrict__ score)
+{
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * FUSED_THREADS + threadIdx.x) * PX_PER_THREAD;
+    if (p0 >= P) return;
+    const int nvalid = min(4, P - p0);
+    const size_t img = (size_t)b * C * P;
+    ArgmaxState st;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { st.m[j] = -INFINITY; st.am[j] = 0; st.se[j] = 0.f; st.bad[j] = false; }
+    int c = 0;
+    for (; c + 8 <= C; c += 8) {
+        float4 v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+            v[u] = load_px4<DTYPE, VEC>(logits, img + (size_t)(c + u) * P + p0, nvalid);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            argmax_step<WITH_SCORE>(st, 0, v[u].x, c + u);
+            argmax_step<WITH_SCORE>(st, 1, v[u].y, c + u);
+            argmax_step<WITH_SCORE>(st, 2, v[u].z, c + u);
+            argmax_step<WITH_SCORE>(st, 3, v[u].w, c + u);
+        }
+    }
+    for (; c < C; ++c) {
+        const float4 v = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
+        argmax_step<WITH_SCORE>(st, 0, v.x, c);
+        argmax_step<WITH_SCORE>(st, 1, v.y, c);
+        argmax_step<WITH_SCORE>(st, 2, v.z, c);
+        argmax_step<WITH_SCORE>(st, 3, v.w, c);
+    }
+    for (int j = 0; j < nvalid; ++j) {
+        const bool degenerate = st.bad[j] || !(fabsf(st.m[j]) < INFINITY);
+        const int cls = degenerate ? 0 : st.am[j];
+        const size_t o = (size_t)b * P + p0 + j;
+        if (idx_u8) idx_u8[o] = (uint8_t)cls;
+        if (idx_i64) idx_i64[o] = cls;
+        if (WITH_SCORE) score[o] = degenerate ? __int_as_float(0x7fc00000) : (1.0f / st.se[j]);
+    }
+}
+
+// softmax over the class axis, f32 out (semantic.py:52 'semantic_softmax_scores')
+template <int DTYPE, bool VEC>
+__global__ __launch_bounds__(FUSED_THREADS) void k_semantic_softmax(
+    const void* __restrict__ logits, int C, int P, float* __restrict__ probs)
+{
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * FUSED_THREADS + threadIdx.x) * PX_PER_THREAD;
+    if (p0 >= P) return;
+    const int nvalid = min(4, P - p0);
+    const size_t img = (size_t)b * C * P;
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int c = 0; c < C; ++c) {
+        const float4 v = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
+        // fmaxf drops NaN; propagate it explicitly like ATen's max reduction
+        m[0] = (v.x != v.x) ? v.x : ((m[0] != m[0]) ? m[0] : fmaxf(m[0], v.x));
+        m[1] = (v.y != v.y) ? v.y : ((m[1] != m[1]) ? m[1] : fmaxf(m[1], v.y));
+        m[2] = (v.z != v.z) ? v.z : ((m[2] != m[2]) ? m[2] : fmaxf(m[2], v.z));
+        m[3] = (v.w != v.w) ? v.w : ((m[3] != m[3]) ? m[3] : fmaxf(m[3], v.w));
+    }
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < C; ++c) {
+        const float4 v = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
+        s[0] += expf(v.x - m[0]); s[1] += expf(v.y - m[1]);
+        s[2] += expf(v.z - m[2]); s[3] += expf(v.w - m[3]);
+    }
+    for (int c = 0; c < C; ++c) {
+        const float4 v = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
+        const float r[4] = {expf(v.x - m[0]) / s[0], expf(v.y - m[1]) / s[1],
+                            expf(v.z - m[2]) / s[2], expf(v.w - m[3]) / s[3]};
+        float* o = probs + img + (size_t)c * P + p0;
+        if (VEC) *(float4*)o = make_float4(r[0], r[1], r[2], r[3]);
+        else for (int j = 0; j < nvalid; ++j) o[j] = r[j];
+    }
+}
+
+// =================================================================================
+// standalone a3: grouping with a given foreground mask (+ per-id area)
+// dynamic LDS: float2 centers[max_centers] | u32 area_hist[256]
+// =================================================================================
+template <bool VEC>
+__global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
+    const float* __restrict__ offset, const uint8_t* __restrict__ fgmask,
+    const int32_t* __restrict__ centers_yx, const int32_t* __restrict__ n_centers,
+    int H, int W, int max_centers, int iters,
+    float scale_y, float scale_x, int use_thr, float thr,
+    uint8_t* __restrict__ inst, int32_t* __restrict__ area)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    float2* cen = (float2*)smem;
+    uint32_t* ahist = (uint32_t*)(cen + max_centers);
+    const int b = blockIdx.y;
+    const int P = H * W;
+    const int n = min(n_centers[b], max_centers);
+    for (int i = threadIdx.x; i < n; i += FUSED_THREADS) {
+        const int32_t cy = centers_yx[((size_t)b * max_centers + i) * 2 + 0];
+        const int32_t cx = centers_yx[((size_t)b * max_centers + i) * 2 + 1];
+        cen[i] = make_float2((float)cy, (float)cx);
+    }
+    for (int i = threadIdx.x; i < 256; i += FUSED_THREADS) ahist[i] = 0;
+    __syncthreads();
+
+    const float* offy = offset + (size_t)b * 2 * P;
+    const float* offx = offy + P;
+    const int chunk_start = blockIdx.x * iters * PX_PER_ITER;
+    for (int it = 0; it < iters; ++it) {
+        const int p0 = chunk_start + it * PX_PER_ITER + threadIdx.x * PX_PER_THREAD;
+        if (p0 >= P) break;
+        const int nvalid = min(4, P - p0);
+        bool fg[4] = {false, false, false, false};
+        if (VEC) {
+            const uchar4 f = *(const uchar4*)(fgmask + (size_t)b * P + p0);
+            fg[0] = f.x != 0; fg[1] = f.y != 0; fg[2] = f.z != 0; fg[3] = f.w != 0;
+        } else {
+            for (int j = 0; j < nvalid; ++j) fg[j] = fgmask[(size_t)b * P + p0 + j] != 0;
+        }
+        const bool any_fg = fg[0] || fg[1] || fg[2] || fg[3];
+        uint32_t id[4] = {0u, 0u, 0u, 0u};
+        if (any_fg && n > 0) {
+            const float4 oy = load_px4<NMSA_F32, VEC>(offy, (size_t)p0, nvalid);
+            const float4 ox = load_px4<NMSA_F32, VEC>(offx, (size_t)p0, nvalid);
+            const float oyv[4] = {oy.x, oy.y, oy.z, oy.w};
+            const float oxv[4] = {ox.x, ox.y, ox.z, ox.w};
+            float ly[4], lx[4];
+            int y = p0 / W, x = p0 - y * W;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                ly[j] = __fadd_rn((float)y, __fmul_rn(oyv[j], scale_y));
+                lx[j] = __fadd_rn((float)x, __fmul_rn(oxv[j], scale_x));
+                if (++x == W) { x = 0; ++y; }
+            }
+            group4(cen, n, ly, lx, fg, use_thr, thr, id);
+        }
+        if (VEC) {
+            *(uchar4*)(inst + (size_t)b * P + p0) =
+                make_uchar4((uint8_t)id[0], (uint8_t)id[1], (uint8_t)id[2], (uint8_t)id[3]);
+        } else {
+            for (int j = 0; j < nvalid; ++j) inst[(size_t)b * P + p0 + j] = (uint8_t)id[j];
+        }
+        if (area && n > 0 && __any(any_fg)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                // bincount over the foreground pixels, id 0 included (instance.py:253)
+                const int key = fg[j] ? (int)id[j] : -1;
+                wave_aggregate_add(key, [&](int k, uint32_t cnt) { atomicAdd(&ahist[k], cnt); });
+            }
+        }
+    }
+    if (area) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < 256; i += FUSED_THREADS) {
+            const uint32_t v = ahist[i];
+            if (v) atomicAdd(&area[(size_t)b * 256 + i], (int32_t)v);
+        }
+    }
+}
+
+// =================================================================================
+// a5: per-instance class (mode, smallest on ties) + running per-class counter
+// =================================================================================
+__global__ __launch_bounds__(256) void k_assign(
+    const uint32_t* __restrict__ votes, int NC, int64_t max_inst, int64_t void_label,
+    int64_t* __restrict__ pan_of_inst, int32_t* __restrict__ area,
+    int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins, int32_t* __restrict__ n_ids)
+{
+    __shared__ int s_cls[256];
+    __shared__ int s_valid[256];
+    const int b = blockIdx.x, t = threadIdx.x;
+    const uint32_t* row = votes + ((size_t)b * 256 + t) * NC;
+    uint32_t total = 0;
+    int64_t bestc = -1;
+    int cls = 0;
+    for (int c = 0; c < NC; ++c) {
+        const uint32_t v = row[c];
+        total += v;
+        if ((int64_t)v > bestc) { bestc = v; cls = c; }      // torch.mode: smallest value on ties
+    }
+    // skip id 0, empty masks (panoptic_merge.py:195-200) and void majority (:203-204)
+    const int valid = (t > 0) && (total > 0) && (cls != 0);
+    s_cls[t] = cls;
+    s_valid[t] = valid;
+    __syncthreads();
+    int rank = 1, pos = 0;
+    for (int j = 1; j < t; ++j) {
+        if (s_valid[j]) { ++pos; if (s_cls[j] == cls) ++rank; }
+    }
+    const int64_t pid = (int64_t)cls * max_inst + rank;        // :206-208
+    pan_of_inst[(size_t)b * 256 + t] = valid ? pid : void_label;
+    if (area) area[(size_t)b * 256 + t] = (t > 0) ? (int32_t)total : 0;
+    if (valid) {
+        ids_pan[(size_t)b * 256 + pos] = pid;                   // dict insertion order (:209)
+        ids_ins[(size_t)b * 256 + pos] = t;
+    }
+    if (t == 255) n_ids[b] = pos + valid;
+}
+
+// =================================================================================
+// a5: paint.  8 px / thread: 8-B loads of sem & inst, 4 x 16-B stores of i64.
+// =================================================================================
+template <bool VEC>
+__global__ __launch_bounds__(256) void k_paint(
+    const uint8_t* __restrict__ sem_u8, const uint8_t* __restrict__ inst,
+    const int64_t* __restrict__ pan_of_inst, const uint8_t* __restrict__ is_thing,
+    int C, int P, int64_t max_inst, int64_t void_label,
+    int64_t* __restrict__ pan, int64_t* __restrict__ pan_sem)
+{
+    __shared__ int64_t s_inst[256];
+    __shared__ int64_t s_stuff[256];
+    const int b = blockIdx.y, t = threadIdx.x;
+    s_inst[t] = pan_of_inst[(size_t)b * 256 + t];
+    // stuff paste (panoptic_merge.py:213-223): class value = idx + 1, thing classes stay void
+    s_stuff[t] = (t < C && !is_thing[t]) ? (int64_t)(t + 1) * max_inst : void_label;
+    __syncthreads();
+    const int p0 = (blockIdx.x * 256 + t) * 8;
+    if (p0 >= P) return;
+    const size_t o = (size_t)b * P + p0;
+    uint8_t s[8], in[8];
+    const int nvalid = min(8, P - p0);
+    if (VEC) {
+        const uint2 sv = *(const uint2*)(sem_u8 + o);
+        const uint2 iv = *(const uint2*)(inst + o);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s[j] = (sv.x >> (8 * j)) & 0xFF; s[4 + j] = (sv.y >> (8 * j)) & 0xFF;
+            in[j] = (iv.x >> (8 * j)) & 0xFF; in[4 + j] = (iv.y >> (8 * j)) & 0xFF;
+        }
+    } else {
+        for (int j = 0; j < 8; ++j) {
+            s[j] = (j < nvalid) ? sem_u8[o + j] : 0;
+            in[j] = (j < nvalid) ? inst[o + j] : 0;
+        }
+    }
+    int64_t r[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] = in[j] ? s_inst[in[j]] : s_stuff[s[j]];
+    if (VEC) {
+#pragma unroll
+        for (int j = 0; j < 8; j += 2)
+            *(longlong2*)(pan + o + j) = make_longlong2(r[j], r[j + 1]);
+        if (pan_sem) {
+#pragma unroll
+            for (int j = 0; j < 8; j += 2)
+                *(longlong2*)(pan_sem + o + j) = make_longlong2(r[j] / max_inst, r[j + 1] / max_inst);
+        }
+    } else {
+        for (int j = 0; j < nvalid; ++j) {
+            pan[o + j] = r[j];
+            if (pan_sem) pan_sem[o + j] = r[j] / max_inst;
+        }
+    }
+}
+
+// =================================================================================
+// generic a5 (deeplab_merge_batch with arbitrary integer dtypes; GT path)
+// =================================================================================
+__device__ __forceinline__ int64_t load_int(const void* p, int dtype, size_t i)
+{
+    switch (dtype) {
+        case NMSA_U8: return ((const uint8_t*)p)[i];
+        case NMSA_I16: return ((const int16_t*)p)[i];
+        case NMSA_I32: return ((const int32_t*)p)[i];
+        default: return ((const int64_t*)p)[i];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_votes(
+    const void* __restrict__ sem, int sem_dtype, const void* __restrict__ ins, int ins_dtype,
+    const uint8_t* __restrict__ thing_seg, int NC, int P, uint32_t* __restrict__ votes)
+{
+    const int b = blockIdx.y;
+    const int stride = gridDim.x * blockDim.x;
+    uint32_t* votes_b = votes + (size_t)b * 256 * NC;
+    // uniform trip count so that every lane reaches the wave-level aggregation
+    const int trips = (P + stride - 1) / stride;
+    for (int k = 0; k < trips; ++k) {
+        const int p = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        int key = -1;
+        if (p < P) {
+            const size_t o = (size_t)b * P + p;
+            const int64_t i = load_int(ins, ins_dtype, o);
+            const int64_t s = load_int(sem, sem_dtype, o);
+            // is_thing = (ins > 0) & thing_seg  (panoptic_merge.py:182,198)
+            if (i > 0 && i < 256 && thing_seg[o] && s >= 0 && s < NC) key = (int)(i * NC + s);
+        }
+        wave_aggregate_add(key, [&](int kk, uint32_t cnt) { atomicAdd(&votes_b[kk], cnt); });
+    }
+}
+
+__global__ __launch_bounds__(256) void k_merge_paint(
+    const void* __restrict__ sem, int sem_dtype, const void* __restrict__ ins, int ins_dtype,
+    const uint8_t* __restrict__ thing_seg, const uint8_t* __restrict__ is_thing_class,
+    const int64_t* __restrict__ pan_of_inst, int NC, int P,
+    int64_t max_inst, int64_t void_label, int64_t* __restrict__ pan)
+{
+    __shared__ int64_t s_inst[256];
+    const int b = blockIdx.y;
+    s_inst[threadIdx.x] = pan_of_inst[(size_t)b * 256 + threadIdx.x];
+    __syncthreads();
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)b * P + p;
+        const int64_t i = load_int(ins, ins_dtype, o);
+        const int64_t s = load_int(sem, sem_dtype, o);
+        int64_t r = void_label;
+        if (i != 0) {
+            if (i > 0 && i < 256 && thing_seg[o]) r = s_inst[i];
+        } else if (s > 0 && s < NC && !is_thing_class[s]) {
+            r = s * max_inst;                                  // panoptic_merge.py:222-223
+        }
+        pan[o] = r;
+    }
+}
+
+// =================================================================================
+// next-1: per-instance biternion sums (instance.py:300-313)
+// =================================================================================
+__global__ __launch_bounds__(256) void k_orientation_sums(
+    const float* __restrict__ orientation, const uint8_t* __restrict__ inst,
+    const uint8_t* __restrict__ mask, int P, double* __restrict__ sums, int32_t* __restrict__ count)
+{
+    __shared__ double s_sum[256 * 2];
+    __shared__ int s_cnt[256];
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < 512; i += 256) s_sum[i] = 0.0;
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    const float* o0 = orientation + (size_t)b * 2 * P;
+    const float* o1 = o0 + P;
+    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
+        const size_t o = (size_t)b * P + p;
+        const uint8_t id = inst[o];
+        if (!id) continue;
+        if (mask && !mask[o]) continue;
+        atomicAdd(&s_sum[id * 2 + 0], (double)o0[p]);
+        atomicAdd(&s_sum[id * 2 + 1], (double)o1[p]);
+        atomicAdd(&s_cnt[id], 1);
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (s_cnt[t]) {
+        atomicAdd(&sums[((size_t)b * 256 + t) * 2 + 0], s_sum[t * 2 + 0]);
+        atomicAdd(&sums[((size_t)b * 256 + t) * 2 + 1], s_sum[t * 2 + 1]);
+        atomicAdd(&count[(size_t)b * 256 + t], s_cnt[t]);
+    }
+}
+
+}  // namespace nmsa
+
+using namespace nmsa;
+
+// ---------------------------------------------------------------------------------
+namespace {
+
+int fused_iters(int P)
+{
+    // 2 x 1024 px per workgroup: 150 workgroups per 640x480 image -> >= 4800 at B=32,
+    // >> 256 CUs x 8 resident, so the last partial wave of blocks is < 3 % of the grid
+    (void)P;
+    return 2;
+}
+
+template <int DTYPE>
+int launch_fused(const void* logits, const float* offset, const int32_t* centers_yx,
+                 const int32_t* n_centers, const uint8_t* is_thing,
+                 int B, int C, int H, int W, int max_centers,
+                 float sy, float sx, int use_thr, float thr,
+                 uint8_t* sem_u8, uint8_t* inst, uint8_t* fg_out, float* score,
+                 uint32_t* votes, int vote_rows_hint, hipStream_t stream)
+{
+    const int P = H * W;
+    const int iters = fused_iters(P);
+    const int chunks = (P + iters * PX_PER_ITER - 1) / (iters * PX_PER_ITER);
+    const int NC = C + 1;
+    // LDS-privatised vote rows: the ids the caller expects (top_k + 1), capped at
+    // ~40 KB; votes for ids beyond (ties at the k-th value) go to global atomics
+    int lds_rows = (40 * 1024) / (NC * 4);
+    if (lds_rows > 256) lds_rows = 256;
+    if (vote_rows_hint > 0 && vote_rows_hint < lds_rows) lds_rows = vote_rows_hint;
+    if (lds_rows < 1) lds_rows = 1;
+    const size_t lds = (size_t)max_centers * sizeof(float2) + (size_t)lds_rows * NC * 4 + 256;
+    if (lds > 64 * 1024) return NMSA_ERR_ARG;
+    const bool vec = (P % 4 == 0) &&
+                     (((uintptr_t)logits | (uintptr_t)offset | (uintptr_t)sem_u8 |
+                       (uintptr_t)inst | (uintptr_t)fg_out | (uintptr_t)score) % 16 == 0);
+    dim3 grid(chunks, B), block(FUSED_THREADS);
+#define NMSA_LAUNCH_FUSED(V, S)                                                              \
+    hipLaunchKernelGGL((k_panoptic_fused<DTYPE, V, S>), grid, block, lds, stream, logits,    \
+                       offset, centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, \
+                       sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows)
+    if (vec) { if (score) NMSA_LAUNCH_FUSED(true, true); else NMSA_LAUNCH_FUSED(true, false); }
+    else { if (score) NMSA_LAUNCH_FUSED(false, true); else NMSA_LAUNCH_FUSED(false, false); }
+#undef NMSA_LAUNCH_FUSED
+    return check_launch();
+}
+
+template <int DTYPE>
+int launch_argmax(const void* logits, int B, int C, int P, uint8_t* idx_u8, int64_t* idx_i64,
+                  float* score, hipStream_t stream)
+{
+    const bool vec = (P % 4 == 0) && ((uintptr_t)logits % 16 == 0);
+    dim3 grid((P + PX_PER_ITER - 1) / PX_PER_ITER, B), block(FUSED_THREADS);
+#define NMSA_LAUNCH_ARGMAX(V, S)                                                          \
+    hipLaunchKernelGGL((k_semantic_argmax<DTYPE, V, S>), grid, block, 0, stream, logits,  \
+                       C, P, idx_u8, idx_i64, score)
+    if (vec) { if (score) NMSA_LAUNCH_ARGMAX(true, true); else NMSA_LAUNCH_ARGMAX(true, false); }
+    else { if (score) NMSA_LAUNCH_ARGMAX(false, true); else NMSA_LAUNCH_ARGMAX(false, false); }
+#undef NMSA_LAUNCH_ARGMAX
+    return check_launch();
+}
+
+template <int DTYPE>
+int launch_softmax(const void* logits, int B, int C, int P, float* probs, hipStream_t stream)
+{
+    const bool vec = (P % 4 == 0) && (((uintptr_t)logits | (uintptr_t)probs) % 16 == 0);
+    dim3 grid((P + PX_PER_ITER - 1) / PX_PER_ITER, B), block(FUSED_THREADS);
+    if (vec) hipLaunchKernelGGL((k_semantic_softmax<DTYPE, true>), grid, block, 0, stream, logits, C, P, probs);
+    else hipLaunchKernelGGL((k_semantic_softmax<DTYPE, false>), grid, block, 0, stream, logits, C, P, probs);
+    return check_launch();
+}
+
+bool bad_dims(int B, int H, int W)
+{
+    return B <= 0 || H <= 0 || W <= 0 || (int64_t)H * W > ((int64_t)1 << 30) || B > 65535;
+}
+
+}  // namespace
+
+extern "C" int nmsa_group_offsets(const float* offset, const uint8_t* fg,
+                                  const int32_t* centers_yx, const int32_t* n_centers,
+                                  int B, int H, int W, int max_centers,
+                                  float scale_y, float scale_x,
+                                  int use_dist_thr, float dist_thr,
+                                  uint8_t* inst, int32_t* area, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!offset || !fg || !centers_yx || !n_centers || !inst) return NMSA_ERR_ARG;
+    if (bad_dims(B, H, W) || max_centers <= 0) return NMSA_ERR_ARG;
+    const int P = H * W;
+    const size_t lds = (size_t)max_centers * sizeof(float2) + 256 * 4;
+    if (lds > 64 * 1024) return NMSA_ERR_ARG;
+    int rc;
+    if (area) {
+        rc = check_hip(hipMemsetAsync(area, 0, (size_t)B * 256 * sizeof(int32_t), stream));
+        if (rc) return rc;
+    }
+    const int iters = 2;
+    const int chunks = (P + iters * PX_PER_ITER - 1) / (iters * PX_PER_ITER);
+    const bool vec = (P % 4 == 0) &&
+                     (((uintptr_t)offset | (uintptr_t)fg | (uintptr_t)inst) % 16 == 0);
+    dim3 grid(chunks, B), block(FUSED_THREADS);
+    if (vec)
+        hipLaunchKernelGGL(k_group_offsets<true>, grid, block, lds, stream, offset, fg, centers_yx,
+                           n_centers, H, W, max_centers, iters, scale_y, scale_x, use_dist_thr,
+                           dist_thr, inst, area);
+    else
+        hipLaunchKernelGGL(k_group_offsets<false>, grid, block, lds, stream, offset, fg, centers_yx,
+                           n_centers, H, W, max_centers, iters, scale_y, scale_x, use_dist_thr,
+                           dist_thr, inst, area);
+    return check_launch();
+}
+
+extern "C" int nmsa_semantic_argmax(const void* logits, int logits_dtype,
+                                    int B, int C, int H, int W,
+                                    uint8_t* idx_u8, int64_t* idx_i64, float* score,
+                                    nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!logits || bad_dims(B, H, W) || C <= 0) return NMSA_ERR_ARG;
+    if (idx_u8 && C > 256) return NMSA_ERR_ARG;
+    const int P = H * W;
+    switch (logits_dtype) {
+        case NMSA_F32: return launch_argmax<NMSA_F32>(logits, B, C, P, idx_u8, idx_i64, score, stream);
+        case NMSA_BF16: return launch_argmax<NMSA_BF16>(logits, B, C, P, idx_u8, idx_i64, score, stream);
+        case NMSA_F16: return launch_argmax<NMSA_F16>(logits, B, C, P, idx_u8, idx_i64, score, stream);
+        default: return NMSA_ERR_ARG;
+    }
+}
+
+extern "C" int nmsa_semantic_softmax(const void* logits, int logits_dtype,
+                                     int B, int C, int H, int W, float* probs,
+                                     nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!logits || !probs || bad_dims(B, H, W) || C <= 0) return NMSA_ERR_ARG;
+    const int P = H * W;
+    switch (logits_dtype) {
+        case NMSA_F32: return launch_softmax<NMSA_F32>(logits, B, C, P, probs, stream);
+        case NMSA_BF16: return launch_softmax<NMSA_BF16>(logits, B, C, P, probs, stream);
+        case NMSA_F16: return launch_softmax<NMSA_F16>(logits, B, C, P, probs, stream);
+        default: return NMSA_ERR_ARG;
+    }
+}
+
+extern "C" int nmsa_panoptic_fused(const void* logits, int logits_dtype, const float* offset,
+                                   const int32_t* centers_yx, const int32_t* n_centers,
+                                   const uint8_t* is_thing,
+                                   int B, int C, int H, int W, int max_centers,
+                                   float scale_y, float scale_x,
+                                   int use_dist_thr, float dist_thr,
+                                   uint8_t* sem_u8, uint8_t* inst, uint8_t* fg_out, float* score,
+                                   uint32_t* votes, int vote_rows_hint, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!logits || !offset || !centers_yx || !n_centers || !is_thing || !sem_u8 || !inst || !votes)
+        return NMSA_ERR_ARG;
+    if (bad_dims(B, H, W) || C <= 0 || C > 256 || max_centers <= 0) return NMSA_ERR_ARG;
+    int rc = check_hip(hipMemsetAsync(votes, 0, (size_t)B * 256 * (C + 1) * sizeof(uint32_t), stream));
+    if (rc) return rc;
+    switch (logits_dtype) {
+        case NMSA_F32:
+            return launch_fused<NMSA_F32>(logits, offset, centers_yx, n_centers, is_thing, B, C, H, W,
+                                          max_centers, scale_y, scale_x, use_dist_thr, dist_thr,
+                                          sem_u8, inst, fg_out, score, votes, vote_rows_hint, stream);
+        case NMSA_BF16:
+            return launch_fused<NMSA_BF16>(logits, offset, centers_yx, n_centers, is_thing, B, C, H, W,
+                                           max_centers, scale_y, scale_x, use_dist_thr, dist_thr,
+                                           sem_u8, inst, fg_out, score, votes, vote_rows_hint, stream);
+        case NMSA_F16:
+            return launch_fused<NMSA_F16>(logits, offset, centers_yx, n_centers, is_thing, B, C, H, W,
+                                          max_centers, scale_y, scale_x, use_dist_thr, dist_thr,
+                                          sem_u8, inst, fg_out, score, votes, vote_rows_hint, stream);
+        default: return NMSA_ERR_ARG;
+    }
+}
+
+extern "C" int nmsa_panoptic_assign(const uint32_t* votes, int B, int n_vote_classes,
+                                    int64_t max_instances_per_category, int64_t void_label,
+                                    int64_t* pan_of_inst, int32_t* area,
+                                    int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
+                                    nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!votes || !pan_of_inst || !ids_pan || !ids_ins || !n_ids) return NMSA_ERR_ARG;
+    if (B <= 0 || n_vote_classes <= 0) return NMSA_ERR_ARG;
+    hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_vote_classes,
+                       max_instances_per_category, void_label, pan_of_inst, area,
+                       ids_pan, ids_ins, n_ids);
+    return check_launch();
+}
+
+extern "C" int nmsa_panoptic_paint(const uint8_t* sem_u8, const uint8_t* inst,
+                                   const int64_t* pan_of_inst, const uint8_t* is_thing,
+                                   int B, int C, int H, int W,
+                                   int64_t max_instances_per_category, int64_t void_label,
+                                   int64_t* pan, int64_t* pan_sem, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!sem_u8 || !inst || !pan_of_inst || !is_thing || !pan) return NMSA_ERR_ARG;
+    if (bad_dims(B, H, W) || C <= 0 || C > 256 || max_instances_per_category <= 0) return NMSA_ERR_ARG;
+    const int P = H * W;
+    const bool vec = (P % 8 == 0) &&
+                     (((uintptr_t)sem_u8 | (uintptr_t)inst | (uintptr_t)pan | (uintptr_t)pan_sem) % 16 == 0);
+    dim3 grid((P + 2047) / 2048, B), block(256);
+    if (vec)
+        hipLaunchKernelGGL(k_paint<true>, grid, block, 0, stream, sem_u8, inst, pan_of_inst, is_thing,
+                           C, P, max_instances_per_category, void_label, pan, pan_sem);
+    else
+        hipLaunchKernelGGL(k_paint<false>, grid, block, 0, stream, sem_u8, inst, pan_of_inst, is_thing,
+                           C, P, max_instances_per_category, void_label, pan, pan_sem);
+    return check_launch();
+}
+
+extern "C" int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* ins, int ins_dtype,
+                                   const uint8_t* thing_seg, const uint8_t* is_thing_class,
+                                   int B, int n_classes, int H, int W,
+                                   int64_t max_instances_per_category, int64_t void_label,
+                                   uint32_t* votes, int64_t* pan_of_inst,
+                                   int64_t* pan, int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
+                                   nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!sem || !ins || !thing_seg || !is_thing_class || !votes || !pan_of_inst || !pan ||
+        !ids_pan || !ids_ins || !n_ids)
+        return NMSA_ERR_ARG;
+    if (bad_dims(B, H, W) || n_classes <= 0) return NMSA_ERR_ARG;
+    if (sem_dtype < NMSA_U8 || sem_dtype > NMSA_I64 || ins_dtype < NMSA_U8 || ins_dtype > NMSA_I64)
+        return NMSA_ERR_ARG;
+    const int P = H * W;
+    int rc = check_hip(hipMemsetAsync(votes, 0, (size_t)B * 256 * n_classes * sizeof(uint32_t), stream));
+    if (rc) return rc;
+    int gx = (P + 255) / 256;
+    if (gx > 1024) gx = 1024;
+    hipLaunchKernelGGL(k_merge_votes, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins, ins_dtype,
+                       thing_seg, n_classes, P, votes);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_classes,
+                       max_instances_per_category, void_label, pan_of_inst, (int32_t*)nullptr,
+                       ids_pan, ids_ins, n_ids);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_merge_paint, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins, ins_dtype,
+                       thing_seg, is_thing_class, pan_of_inst, n_classes, P,
+                       max_instances_per_category, void_label, pan);
+    return check_launch();
+}
+
+extern "C" int nmsa_instance_orientation(const float* orientation, const uint8_t* inst,
+                                         const uint8_t* mask, int B, int H, int W,
+                                         double* sums, int32_t* count, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!orientation || !inst || !sums || !count || bad_dims(B, H, W)) return NMSA_ERR_ARG;
+    const int P = H * W;
+    int rc = check_hip(hipMemsetAsync(sums, 0, (size_t)B * 256 * 2 * sizeof(double), stream));
+    if (rc) return rc;
+    rc = check_hip(hipMemsetAsync(count, 0, (size_t)B * 256 * sizeof(int32_t), stream));
+    if (rc) return rc;
+    int gx = (P + 4095) / 4096;
+    hipLaunchKernelGGL(k_orientation_sums, dim3(gx, B), dim3(256), 0, stream, orientation, inst, mask,
+                       P, sums, count);
+    return check_launch();
+}

@@ -1,0 +1,277 @@
+"""
+Functional front-end of the HIP hot path: torch device tensors in, torch device
+tensors out, every call stream-ordered on torch's current HIP stream, no host
+synchronisation.  These are thin argument marshallers over include/nmsa.h; the
+reference-shaped classes (model/postprocessing, utils/panoptic_merge, metric,
+loss) are built on top of them.
+"""
+from typing import Dict, Optional
+
+import torch
+
+from . import _lib as L
+
+DEFAULT_MAX_CENTERS = 256
+
+
+def _u8(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """bool / uint8 tensor viewed as uint8 (torch.bool storage is one byte)."""
+    if t is None:
+        return None
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)
+    if t.dtype == torch.uint8:
+        return t.contiguous()
+    return (t != 0).contiguous().view(torch.uint8)
+
+
+# ----------------------------------------------------------------------------- a2
+def center_nms_topk(
+    center_heatmap: torch.Tensor,
+    foreground_mask: Optional[torch.Tensor] = None,
+    threshold: float = 0.1,
+    kernel_size: int = 3,
+    top_k: int = 64,
+    apply_foreground_mask: bool = False,
+    max_centers: int = DEFAULT_MAX_CENTERS,
+    want_mask: bool = False,
+) -> Dict[str, torch.Tensor]:
+    """reference: InstancePostprocessing._get_instance_centers (instance.py:79-168)"""
+    c = L.require_device_tensor(center_heatmap, 'center_heatmap')
+    if c.dtype != torch.float32:
+        c = c.float()
+    if c.ndim == 4:
+        assert c.shape[1] == 1
+        c = c[:, 0]
+    c = c.contiguous()
+    B, H, W = c.shape
+    dev = c.device
+    fg = _u8(foreground_mask) if apply_foreground_mask else None
+    cyx = torch.empty((B, max_centers, 2), dtype=torch.int32, device=dev)
+    n = torch.empty((B,), dtype=torch.int32, device=dev)
+    scores = torch.empty((B, max_centers), dtype=torch.float32, device=dev)
+    mask = torch.empty((B, H, W), dtype=torch.uint8, device=dev) if want_mask else None
+    ws_bytes = L.lib().nmsa_center_nms_workspace_bytes(B, H, W)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    L.check(L.lib().nmsa_center_nms_topk(
+        L.ptr(c), L.ptr(fg), B, H, W, float(threshold), int(kernel_size), int(top_k),
+        int(bool(apply_foreground_mask)), int(max_centers),
+        L.ptr(cyx), L.ptr(n), L.ptr(scores), L.ptr(mask), L.ptr(ws), ws_bytes,
+        L.stream_ptr(dev)), 'nmsa_center_nms_topk')
+    out = {'centers_yx': cyx, 'n_centers': n, 'scores': scores}
+    if want_mask:
+        out['center_mask'] = mask.view(torch.bool)
+    return out
+
+
+# ----------------------------------------------------------------------------- a3
+def group_offsets(
+    center_offset: torch.Tensor,
+    foreground_mask: torch.Tensor,
+    centers_yx: torch.Tensor,
+    n_centers: torch.Tensor,
+    scale_y: float = 1.0,
+    scale_x: float = 1.0,
+    distance_threshold: Optional[float] = None,
+    want_area: bool = True,
+) -> Dict[str, torch.Tensor]:
+    """reference: InstancePostprocessing._get_instance_segmentation (instance.py:187-253)"""
+    off = L.require_device_tensor(center_offset, 'center_offset')
+    if off.dtype != torch.float32:
+        off = off.float()
+    B, two, H, W = off.shape
+    assert two == 2
+    dev = off.device
+    fg = _u8(foreground_mask)
+    inst = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    area = torch.empty((B, 256), dtype=torch.int32, device=dev) if want_area else None
+    L.check(L.lib().nmsa_group_offsets(
+        L.ptr(off), L.ptr(fg), L.ptr(centers_yx), L.ptr(n_centers), B, H, W,
+        int(centers_yx.shape[1]), float(scale_y), float(scale_x),
+        0 if distance_threshold is None else 1,
+        0.0 if distance_threshold is None else float(distance_threshold),
+        L.ptr(inst), L.ptr(area), L.stream_ptr(dev)), 'nmsa_group_offsets')
+    return {'instance': inst, 'area': area}
+
+
+# ----------------------------------------------------------------------------- a1
+def semantic_argmax(
+    logits: torch.Tensor,
+    want_u8: bool = False,
+    want_i64: bool = True,
+    want_score: bool = True,
+) -> Dict[str, torch.Tensor]:
+    """reference: SemanticPostprocessing._postprocess_inference (semantic.py:52-53)"""
+    x = L.require_device_tensor(logits, 'logits')
+    B, Cn, H, W = x.shape
+    dev = x.device
+    u8 = torch.empty((B, H, W), dtype=torch.uint8, device=dev) if want_u8 else None
+    i64 = torch.empty((B, H, W), dtype=torch.int64, device=dev) if want_i64 else None
+    sc = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_score else None
+    L.check(L.lib().nmsa_semantic_argmax(
+        L.ptr(x), L.float_dtype_code(x), B, Cn, H, W, L.ptr(u8), L.ptr(i64), L.ptr(sc),
+        L.stream_ptr(dev)), 'nmsa_semantic_argmax')
+    return {'idx_u8': u8, 'idx': i64, 'score': sc}
+
+
+def semantic_softmax(logits: torch.Tensor) -> torch.Tensor:
+    """reference: F.softmax(output, dim=1) (semantic.py:52)"""
+    x = L.require_device_tensor(logits, 'logits')
+    B, Cn, H, W = x.shape
+    probs = torch.empty((B, Cn, H, W), dtype=torch.float32, device=x.device)
+    L.check(L.lib().nmsa_semantic_softmax(
+        L.ptr(x), L.float_dtype_code(x), B, Cn, H, W, L.ptr(probs),
+        L.stream_ptr(x.device)), 'nmsa_semantic_softmax')
+    return probs
+
+
+# ------------------------------------------------------------------ a1+a3+a4+a5
+def panoptic_pipeline(
+    semantic_logits: torch.Tensor,
+    center_heatmap: torch.Tensor,
+    center_offset: torch.Tensor,
+    is_thing: torch.Tensor,                 # u8/bool [C], on device
+    threshold: float = 0.1,
+    kernel_size: int = 3,
+    top_k: int = 64,
+    apply_foreground_mask: bool = False,
+    normalized_offset: bool = True,
+    distance_threshold: Optional[float] = None,
+    max_instances_per_category: int = 1 << 16,
+    void_label: int = 0,
+    max_centers: int = DEFAULT_MAX_CENTERS,
+    want_score: bool = False,
+    want_foreground: bool = True,
+    want_panoptic_semantic: bool = False,
+    fused_kernel_events: Optional[list] = None,
+) -> Dict[str, torch.Tensor]:
+    """center-NMS -> fused argmax/grouping/votes -> assign -> paint.
+
+    `fused_kernel_events`: if a list is given, a (start, end) pair of HIP events
+    recorded on the launch stream around the dominant kernel is appended
+    (bench.py's live roofline measurement).
+
+    reference: PanopticPostprocessing._postprocess_inference (panoptic.py:77-168).
+    When the foreground-masked heatmap option is on, the foreground depends on
+    the semantic argmax, so the argmax runs first as its own kernel.
+    """
+    lib = L.lib()
+    x = L.require_device_tensor(semantic_logits, 'semantic_logits')
+    off = L.require_device_tensor(center_offset, 'center_offset')
+    if off.dtype != torch.float32:
+        off = off.float()
+    B, Cn, H, W = x.shape
+    dev = x.device
+    st = L.stream_ptr(dev)
+    thing = _u8(is_thing)
+
+    fg_for_nms = None
+    if apply_foreground_mask:
+        pre = semantic_argmax(x, want_u8=True, want_i64=False, want_score=False)
+        fg_for_nms = thing[pre['idx_u8'].long()]
+    cen = center_nms_topk(center_heatmap, fg_for_nms, threshold, kernel_size, top_k,
+                          apply_foreground_mask, max_centers)
+
+    sem_u8 = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    inst = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    fg = torch.empty((B, H, W), dtype=torch.uint8, device=dev) if want_foreground else None
+    score = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_score else None
+    votes = torch.empty((B, 256, Cn + 1), dtype=torch.int32, device=dev)
+    sy, sx = (float(H), float(W)) if normalized_offset else (1.0, 1.0)
+    if fused_kernel_events is not None:
+        ev0 = torch.cuda.Event(enable_timing=True)
+        ev1 = torch.cuda.Event(enable_timing=True)
+        ev0.record(torch.cuda.current_stream(dev))
+    L.check(lib.nmsa_panoptic_fused(
+        L.ptr(x), L.float_dtype_code(x), L.ptr(off), L.ptr(cen['centers_yx']),
+        L.ptr(cen['n_centers']), L.ptr(thing), B, Cn, H, W, int(max_centers), sy, sx,
+        0 if distance_threshold is None else 1,
+        0.0 if distance_threshold is None else float(distance_threshold),
+        L.ptr(sem_u8), L.ptr(inst), L.ptr(fg), L.ptr(score), L.ptr(votes),
+        int(top_k) + 1, st), 'nmsa_panoptic_fused')
+    if fused_kernel_events is not None:
+        ev1.record(torch.cuda.current_stream(dev))
+        fused_kernel_events.append((ev0, ev1))
+
+    pan_of_inst = torch.empty((B, 256), dtype=torch.int64, device=dev)
+    area = torch.empty((B, 256), dtype=torch.int32, device=dev)
+    ids_pan = torch.empty((B, 256), dtype=torch.int64, device=dev)
+    ids_ins = torch.empty((B, 256), dtype=torch.int64, device=dev)
+    n_ids = torch.empty((B,), dtype=torch.int32, device=dev)
+    L.check(lib.nmsa_panoptic_assign(
+        L.ptr(votes), B, Cn + 1, int(max_instances_per_category), int(void_label),
+        L.ptr(pan_of_inst), L.ptr(area), L.ptr(ids_pan), L.ptr(ids_ins), L.ptr(n_ids), st),
+        'nmsa_panoptic_assign')
+
+    pan = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    pan_sem = torch.empty((B, H, W), dtype=torch.int64, device=dev) \
+        if want_panoptic_semantic else None
+    L.check(lib.nmsa_panoptic_paint(
+        L.ptr(sem_u8), L.ptr(inst), L.ptr(pan_of_inst), L.ptr(thing), B, Cn, H, W,
+        int(max_instances_per_category), int(void_label), L.ptr(pan), L.ptr(pan_sem), st),
+        'nmsa_panoptic_paint')
+
+    return {
+        'semantic_idx_u8': sem_u8, 'semantic_score': score,
+        'foreground': None if fg is None else fg.view(torch.bool),
+        'instance': inst, 'panoptic': pan, 'panoptic_semantic': pan_sem,
+        'centers_yx': cen['centers_yx'], 'n_centers': cen['n_centers'],
+        'center_scores': cen['scores'], 'area': area,
+        'ids_pan': ids_pan, 'ids_ins': ids_ins, 'n_ids': n_ids,
+        'pan_of_inst': pan_of_inst, 'votes': votes,
+    }
+
+
+# ----------------------------------------------------------------------------- a5
+def panoptic_merge(
+    semantic: torch.Tensor,
+    instance: torch.Tensor,
+    thing_seg: torch.Tensor,
+    is_thing_class: torch.Tensor,           # u8/bool [n_classes] (class VALUE domain)
+    max_instances_per_category: int,
+    void_label: int = 0,
+) -> Dict[str, torch.Tensor]:
+    """reference: deeplab_merge_batch (panoptic_merge.py:18-40,172-225)"""
+    sem = L.require_device_tensor(semantic, 'semantic')
+    ins = L.require_device_tensor(instance, 'instance')
+    if sem.dtype == torch.bool:
+        sem = sem.view(torch.uint8)
+    B, H, W = sem.shape
+    dev = sem.device
+    thing = _u8(thing_seg)
+    lut = _u8(is_thing_class)
+    n_classes = int(lut.numel())
+    votes = torch.empty((B, 256, n_classes), dtype=torch.int32, device=dev)
+    pan_of_inst = torch.empty((B, 256), dtype=torch.int64, device=dev)
+    pan = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    ids_pan = torch.empty((B, 256), dtype=torch.int64, device=dev)
+    ids_ins = torch.empty((B, 256), dtype=torch.int64, device=dev)
+    n_ids = torch.empty((B,), dtype=torch.int32, device=dev)
+    L.check(L.lib().nmsa_panoptic_merge(
+        L.ptr(sem), L.int_dtype_code(sem), L.ptr(ins), L.int_dtype_code(ins), L.ptr(thing),
+        L.ptr(lut), B, n_classes, H, W, int(max_instances_per_category), int(void_label),
+        L.ptr(votes), L.ptr(pan_of_inst), L.ptr(pan), L.ptr(ids_pan), L.ptr(ids_ins),
+        L.ptr(n_ids), L.stream_ptr(dev)), 'nmsa_panoptic_merge')
+    return {'panoptic': pan, 'ids_pan': ids_pan, 'ids_ins': ids_ins, 'n_ids': n_ids}
+
+
+# ------------------------------------------------------------------------- next-1
+def instance_orientation_sums(
+    orientation: torch.Tensor,
+    instance: torch.Tensor,
+    mask: Optional[torch.Tensor] = None,
+) -> Dict[str, torch.Tensor]:
+    """reference: InstancePostprocessing._get_instance_orientation (instance.py:271-319)"""
+    o = L.require_device_tensor(orientation, 'orientation')
+    if o.dtype != torch.float32:
+        o = o.float()
+    ins = L.require_device_tensor(instance, 'instance')
+    assert ins.dtype == torch.uint8
+    B, two, H, W = o.shape
+    dev = o.device
+    sums = torch.empty((B, 256, 2), dtype=torch.float64, device=dev)
+    count = torch.empty((B, 256), dtype=torch.int32, device=dev)
+    L.check(L.lib().nmsa_instance_orientation(
+        L.ptr(o), L.ptr(ins), L.ptr(_u8(mask)), B, H, W, L.ptr(sums), L.ptr(count),
+        L.stream_ptr(dev)), 'nmsa_instance_orientation')
+    return {'sums': sums, 'count': count}

@@ -7,3 +7,4 @@ from .synthetic import make_panoptic_inputs
 from .synthetic import make_metric_inputs
 from .synthetic import make_loss_inputs
 from .synthetic import input_digest
+from .synthetic import make_panoptic_inputs_torch

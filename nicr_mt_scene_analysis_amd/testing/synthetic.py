@@ -186,3 +186,48 @@ def input_digest(*arrays: np.ndarray) -> str:
         h.update(str(a.shape).encode())
         h.update(a.tobytes())
     return h.hexdigest()
+
+
+def make_panoptic_inputs_torch(batch_size, n_classes=40, height=480, width=640,
+                               n_centers=24, seed=0, device='cuda', sigma=8.0,
+                               offset_noise_px=2.0, quantize_offsets=True,
+                               logits_dtype=None, chunk=8):
+    """Same recipe as `make_panoptic_inputs`, generated on `device` with torch
+    (for bench.py / full-size property tests: fast, not bit-reproducible
+    across devices — parity there is checked against the oracle on the very
+    tensors that were generated)."""
+    import torch
+    B, Cn, H, W = batch_size, n_classes, height, width
+    g = torch.Generator(device=device).manual_seed(seed)
+    gh, gw = max(H // 32, 2), max(W // 32, 2)
+    coarse = torch.randn((B, Cn, gh, gw), device=device, generator=g)
+    logits = 4.0 * torch.nn.functional.interpolate(coarse, size=(H, W), mode='bilinear',
+                                                   align_corners=False)
+    if logits_dtype is not None:
+        logits = logits.to(logits_dtype)
+    border = int(min(8, H // 4, W // 4))
+    cy = torch.randint(border, H - border, (B, n_centers), device=device, generator=g)
+    cx = torch.randint(border, W - border, (B, n_centers), device=device, generator=g)
+    yy = torch.arange(H, device=device, dtype=torch.float32).view(1, 1, H, 1)
+    xx = torch.arange(W, device=device, dtype=torch.float32).view(1, 1, 1, W)
+    center = torch.empty((B, 1, H, W), device=device)
+    offset = torch.empty((B, 2, H, W), device=device)
+    for b0 in range(0, B, chunk):
+        b1 = min(b0 + chunk, B)
+        dy = cy[b0:b1].float().view(-1, n_centers, 1, 1) - yy
+        dx = cx[b0:b1].float().view(-1, n_centers, 1, 1) - xx
+        d2 = dy * dy + dx * dx
+        center[b0:b1, 0] = torch.exp(-d2 / (2.0 * sigma * sigma)).amax(dim=1)
+        near = d2.argmin(dim=1, keepdim=True)
+        oy = torch.gather(dy.expand_as(d2), 1, near)[:, 0]
+        ox = torch.gather(dx.expand_as(d2), 1, near)[:, 0]
+        oy = oy + offset_noise_px * torch.randn(oy.shape, device=device, generator=g)
+        ox = ox + offset_noise_px * torch.randn(ox.shape, device=device, generator=g)
+        if quantize_offsets:
+            oy = torch.round(oy * 2.0) / 2.0
+            ox = torch.round(ox * 2.0) / 2.0
+        offset[b0:b1, 0] = oy / H
+        offset[b0:b1, 1] = ox / W
+    is_thing = torch.arange(Cn, device=device) >= Cn // 2
+    return {'semantic_logits': logits.contiguous(), 'instance_center': center,
+            'instance_offset': offset, 'semantic_classes_is_thing': is_thing}

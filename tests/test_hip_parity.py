@@ -1,0 +1,262 @@
+"""
+GPU tier (pytest -m gpu): the HIP path, called through the C ABI, against
+ (1) the committed golden vectors from the reference's own Python and
+ (2) the C oracle on the same seeded inputs.
+Integer / id outputs must be bit-identical; the softmax score is fp32 within
+rtol 1e-5 (north_star tolerance).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _golden import load, jload, ids_from_arrays
+from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope='module')
+def ops():
+    assert torch.cuda.is_available(), 'needs the MI355X'
+    from nicr_mt_scene_analysis_amd import ops as o
+    return o
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def run_hip_pipeline(ops, logits, center, offset, is_thing, kw=None, **extra):
+    kw = dict(kw or {})
+    r = ops.panoptic_pipeline(
+        dev(logits), dev(center), dev(offset), dev(is_thing),
+        threshold=kw.get('heatmap_threshold', 0.1),
+        kernel_size=kw.get('heatmap_nms_kernel_size', 3),
+        top_k=kw.get('top_k_instances', 64),
+        apply_foreground_mask=kw.get('heatmap_apply_foreground_mask', False),
+        distance_threshold=kw.get('offset_distance_threshold'),
+        want_score=True, want_panoptic_semantic=True, **extra)
+    torch.cuda.synchronize()
+    return {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in r.items()}
+
+
+def check_against_golden(g, r):
+    assert (r['semantic_idx_u8'] == g['semantic_idx']).all()
+    st = int(g['semantic_score_stride']) if 'semantic_score_stride' in g else 1
+    np.testing.assert_allclose(r['semantic_score'][:, ::st, ::st], g['semantic_score'],
+                               rtol=1e-5, atol=1e-7)
+    assert (r['foreground'] == g['foreground']).all()
+    assert (r['n_centers'] == g['meta_n']).all()
+    for b in range(len(r['n_centers'])):
+        nb = int(r['n_centers'][b])
+        assert (r['centers_yx'][b, :nb] == g['meta_center_yx'][b, :nb]).all()
+        assert (r['center_scores'][b, :nb] == g['meta_score'][b, :nb]).all()
+        assert (r['area'][b, 1:nb + 1] == g['meta_area'][b, :nb]).all()
+    assert (r['instance'] == g['instance']).all()
+    assert (r['panoptic'] == g['panoptic']).all()
+    assert (r['panoptic_semantic'] == g['panoptic_semantic']).all()
+    want = ids_from_arrays(g['ids_n'], g['ids_pan'], g['ids_ins'])
+    got = ids_from_arrays(r['n_ids'], r['ids_pan'], r['ids_ins'])
+    for a, b in zip(got, want):
+        assert list(a.items()) == list(b.items())
+
+
+@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_small_kwargs'])
+def test_pipeline_small_vs_golden(ops, name):
+    g = load(name)
+    kw = jload(g['kwargs']) if 'kwargs' in g else None
+    r = run_hip_pipeline(ops, g['in_semantic_logits'], g['in_instance_center'],
+                         g['in_instance_offset'], g['in_semantic_classes_is_thing'], kw)
+    check_against_golden(g, r)
+
+
+@pytest.mark.parametrize('name', ['panoptic_cfg1_q', 'panoptic_cfg1_r'])
+def test_pipeline_cfg1_vs_golden(ops, name):
+    g = load(name)
+    p = jload(g['params'])
+    inp = syn.make_panoptic_inputs(p['batch_size'], seed=p['seed'],
+                                   quantize_offsets=p['quantize_offsets'])
+    digest = syn.input_digest(inp['semantic_logits'], inp['instance_center'],
+                              inp['instance_offset'])
+    if digest != jload(g['digest']):
+        pytest.skip('synthetic inputs differ bit-wise on this host (numpy/libm)')
+    r = run_hip_pipeline(ops, inp['semantic_logits'], inp['instance_center'],
+                         inp['instance_offset'], inp['semantic_classes_is_thing'])
+    check_against_golden(g, r)
+
+
+@pytest.mark.parametrize('shape', [(3, 7, 50, 37), (2, 40, 120, 160), (1, 150, 96, 128)])
+@pytest.mark.parametrize('quant', [True, False])
+def test_pipeline_vs_oracle(ops, oracle, shape, quant):
+    """odd shapes (scalar path: H*W % 4 != 0), C=150, vs the C oracle."""
+    B, C, H, W = shape
+    inp = syn.make_panoptic_inputs(B, C, H, W, n_centers=9, seed=21, quantize_offsets=quant)
+    r = run_hip_pipeline(ops, inp['semantic_logits'], inp['instance_center'],
+                         inp['instance_offset'], inp['semantic_classes_is_thing'])
+    is_thing = inp['semantic_classes_is_thing']
+    idx, score = oracle.semantic_argmax(inp['semantic_logits'])
+    fg = is_thing[idx]
+    cyx, n, scores, _ = oracle.center_nms_topk(inp['instance_center'], max_centers=256)
+    inst, area = oracle.group_offsets(inp['instance_offset'], fg, cyx, n, scale_y=H, scale_x=W)
+    pan, ids = oracle.deeplab_merge(idx + 1, inst, fg, 1 << 16, np.where(is_thing)[0] + 1, 0)
+    assert (r['semantic_idx_u8'] == idx).all()
+    np.testing.assert_allclose(r['semantic_score'], score, rtol=1e-5, atol=1e-7)
+    assert (r['n_centers'] == n).all()
+    for b in range(B):
+        assert (r['centers_yx'][b, :n[b]] == cyx[b, :n[b]]).all()
+    assert (r['instance'] == inst).all()
+    assert (r['panoptic'] == pan).all()
+    got = ids_from_arrays(r['n_ids'], r['ids_pan'], r['ids_ins'])
+    for a, b in zip(got, ids):
+        assert list(a.items()) == list(b.items())
+
+
+def test_bf16_logits_vs_oracle(ops, oracle):
+    inp = syn.make_panoptic_inputs(2, 40, 96, 128, n_centers=7, seed=5)
+    lb = torch.from_numpy(inp['semantic_logits']).to(torch.bfloat16)
+    r = ops.panoptic_pipeline(lb.cuda(), dev(inp['instance_center']), dev(inp['instance_offset']),
+                              dev(inp['semantic_classes_is_thing']), want_score=True)
+    torch.cuda.synchronize()
+    idx, score = oracle.semantic_argmax(lb.float().numpy())
+    assert (r['semantic_idx_u8'].cpu().numpy() == idx).all()
+    np.testing.assert_allclose(r['semantic_score'].cpu().numpy(), score, rtol=1e-5, atol=1e-7)
+
+
+def test_centers_adversarial(ops):
+    g = load('centers_adversarial')
+    for name in jload(g['names']):
+        kw = jload(g[f'{name}__kwargs'])
+        fg = dev(g[f'{name}__fg']) if f'{name}__fg' in g else None
+        r = ops.center_nms_topk(
+            dev(g[f'{name}__heat']), fg,
+            threshold=kw.get('heatmap_threshold', 0.1),
+            kernel_size=kw.get('heatmap_nms_kernel_size', 3),
+            top_k=kw.get('top_k_instances', 64),
+            apply_foreground_mask=kw.get('heatmap_apply_foreground_mask', False),
+            max_centers=1024, want_mask=True)
+        torch.cuda.synchronize()
+        n = r['n_centers'].cpu().numpy()
+        assert (n == g[f'{name}__n']).all(), name
+        assert (r['center_mask'].cpu().numpy() == g[f'{name}__mask']).all(), name
+        cyx = r['centers_yx'].cpu().numpy()
+        for b in range(len(n)):
+            assert (cyx[b, :n[b]] == g[f'{name}__centers'][b, :n[b]]).all(), name
+
+
+def test_centers_many_candidates_vs_oracle(ops, oracle):
+    """radix select with > 30k candidates per image and heavy ties."""
+    rng = np.random.default_rng(3)
+    heat = rng.random((2, 1, 480, 640)).astype(np.float32)
+    heat[1] = np.round(heat[1] * 64) / 64
+    for k, ks in ((64, 3), (1, 3), (254, 1), (17, 5)):
+        cyx, n, scores, mask = oracle.center_nms_topk(heat, ksize=ks, topk=k, max_centers=8192)
+        r = ops.center_nms_topk(dev(heat), kernel_size=ks, top_k=k, max_centers=8192,
+                                want_mask=True)
+        torch.cuda.synchronize()
+        assert (r['n_centers'].cpu().numpy() == n).all(), (k, ks)
+        assert (r['center_mask'].cpu().numpy() == mask).all(), (k, ks)
+        for b in range(2):
+            assert (r['centers_yx'].cpu().numpy()[b, :n[b]] == cyx[b, :n[b]]).all()
+            assert (r['scores'].cpu().numpy()[b, :n[b]] == scores[b, :n[b]]).all()
+
+
+def test_grouping_adversarial(ops):
+    g = load('grouping_adversarial')
+    for name in jload(g['names']):
+        kw = jload(g[f'{name}__kwargs'])
+        cen = ops.center_nms_topk(dev(g[f'{name}__heat']),
+                                  top_k=kw.get('top_k_instances', 64), max_centers=512)
+        r = ops.group_offsets(dev(g[f'{name}__offset']), dev(g[f'{name}__fg']),
+                              cen['centers_yx'], cen['n_centers'],
+                              distance_threshold=kw.get('offset_distance_threshold'))
+        torch.cuda.synchronize()
+        assert (r['instance'].cpu().numpy() == g[f'{name}__inst']).all(), name
+        n = cen['n_centers'].cpu().numpy()
+        assert (n == g[f'{name}__meta_n']).all(), name
+        area = r['area'].cpu().numpy()
+        for b in range(len(n)):
+            nb = int(n[b])
+            got = np.array([area[b, i] if i <= 255 else 0 for i in range(1, nb + 1)])
+            assert (got == g[f'{name}__meta_area'][b, :nb]).all(), name
+
+
+def test_merge_cases(ops):
+    g = load('merge_cases')
+    for name in jload(g['names']):
+        p = jload(g[f'{name}__params'])
+        sem, ins = g[f'{name}__sem'], g[f'{name}__ins']
+        n_classes = int(sem.max()) + 1
+        lut = np.zeros((n_classes,), np.uint8)
+        for t in p['thing_ids']:
+            if t < n_classes:
+                lut[t] = 1
+        r = ops.panoptic_merge(dev(sem), dev(ins), dev(g[f'{name}__thing']), dev(lut),
+                               p['max_inst'], p['void'])
+        torch.cuda.synchronize()
+        assert (r['panoptic'].cpu().numpy() == g[f'{name}__pan']).all(), name
+        got = ids_from_arrays(r['n_ids'].cpu().numpy(), r['ids_pan'].cpu().numpy(),
+                              r['ids_ins'].cpu().numpy())
+        want = ids_from_arrays(g[f'{name}__ids_n'], g[f'{name}__ids_pan'], g[f'{name}__ids_ins'])
+        for a, b in zip(got, want):
+            assert list(a.items()) == list(b.items()), name
+
+
+def test_orientation_cases(ops):
+    g = load('orientation_cases')
+    for name, mask in (('masked', g['mask']), ('nomask', None)):
+        r = ops.instance_orientation_sums(dev(g['orientation']), dev(g['inst']),
+                                          None if mask is None else dev(mask))
+        torch.cuda.synchronize()
+        sums = r['sums'].cpu().numpy()
+        cnt = r['count'].cpu().numpy()
+        want = g[f'{name}__angle']
+        assert ((cnt > 0) == ~np.isnan(want)).all()
+        ang = np.arctan2(sums[..., 1].astype(np.float32), sums[..., 0].astype(np.float32))
+        np.testing.assert_allclose(ang[cnt > 0], want[cnt > 0], rtol=1e-5, atol=1e-5)
+
+
+def test_full_size_properties(ops):
+    """B=32 640x480 (BASELINE cfg2): size-independent properties of the merge."""
+    B, C, H, W = 32, 40, 480, 640
+    g = torch.Generator(device='cuda').manual_seed(0)
+    coarse = torch.randn((B, C, H // 32, W // 32), device='cuda', generator=g)
+    logits = 4 * torch.nn.functional.interpolate(coarse, size=(H, W), mode='bilinear')
+    center = torch.zeros((B, 1, H, W), device='cuda')
+    cy = torch.randint(8, H - 8, (B, 24), device='cuda', generator=g)
+    cx = torch.randint(8, W - 8, (B, 24), device='cuda', generator=g)
+    yy = torch.arange(H, device='cuda').view(1, 1, H, 1)
+    xx = torch.arange(W, device='cuda').view(1, 1, 1, W)
+    d2 = (yy - cy.view(B, 24, 1, 1)) ** 2 + (xx - cx.view(B, 24, 1, 1)) ** 2
+    center[:, 0] = torch.exp(-d2 / 128.0).amax(dim=1)
+    nearest = d2.argmin(dim=1)
+    oy = (torch.gather(cy, 1, nearest.view(B, -1)).view(B, H, W) - yy[0]) / H
+    ox = (torch.gather(cx, 1, nearest.view(B, -1)).view(B, H, W) - xx[0]) / W
+    offset = torch.stack([oy, ox], 1).float().contiguous()
+    is_thing = (torch.arange(C, device='cuda') >= C // 2)
+    r = ops.panoptic_pipeline(logits, center, offset, is_thing, want_panoptic_semantic=True)
+    torch.cuda.synchronize()
+    pan, inst, sem = r['panoptic'], r['instance'], r['semantic_idx_u8'].long()
+    fg = r['foreground']
+    # argmax agrees with torch on the device
+    assert (sem == logits.argmax(dim=1)).all()
+    assert (fg == is_thing[sem]).all()
+    # instances only on foreground, every fg pixel got one (no threshold)
+    assert ((inst > 0) == fg).all()
+    # stuff pixels carry class*65536; thing pixels carry a per-class running number
+    stuff = ~fg
+    assert (pan[stuff] == (sem[stuff] + 1) * 65536).all()
+    assert (pan[fg] % 65536 > 0).all()
+    assert (r['panoptic_semantic'] == pan // 65536).all()
+    # the id dict is a bijection between used instance ids and panoptic ids
+    n_ids = r['n_ids'].cpu().numpy()
+    for b in range(B):
+        used = torch.unique(inst[b][inst[b] > 0]).cpu().numpy()
+        ids_ins = r['ids_ins'][b, :n_ids[b]].cpu().numpy()
+        assert (np.sort(ids_ins) == used).all()
+        pans = torch.unique(pan[b][fg[b]]).cpu().numpy()
+        assert (np.sort(r['ids_pan'][b, :n_ids[b]].cpu().numpy()) == pans).all()
+    # area sums to the number of foreground pixels
+    assert (r['area'].sum(dim=1).cpu() == fg.flatten(1).sum(dim=1).cpu()).all()
+    # idempotence / determinism: a second run is bit-identical
+    r2 = ops.panoptic_pipeline(logits, center, offset, is_thing)
+    assert (r2['panoptic'] == pan).all() and (r2['instance'] == inst).all()
