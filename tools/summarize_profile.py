@@ -1,0 +1,80 @@
+#!/usr/bin/env python3
+"""Condense rocprofv3 CSV output (gpurun_out/prof/...) into the small summaries
+committed under profiles/.
+
+    python tools/summarize_profile.py <tag> <kernel_stats.csv> [<fetch_counter.csv> <write_counter.csv>] [<bench.log>]
+
+Writes profiles/<tag>_kernel_stats.csv (nmsa kernels + memsets only),
+profiles/<tag>_traffic.json (per-launch HBM bytes per kernel; FETCH_SIZE is
+doubled for the 16-B-per-lane streaming kernels as MI355X_MICROARCH.md §HBM
+prescribes for gfx950) and copies the bench JSON line.
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+PROF = os.path.join(ROOT, 'profiles')
+
+# kernels whose global loads are 16 B (or 8 B) per lane coalesced streams: FETCH_SIZE x2
+WIDE_STREAM = ('k_panoptic_fused', 'k_paint', 'k_semantic_argmax', 'k_group_offsets',
+               'k_confmat', 'k_pq_count', 'k_loss')
+
+
+def short(name):
+    name = name.replace('void ', '')
+    for tok in name.replace('(', ' ').replace('<', ' ').split():
+        if 'k_' in tok or 'rocclr' in tok:
+            return tok.split('::')[-1]
+    return name[:40]
+
+
+def main():
+    tag = sys.argv[1]
+    stats = sys.argv[2]
+    os.makedirs(PROF, exist_ok=True)
+    rows = list(csv.DictReader(open(stats)))
+    keep = [r for r in rows if 'nmsa' in r['Name'] or 'rocclr' in r['Name']]
+    with open(os.path.join(PROF, f'{tag}_kernel_stats.csv'), 'w', newline='') as f:
+        w = csv.writer(f)
+        w.writerow(['Kernel', 'Calls', 'AverageNs', 'MinNs', 'MaxNs', 'StdDev', 'TotalDurationNs',
+                    'FullName'])
+        for r in keep:
+            w.writerow([short(r['Name']), r['Calls'], r['AverageNs'], r['MinNs'], r['MaxNs'],
+                        r['StdDev'], r['TotalDurationNs'], r['Name'][:160]])
+    print(f'wrote profiles/{tag}_kernel_stats.csv ({len(keep)} kernels)')
+
+    args = sys.argv[3:]
+    counter_files = [a for a in args if a.endswith('.csv')]
+    logs = [a for a in args if not a.endswith('.csv')]
+    if counter_files:
+        agg = collections.defaultdict(lambda: collections.defaultdict(list))
+        for cf in counter_files:
+            for r in csv.DictReader(open(cf)):
+                if 'nmsa' in r['Kernel_Name']:
+                    agg[short(r['Kernel_Name'])][r['Counter_Name']].append(float(r['Counter_Value']))
+        out = {}
+        for k, d in agg.items():
+            fetch_kb = sum(d['FETCH_SIZE']) / max(len(d['FETCH_SIZE']), 1) if 'FETCH_SIZE' in d else None
+            write_kb = sum(d['WRITE_SIZE']) / max(len(d['WRITE_SIZE']), 1) if 'WRITE_SIZE' in d else None
+            wide = any(k.startswith(w_) for w_ in WIDE_STREAM)
+            e = {'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
+                 'fetch_correction': 2.0 if wide else 1.0}
+            if fetch_kb is not None and write_kb is not None:
+                e['hbm_bytes_per_launch'] = (fetch_kb * e['fetch_correction'] + write_kb) * 1024
+            out[k] = e
+        with open(os.path.join(PROF, f'{tag}_traffic.json'), 'w') as f:
+            json.dump(out, f, indent=1)
+        print(f'wrote profiles/{tag}_traffic.json')
+    for lg in logs:
+        for line in open(lg):
+            if line.startswith('{"metric"'):
+                with open(os.path.join(PROF, f'{tag}_bench.json'), 'w') as f:
+                    f.write(line)
+                print(f'wrote profiles/{tag}_bench.json')
+
+
+if __name__ == '__main__':
+    main()
