@@ -1,0 +1,210 @@
+"""
+`PanopticPostprocessing` on the MI355X
+(reference model/postprocessing/panoptic.py:23-316).
+
+The reference runs softmax -> max -> isin -> per-image nearest-center loops ->
+`.cpu()` -> per-instance Python loops of `deeplab_merge_batch`.  Here the
+inference path is four stream-ordered HIP launches (ops.panoptic_pipeline):
+center NMS/top-k, ONE fused pass over the logits (argmax + foreground +
+offset grouping + per-instance class votes), the per-instance class/rank
+assignment and the paint kernel; everything stays on the GPU and the Python
+dicts (`..._ids`, `..._instance_meta`) are built from one small D2H copy.
+"""
+from typing import Dict, List, Tuple
+
+import numpy as np
+import torch
+
+from ... import ops
+from ...data.preprocessing.resize import get_fullres_key
+from ...data.preprocessing.resize import get_valid_region_slices_and_fullres_shape
+from ...types import BatchType
+from ...types import DecoderRawOutputType
+from ...types import PostprocessingOutputType
+from ...utils.panoptic_merge import _ids_to_dicts
+from ._lazy import LazyDict
+from .dense_base import DensePostprocessingBase
+from .instance import InstancePostprocessing
+from .semantic import SemanticPostprocessing
+
+
+class PanopticPostprocessing(DensePostprocessingBase):
+    def __init__(
+        self,
+        semantic_postprocessing: SemanticPostprocessing,
+        instance_postprocessing: InstancePostprocessing,
+        semantic_classes_is_thing: Tuple[bool],
+        semantic_class_has_orientation: Tuple[bool],
+        normalized_offset: bool = True,
+        compute_scores: bool = False,
+        **kwargs
+    ) -> None:
+        super().__init__()
+        self._semantic_postprocessing = semantic_postprocessing
+        self._instance_postprocessing = instance_postprocessing
+
+        self._is_thing = np.asarray(semantic_classes_is_thing, dtype=bool)
+        self._has_orientation = np.asarray(semantic_class_has_orientation, dtype=bool)
+        # class indices (network output domain, no void) / panoptic class values (+1)
+        self._thing_class_ids = np.where(self._is_thing)[0]
+        self._thing_ids_panoptic = self._thing_class_ids + 1
+        self._orientation_ids = np.where(self._has_orientation)[0] + 1
+
+        self._normalized_offset = normalized_offset
+        self._compute_scores = compute_scores
+        self._max_instances_per_category = 1 << 16
+        self._device_luts: Dict[torch.device, Tuple[torch.Tensor, torch.Tensor]] = {}
+
+    @property
+    def max_instances_per_category(self):
+        return self._max_instances_per_category
+
+    def _luts(self, device):
+        if device not in self._device_luts:
+            thing = torch.from_numpy(self._is_thing.astype(np.uint8)).to(device)
+            # orientation lut in the panoptic class-value domain (0 = void)
+            ori = np.zeros((len(self._has_orientation) + 1,), np.uint8)
+            ori[1:] = self._has_orientation
+            self._device_luts[device] = (thing, torch.from_numpy(ori).to(device))
+        return self._device_luts[device]
+
+    def _postprocess_training(
+        self, data: DecoderRawOutputType, batch: BatchType
+    ) -> PostprocessingOutputType:
+        (s_output, i_output), (s_side_outputs, i_side_outputs) = data
+        r = self._semantic_postprocessing._postprocess_training((s_output, s_side_outputs), batch)
+        r.update(self._instance_postprocessing._postprocess_training((i_output, i_side_outputs), batch))
+        return r
+
+    def _postprocess_inference(
+        self, data: DecoderRawOutputType, batch: BatchType
+    ) -> PostprocessingOutputType:
+        (s_output, i_output), (s_side_outputs, i_side_outputs) = data
+        post = self._instance_postprocessing
+        with_orientation = (len(i_output) == 3)
+        if with_orientation:
+            center_heatmap, center_offset, orientation = i_output
+        else:
+            center_heatmap, center_offset = i_output
+        dev = s_output.device
+        thing_lut, ori_lut = self._luts(dev)
+
+        # ---- the hot path: 4 launches, no host sync ---------------------------------
+        while True:
+            p = ops.panoptic_pipeline(
+                s_output, center_heatmap, center_offset, thing_lut,
+                threshold=post._heatmap_threshold,
+                kernel_size=post._heatmap_nms_kernel_size,
+                top_k=post._top_k_instances,
+                apply_foreground_mask=post._heatmap_apply_foreground_mask,
+                normalized_offset=self._normalized_offset,
+                distance_threshold=post._offset_distance_threshold,
+                max_instances_per_category=self._max_instances_per_category,
+                void_label=0, max_centers=post._max_centers,
+                want_score=True, want_foreground=True, want_panoptic_semantic=True)
+            n_host = p['n_centers'].cpu()          # the one sync of this step
+            n_max = int(n_host.max()) if n_host.numel() else 0
+            if n_max <= post._max_centers:
+                break
+            post._max_centers = 1 << (n_max - 1).bit_length()
+
+        # ---- semantic entries (semantic.py:46-80) -------------------------------------
+        r = LazyDict(semantic_output=s_output, semantic_side_outputs=s_side_outputs)
+        sem_u8 = p['semantic_idx_u8']
+        r.set_lazy('semantic_softmax_scores', lambda: ops.semantic_softmax(s_output))
+        r['semantic_segmentation_score'] = p['semantic_score']
+        r.set_lazy('semantic_segmentation_idx', lambda: sem_u8.long())
+        self._semantic_postprocessing._fullres_entries(r, s_output, batch)
+
+        # ---- instance entries (instance.py:337-468): GT-foreground variants etc. ------
+        r.merge(post._postprocess_inference((i_output, i_side_outputs), batch))
+
+        # ---- panoptic entries (panoptic.py:118-167) ---------------------------------------
+        panoptic_seg = p['panoptic']
+        instance_seg = p['instance']
+        pan_semantic = p['panoptic_semantic']
+        r['panoptic_foreground_mask'] = p['foreground']
+        r['panoptic_segmentation_deeplab'] = panoptic_seg
+        panoptic_ids = _ids_to_dicts(p['ids_pan'], p['ids_ins'], p['n_ids'])
+        r['panoptic_segmentation_deeplab_ids'] = panoptic_ids
+        r['panoptic_segmentation_deeplab_semantic_idx'] = pan_semantic
+        r['panoptic_segmentation_deeplab_instance_idx'] = instance_seg
+        meta = InstancePostprocessing._meta_from_tables(
+            n_host.tolist(), p['centers_yx'], p['center_scores'], p['area'])
+        r['panoptic_segmentation_deeplab_instance_meta'] = meta
+
+        if self._compute_scores:
+            self._add_scores(r, p, panoptic_ids, meta)
+
+        # ---- full resolution (panoptic.py:242-291) --------------------------------------
+        crop, shape = get_valid_region_slices_and_fullres_shape(batch, 'instance')
+
+        def _fullres(t):
+            return self._crop_to_valid_region_and_resize_prediction(
+                t, valid_region_slices=crop, shape=shape, mode='nearest')
+
+        keys = ['panoptic_segmentation_deeplab',
+                'panoptic_segmentation_deeplab_instance_idx',
+                'panoptic_segmentation_deeplab_semantic_idx']
+        if self._compute_scores:
+            keys += ['panoptic_segmentation_deeplab_semantic_score',
+                     'panoptic_segmentation_deeplab_instance_score',
+                     'panoptic_segmentation_deeplab_panoptic_score']
+        for k in keys:
+            r[get_fullres_key(k)] = _fullres(r[k])
+
+        # ---- orientation (panoptic.py:294-314) ---------------------------------------------
+        if with_orientation:
+            fg_orientation = ori_lut[pan_semantic].to(torch.bool)
+            ori = post._get_instance_orientation(orientation, instance_seg, fg_orientation)
+            r['orientations_panoptic_segmentation_deeplab_instance'] = ori
+            for b, m in enumerate(meta):
+                for id_ in m:
+                    m[id_]['orientation'] = ori[b].get(id_, float('nan'))
+        return r
+
+    # next-3: per-instance score maps of panoptic.py:171-239, vectorised
+    # on the device with torch segment reductions (no per-instance Python loops over
+    # full images); not part of the HIP-kernel rows yet.
+    def _add_scores(self, r, p, panoptic_ids: List[dict], meta: List[dict]) -> None:
+        probs = r['semantic_softmax_scores']
+        pan_semantic = p['panoptic_semantic']
+        panoptic_seg = p['panoptic']
+        inst = p['instance'].long()
+        B = inst.shape[0]
+        void = pan_semantic == 0
+        idx = (pan_semantic - 1).clamp_(min=0).unsqueeze(1)
+        sem_score = torch.take_along_dim(probs, idx, dim=1).squeeze(1)
+        sem_score = sem_score.masked_fill(void, 0.0)
+        r['panoptic_segmentation_deeplab_semantic_score'] = sem_score
+
+        # pixels painted with an instance's panoptic id: inst > 0 and pan == pan_of_inst
+        pan_of_inst = p['pan_of_inst']                                    # [B,256]
+        painted = (inst > 0) & (panoptic_seg == torch.gather(pan_of_inst, 1, inst.flatten(1)).view_as(inst))
+        flat_key = (torch.arange(B, device=inst.device).view(B, 1, 1) * 256 + inst)[painted]
+        sums = torch.zeros((B * 256,), dtype=torch.float32, device=inst.device)
+        cnts = torch.zeros((B * 256,), dtype=torch.float32, device=inst.device)
+        sums.index_add_(0, flat_key, sem_score[painted])
+        cnts.index_add_(0, flat_key, torch.ones_like(sem_score[painted]))
+        mean_sem = (sums / cnts.clamp(min=1)).view(B, 256)
+        score_tab = torch.zeros((B, 256), dtype=torch.float32, device=inst.device)
+        k = min(p['center_scores'].shape[1], 255)
+        score_tab[:, 1:k + 1] = p['center_scores'][:, :k]
+        inst_score = torch.where(painted, torch.gather(score_tab, 1, inst.flatten(1)).view_as(inst),
+                                 torch.zeros((), device=inst.device))
+        pan_score = torch.where(
+            painted,
+            (torch.gather(mean_sem, 1, inst.flatten(1)) * torch.gather(score_tab, 1, inst.flatten(1))).view_as(inst),
+            sem_score)
+        r['panoptic_segmentation_deeplab_instance_score'] = inst_score
+        r['panoptic_segmentation_deeplab_panoptic_score'] = pan_score
+
+        mean_host = mean_sem.cpu().tolist()
+        sem_of_inst = (pan_of_inst // self._max_instances_per_category).cpu().tolist()
+        for b in range(B):
+            for pan_id, ins_id in panoptic_ids[b].items():
+                m = meta[b][ins_id]
+                m['semantic_score'] = mean_host[b][ins_id]
+                m['semantic_idx'] = sem_of_inst[b][ins_id]
+                m['panoptic_score'] = mean_host[b][ins_id] * m['score']
+                m['panoptic_id'] = pan_id

@@ -1,0 +1,64 @@
+"""`SemanticPostprocessing` on the MI355X
+(reference model/postprocessing/semantic.py:17-82).
+
+argmax + score come from ONE pass of `nmsa_semantic_argmax` over the logits
+(the reference materialises the full softmax first); the softmax map itself is
+a lazy entry produced by `nmsa_semantic_softmax` when somebody reads it.
+"""
+import torch
+
+from ... import ops
+from ...data.preprocessing.resize import get_fullres_key
+from ...data.preprocessing.resize import get_valid_region_slices_and_fullres_shape
+from ...types import BatchType
+from ...types import DecoderRawOutputType
+from ...types import PostprocessingOutputType
+from ._lazy import LazyDict
+from .dense_base import DensePostprocessingBase
+
+
+class SemanticPostprocessing(DensePostprocessingBase):
+    def __init__(self, **kwargs):
+        super().__init__()
+
+    def _postprocess_training(
+        self, data: DecoderRawOutputType, batch: BatchType
+    ) -> PostprocessingOutputType:
+        output, side_outputs = data
+        return {'semantic_output': output, 'semantic_side_outputs': side_outputs}
+
+    @staticmethod
+    def _argmax_entries(r: LazyDict, logits: torch.Tensor, suffix: str = '') -> None:
+        """idx / score now, softmax lazily (semantic.py:52-59 / :71-80)."""
+        am = ops.semantic_argmax(logits, want_u8=False, want_i64=True, want_score=True)
+        r.set_lazy('semantic_softmax_scores' + suffix, lambda: ops.semantic_softmax(logits))
+        r['semantic_segmentation_score' + suffix] = am['score']
+        r['semantic_segmentation_idx' + suffix] = am['idx']
+
+    def _fullres_entries(self, r: LazyDict, output: torch.Tensor, batch: BatchType,
+                         same_resolution_source: str = '') -> None:
+        crop, shape = get_valid_region_slices_and_fullres_shape(batch, 'semantic')
+        output_fullres = self._crop_to_valid_region_and_resize_prediction(
+            output, valid_region_slices=crop, shape=shape, mode='bilinear')
+        r[get_fullres_key('semantic_output')] = output_fullres
+        if output_fullres.shape == output.shape and \
+                output_fullres.data_ptr() == output.data_ptr():
+            # nothing was cropped or resized: the fullres entries are the same
+            # functions of the same logits -> share them (bit-identical)
+            for k in ('semantic_softmax_scores', 'semantic_segmentation_score',
+                      'semantic_segmentation_idx'):
+                if r.is_pending(k):
+                    r.set_lazy(get_fullres_key(k), (lambda kk: (lambda: r[kk]))(k))
+                else:
+                    r[get_fullres_key(k)] = r[k]
+        else:
+            self._argmax_entries(r, output_fullres.contiguous(), suffix='_fullres')
+
+    def _postprocess_inference(
+        self, data: DecoderRawOutputType, batch: BatchType
+    ) -> PostprocessingOutputType:
+        output, side_outputs = data
+        r = LazyDict(semantic_output=output, semantic_side_outputs=side_outputs)
+        self._argmax_entries(r, output)
+        self._fullres_entries(r, output, batch)
+        return r

@@ -1,0 +1,95 @@
+"""
+Semantic + instance -> panoptic merge on the MI355X.
+
+Drop-in for the reference's `utils/panoptic_merge.py` entry points that sit on
+the hot path (`deeplab_merge_batch` :18-40, `deeplab_merge_semantic_and_instance`
+:172-225).  The arithmetic runs in the HIP kernels k_merge_votes / k_assign /
+k_merge_paint (csrc/panoptic.hip) through `nmsa_panoptic_merge`.
+
+The numpy twins of the reference (`*_np`, used only by the CPU dataloader's
+PanopticTargetGenerator) are GT-side and out of scope (SURVEY.md §8 a5').
+"""
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import ops
+
+_MAX_INSTANCE_ID = 255
+
+
+def _ids_to_dicts(ids_pan: torch.Tensor, ids_ins: torch.Tensor,
+                  n_ids: torch.Tensor) -> List[Dict[int, int]]:
+    """ONE device->host copy of the small per-image id tables."""
+    packed = torch.cat([ids_pan, ids_ins, n_ids.to(torch.int64).unsqueeze(1)], dim=1).cpu()
+    k = ids_pan.shape[1]
+    out = []
+    for row in packed.tolist():
+        n = row[2 * k]
+        out.append({row[i]: row[k + i] for i in range(n)})    # insertion order = ascending id
+    return out
+
+
+def deeplab_merge_batch(
+    semantic_batch: torch.Tensor,
+    instance_batch: torch.Tensor,
+    instance_fg_batch: torch.Tensor,
+    max_instances_per_category: int,
+    thing_ids: Sequence[int],
+    void_label: int,
+    n_classes: Optional[int] = None,
+) -> Tuple[torch.Tensor, List[Dict[int, int]]]:
+    """Same signature/returns as the reference (panoptic_merge.py:18-40) plus the
+    optional `n_classes` (number of class VALUES incl. void; saves one device
+    reduction).  Tensors on the GPU stay there; CPU tensors (what the reference's
+    callers pass after `.cpu()`) are uploaded, merged by the HIP kernels and the
+    panoptic map is returned on the CPU like the reference does."""
+    if not torch.cuda.is_available():
+        raise ops.L.NmsaError('deeplab_merge_batch needs the MI355X HIP path '
+                              '(no CPU fallback in this package)')
+    in_device = semantic_batch.device
+    dev = in_device if in_device.type == 'cuda' else torch.device('cuda', torch.cuda.current_device())
+    sem = semantic_batch.to(dev)
+    ins = instance_batch.to(dev)
+    fg = instance_fg_batch.to(dev)
+    if sem.is_floating_point() or ins.is_floating_point():
+        raise TypeError('semantic / instance maps must be integer tensors')
+    if sem.ndim != 3 or ins.shape != sem.shape or fg.shape != sem.shape:
+        raise ValueError('expected three tensors of shape (B, H, W)')
+
+    # value-range checks: one small reduction (ids are uint8 on the prediction path)
+    if ins.dtype not in (torch.uint8, torch.bool):
+        if int(ins.max()) > _MAX_INSTANCE_ID:
+            raise NotImplementedError(
+                f'instance ids > {_MAX_INSTANCE_ID} are not supported by the HIP merge yet '
+                '(the prediction path produces uint8 ids, reference instance.py:236)')
+    if n_classes is None:
+        n_classes = int(sem.max()) + 1
+    thing_list = [int(t) for t in thing_ids]
+    n_classes = max(n_classes, 1)
+    lut = torch.zeros((n_classes,), dtype=torch.uint8)
+    for t in thing_list:
+        if 0 <= t < n_classes:
+            lut[t] = 1
+    r = ops.panoptic_merge(sem, ins, fg, lut.to(dev), int(max_instances_per_category),
+                           int(void_label))
+    dicts = _ids_to_dicts(r['ids_pan'], r['ids_ins'], r['n_ids'])
+    pan = r['panoptic']
+    if in_device.type != 'cuda':
+        pan = pan.to(in_device)
+    return pan, dicts
+
+
+def deeplab_merge_semantic_and_instance(
+    sem_seg: torch.Tensor,
+    ins_seg: torch.Tensor,
+    semantic_thing_seg: torch.Tensor,
+    max_instances_per_category: int,
+    thing_ids: Sequence[int],
+    void_label: int,
+) -> Tuple[torch.Tensor, Dict[int, int]]:
+    """Single-image form (panoptic_merge.py:172-225)."""
+    pan, dicts = deeplab_merge_batch(sem_seg.unsqueeze(0), ins_seg.unsqueeze(0),
+                                     semantic_thing_seg.unsqueeze(0),
+                                     max_instances_per_category, thing_ids, void_label)
+    return pan[0], dicts[0]
