@@ -185,6 +185,52 @@ int nmsa_instance_orientation(const float* orientation, const uint8_t* inst,
                               const uint8_t* mask, int B, int H, int W,
                               double* sums, int32_t* count, nmsa_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * a11  MeanIntersectionOverUnion.update   metric/miou.py:44-56
+ *   confmat[t, p] += 1 for every element (bincount(t*n + p, minlength=n*n)).
+ *   preds / target: any integer dtype, n_px elements each.
+ *   pred_div : preds are used as raw // pred_div (1 = as is; 65536 gives the
+ *              `pan // max_instances_per_category` of task_helper/panoptic.py:123)
+ *   mode 0   : every element counts
+ *   mode 1   : elements with target == 0 are skipped and target-1 is used
+ *              (the void masking of task_helper/semantic.py:124-128)
+ *   confmat  : i64 [n_classes, n_classes], accumulated into (not zeroed)
+ *   status   : i32 [1] device word, OR-ed with NMSA_ST_* bits (value out of range
+ *              = what makes the reference's bincount/reshape raise)
+ * ------------------------------------------------------------------------- */
+#define NMSA_ST_TABLE_OVERFLOW 1
+#define NMSA_ST_CATEGORY_RANGE 2
+#define NMSA_ST_MISSING_KEY 4
+#define NMSA_ST_VALUE_RANGE 8
+#define NMSA_ST_SENTINEL_KEY 16
+int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pred_div,
+                        const void* target, int target_dtype,
+                        int64_t n_px, int n_classes, int mode,
+                        int64_t* confmat, int32_t* status, nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * a12/a13  compare_and_accumulate + PanopticQuality.update
+ *     metric/pq.py:60-179, :262-296
+ *   pred, target : i64 [B,H,W] panoptic maps (category*max_inst + instance)
+ *   iou/tp/fn/fp : f64 [num_categories] states, accumulated into (image order;
+ *                  the IoU sums are bit-identical to the reference's fp64 sums)
+ *   matches      : i64 [B,match_capacity,2] (gt id, pred id) of the TP pairs in
+ *                  ascending intersection-id order, or NULL; n_matches i32 [B]
+ *   status       : i32 [1] device word, OR-ed with NMSA_ST_* bits
+ *   limits       : <= 2048 distinct ids per image and side, <= 4096 distinct
+ *                  intersections per image, num_categories <= 1024
+ * ------------------------------------------------------------------------- */
+size_t nmsa_pq_workspace_bytes(int B, int num_categories);
+int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int W,
+                   int num_categories, int64_t ignored_label,
+                   int64_t max_instances_per_category, int64_t offset,
+                   int64_t void_segment_id,
+                   double* iou_per_class, double* tp_per_class,
+                   double* fn_per_class, double* fp_per_class,
+                   int64_t* matches, int match_capacity, int32_t* n_matches,
+                   int32_t* status, void* workspace, size_t workspace_bytes,
+                   nmsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

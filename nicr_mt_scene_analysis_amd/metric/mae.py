@@ -1,0 +1,111 @@
+"""Orientation MAE on matched instances (reference metric/mae.py:15-172).
+
+The PQ part runs on the device; the per-matched-pair angle bookkeeping works on
+Python dicts of <= a few dozen floats per image and stays on the host
+("MAAE scalars stay host-side")."""
+import math
+from typing import Dict, List, Optional, Tuple
+
+import torch
+
+from .base import Metric
+from .pq import PanopticQuality
+
+OrientationDict = Dict[int, float]
+
+
+def abs_angle_error_rad(pred_angle: torch.Tensor, target_angle: torch.Tensor) -> torch.Tensor:
+    two_pi = 2 * math.pi
+    diff = (pred_angle % two_pi) - (target_angle % two_pi)
+    return torch.abs((diff + math.pi) % two_pi - math.pi)        # in [0, pi]
+
+
+def _abs_angle_error_f32(pred_angle: float, target_angle: float) -> float:
+    """same fp32 arithmetic as `abs_angle_error_rad(torch.tensor(a), torch.tensor(b))`"""
+    return float(abs_angle_error_rad(torch.tensor(pred_angle), torch.tensor(target_angle)))
+
+
+class MeanAbsoluteAngularError(Metric):
+    def __init__(self, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self.add_state('sum_angular_error', torch.tensor(0, dtype=torch.float64),
+                       dist_reduce_fx='sum')
+        self.add_state('n_elements', torch.tensor(0, dtype=torch.int64),
+                       dist_reduce_fx='sum')
+
+    def update(self, orientation_preds: List[OrientationDict],
+               orientation_target: List[OrientationDict]) -> None:
+        total, n = 0.0, 0
+        for preds, targets in zip(orientation_preds, orientation_target):
+            for key, pred_angle in preds.items():
+                total += _abs_angle_error_f32(float(pred_angle), float(targets[key]))
+                n += 1
+        self.sum_angular_error += total
+        self.n_elements += n
+
+    def compute(self) -> Tuple[torch.Tensor, torch.Tensor]:
+        rad = self.sum_angular_error / self.n_elements
+        return rad, torch.rad2deg(rad)
+
+
+class PanopticQualityWithOrientationMAE(PanopticQuality):
+    def __init__(self, *args, **kwargs) -> None:
+        super().__init__(*args, **kwargs)
+        self.add_state('sum_angular_error', torch.tensor(0, dtype=torch.float64),
+                       dist_reduce_fx='sum')
+        self.add_state('n_elements', torch.tensor(0, dtype=torch.int64),
+                       dist_reduce_fx='sum')
+
+    def update(self,
+               panoptic_preds: torch.Tensor,
+               orientation_preds: Optional[List[OrientationDict]],
+               panoptic_preds_id_dicts: Optional[List[Dict]],
+               panoptic_target: torch.Tensor,
+               orientation_target: Optional[List[OrientationDict]],
+               panoptic_target_id_dicts: Optional[List[Dict]]) -> None:
+        assert panoptic_preds.ndim == 3
+        assert len(panoptic_target) == len(panoptic_preds)
+        with_mae = orientation_preds is not None and orientation_target is not None
+        res = self._device_update(panoptic_preds, panoptic_target, want_matches=with_mae)
+        if not with_mae:
+            return
+        matches, n_matches = res
+        n_host = n_matches.cpu().tolist()               # the one sync of this update
+        self._check_status()
+        if max(n_host, default=0) > self._match_capacity:
+            raise ValueError('more matched segments per image than the match table holds')
+        m_host = matches.cpu().tolist()
+        for b, n in enumerate(n_host):
+            self.update_mae(orientation_preds[b], panoptic_preds_id_dicts[b],
+                            orientation_target[b], panoptic_target_id_dicts[b],
+                            [tuple(m_host[b][i]) for i in range(n)])
+
+    def update_mae(self, orientation_preds: OrientationDict, panoptic_preds_id_dicts: Dict,
+                   orientation_target: OrientationDict, panoptic_target_id_dicts: Dict,
+                   matching: List[Tuple[int, int]]) -> None:
+        total, n = 0.0, 0
+        for target_id, pred_id in matching:
+            if target_id == 0:                                  # stuff / void / background
+                continue
+            if target_id not in panoptic_target_id_dicts:
+                continue
+            target_instance = panoptic_target_id_dicts[target_id]
+            if target_instance not in orientation_target:
+                continue
+            if pred_id not in panoptic_preds_id_dicts:
+                continue
+            pred_instance = panoptic_preds_id_dicts[pred_id]
+            if pred_instance not in orientation_preds:
+                continue
+            total += _abs_angle_error_f32(float(orientation_preds[pred_instance]),
+                                          float(orientation_target[target_instance]))
+            n += 1
+        self.sum_angular_error += total
+        self.n_elements += n
+
+    def compute(self, suffix: str = '') -> Dict[str, torch.Tensor]:
+        r = super().compute(suffix=suffix)
+        rad = self.sum_angular_error / self.n_elements
+        r[f'mae{suffix}_rad'] = rad
+        r[f'mae{suffix}_deg'] = torch.rad2deg(rad)
+        return r

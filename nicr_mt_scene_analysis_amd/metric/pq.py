@@ -1,0 +1,153 @@
+"""`PanopticQuality` with device-resident accumulators
+(reference metric/pq.py:190-361; per-image matching pq.py:60-179).
+
+`update` runs k_pq_init / k_pq_count / k_pq_match / k_pq_accumulate
+(csrc/metrics.hip) through `nmsa_pq_update`; no process pool, no `.cpu()` of
+the panoptic maps.  The fp64 IoU sums are accumulated in the reference's order
+(ascending intersection id per image, images in batch order), so the states
+are bit-identical to the reference's for the same inputs.
+"""
+from typing import Dict, List, Optional, Tuple, Union
+
+import torch
+
+from .. import _lib as L
+from .base import Metric
+
+_EPSILON = 1e-10
+_STATUS_MESSAGES = {
+    1: 'more distinct segments / intersections per image than the device tables hold '
+       '(2048 ids per side, 4096 intersections)',
+    2: 'segment category outside [0, num_categories) (the reference raises IndexError)',
+    4: 'inconsistent segment ids: intersection id decodes to an unknown segment '
+       '(offset too small? the reference raises KeyError)',
+    16: 'segment id equal to INT64_MIN is reserved',
+}
+
+
+def realdiv_maybe_zero(x: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    return torch.where(torch.abs(y) < _EPSILON, torch.zeros_like(x), x / y)
+
+
+class PanopticQuality(Metric):
+    def __init__(
+        self,
+        num_categories: int,
+        ignored_label: int,
+        max_instances_per_category: int,
+        offset: int,
+        is_thing: Union[torch.Tensor, List[bool]],
+        num_workers=None,        # reference: size of the spawn pool; unused on the GPU
+        device: Optional[torch.device] = None,
+    ) -> None:
+        super().__init__(device=device)
+        self.num_categories = num_categories
+        self.ignored_label = ignored_label
+        self.max_instances_per_category = max_instances_per_category
+        self.offset = offset
+        self.is_thing = torch.as_tensor(is_thing, dtype=torch.bool).clone()
+        self.is_stuff = torch.logical_not(self.is_thing)
+        assert len(self.is_thing) == self.num_categories
+        # one void segment with instance id 0 (pq.py:220-222)
+        self.void_segment_id = self.ignored_label * self.max_instances_per_category
+        for name in ('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class'):
+            self.add_state(name, torch.zeros(self.num_categories, dtype=torch.float64),
+                           dist_reduce_fx='sum')
+        self._status = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        self._match_capacity = 1024
+
+    def to(self, device, *args, **kwargs):
+        super().to(device)
+        self._status = self._status.to(self.device)
+        return self
+
+    def reset(self) -> None:
+        super().reset()
+        if hasattr(self, '_status'):
+            self._status = torch.zeros((1,), dtype=torch.int32, device=self.device)
+
+    # ------------------------------------------------------------------ update
+    def _device_update(self, preds: torch.Tensor, targets: torch.Tensor,
+                       want_matches: bool) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+        if self.device.type != 'cuda':
+            raise L.NmsaError('PanopticQuality.update needs the MI355X '
+                              '(states live on the GPU; no CPU fallback)')
+        assert preds.ndim == 3
+        assert targets.shape == preds.shape
+        dev = self.device
+        p = preds.to(dev, dtype=torch.int64).contiguous()
+        t = targets.to(dev, dtype=torch.int64).contiguous()
+        B, H, W = p.shape
+        lib = L.lib()
+        ws_bytes = lib.nmsa_pq_workspace_bytes(B, self.num_categories)
+        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        matches = n_matches = None
+        if want_matches:
+            matches = torch.empty((B, self._match_capacity, 2), dtype=torch.int64, device=dev)
+            n_matches = torch.empty((B,), dtype=torch.int32, device=dev)
+        L.check(lib.nmsa_pq_update(
+            L.ptr(p), L.ptr(t), B, H, W, self.num_categories, int(self.ignored_label),
+            int(self.max_instances_per_category), int(self.offset), int(self.void_segment_id),
+            L.ptr(self.iou_per_class), L.ptr(self.tp_per_class), L.ptr(self.fn_per_class),
+            L.ptr(self.fp_per_class), L.ptr(matches), self._match_capacity, L.ptr(n_matches),
+            L.ptr(self._status), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), 'nmsa_pq_update')
+        if want_matches:
+            return matches, n_matches
+        return None
+
+    def update(self, preds: torch.Tensor, targets: torch.Tensor) -> None:
+        self._device_update(preds, targets, want_matches=False)
+
+    def _check_status(self) -> None:
+        st = int(self._status.item())
+        if st:
+            self._status.zero_()
+            msgs = [m for bit, m in _STATUS_MESSAGES.items() if st & bit]
+            raise ValueError('PanopticQuality: ' + '; '.join(msgs))
+
+    # ----------------------------------------------------------------- compute
+    def _valid_categories(self) -> torch.Tensor:
+        valid = (self.tp_per_class + self.fn_per_class + self.fp_per_class) != 0
+        if 0 <= self.ignored_label < self.num_categories:
+            valid[self.ignored_label] = False
+        return valid
+
+    def _valid_categories_with_gt(self) -> torch.Tensor:
+        valid = (self.tp_per_class + self.fn_per_class) != 0
+        if 0 <= self.ignored_label < self.num_categories:
+            valid[self.ignored_label] = False
+        return valid
+
+    def result_per_category(self) -> Dict[str, torch.Tensor]:
+        sq = realdiv_maybe_zero(self.iou_per_class, self.tp_per_class)
+        rq = realdiv_maybe_zero(
+            self.tp_per_class,
+            self.tp_per_class + 0.5 * self.fn_per_class + 0.5 * self.fp_per_class)
+        return {'sq_per_class': sq, 'rq_per_class': rq, 'pq_per_class': sq * rq}
+
+    def compute(self, suffix: str = '') -> Dict[str, torch.Tensor]:
+        self._check_status()
+        results = self.result_per_category()
+        valid = self._valid_categories()
+        valid_gt = self._valid_categories_with_gt()
+        thing = self.is_thing.to(valid.device)
+        stuff = self.is_stuff.to(valid.device)
+        sets = {
+            f'all{suffix}': valid,
+            f'things{suffix}': valid & thing,
+            f'stuff{suffix}': valid & stuff,
+            # variants that ignore FPs of classes without GT (fixed #categories)
+            f'all_with_gt{suffix}': valid_gt,
+            f'things_with_gt{suffix}': valid_gt & thing,
+            f'stuff_with_gt{suffix}': valid_gt & stuff,
+        }
+        for name, sel in sets.items():
+            if bool(sel.any()):
+                results[f'{name}_pq'] = results['pq_per_class'][sel].mean()
+                results[f'{name}_sq'] = results['sq_per_class'][sel].mean()
+                results[f'{name}_rq'] = results['rq_per_class'][sel].mean()
+                results[f'{name}_num_categories'] = sel.int().sum()
+            else:
+                for k in ('pq', 'sq', 'rq', 'num_categories'):
+                    results[f'{name}_{k}'] = torch.tensor(0)
+        return results

@@ -1,0 +1,354 @@
+"""
+Metric accumulators.
+
+* The six 6x6 PQ known-answer tables and the 0.63177083 / 0.84236111 case restate
+  reference tests/test_metrics.py:76-446 (values are the reference's own).  They
+  run against the C oracle on the CPU tier and against the HIP path (through
+  the PanopticQuality class, like the reference's tests) on the GPU tier.
+* Random-map goldens come from the reference's compare_and_accumulate /
+  MeanIntersectionOverUnion (oracle/gen_golden.py).
+* MAAE restates reference tests/test_metrics.py:650-688.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from _golden import load, jload
+
+T = torch.tensor
+
+
+# ---- the reference's 6x6 tables ------------------------------------------------------
+INST_A = [[1, 1, 1, 1, 1, 1],
+          [1, 2, 2, 2, 2, 1],
+          [1, 2, 2, 2, 2, 1],
+          [1, 2, 2, 2, 2, 1],
+          [1, 2, 2, 1, 1, 1],
+          [1, 2, 1, 1, 1, 1]]
+CAT_WRONG = [[0, 0, 0, 0, 0, 0],
+             [0, 1, 0, 0, 1, 0],
+             [0, 1, 1, 1, 1, 0],
+             [0, 1, 1, 1, 1, 0],
+             [0, 0, 0, 0, 0, 0],
+             [0, 0, 0, 0, 0, 0]]
+GT_IOU = [[1, 1, 1, 1, 1, 1],
+          [1, 1, 1, 1, 1, 1],
+          [1, 1, 2, 2, 2, 1],
+          [1, 2, 2, 2, 2, 1],
+          [1, 1, 1, 1, 1, 1],
+          [1, 1, 1, 1, 1, 1]]
+GOOD_DET = [[1, 1, 1, 1, 1, 1],
+            [1, 1, 1, 1, 1, 1],
+            [1, 2, 2, 2, 2, 1],
+            [1, 2, 2, 2, 1, 1],
+            [1, 1, 1, 1, 1, 1],
+            [1, 1, 1, 1, 1, 1]]
+BAD_DET = [[1, 1, 1, 1, 1, 1],
+           [1, 1, 1, 1, 1, 1],
+           [1, 1, 1, 2, 2, 1],
+           [1, 1, 1, 2, 2, 1],
+           [1, 1, 1, 2, 2, 1],
+           [1, 1, 1, 1, 1, 1]]
+CAT_STRIPES = [[1, 1, 1, 1, 1, 1],
+               [1, 1, 1, 1, 1, 1],
+               [1, 2, 2, 1, 2, 2],
+               [1, 2, 2, 1, 2, 2],
+               [1, 1, 1, 1, 1, 1],
+               [1, 1, 1, 1, 1, 1]]
+INST_RIGHT = [[0, 0, 0, 0, 0, 0],
+              [0, 0, 0, 0, 0, 0],
+              [0, 0, 0, 0, 1, 1],
+              [0, 0, 0, 0, 1, 1],
+              [0, 0, 0, 0, 0, 0],
+              [0, 0, 0, 0, 0, 0]]
+INST_LEFT = [[0, 0, 0, 0, 0, 0],
+             [0, 0, 0, 0, 0, 0],
+             [0, 1, 1, 0, 0, 0],
+             [0, 1, 1, 0, 0, 0],
+             [0, 0, 0, 0, 0, 0],
+             [0, 0, 0, 0, 0, 0]]
+
+
+def A(x):
+    return np.asarray(x, dtype=np.int64)[None]
+
+
+KNOWN = {
+    # name: (params, [(pred, target), ...], expected state rows iou/tp/fn/fp)
+    'perfect_match': (dict(num_categories=1, ignored_label=2, max_instances_per_category=16,
+                           offset=16, is_thing=[True]),
+                      [(A(INST_A), A(INST_A))],
+                      [[2.0], [2], [0], [0]]),
+    'totally_wrong': (dict(num_categories=2, ignored_label=2, max_instances_per_category=1,
+                           offset=16, is_thing=[True, True]),
+                      [(1 - A(CAT_WRONG), A(CAT_WRONG))],
+                      [[0.0, 0.0], [0, 0], [1, 1], [1, 1]]),
+    'matches_by_iou_good': (dict(num_categories=1, ignored_label=2,
+                                 max_instances_per_category=16, offset=16, is_thing=[True]),
+                            [(A(GOOD_DET), A(GT_IOU))],
+                            [[28 / 30 + 6 / 8], [2], [0], [0]]),
+    'matches_by_iou_bad': (dict(num_categories=1, ignored_label=2,
+                                max_instances_per_category=16, offset=16, is_thing=[True]),
+                           [(A(BAD_DET), A(GT_IOU))],
+                           [[27 / 32], [1], [1], [1]]),
+    'wrong_instances': (dict(num_categories=3, ignored_label=0, max_instances_per_category=10,
+                             offset=100, is_thing=[True, True, True]),
+                        [(A(CAT_STRIPES) * 10 + A(INST_RIGHT), A(CAT_STRIPES) * 10)],
+                        [[0.0, 1.0, 0.0], [0, 1, 0], [0, 0, 1], [0, 0, 2]]),
+    'instance_order_is_arbitrary': (dict(num_categories=3, ignored_label=0,
+                                         max_instances_per_category=10, offset=100,
+                                         is_thing=[True, True, True]),
+                                    [(A(CAT_STRIPES) * 10 + A(INST_RIGHT),
+                                      A(CAT_STRIPES) * 10 + A(INST_LEFT))],
+                                    [[0.0, 1.0, 2.0], [0, 1, 2], [0, 0, 0], [0, 0, 0]]),
+}
+
+
+@pytest.mark.parametrize('name', list(KNOWN.keys()))
+def test_pq_known_answers_oracle(oracle, name):
+    params, updates, want = KNOWN[name]
+    state = None
+    for pred, tgt in updates:
+        for b in range(pred.shape[0]):
+            *state, _ = oracle.pq_compare_and_accumulate(
+                pred[b], tgt[b], params['num_categories'], params['ignored_label'],
+                params['max_instances_per_category'], params['offset'], state=state)
+    np.testing.assert_array_almost_equal(state[0], want[0])
+    for s, w in zip(state[1:], want[1:]):
+        np.testing.assert_array_equal(s, w)
+
+
+# ---- GPU tier ------------------------------------------------------------------------
+gpu = pytest.mark.gpu
+
+
+@gpu
+@pytest.mark.parametrize('name', list(KNOWN.keys()))
+def test_pq_known_answers_hip(name):
+    from nicr_mt_scene_analysis_amd import metric
+    params, updates, want = KNOWN[name]
+    pq = metric.PanopticQuality(**params)
+    for pred, tgt in updates:
+        pq.update(torch.from_numpy(pred), torch.from_numpy(tgt))
+    np.testing.assert_array_almost_equal(pq.iou_per_class.cpu().numpy(), want[0])
+    np.testing.assert_array_equal(pq.tp_per_class.cpu().numpy(), want[1])
+    np.testing.assert_array_equal(pq.fn_per_class.cpu().numpy(), want[2])
+    np.testing.assert_array_equal(pq.fp_per_class.cpu().numpy(), want[3])
+
+
+@gpu
+def test_pq_compute_values_hip():
+    """compute(): numbers of reference tests/test_metrics.py:76-446"""
+    from nicr_mt_scene_analysis_amd import metric
+    p, _, _ = KNOWN['matches_by_iou_good']
+    pq = metric.PanopticQuality(**p)
+    pq.update(torch.from_numpy(A(GOOD_DET)), torch.from_numpy(A(GT_IOU)))
+    r = pq.compute()
+    assert r['pq_per_class'].cpu().numpy() == pytest.approx([(28 / 30 + 6 / 8) / 2], abs=0)
+    assert float(r['all_pq']) == (28 / 30 + 6 / 8) / 2
+    assert float(r['all_rq']) == 1.0 and int(r['all_num_categories']) == 1
+    pq.reset()
+    pq.update(torch.from_numpy(A(BAD_DET)), torch.from_numpy(A(GT_IOU)))
+    r = pq.compute()
+    assert float(r['all_pq']) == 27 / 32 / 2 and float(r['all_rq']) == 0.5
+    assert float(r['all_sq']) == 27 / 32
+
+    p, updates, _ = KNOWN['wrong_instances']
+    pq = metric.PanopticQuality(**p)
+    pq.update(*[torch.from_numpy(x) for x in updates[0]])
+    r = pq.compute()
+    np.testing.assert_array_equal(r['pq_per_class'].cpu().numpy(), [0.0, 1.0, 0.0])
+    assert float(r['all_pq']) == 0.5 and int(r['all_num_categories']) == 2
+
+    # multiple batches (batch size 2, two updates; note the swapped argument order of the
+    # reference test :406 / :423)
+    pq = metric.PanopticQuality(num_categories=1, ignored_label=2, max_instances_per_category=16,
+                                offset=16, is_thing=[True])
+    gt2 = torch.from_numpy(np.concatenate([A(GT_IOU), A(GT_IOU)]))
+    good2 = torch.from_numpy(np.concatenate([A(GOOD_DET), A(GOOD_DET)]))
+    bad2 = torch.from_numpy(np.concatenate([A(BAD_DET), A(BAD_DET)]))
+    pq.update(gt2, good2)
+    pq.update(gt2, bad2)
+    r = pq.compute()
+    np.testing.assert_array_equal(r['pq_per_class'].cpu().numpy(),
+                                  [((28 / 30 + 6 / 8) + (27 / 32)) / 2 / 2])
+    np.testing.assert_array_equal(r['rq_per_class'].cpu().numpy(), [3 / 4])
+    np.testing.assert_array_equal(r['sq_per_class'].cpu().numpy(),
+                                  [((28 / 30 + 6 / 8) + (27 / 32)) / 3])
+    np.testing.assert_almost_equal(float(r['all_pq']), 0.63177083)
+    np.testing.assert_almost_equal(float(r['all_sq']), 0.84236111)
+    assert float(r['all_rq']) == 0.75
+
+    # nothing valid -> zeros (pq.py:352-359)
+    pq = metric.PanopticQuality(num_categories=2, ignored_label=0, max_instances_per_category=16,
+                                offset=256, is_thing=[False, True])
+    r = pq.compute()
+    assert int(r['all_pq']) == 0 and int(r['things_num_categories']) == 0
+
+
+@gpu
+def test_pq_random_vs_golden_bit_exact():
+    from nicr_mt_scene_analysis_amd import metric
+    g = load('metric_cases')
+    p = jload(g['pq_params'])
+    for name in ('shift', 'indep'):
+        pq = metric.PanopticQualityWithOrientationMAE(is_thing=[c >= p['num_categories'] // 2
+                                                                for c in range(p['num_categories'])],
+                                                      **p)
+        pred, tgt = g[f'pq_{name}__pred'], g[f'pq_{name}__target']
+        B = pred.shape[0]
+        res = pq._device_update(torch.from_numpy(pred), torch.from_numpy(tgt), want_matches=True)
+        state = np.stack([getattr(pq, n).cpu().numpy() for n in
+                          ('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class')])
+        assert (state == g[f'pq_{name}__state']).all()          # fp64 sums bit-identical
+        matches, n = res[0].cpu().numpy(), res[1].cpu().numpy()
+        want = jload(g[f'pq_{name}__matches'])
+        for b in range(B):
+            assert sorted(map(tuple, matches[b, :n[b]].tolist())) == [tuple(x) for x in want[b]]
+        pq._check_status()
+
+
+@gpu
+def test_pq_full_size_vs_oracle(oracle):
+    """cfg4 shapes: 640x480 panoptic maps with ~50 segments, 41 categories."""
+    from nicr_mt_scene_analysis_amd import metric
+    rng = np.random.default_rng(5)
+    H, W, ncat = 480, 640, 41
+    B = 3
+    cls = np.repeat(np.repeat(rng.integers(0, ncat, (B, H // 32, W // 32)), 32, 1), 32, 2)
+    ins = np.repeat(np.repeat(rng.integers(0, 3, (B, H // 16, W // 16)), 16, 1), 16, 2)
+    pred = (cls * 65536 + ins * (cls >= 20)).astype(np.int64)
+    tgt = np.roll(pred, (5, 7), axis=(1, 2))
+    tgt[:, :11] = 0
+    pq = metric.PanopticQuality(ncat, 0, 65536, 256 ** 3, [c >= 20 for c in range(ncat)])
+    pq.update(torch.from_numpy(pred), torch.from_numpy(tgt))
+    state = None
+    for b in range(B):
+        *state, _ = oracle.pq_compare_and_accumulate(pred[b], tgt[b], ncat, 0, 65536, 256 ** 3,
+                                                     state=state)
+    got = np.stack([getattr(pq, n).cpu().numpy() for n in
+                    ('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class')])
+    assert (got == np.stack(state)).all()
+    pq.compute()
+
+
+@gpu
+def test_pq_error_reporting():
+    from nicr_mt_scene_analysis_amd import metric
+    pq = metric.PanopticQuality(2, 0, 16, 256, [False, True])
+    pq.update(T([[[5 * 16 + 1, 17]]]), T([[[5 * 16 + 1, 17]]]))     # category 5 >= 2
+    with pytest.raises(ValueError):
+        pq.compute()
+
+
+@gpu
+def test_miou_vs_golden():
+    from nicr_mt_scene_analysis_amd import metric
+    g = load('metric_cases')
+    for n in (5, 41, 101):
+        pred, tgt = g[f'miou_{n}__pred'], g[f'miou_{n}__target']
+        for ign in (0, 1):
+            m = metric.MeanIntersectionOverUnion(n, ignore_first_class=bool(ign))
+            m.update(torch.from_numpy(pred[:2]).cuda(), torch.from_numpy(tgt[:2]).cuda())
+            m.update(torch.from_numpy(pred[2:]).long(), torch.from_numpy(tgt[2:]))   # CPU in, mixed dtypes
+            assert (m.confmat.cpu().numpy() == g[f'miou_{n}_{ign}__confmat']).all()
+            miou, ious = m.compute(return_ious=True)
+            np.testing.assert_allclose(float(miou), g[f'miou_{n}_{ign}__miou'], rtol=1e-5)
+            np.testing.assert_allclose(ious.cpu().numpy(), g[f'miou_{n}_{ign}__ious'], rtol=1e-5,
+                                       equal_nan=True)
+            m.reset()
+            assert int(m.confmat.sum()) == 0
+
+
+@gpu
+@pytest.mark.parametrize('n_classes_without_void', (5, 40, 100))
+def test_own_miou_void_handling(n_classes_without_void):
+    """restates reference tests/test_miou.py:92-164 (without torchmetrics: the
+    two void treatments must agree, and equal a direct confusion-matrix IoU)"""
+    from nicr_mt_scene_analysis_amd import metric
+    n = n_classes_without_void
+    g = torch.Generator().manual_seed(n)
+    m = metric.MeanIntersectionOverUnion(n_classes=n)
+    m_void = metric.MeanIntersectionOverUnion(n_classes=n + 1, ignore_first_class=True)
+    m_fused = metric.MeanIntersectionOverUnion(n_classes=n)
+    cm = np.zeros((n, n), np.int64)
+    for _ in range(4):
+        preds = torch.rand((16, n, 100, 100), generator=g).argmax(dim=1)
+        target = (torch.rand((16, 100, 100), generator=g) * (n + 1)).long()
+        m_void.update(preds + 1, target)
+        m_fused.update_masked_void(preds, target)
+        mask = target != 0
+        p, t = preds[mask], target[mask] - 1
+        m.update(p, t)
+        np.add.at(cm, (t.numpy(), p.numpy()), 1)
+    miou, ious = m.compute(return_ious=True)
+    miou_v, ious_v = m_void.compute(return_ious=True)
+    assert (m.confmat.cpu().numpy() == cm).all()
+    assert (m_fused.confmat.cpu().numpy() == cm).all()
+    tp = np.diag(cm).astype(np.float64)
+    ref = (tp / (cm.sum(0) + cm.sum(1) - tp)).mean()
+    assert torch.allclose(miou, miou_v)
+    np.testing.assert_allclose(float(miou), ref, rtol=1e-5)
+    assert torch.isnan(ious_v[0])
+    assert (ious_v[1:] == ious).all()
+
+
+@gpu
+def test_miou_out_of_range_raises():
+    from nicr_mt_scene_analysis_amd import metric
+    m = metric.MeanIntersectionOverUnion(4)
+    m.update(T([0, 1, 7]), T([0, 1, 3]))     # bin 3*4+7 = 19 >= 16 (reshape fails in the reference)
+    with pytest.raises(ValueError):
+        m.compute()
+
+
+@gpu
+def test_miou_from_panoptic():
+    from nicr_mt_scene_analysis_amd import metric
+    rng = np.random.default_rng(0)
+    sem = rng.integers(0, 41, (2, 60, 80))
+    pan = torch.from_numpy(sem * 65536 + rng.integers(0, 5, sem.shape))
+    tgt = torch.from_numpy(rng.integers(0, 41, sem.shape).astype(np.uint8))
+    a = metric.MeanIntersectionOverUnion(41, ignore_first_class=True)
+    b = metric.MeanIntersectionOverUnion(41, ignore_first_class=True)
+    a.update_from_panoptic(pan, tgt, 65536)
+    b.update(pan // 65536, tgt)
+    assert (a.confmat == b.confmat).all()
+
+
+@pytest.mark.parametrize('mode', ('min', 'max'))
+def test_mean_absolute_angular_error(mode):
+    """restates reference tests/test_metrics.py:650-688 (pure host arithmetic)"""
+    from nicr_mt_scene_analysis_amd.metric.mae import MeanAbsoluteAngularError
+    mae = MeanAbsoluteAngularError(device='cpu')
+    target_deg = 180.0 if mode == 'min' else 0.0
+    g = torch.Generator().manual_seed(0)
+    for _ in range(20):
+        angles = torch.rand(50, generator=g) * 8 * math.pi - 4 * math.pi
+        tgt, pred = {}, {}
+        for k, a in enumerate(angles.tolist()):
+            tgt[k] = a
+            if mode == 'min':
+                a = a - math.pi if torch.rand(1, generator=g).item() < 0.5 else a + math.pi
+            pred[k] = a
+        mae.update([tgt], [pred])
+    rad, deg = mae.compute()
+    np.testing.assert_almost_equal(float(torch.rad2deg(rad)), float(deg), decimal=5)
+    np.testing.assert_almost_equal(float(deg), target_deg, decimal=4)
+
+
+@gpu
+def test_pq_with_orientation_mae():
+    from nicr_mt_scene_analysis_amd import metric
+    params, updates, _ = KNOWN['instance_order_is_arbitrary']
+    pq = metric.PanopticQualityWithOrientationMAE(**params)
+    pred, tgt = [torch.from_numpy(x) for x in updates[0]]
+    # the left block is pred id 20 / target id 21 (the ids are swapped between the two maps):
+    # pred id 20 <-> instance 1 with angle 0.5; target id 21 <-> instance 7 with angle 1.0
+    pq.update(pred, [{1: 0.5}], [{20: 1}], tgt, [{7: 1.0}], [{21: 7}])
+    r = pq.compute(suffix='_deeplab')
+    np.testing.assert_allclose(float(r['mae_deeplab_rad']), 0.5, rtol=1e-6)
+    assert int(pq.n_elements) == 1
+    assert float(r['all_deeplab_pq']) == 1.0
