@@ -45,16 +45,19 @@ def parse_args():
     ap.add_argument('--centers', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-metrics', action='store_true')
-    ap.add_argument('--cpu-sample-images', type=int, default=4)
+    ap.add_argument('--cpu-sample-images', type=int, default=32)
     return ap.parse_args()
 
 
-def cpu_baseline(inp_dev, n_images, C, H, W):
+def cpu_baseline(inp_dev, n_images, C, H, W, metrics=None):
     """The C oracle ("port" of the reference's CPU path) timed on the host, single
     thread, on the first `n_images` images of the very batch the GPU processes."""
     from oracle import oracle as orc
     orc.build()
     n = min(n_images, inp_dev['semantic_logits'].shape[0])
+    if metrics is not None:
+        tgt_pan = metrics.target_panoptic[:n].cpu().numpy()
+        tgt_sem = metrics.target_semantic[:n].cpu().numpy()
     logits = inp_dev['semantic_logits'][:n].float().cpu().numpy()
     center = inp_dev['instance_center'][:n].cpu().numpy()
     offset = inp_dev['instance_offset'][:n].cpu().numpy()
@@ -65,10 +68,19 @@ def cpu_baseline(inp_dev, n_images, C, H, W):
     cyx, nc, _, _ = orc.center_nms_topk(center, max_centers=256)
     inst, _ = orc.group_offsets(offset, fg, cyx, nc, scale_y=H, scale_x=W)
     pan, _ = orc.deeplab_merge(idx + 1, inst, fg, 1 << 16, np.where(is_thing)[0] + 1, 0)
+    what = 'argmax+NMS+grouping+merge'
+    if metrics is not None:
+        state = None
+        cm = None
+        for b in range(n):
+            *state, _ = orc.pq_compare_and_accumulate(pan[b], tgt_pan[b], C + 1, 0, 1 << 16,
+                                                      256 ** 3, state=state)
+            cm = orc.confmat_update(pan[b] // 65536, tgt_sem[b], C + 1, cm)
+        what += '+confmat+PQ'
     dt = time.perf_counter() - t0
-    return {'value': n * H * W / dt / 1e6, 'unit': 'Mpix/s', 'cores': 1, 'kind': 'port',
+    return {'value': round(n * H * W / dt / 1e6, 3), 'unit': 'Mpix/s', 'cores': 1, 'kind': 'port',
             'sample': f'{n} images {W}x{H}x{C} of the bench batch, C oracle '
-                      f'(argmax+NMS+grouping+merge), {dt:.2f} s'}, (idx, inst, pan)
+                      f'({what}), {dt:.2f} s'}, (idx, inst, pan)
 
 
 def main():
@@ -176,7 +188,7 @@ def main():
     }
 
     if rank == 0 and not args.no_cpu_baseline:
-        cb, (idx, inst, pan) = cpu_baseline(inp, args.cpu_sample_images, C, H, W)
+        cb, (idx, inst, pan) = cpu_baseline(inp, args.cpu_sample_images, C, H, W, metrics)
         n = idx.shape[0]
         ok = bool((r['semantic_idx_u8'][:n].cpu().numpy() == idx).all()
                   and (r['instance'][:n].cpu().numpy() == inst).all()

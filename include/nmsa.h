@@ -203,10 +203,12 @@ int nmsa_instance_orientation(const float* orientation, const uint8_t* inst,
 #define NMSA_ST_MISSING_KEY 4
 #define NMSA_ST_VALUE_RANGE 8
 #define NMSA_ST_SENTINEL_KEY 16
+size_t nmsa_confmat_workspace_bytes(int n_classes);
 int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pred_div,
                         const void* target, int target_dtype,
                         int64_t n_px, int n_classes, int mode,
-                        int64_t* confmat, int32_t* status, nmsa_stream_t stream);
+                        int64_t* confmat, int32_t* status,
+                        void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * a12/a13  compare_and_accumulate + PanopticQuality.update

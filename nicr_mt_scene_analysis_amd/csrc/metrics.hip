@@ -62,12 +62,50 @@ __device__ __forceinline__ int64_t floormod64(int64_t a, int64_t b)
 // pred_div: preds are raw / pred_div (panoptic id // max_instances, panoptic.py:123)
 // =================================================================================
 constexpr int CM_LDS_BINS = 24 * 1024;     // 96 KB of u32 (n <= 156)
+constexpr int CM_CHUNK = 8;                // consecutive elements per lane and load group
 
+// 8 consecutive elements starting at i (i % 8 == 0) as int64; VEC = one or a few
+// 8/16-B loads (pointer suitably aligned, chunk fully inside the array)
+template <int DT, bool VEC>
+__device__ __forceinline__ void load8(const void* p, int64_t i, int64_t n, int64_t out[CM_CHUNK])
+{
+    if (VEC && i + CM_CHUNK <= n) {
+        if (DT == NMSA_U8) {
+            const uint2 v = *(const uint2*)((const uint8_t*)p + i);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { out[j] = (v.x >> (8 * j)) & 0xFF; out[4 + j] = (v.y >> (8 * j)) & 0xFF; }
+        } else if (DT == NMSA_I16) {
+            const int4 v = *(const int4*)((const int16_t*)p + i);
+            const int w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { out[2 * j] = (int16_t)(w[j] & 0xFFFF); out[2 * j + 1] = (int16_t)(w[j] >> 16); }
+        } else if (DT == NMSA_I32) {
+            const int4 a = *(const int4*)((const int32_t*)p + i);
+            const int4 c = *(const int4*)((const int32_t*)p + i + 4);
+            out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
+            out[4] = c.x; out[5] = c.y; out[6] = c.z; out[7] = c.w;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const longlong2 v = *(const longlong2*)((const int64_t*)p + i + 2 * j);
+                out[2 * j] = v.x; out[2 * j + 1] = v.y;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int j = 0; j < CM_CHUNK; ++j) out[j] = (i + j < n) ? load_int_m(p, DT, (size_t)(i + j)) : 0;
+    }
+}
+
+// Every lane owns 8 CONSECUTIVE elements per step: label maps are coherent along a row,
+// so the lane run-length-encodes its 8 bins in registers and issues one LDS atomic per
+// run (no cross-lane traffic at all); two steps are kept in flight for latency hiding.
+template <int PD, int TD, bool VEC>
 __global__ __launch_bounds__(256) void k_confmat(
-    const void* __restrict__ preds, int pred_dtype, int64_t pred_div,
-    const void* __restrict__ target, int target_dtype,
+    const void* __restrict__ preds, int64_t pred_div, const void* __restrict__ target,
     int64_t n_px, int n, int mode, int use_lds,
-    unsigned long long* __restrict__ confmat, int* __restrict__ status)
+    unsigned long long* __restrict__ confmat, uint32_t* __restrict__ slab,
+    int* __restrict__ status)
 {
     extern __shared__ uint32_t cm_hist[];
     const int nbins = n * n;
@@ -75,70 +113,114 @@ __global__ __launch_bounds__(256) void k_confmat(
         for (int i = threadIdx.x; i < nbins; i += blockDim.x) cm_hist[i] = 0;
         __syncthreads();
     }
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    const int64_t trips = (n_px + stride - 1) / stride;
     bool bad = false;
-    for (int64_t k = 0; k < trips; ++k) {
-        const int64_t i = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-        int key = -1;
-        if (i < n_px) {
-            int64_t t = load_int_m(target, target_dtype, (size_t)i);
-            int64_t p = load_int_m(preds, pred_dtype, (size_t)i);
-            if (p < 0) bad = true;                          // bincount rejects negatives
-            if (pred_div != 1) p = p / pred_div;           // torch `//` on non-negative ids
-            bool skip = false;
-            if (mode == 1) { skip = (t == 0); t -= 1; }
-            if (!skip) {
-                const int64_t bin = t * n + p;              // miou.py:50
-                if (t < 0 || p < 0 || bin >= nbins || bin < 0) bad = true;
-                else key = (int)bin;
+    auto bump = [&](int key, uint32_t len) {
+        if (key < 0) return;
+        if (use_lds) atomicAdd(&cm_hist[key], len);
+        else atomicAdd(&confmat[key], (unsigned long long)len);
+    };
+    auto consume = [&](int64_t i0, const int64_t tv[CM_CHUNK], const int64_t pv[CM_CHUNK]) {
+        int run_key = -1;
+        uint32_t run_len = 0;
+#pragma unroll
+        for (int j = 0; j < CM_CHUNK; ++j) {
+            int key = -1;
+            if (i0 + j < n_px) {
+                int64_t t = tv[j], p = pv[j];
+                if (p < 0) bad = true;                          // bincount rejects negatives
+                if (pred_div != 1) p = p / pred_div;           // torch `//` on non-negative ids
+                bool skip = false;
+                if (mode == 1) { skip = (t == 0); t -= 1; }
+                if (!skip) {
+                    const int64_t bin = t * n + p;              // miou.py:50
+                    if (t < 0 || p < 0 || bin >= nbins || bin < 0) bad = true;
+                    else key = (int)bin;
+                }
             }
+            if (key == run_key) ++run_len;
+            else { bump(run_key, run_len); run_key = key; run_len = 1; }
         }
-        // coherent label maps: whole wave often hits one bin -> one atomic
-        const int first = __shfl(key, __ffsll((long long)__ballot(key >= 0)) - 1);
-        const unsigned long long act = __ballot(key >= 0);
-        if (act && __ballot(key == first) == act) {
-            if (lane_id() == __ffsll((long long)act) - 1) {
-                if (use_lds) atomicAdd(&cm_hist[first], (uint32_t)__popcll(act));
-                else atomicAdd(&confmat[first], (unsigned long long)__popcll(act));
-            }
-        } else if (key >= 0) {
-            if (use_lds) atomicAdd(&cm_hist[key], 1u);
-            else atomicAdd(&confmat[key], 1ull);
+        bump(run_key, run_len);
+    };
+
+    const int64_t n_chunks = (n_px + CM_CHUNK - 1) / CM_CHUNK;
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += 2 * stride) {
+        const int64_t i0 = c * CM_CHUNK, i1 = (c + stride) * CM_CHUNK;
+        const bool second = (c + stride) < n_chunks;
+        int64_t t0[CM_CHUNK], p0[CM_CHUNK], t1[CM_CHUNK], p1[CM_CHUNK];
+        load8<TD, VEC>(target, i0, n_px, t0);
+        load8<PD, VEC>(preds, i0, n_px, p0);
+        if (second) {
+            load8<TD, VEC>(target, i1, n_px, t1);
+            load8<PD, VEC>(preds, i1, n_px, p1);
         }
+        consume(i0, t0, p0);
+        if (second) consume(i1, t1, p1);
     }
     if (bad) atomicOr(status, ST_VALUE_RANGE);
     if (use_lds) {
+        // no atomics: every block stores its private histogram as one coalesced slab;
+        // k_confmat_reduce sums the slabs (with random labels every bin of every block
+        // is non-zero, and thousands of same-address atomics would dominate the kernel)
         __syncthreads();
-        for (int i = threadIdx.x; i < nbins; i += blockDim.x) {
-            const uint32_t v = cm_hist[i];
-            if (v) atomicAdd(&confmat[i], (unsigned long long)v);
-        }
+        uint32_t* mine = slab + (size_t)blockIdx.x * nbins;
+        for (int i = threadIdx.x; i < nbins; i += blockDim.x) mine[i] = cm_hist[i];
     }
 }
 
+constexpr int CM_REDUCE_GROUPS = 16;
+
+__global__ __launch_bounds__(256) void k_confmat_reduce(
+    const uint32_t* __restrict__ slab, int n_slabs, int nbins,
+    unsigned long long* __restrict__ confmat)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= nbins) return;
+    unsigned long long acc = 0;
+    int k = blockIdx.y;
+    for (; k + 7 * CM_REDUCE_GROUPS < n_slabs; k += 8 * CM_REDUCE_GROUPS) {
+        uint32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = slab[(size_t)(k + u * CM_REDUCE_GROUPS) * nbins + i];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc += v[u];
+    }
+    for (; k < n_slabs; k += CM_REDUCE_GROUPS) acc += slab[(size_t)k * nbins + i];
+    if (acc) atomicAdd(&confmat[i], acc);
+}
+
 // =================================================================================
-// a12: hash tables
+// a12: panoptic quality
+// The hot kernel keeps ONE table per image: counts per intersection id
+// target*offset+pred (pq.py:104-109).  Target / prediction segment areas
+// (pq.py:83-84) are the marginals of that table and are rebuilt per image in
+// k_pq_match — valid whenever every id decodes uniquely (0 <= pred < offset,
+// target >= 0); otherwise the reference itself fails (KeyError) or silently
+// mixes segments, and ST_MISSING_KEY is raised here.
 // =================================================================================
 constexpr int64_t KEY_EMPTY = INT64_MIN;
-constexpr int PQ_T_CAP = 2048;      // distinct target ids / image
-constexpr int PQ_P_CAP = 2048;      // distinct predicted ids / image
+constexpr int PQ_T_CAP = 2048;      // distinct target ids / image      (LDS, k_pq_match)
+constexpr int PQ_P_CAP = 2048;      // distinct predicted ids / image   (LDS, k_pq_match)
 constexpr int PQ_I_CAP = 4096;      // distinct (target, pred) intersections / image
-constexpr int PQ_LT = 256, PQ_LP = 256, PQ_LI = 1024;   // LDS-privatised tables per block
+constexpr int PQ_LI = 1024;         // LDS-privatised intersection table per block
 
-__device__ __forceinline__ uint32_t hash64(uint64_t k)
+// cheap id hash: one 32-bit multiply per half (64-bit multiplies are quarter rate
+// and dominated the first version of k_pq_count)
+__device__ __forceinline__ uint32_t hash_id(int64_t k)
 {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdULL;
-    k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ULL;
-    k ^= k >> 33;
-    return (uint32_t)k;
+    const uint32_t lo = (uint32_t)k, hi = (uint32_t)((uint64_t)k >> 32);
+    uint32_t h = lo * 0x9E3779B1u;
+    h ^= (hi + 0x7F4A7C15u) * 0x85EBCA6Bu;
+    h ^= h >> 15;
+    return h;
 }
 
 // insert-or-add; returns false when no slot was found within `max_probe` probes
 __device__ __forceinline__ bool table_add(int64_t* keys, uint32_t* cnts, uint32_t mask,
                                           int64_t key, uint32_t n, int max_probe)
 {
-    uint32_t slot = hash64((uint64_t)key) & mask;
+    uint32_t slot = hash_id(key) & mask;
     for (int probe = 0; probe < max_probe; ++probe) {
         const int64_t cur = *(volatile int64_t*)&keys[slot];
         if (cur == key) { atomicAdd(&cnts[slot], n); return true; }
@@ -156,7 +238,7 @@ __device__ __forceinline__ bool table_add(int64_t* keys, uint32_t* cnts, uint32_
 // lookup in a quiescent table: slot index or -1
 __device__ __forceinline__ int table_find(const int64_t* keys, uint32_t mask, int64_t key)
 {
-    uint32_t slot = hash64((uint64_t)key) & mask;
+    uint32_t slot = hash_id(key) & mask;
     for (uint32_t probe = 0; probe <= mask; ++probe) {
         const int64_t cur = keys[slot];
         if (cur == key) return (int)slot;
@@ -166,102 +248,120 @@ __device__ __forceinline__ int table_find(const int64_t* keys, uint32_t mask, in
     return -1;
 }
 
-struct PqTables {            // per-image views into the workspace
-    int64_t* keyT; uint32_t* cntT;
-    int64_t* keyP; uint32_t* cntP;
-    int64_t* keyI; uint32_t* cntI;
-};
-
 __host__ __device__ inline size_t pq_image_bytes()
 {
-    return (size_t)(PQ_T_CAP + PQ_P_CAP + PQ_I_CAP) * (sizeof(int64_t) + sizeof(uint32_t));
+    return (size_t)PQ_I_CAP * (sizeof(int64_t) + sizeof(uint32_t));
 }
-
-__device__ __forceinline__ PqTables pq_tables(unsigned char* ws, int b)
+__device__ __forceinline__ int64_t* pq_keys(unsigned char* ws, int b)
 {
-    unsigned char* base = ws + (size_t)b * pq_image_bytes();
-    PqTables t;
-    t.keyT = (int64_t*)base;
-    t.keyP = t.keyT + PQ_T_CAP;
-    t.keyI = t.keyP + PQ_P_CAP;
-    t.cntT = (uint32_t*)(t.keyI + PQ_I_CAP);
-    t.cntP = t.cntT + PQ_T_CAP;
-    t.cntI = t.cntP + PQ_P_CAP;
-    return t;
+    return (int64_t*)(ws + (size_t)b * pq_image_bytes());
+}
+__device__ __forceinline__ uint32_t* pq_cnts(unsigned char* ws, int b)
+{
+    return (uint32_t*)(pq_keys(ws, b) + PQ_I_CAP);
 }
 
-__global__ __launch_bounds__(256) void k_pq_init(unsigned char* __restrict__ ws, int B)
+__global__ __launch_bounds__(256) void k_pq_init(unsigned char* __restrict__ ws)
 {
     const int b = blockIdx.y;
-    PqTables t = pq_tables(ws, b);
-    const int total = PQ_T_CAP + PQ_P_CAP + PQ_I_CAP;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
-        t.keyT[i] = KEY_EMPTY;        // the three key arrays are contiguous
-        t.cntT[i] = 0;                // ... and so are the three count arrays
+    int64_t* k = pq_keys(ws, b);
+    uint32_t* c = pq_cnts(ws, b);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PQ_I_CAP; i += gridDim.x * blockDim.x) {
+        k[i] = KEY_EMPTY;
+        c[i] = 0;
     }
 }
+
+constexpr int PQ_UNROLL = 4;      // 16-B loads in flight per lane and map (2 px each)
 
 __global__ __launch_bounds__(256) void k_pq_count(
     const int64_t* __restrict__ pred, const int64_t* __restrict__ target,
     int P, int64_t offset, int px_per_block,
     unsigned char* __restrict__ ws, int* __restrict__ status)
 {
-    __shared__ int64_t lkT[PQ_LT], lkP[PQ_LP], lkI[PQ_LI];
-    __shared__ uint32_t lcT[PQ_LT], lcP[PQ_LP], lcI[PQ_LI];
+    __shared__ int64_t lkI[PQ_LI];
+    __shared__ uint32_t lcI[PQ_LI];
     const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) {
-        lkI[i] = KEY_EMPTY; lcI[i] = 0;
-        if (i < PQ_LT) { lkT[i] = KEY_EMPTY; lcT[i] = 0; lkP[i] = KEY_EMPTY; lcP[i] = 0; }
-    }
+    for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) { lkI[i] = KEY_EMPTY; lcI[i] = 0; }
     __syncthreads();
-    PqTables g = pq_tables(ws, b);
+    int64_t* gk = pq_keys(ws, b);
+    uint32_t* gc = pq_cnts(ws, b);
     const int64_t* pr = pred + (size_t)b * P;
     const int64_t* tg = target + (size_t)b * P;
     const int start = blockIdx.x * px_per_block;
     const int end = min(start + px_per_block, P);
     int st = 0;
 
-    auto add3 = [&](int64_t t, int64_t p, uint32_t cnt) {
+    // called by MANY lanes at once (one per run of equal pixels)
+    auto add = [&](int64_t t, int64_t p, uint32_t cnt) {
+        if (t < 0 || p < 0 || p >= offset) st |= ST_MISSING_KEY;      // ids would not decode
         // intersection id with torch's int64 wrap-around arithmetic (pq.py:104)
         const int64_t iid = (int64_t)((uint64_t)t * (uint64_t)offset + (uint64_t)p);
-        if (t == KEY_EMPTY || p == KEY_EMPTY || iid == KEY_EMPTY) { st |= ST_SENTINEL_KEY; return; }
-        if (!table_add(lkT, lcT, PQ_LT - 1, t, cnt, 16) &&
-            !table_add(g.keyT, g.cntT, PQ_T_CAP - 1, t, cnt, PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
-        if (!table_add(lkP, lcP, PQ_LP - 1, p, cnt, 16) &&
-            !table_add(g.keyP, g.cntP, PQ_P_CAP - 1, p, cnt, PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
+        if (iid == KEY_EMPTY) { st |= ST_SENTINEL_KEY; return; }
+        // fast path: key already in its home slot -> one LDS read, one LDS atomic
+        const uint32_t sI = hash_id(iid) & (PQ_LI - 1);
+        if (lkI[sI] == iid) { atomicAdd(&lcI[sI], cnt); return; }
         if (!table_add(lkI, lcI, PQ_LI - 1, iid, cnt, 32) &&
-            !table_add(g.keyI, g.cntI, PQ_I_CAP - 1, iid, cnt, PQ_I_CAP)) st |= ST_TABLE_OVERFLOW;
+            !table_add(gk, gc, PQ_I_CAP - 1, iid, cnt, PQ_I_CAP)) st |= ST_TABLE_OVERFLOW;
+    };
+    // One (target, pred) pair per lane, lanes = consecutive pixels.  Neighbouring pixels
+    // mostly share the pair, so the wave is cut into RUNS of equal lanes: every run head
+    // inserts its run length — all heads in parallel, no leader-serial loop.
+    auto wave_runs = [&](bool valid, int64_t t, int64_t p, uint32_t weight) {
+        const int64_t pt = __shfl_up(t, 1);
+        const int64_t pp = __shfl_up(p, 1);
+        const bool pvalid = __shfl_up((int)valid, 1) != 0;
+        const bool head = valid && (lane_id() == 0 || !pvalid || pt != t || pp != p);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long vmask = __ballot(valid);
+        if (head) {
+            const int l = lane_id();
+            const unsigned long long stop = (heads | ~vmask) & ~((2ull << l) - 1ull);
+            const int nxt = stop ? (__ffsll((long long)stop) - 1) : 64;
+            add(t, p, weight * (uint32_t)(nxt - l));
+        }
     };
 
-    const int span = end - start;
-    const int trips = (span + (int)blockDim.x - 1) / (int)blockDim.x;
-    for (int k = 0; k < trips; ++k) {
-        const int i = start + k * blockDim.x + threadIdx.x;
-        const bool valid = i < end;
-        const int64_t t = valid ? tg[i] : 0;
-        const int64_t p = valid ? pr[i] : 0;
-        unsigned long long todo = __ballot(valid);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int64_t lt = __shfl(t, leader);
-            const int64_t lp = __shfl(p, leader);
-            const unsigned long long same = __ballot(valid && t == lt && p == lp) & todo;
-            if (lane_id() == leader) add3(lt, lp, (uint32_t)__popcll(same));
-            todo &= ~same;
+    // the image plane is consumed as 16-B (2 px) loads when the rows allow it
+    const bool vec = ((P & 1) == 0) && ((start & 1) == 0) &&
+                     ((((uintptr_t)pr | (uintptr_t)tg) & 15) == 0);
+    if (vec) {
+        const int tile = blockDim.x * 2 * PQ_UNROLL;            // px per block iteration
+        for (int base = start; base < end; base += tile) {
+            longlong2 tv[PQ_UNROLL], pv[PQ_UNROLL];
+            bool ok[PQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PQ_UNROLL; ++u) {
+                const int i = base + (u * blockDim.x + threadIdx.x) * 2;
+                ok[u] = i < end;                                // end is even on this path
+                tv[u] = ok[u] ? *(const longlong2*)(tg + i) : make_longlong2(0, 0);
+                pv[u] = ok[u] ? *(const longlong2*)(pr + i) : make_longlong2(0, 0);
+            }
+#pragma unroll
+            for (int u = 0; u < PQ_UNROLL; ++u) {
+                const bool same2 = tv[u].x == tv[u].y && pv[u].x == pv[u].y;
+                if (__all(same2 || !ok[u])) {
+                    wave_runs(ok[u], tv[u].x, pv[u].x, 2u);     // both px of every lane agree
+                } else {
+                    wave_runs(ok[u], tv[u].x, pv[u].x, 1u);
+                    wave_runs(ok[u], tv[u].y, pv[u].y, 1u);
+                }
+            }
+        }
+    } else {
+        const int span = end - start;
+        const int trips = (span + (int)blockDim.x - 1) / (int)blockDim.x;
+        for (int k = 0; k < trips; ++k) {
+            const int i = start + k * blockDim.x + threadIdx.x;
+            const bool valid = i < end;
+            wave_runs(valid, valid ? tg[i] : 0, valid ? pr[i] : 0, 1u);
         }
     }
     __syncthreads();
-    // flush the block-private tables
-    for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) {
-        if (lkI[i] != KEY_EMPTY &&
-            !table_add(g.keyI, g.cntI, PQ_I_CAP - 1, lkI[i], lcI[i], PQ_I_CAP)) st |= ST_TABLE_OVERFLOW;
-        if (i < PQ_LT) {
-            if (lkT[i] != KEY_EMPTY &&
-                !table_add(g.keyT, g.cntT, PQ_T_CAP - 1, lkT[i], lcT[i], PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
-            if (lkP[i] != KEY_EMPTY &&
-                !table_add(g.keyP, g.cntP, PQ_P_CAP - 1, lkP[i], lcP[i], PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
-        }
-    }
+    // flush the block-private table
+    for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x)
+        if (lkI[i] != KEY_EMPTY && !table_add(gk, gc, PQ_I_CAP - 1, lkI[i], lcI[i], PQ_I_CAP))
+            st |= ST_TABLE_OVERFLOW;
     if (st) atomicOr(status, st);
 }
 
@@ -295,6 +395,20 @@ __device__ __forceinline__ int block_incl_scan_i(int v, int* scratch, int* total
 
 constexpr int PQ_MATCH_THREADS = 1024;
 constexpr int PQ_MAX_CATEGORIES = 1024;
+constexpr int PQ_TP_CAP = 2048;             // matched pairs per image
+
+__device__ __forceinline__ int64_t sorted_lookup(const int64_t* keys, const uint32_t* cnts,
+                                                 int n, int64_t key)
+{
+    int lo = 0, hi = n - 1;
+    while (lo <= hi) {
+        const int mid = (lo + hi) >> 1;
+        const int64_t k = keys[mid];
+        if (k == key) return cnts[mid];
+        if (k < key) lo = mid + 1; else hi = mid - 1;
+    }
+    return 0;
+}
 
 __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     unsigned char* __restrict__ ws, int num_categories, int64_t ignored_label,
@@ -303,34 +417,47 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     int64_t* __restrict__ matches /* [B,match_cap,2] or null */, int match_cap,
     int32_t* __restrict__ n_matches, int* __restrict__ status)
 {
-    __shared__ int64_t sKey[PQ_I_CAP];
+    __shared__ int64_t sKey[PQ_I_CAP];          // intersection ids, sorted ascending
     __shared__ uint32_t sCnt[PQ_I_CAP];
-    __shared__ double sIou[PQ_I_CAP];
     __shared__ int16_t sCat[PQ_I_CAP];          // category of a TP entry, -1 otherwise
-    __shared__ uint8_t fT[PQ_T_CAP], fP[PQ_P_CAP];
+    __shared__ int64_t kT[PQ_T_CAP], kP[PQ_P_CAP];     // segment-area tables (marginals)
+    __shared__ uint32_t cT[PQ_T_CAP], cP[PQ_P_CAP];
+    __shared__ uint8_t fT[PQ_T_CAP], fP[PQ_P_CAP];     // matched flags
+    __shared__ double tpIou[PQ_TP_CAP];         // TP entries compacted in id order
+    __shared__ int16_t tpCat[PQ_TP_CAP];
+    __shared__ uint16_t tpIdx[PQ_TP_CAP];
     __shared__ int fnI[PQ_MAX_CATEGORIES], fpI[PQ_MAX_CATEGORIES];
     __shared__ int64_t ignKeys[64];
     __shared__ int nIgn;
     __shared__ int scratch[32];
 
     const int b = blockIdx.x, tid = threadIdx.x;
-    PqTables g = pq_tables(ws, b);
+    const int64_t* gk = pq_keys(ws, b);
+    const uint32_t* gc = pq_cnts(ws, b);
     int st = 0;
 
-    for (int i = tid; i < PQ_T_CAP; i += PQ_MATCH_THREADS) { fT[i] = 0; fP[i] = 0; }
+    for (int i = tid; i < PQ_T_CAP; i += PQ_MATCH_THREADS) {
+        fT[i] = 0; fP[i] = 0; kT[i] = KEY_EMPTY; kP[i] = KEY_EMPTY; cT[i] = 0; cP[i] = 0;
+    }
     for (int i = tid; i < num_categories; i += PQ_MATCH_THREADS) { fnI[i] = 0; fpI[i] = 0; }
     if (tid == 0) nIgn = 0;
 
     // ---- 1. compact the intersection table --------------------------------------------
     const int per = PQ_I_CAP / PQ_MATCH_THREADS;      // 4 slots / thread
+    int64_t myk[per];
+    uint32_t myc[per];
     int mine = 0;
-    for (int j = 0; j < per; ++j) mine += (g.keyI[tid * per + j] != KEY_EMPTY);
+#pragma unroll
+    for (int j = 0; j < per; ++j) {
+        myk[j] = gk[tid * per + j];
+        myc[j] = gc[tid * per + j];
+        mine += (myk[j] != KEY_EMPTY);
+    }
     int nI;
     int pos = block_incl_scan_i(mine, scratch, &nI) - mine;
-    for (int j = 0; j < per; ++j) {
-        const int s = tid * per + j;
-        if (g.keyI[s] != KEY_EMPTY) { sKey[pos] = g.keyI[s]; sCnt[pos] = g.cntI[s]; ++pos; }
-    }
+#pragma unroll
+    for (int j = 0; j < per; ++j)
+        if (myk[j] != KEY_EMPTY) { sKey[pos] = myk[j]; sCnt[pos] = myc[j]; ++pos; }
     int n2 = 1;
     while (n2 < nI) n2 <<= 1;
     for (int i = nI + tid; i < n2; i += PQ_MATCH_THREADS) { sKey[i] = INT64_MAX; sCnt[i] = 0; }
@@ -354,92 +481,109 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
         }
     }
 
+    // ---- 3. segment areas = marginals of the intersection table (pq.py:83-84) ------------
+    for (int e = tid; e < nI; e += PQ_MATCH_THREADS) {
+        const int64_t iid = sKey[e];
+        const int64_t gt = floordiv64(iid, offset), pr = floormod64(iid, offset);
+        if (!table_add(kT, cT, PQ_T_CAP - 1, gt, sCnt[e], PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
+        if (!table_add(kP, cP, PQ_P_CAP - 1, pr, sCnt[e], PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
+    }
+    __syncthreads();
     // ignored segments: target ids whose category is the ignored label (pq.py:89-93)
     for (int s = tid; s < PQ_T_CAP; s += PQ_MATCH_THREADS) {
-        const int64_t k = g.keyT[s];
+        const int64_t k = kT[s];
         if (k != KEY_EMPTY && floordiv64(k, max_inst) == ignored_label) {
             const int at = atomicAdd(&nIgn, 1);
             if (at < 64) ignKeys[at] = k;
         }
     }
 
-    // ---- 3. TP decision per intersection (pq.py:119-153) ----------------------------------
+    // ---- 4. TP decision per intersection (pq.py:119-153) ----------------------------------
+    auto entry_iou = [&](int e, int* sT_out, int* sP_out) -> double {
+        const int64_t iid = sKey[e];
+        const int64_t gt = floordiv64(iid, offset), pr = floormod64(iid, offset);
+        // prediction_void_overlap (pq.py:35-44)
+        const int64_t vid = (int64_t)((uint64_t)void_segment_id * (uint64_t)offset + (uint64_t)pr);
+        const int64_t r = sorted_lookup(sKey, sCnt, nI, vid);
+        const int sT = table_find(kT, PQ_T_CAP - 1, gt);
+        const int sP = table_find(kP, PQ_P_CAP - 1, pr);
+        *sT_out = sT; *sP_out = sP;
+        if (sT < 0 || sP < 0) return -1.0;
+        const int64_t ia = sCnt[e];
+        const int64_t uni = (int64_t)cT[sT] + (int64_t)cP[sP] - ia - r;       // :143
+        return (double)ia / (double)uni;                                       // :145
+    };
     for (int e = tid; e < nI; e += PQ_MATCH_THREADS) {
         int16_t cat = -1;
-        double iou = 0.0;
         const int64_t iid = sKey[e];
-        if (iid != void_segment_id) {
-            const int64_t gt = floordiv64(iid, offset);
-            const int64_t pr = floormod64(iid, offset);
-            const int64_t gcat = floordiv64(gt, max_inst);
-            const int64_t pcat = floordiv64(pr, max_inst);
-            if (gcat == pcat) {
-                // prediction_void_overlap (pq.py:35-44): binary search in the sorted list
-                const int64_t vid = (int64_t)((uint64_t)void_segment_id * (uint64_t)offset + (uint64_t)pr);
-                int64_t r = 0;
-                {
-                    int lo = 0, hi = nI - 1;
-                    while (lo <= hi) {
-                        const int mid = (lo + hi) >> 1;
-                        if (sKey[mid] == vid) { r = sCnt[mid]; break; }
-                        if (sKey[mid] < vid) lo = mid + 1; else hi = mid - 1;
-                    }
-                }
-                const int sT = table_find(g.keyT, PQ_T_CAP - 1, gt);
-                const int sP = table_find(g.keyP, PQ_P_CAP - 1, pr);
+        if (iid != void_segment_id) {                                          // :120-121
+            const int64_t gcat = floordiv64(floordiv64(iid, offset), max_inst);
+            const int64_t pcat = floordiv64(floormod64(iid, offset), max_inst);
+            if (gcat == pcat) {                                                // :128-129
+                int sT, sP;
+                const double iou = entry_iou(e, &sT, &sP);
                 if (sT < 0 || sP < 0) st |= ST_MISSING_KEY;
-                else {
-                    const int64_t ia = sCnt[e];
-                    const int64_t uni = (int64_t)g.cntT[sT] + (int64_t)g.cntP[sP] - ia - r;   // :143
-                    iou = (double)ia / (double)uni;                                             // :145
-                    if (iou > 0.5) {
-                        if (gcat < 0 || gcat >= num_categories) st |= ST_CATEGORY_RANGE;
-                        else { cat = (int16_t)gcat; fT[sT] = 1; fP[sP] = 1; }
-                    }
+                else if (iou > 0.5) {                                          // :147
+                    if (gcat < 0 || gcat >= num_categories) st |= ST_CATEGORY_RANGE;
+                    else { cat = (int16_t)gcat; fT[sT] = 1; fP[sP] = 1; }
                 }
             }
         }
         sCat[e] = cat;
-        sIou[e] = iou;
     }
     __syncthreads();
 
-    // ---- 4. per-class TP / IoU sums in ascending-id order (bit-exact fp64) -----------------
+    // ---- 5. ordered compaction of the TP entries, then per-class TP / IoU sums in
+    //         ascending-id order (bit-exact fp64: same operand order as the reference) ----
+    int nTP;
+    {
+        const int chunk = (nI + PQ_MATCH_THREADS - 1) / PQ_MATCH_THREADS;
+        const int e0 = min(tid * chunk, nI), e1 = min(e0 + chunk, nI);
+        int m = 0;
+        for (int e = e0; e < e1; ++e) m += (sCat[e] >= 0);
+        int at = block_incl_scan_i(m, scratch, &nTP) - m;
+        for (int e = e0; e < e1; ++e) {
+            if (sCat[e] < 0) continue;
+            if (at < PQ_TP_CAP) {
+                int sT, sP;
+                tpCat[at] = sCat[e]; tpIdx[at] = (uint16_t)e;
+                tpIou[at] = entry_iou(e, &sT, &sP);
+            }
+            ++at;
+        }
+        if (nTP > PQ_TP_CAP) st |= ST_TABLE_OVERFLOW;
+    }
+    __syncthreads();
     double* out = img_state + (size_t)b * 4 * num_categories;
+    const int nTPc = min(nTP, PQ_TP_CAP);
     for (int c = tid; c < num_categories; c += PQ_MATCH_THREADS) {
         double iou = 0.0, tp = 0.0;
-        for (int e = 0; e < nI; ++e)
-            if (sCat[e] == c) { tp += 1.0; iou += sIou[e]; }
+        for (int e = 0; e < nTPc; ++e)
+            if (tpCat[e] == c) { tp += 1.0; iou += tpIou[e]; }
         out[0 * num_categories + c] = iou;
         out[1 * num_categories + c] = tp;
     }
 
-    // ---- 5. false negatives (pq.py:155-163) -----------------------------------------------
+    // ---- 6. false negatives (pq.py:155-163) -----------------------------------------------
     for (int s = tid; s < PQ_T_CAP; s += PQ_MATCH_THREADS) {
-        const int64_t k = g.keyT[s];
+        const int64_t k = kT[s];
         if (k == KEY_EMPTY || fT[s]) continue;
         const int64_t cat = floordiv64(k, max_inst);
         if (cat == ignored_label) continue;
         if (cat < 0 || cat >= num_categories) { st |= ST_CATEGORY_RANGE; continue; }
         atomicAdd(&fnI[cat], 1);
     }
-    // ---- 6. false positives (pq.py:165-177) -------------------------------------------------
+    // ---- 7. false positives (pq.py:165-177) -------------------------------------------------
     const int n_ign = nIgn;
     if (n_ign > 64) st |= ST_TABLE_OVERFLOW;
     for (int s = tid; s < PQ_P_CAP; s += PQ_MATCH_THREADS) {
-        const int64_t k = g.keyP[s];
+        const int64_t k = kP[s];
         if (k == KEY_EMPTY || fP[s]) continue;
         int64_t pio = 0;                                  // prediction_ignored_overlap :47-57
-        for (int q = 0; q < min(n_ign, 64); ++q) {
-            const int64_t id = (int64_t)((uint64_t)ignKeys[q] * (uint64_t)offset + (uint64_t)k);
-            int lo = 0, hi = nI - 1;
-            while (lo <= hi) {
-                const int mid = (lo + hi) >> 1;
-                if (sKey[mid] == id) { pio += sCnt[mid]; break; }
-                if (sKey[mid] < id) lo = mid + 1; else hi = mid - 1;
-            }
-        }
-        if ((double)pio / (double)g.cntP[s] > 0.5) continue;
+        for (int q = 0; q < min(n_ign, 64); ++q)
+            pio += sorted_lookup(sKey, sCnt, nI,
+                                 (int64_t)((uint64_t)ignKeys[q] * (uint64_t)offset + (uint64_t)k));
+        if ((double)pio / (double)cP[s] > 0.5) continue;
         const int64_t cat = floordiv64(k, max_inst);
         if (cat < 0 || cat >= num_categories) { st |= ST_CATEGORY_RANGE; continue; }
         atomicAdd(&fpI[cat], 1);
@@ -450,73 +594,117 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
         out[3 * num_categories + c] = (double)fpI[c];
     }
 
-    // ---- 7. matched (gt, pred) pairs in id order (for the orientation MAE) -------------------
-    {
-        const int chunk = (nI + PQ_MATCH_THREADS - 1) / PQ_MATCH_THREADS;
-        const int e0 = min(tid * chunk, nI), e1 = min(e0 + chunk, nI);
-        int m = 0;
-        for (int e = e0; e < e1; ++e) m += (sCat[e] >= 0);
-        int total;
-        int at = block_incl_scan_i(m, scratch, &total) - m;
-        if (matches) {
-            for (int e = e0; e < e1; ++e) {
-                if (sCat[e] < 0) continue;
-                if (at < match_cap) {
-                    matches[((size_t)b * match_cap + at) * 2 + 0] = floordiv64(sKey[e], offset);
-                    matches[((size_t)b * match_cap + at) * 2 + 1] = floormod64(sKey[e], offset);
-                }
-                ++at;
-            }
+    // ---- 8. matched (gt, pred) pairs in id order (for the orientation MAE) -------------------
+    if (matches) {
+        for (int i = tid; i < nTPc && i < match_cap; i += PQ_MATCH_THREADS) {
+            const int64_t iid = sKey[tpIdx[i]];
+            matches[((size_t)b * match_cap + i) * 2 + 0] = floordiv64(iid, offset);
+            matches[((size_t)b * match_cap + i) * 2 + 1] = floormod64(iid, offset);
         }
-        if (tid == 0 && n_matches) n_matches[b] = total;
     }
+    if (tid == 0 && n_matches) n_matches[b] = nTP;
     if (st) atomicOr(status, st);
 }
 
-__global__ void k_pq_accumulate(const double* __restrict__ img_state, int B, int num_categories,
-                                double* __restrict__ iou, double* __restrict__ tp,
-                                double* __restrict__ fn, double* __restrict__ fp)
+__global__ __launch_bounds__(64) void k_pq_accumulate(
+    const double* __restrict__ img_state, int B, int num_categories,
+    double* __restrict__ iou, double* __restrict__ tp,
+    double* __restrict__ fn, double* __restrict__ fp)
 {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= num_categories) return;
+    __shared__ double buf[4][64];
+    const int c = blockIdx.x, l = threadIdx.x;
     double a0 = iou[c], a1 = tp[c], a2 = fn[c], a3 = fp[c];
-    for (int b = 0; b < B; ++b) {                       // image order, like pq.py:291-296
-        const double* s = img_state + (size_t)b * 4 * num_categories;
-        a0 += s[0 * num_categories + c];
-        a1 += s[1 * num_categories + c];
-        a2 += s[2 * num_categories + c];
-        a3 += s[3 * num_categories + c];
+    for (int b0 = 0; b0 < B; b0 += 64) {
+        const int b = b0 + l;
+        if (b < B) {
+            const double* s = img_state + (size_t)b * 4 * num_categories;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) buf[k][l] = s[k * num_categories + c];
+        }
+        __syncthreads();
+        if (l == 0) {
+            const int nb = min(64, B - b0);
+            for (int j = 0; j < nb; ++j) {              // image order, like pq.py:291-296
+                a0 += buf[0][j]; a1 += buf[1][j]; a2 += buf[2][j]; a3 += buf[3][j];
+            }
+        }
+        __syncthreads();
     }
-    iou[c] = a0; tp[c] = a1; fn[c] = a2; fp[c] = a3;
+    if (l == 0) { iou[c] = a0; tp[c] = a1; fn[c] = a2; fp[c] = a3; }
 }
 
 }  // namespace nmsa
 
 using namespace nmsa;
 
+namespace {
+constexpr int CM_MAX_BLOCKS = 1024;
+}
+
+extern "C" size_t nmsa_confmat_workspace_bytes(int n_classes)
+{
+    if (n_classes <= 0 || n_classes > 46340) return 0;
+    const int64_t nbins = (int64_t)n_classes * n_classes;
+    if (nbins > CM_LDS_BINS) return 16;                 // global-atomic path: no slabs
+    return (size_t)CM_MAX_BLOCKS * nbins * sizeof(uint32_t);
+}
+
 extern "C" int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pred_div,
                                    const void* target, int target_dtype,
                                    int64_t n_px, int n_classes, int mode,
-                                   int64_t* confmat, int32_t* status, nmsa_stream_t stream_)
+                                   int64_t* confmat, int32_t* status,
+                                   void* workspace, size_t workspace_bytes,
+                                   nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!preds || !target || !confmat || !status) return NMSA_ERR_ARG;
+    if (!preds || !target || !confmat || !status || !workspace) return NMSA_ERR_ARG;
     if (n_px < 0 || n_classes <= 0 || n_classes > 46340 || pred_div <= 0) return NMSA_ERR_ARG;
     if (pred_dtype < NMSA_U8 || pred_dtype > NMSA_I64 || target_dtype < NMSA_U8 || target_dtype > NMSA_I64)
         return NMSA_ERR_ARG;
     if (mode != 0 && mode != 1) return NMSA_ERR_ARG;
+    if (workspace_bytes < nmsa_confmat_workspace_bytes(n_classes)) return NMSA_ERR_WORKSPACE;
     if (n_px == 0) return NMSA_OK;
     const int nbins = n_classes * n_classes;
     const int use_lds = nbins <= CM_LDS_BINS;
     const size_t lds = use_lds ? (size_t)nbins * 4 : 0;
-    // enough blocks to fill the chip, few enough that the per-block flush stays small
-    int64_t blocks = (n_px + 256 * 16 - 1) / (256 * 16);
-    const int64_t cap = (lds > 40 * 1024) ? 256 : 2048;
-    if (blocks > cap) blocks = cap;
+    const int64_t n_chunks = (n_px + CM_CHUNK - 1) / CM_CHUNK;
+    // >= 4 workgroups per CU for latency hiding; a big LDS histogram allows only one
+    int64_t blocks = (lds > 40 * 1024) ? 256 : CM_MAX_BLOCKS;
+    const int64_t need = (n_chunks + 2 * 256 - 1) / (2 * 256);
+    if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(k_confmat, dim3((unsigned)blocks), dim3(256), lds, stream, preds, pred_dtype,
-                       pred_div, target, target_dtype, n_px, n_classes, mode, use_lds,
-                       (unsigned long long*)confmat, status);
+    const bool vec = (((uintptr_t)preds | (uintptr_t)target) & 15) == 0;
+    dim3 grid((unsigned)blocks), block(256);
+    unsigned long long* cm = (unsigned long long*)confmat;
+    uint32_t* slab = (uint32_t*)workspace;
+#define NMSA_CM_LAUNCH(PD, TD)                                                                   \
+    do {                                                                                         \
+        if (vec) hipLaunchKernelGGL((k_confmat<PD, TD, true>), grid, block, lds, stream, preds,  \
+                                    pred_div, target, n_px, n_classes, mode, use_lds, cm, slab,  \
+                                    status);                                                     \
+        else hipLaunchKernelGGL((k_confmat<PD, TD, false>), grid, block, lds, stream, preds,     \
+                                pred_div, target, n_px, n_classes, mode, use_lds, cm, slab,      \
+                                status);                                                         \
+    } while (0)
+#define NMSA_CM_TD(PD)                                                      \
+    switch (target_dtype) {                                                 \
+        case NMSA_U8: NMSA_CM_LAUNCH(PD, NMSA_U8); break;                   \
+        case NMSA_I16: NMSA_CM_LAUNCH(PD, NMSA_I16); break;                 \
+        case NMSA_I32: NMSA_CM_LAUNCH(PD, NMSA_I32); break;                 \
+        default: NMSA_CM_LAUNCH(PD, NMSA_I64); break;                       \
+    }
+    switch (pred_dtype) {
+        case NMSA_U8: NMSA_CM_TD(NMSA_U8); break;
+        case NMSA_I16: NMSA_CM_TD(NMSA_I16); break;
+        case NMSA_I32: NMSA_CM_TD(NMSA_I32); break;
+        default: NMSA_CM_TD(NMSA_I64); break;
+    }
+#undef NMSA_CM_TD
+#undef NMSA_CM_LAUNCH
+    int rc = check_launch();
+    if (rc || !use_lds) return rc;
+    hipLaunchKernelGGL(k_confmat_reduce, dim3((nbins + 255) / 256, CM_REDUCE_GROUPS), dim3(256), 0,
+                       stream, (const uint32_t*)workspace, (int)blocks, nbins, cm);
     return check_launch();
 }
 
@@ -549,7 +737,7 @@ extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B,
     unsigned char* ws = (unsigned char*)workspace;
     double* img_state = (double*)(ws + (size_t)B * pq_image_bytes());
 
-    hipLaunchKernelGGL(k_pq_init, dim3(8, B), dim3(256), 0, stream, ws, B);
+    hipLaunchKernelGGL(k_pq_init, dim3(2, B), dim3(256), 0, stream, ws);
     int rc = check_launch();
     if (rc) return rc;
     const int px_per_block = 4096;
@@ -562,7 +750,7 @@ extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B,
                        img_state, matches, match_capacity, n_matches, status);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pq_accumulate, dim3((num_categories + 63) / 64), dim3(64), 0, stream,
+    hipLaunchKernelGGL(k_pq_accumulate, dim3(num_categories), dim3(64), 0, stream,
                        img_state, B, num_categories, iou_per_class, tp_per_class, fn_per_class,
                        fp_per_class);
     return check_launch();

@@ -460,8 +460,8 @@ __global__ __launch_bounds__(256) void k_assign(
     int64_t* __restrict__ pan_of_inst, int32_t* __restrict__ area,
     int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins, int32_t* __restrict__ n_ids)
 {
-    __shared__ int s_cls[256];
-    __shared__ int s_valid[256];
+    __shared__ int s_vcls[256];          // classes of the valid instances, ascending id
+    __shared__ int s_wcnt[4];
     const int b = blockIdx.x, t = threadIdx.x;
     const uint32_t* row = votes + ((size_t)b * 256 + t) * NC;
     uint32_t total = 0;
@@ -473,22 +473,28 @@ __global__ __launch_bounds__(256) void k_assign(
         if ((int64_t)v > bestc) { bestc = v; cls = c; }      // torch.mode: smallest value on ties
     }
     // skip id 0, empty masks (panoptic_merge.py:195-200) and void majority (:203-204)
-    const int valid = (t > 0) && (total > 0) && (cls != 0);
-    s_cls[t] = cls;
-    s_valid[t] = valid;
+    const bool valid = (t > 0) && (total > 0) && (cls != 0);
+    // order-preserving compaction of the valid instances (ballot + popcount)
+    const unsigned long long m = __ballot(valid);
+    const int w = t >> 6, l = t & 63;
+    if (l == 0) s_wcnt[w] = __popcll(m);
     __syncthreads();
-    int rank = 1, pos = 0;
-    for (int j = 1; j < t; ++j) {
-        if (s_valid[j]) { ++pos; if (s_cls[j] == cls) ++rank; }
-    }
-    const int64_t pid = (int64_t)cls * max_inst + rank;        // :206-208
+    int pos = __popcll(m & ((1ull << l) - 1ull));
+    for (int k = 0; k < w; ++k) pos += s_wcnt[k];
+    if (valid) s_vcls[pos] = cls;
+    __syncthreads();
+    // running per-class counter in ascending instance-id order (:206-207)
+    int rank = 1;
+    if (valid)
+        for (int j = 0; j < pos; ++j) rank += (s_vcls[j] == cls);
+    const int64_t pid = (int64_t)cls * max_inst + rank;        // :208
     pan_of_inst[(size_t)b * 256 + t] = valid ? pid : void_label;
     if (area) area[(size_t)b * 256 + t] = (t > 0) ? (int32_t)total : 0;
     if (valid) {
         ids_pan[(size_t)b * 256 + pos] = pid;                   // dict insertion order (:209)
         ids_ins[(size_t)b * 256 + pos] = t;
     }
-    if (t == 255) n_ids[b] = pos + valid;
+    if (t == 0) n_ids[b] = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
 }
 
 // =================================================================================

@@ -2,9 +2,12 @@
 
 The reference subclasses `torchmetrics.Metric` only for `add_state` / `reset`
 and the `dist_reduce_fx='sum'` declaration (metric/miou.py:21-25,
-metric/pq.py:228-246).  torchmetrics is not a dependency here: states are plain
-device tensors, `sync()` is ONE explicit all-reduce (RCCL when the process
-group is 'nccl', gloo in the CPU tests) of all states packed per dtype.
+metric/pq.py:228-246).  torchmetrics is not a dependency here: states are views
+into ONE flat device buffer per dtype, so that
+
+  * `sync()` is one in-place all-reduce per dtype (RCCL when the process group
+    is 'nccl', gloo in the CPU tests) — no packing kernels, no copies,
+  * `zero_()` / `reset()` is one memset per dtype.
 """
 from typing import Dict, List, Optional
 
@@ -18,6 +21,7 @@ class Metric(torch.nn.Module):
         super().__init__()
         self._state_defaults: Dict[str, torch.Tensor] = {}
         self._state_reduce: Dict[str, Optional[str]] = {}
+        self._flat: Optional[Dict[torch.dtype, torch.Tensor]] = None
         if device is None:
             device = torch.device('cuda', torch.cuda.current_device()) \
                 if torch.cuda.is_available() else torch.device('cpu')
@@ -32,39 +36,68 @@ class Metric(torch.nn.Module):
         self._state_defaults[name] = default.detach().clone()
         self._state_reduce[name] = dist_reduce_fx
         setattr(self, name, default.detach().clone().to(self._device))
+        self._flat = None                       # re-pack on next use
 
     def state_names(self) -> List[str]:
         return list(self._state_defaults.keys())
 
+    def _pack(self) -> Dict[torch.dtype, torch.Tensor]:
+        """Move the states into one flat buffer per dtype (states become views)."""
+        if self._flat is not None:
+            return self._flat
+        by_dtype: Dict[torch.dtype, List[str]] = {}
+        for n in self._state_defaults:
+            by_dtype.setdefault(getattr(self, n).dtype, []).append(n)
+        flat: Dict[torch.dtype, torch.Tensor] = {}
+        for dtype, names in by_dtype.items():
+            total = sum(getattr(self, n).numel() for n in names)
+            buf = torch.zeros((total,), dtype=dtype, device=self._device)
+            at = 0
+            for n in names:
+                t = getattr(self, n)
+                k = t.numel()
+                buf[at:at + k].copy_(t.reshape(-1))
+                setattr(self, n, buf[at:at + k].view(t.shape))
+                at += k
+            flat[dtype] = buf
+        self._flat = flat
+        return flat
+
+    def zero_(self) -> None:
+        """In-place reset of all states (one memset per dtype)."""
+        for buf in self._pack().values():
+            buf.zero_()
+
     def reset(self) -> None:
-        for name, default in self._state_defaults.items():
-            setattr(self, name, default.clone().to(self._device))
+        self._pack()
+        all_zero = all(not bool(d.any()) for d in self._state_defaults.values())
+        if all_zero:
+            self.zero_()
+        else:
+            for name, default in self._state_defaults.items():
+                getattr(self, name).copy_(default)
 
     def to(self, device, *args, **kwargs):          # keeps `.to(device)` of the reference API
         self._device = torch.device(device)
         for name in self._state_defaults:
-            setattr(self, name, getattr(self, name).to(self._device))
+            setattr(self, name, getattr(self, name).to(self._device).clone())
+        self._flat = None
         return self
 
     def sync(self, process_group=None) -> None:
-        """Sum every 'sum' state over the ranks: one all-reduce per dtype."""
+        """Sum the states over the ranks: one in-place all-reduce per dtype."""
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
             return
         if dist.get_world_size(process_group) == 1:
             return
-        names = [n for n, fx in self._state_reduce.items() if fx == 'sum']
+        if any(fx not in ('sum', None) for fx in self._state_reduce.values()):
+            raise NotImplementedError('only dist_reduce_fx="sum" states exist on this path')
         backend = dist.get_backend(process_group)
-        comm_device = self._device if backend == 'nccl' else torch.device('cpu')
-        by_dtype: Dict[torch.dtype, List[str]] = {}
-        for n in names:
-            by_dtype.setdefault(getattr(self, n).dtype, []).append(n)
-        for dtype, group in by_dtype.items():
-            flat = torch.cat([getattr(self, n).reshape(-1) for n in group]).to(comm_device)
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=process_group)
-            flat = flat.to(self._device)
-            at = 0
-            for n in group:
-                t = getattr(self, n)
-                setattr(self, n, flat[at:at + t.numel()].reshape(t.shape).clone())
-                at += t.numel()
+        for buf in self._pack().values():
+            if backend == 'nccl' or buf.device.type == 'cpu':
+                dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
+            else:                                   # gloo with device states (tests)
+                host = buf.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
+                buf.copy_(host)

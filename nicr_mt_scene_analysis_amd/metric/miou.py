@@ -22,10 +22,12 @@ def confmat_update(confmat: torch.Tensor, status: torch.Tensor, preds: torch.Ten
         t = t.view(torch.uint8)
     if p.numel() != t.numel():
         raise ValueError('preds and target must have the same number of elements')
+    ws_bytes = L.lib().nmsa_confmat_workspace_bytes(int(n_classes))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
     L.check(L.lib().nmsa_confmat_update(
         L.ptr(p), L.int_dtype_code(p), int(pred_div), L.ptr(t), L.int_dtype_code(t),
         p.numel(), int(n_classes), int(mode), L.ptr(confmat), L.ptr(status),
-        L.stream_ptr(dev)), 'nmsa_confmat_update')
+        L.ptr(ws), ws_bytes, L.stream_ptr(dev)), 'nmsa_confmat_update')
 
 
 class MeanIntersectionOverUnion(Metric):
