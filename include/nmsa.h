@@ -233,6 +233,61 @@ int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int
                    int32_t* status, void* workspace, size_t workspace_bytes,
                    nmsa_stream_t stream);
 
+/* ---------------------------------------------------------------------------
+ * a6-a10  per-pixel multi-task losses (forward + backward)
+ * Common conventions: predictions f32|bf16|f16 (code in `dtype`), targets f32,
+ * labels / masks u8, planar NCHW.  Forward returns device scalars
+ * loss_sum (f64) and the element count (i64) — the task helpers divide
+ * (task_helper/base.py:161-182); nothing is copied to the host.  Backward
+ * recomputes from the inputs and multiplies by the upstream gradient read from
+ * the device scalar *grad_scale; gradients are written in the prediction dtype.
+ * workspace: nmsa_loss_workspace_bytes(B,H,W) bytes (block partials; the final
+ * sum is taken in a fixed order -> run-to-run deterministic).
+ *
+ * nmsa_loss_ce_*       CrossEntropyLossSemantic._compute_loss  loss/ce.py:40-68
+ *     target u8 [B,H,W], 0 = void (ignored); weights f32 [C] or NULL;
+ *     weight_sum (f64, may be NULL) = sum over non-void px of w[label]: the divisor
+ *     of the ESANet `weighted_reduction` (ce.py:57-68)
+ * nmsa_loss_masked_*   MSELoss / L1Loss (reduction='sum') loss/mse.py:21-41, l1.py:21-41
+ *     with the masking of task_helper/instance.py:129-139,154-167:
+ *     sum_px mean_c f(pred*mask - target), n = sum(mask); mask u8 [B,H,W] or NULL;
+ *     kind 0 = MSE, 1 = L1; C = 1 for [B,H,W] inputs
+ * nmsa_loss_vonmises_* VonMisesLossBiternion  loss/vonmises.py:27-51 over the px
+ *     where mask != 0 (gather of task_helper/instance.py:186-216), pred/target [B,2,H,W]
+ * nmsa_loss_cos_emb_*  CosineEmbeddingLoss  loss/cos_emb.py:21-56 with the LUT gather of
+ *     task_helper/dense_visual_embedding.py:110-171: pred [B,D,H,W], indices i32
+ *     [B,H,W] (0 = no target), lut f32 [B,L,D]
+ * ------------------------------------------------------------------------- */
+size_t nmsa_loss_workspace_bytes(int B, int H, int W);
+int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* target, const float* weights,
+                     int B, int C, int H, int W, float label_smoothing,
+                     double* loss_sum, int64_t* n_elements, double* weight_sum, int32_t* status,
+                     void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* target, const float* weights,
+                     int B, int C, int H, int W, float label_smoothing,
+                     const float* grad_scale, void* grad_logits, nmsa_stream_t stream);
+int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
+                         int B, int C, int H, int W, int kind,
+                         double* loss_sum, int64_t* n_mask,
+                         void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_loss_masked_bwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
+                         int B, int C, int H, int W, int kind,
+                         const float* grad_scale, void* grad_pred, nmsa_stream_t stream);
+int nmsa_loss_vonmises_fwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
+                           int B, int H, int W, float kappa,
+                           double* loss_sum, int64_t* n_rows,
+                           void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_loss_vonmises_bwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
+                           int B, int H, int W, float kappa,
+                           const float* grad_scale, void* grad_pred, nmsa_stream_t stream);
+int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                          int B, int D, int H, int W, int L,
+                          double* loss_sum, int64_t* n_rows, int32_t* status,
+                          void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                          int B, int D, int H, int W, int L,
+                          const float* grad_scale, void* grad_pred, nmsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

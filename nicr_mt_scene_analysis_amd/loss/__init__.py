@@ -1,0 +1,7 @@
+"""Losses of the hot path (reference loss/__init__.py)."""
+from .base import LossBase
+from .ce import CrossEntropyLossSemantic
+from .cos_emb import CosineEmbeddingLoss
+from .l1 import L1Loss
+from .mse import MSELoss
+from .vonmises import VonMisesLossBiternion

@@ -1,0 +1,46 @@
+"""Shared implementation of `MSELoss` / `L1Loss` (reference loss/mse.py, loss/l1.py).
+
+reduction='sum' (what every task helper uses) on [B,H,W] / [B,C,H,W] inputs runs
+in the HIP kernels k_elem_fwd / k_elem_bwd, optionally with the task helpers'
+`pred*mask` folded in (`masked_sum`).  The 'mean' / 'none' reductions and 2-D
+[N,C] inputs are not on the hot path and use plain on-device torch ops.
+"""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _functional as F_
+from .base import LossBase
+
+
+class _ElementwiseLoss(LossBase):
+    _kind = 'mse'
+
+    def __init__(self, reduction: str = 'sum') -> None:
+        super().__init__()
+        assert reduction in ('sum', 'mean', 'none')
+        self._reduction = reduction
+
+    def _pointwise(self, input_, target):
+        d = input_ - target
+        return d * d if self._kind == 'mse' else d.abs()
+
+    def masked_sum(self, input_: torch.Tensor, target: torch.Tensor,
+                   mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """(sum_px mean_c f(input_*mask - target), sum(mask)) — the masking of
+        task_helper/instance.py:129-139,154-167 without materialising input_*mask."""
+        return F_.masked_elementwise_sum(input_, target, mask, self._kind)
+
+    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor):
+        if self._reduction == 'sum' and input_.ndim in (3, 4) and input_.is_cuda:
+            loss, _ = F_.masked_elementwise_sum(input_, target, None, self._kind)
+            n_elements = input_.numel() // (input_.shape[1] if input_.ndim == 4 else 1)
+            return loss, n_elements
+        loss = self._pointwise(input_, target.to(input_.device))
+        if self._reduction == 'sum':
+            if loss.ndim in (2, 4):
+                loss = loss.mean(dim=1)           # channel / feature axis
+            return loss.sum(), loss.numel()
+        if self._reduction == 'mean':
+            return loss.mean(), 1
+        return loss, input_.numel()

@@ -1,0 +1,34 @@
+"""`CrossEntropyLossSemantic` (reference loss/ce.py:13-68) on the HIP kernels
+k_ce_fwd / k_ce_bwd.  `n_elements` is returned as a device int64 scalar (the
+reference syncs with `.item()`); it compares / divides like the int it replaces."""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _functional as F_
+from .base import LossBase
+
+
+class CrossEntropyLossSemantic(LossBase):
+    def __init__(
+        self,
+        weights: Optional[torch.Tensor] = None,
+        label_smoothing: float = 0.0,
+        weighted_reduction: bool = False    # the reduction used in ESANet
+    ) -> None:
+        super().__init__()
+        self._weights = weights
+        self._label_smoothing = label_smoothing
+        self._weighted_reduction = weighted_reduction
+        if weighted_reduction:
+            assert self._weights is not None
+
+    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor
+                      ) -> Tuple[torch.Tensor, torch.Tensor]:
+        loss, n_elements, weight_sum = F_.cross_entropy_sum(
+            input_, target, self._weights, self._label_smoothing)
+        if self._weighted_reduction:
+            # sum(loss) / sum_c n_c * w_c  (ce.py:57-68): the divisor is the sum of the
+            # label weights over the non-void pixels
+            loss = loss / weight_sum.to(loss.dtype)
+        return loss, n_elements

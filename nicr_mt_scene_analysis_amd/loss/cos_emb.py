@@ -1,0 +1,40 @@
+"""`CosineEmbeddingLoss` (reference loss/cos_emb.py:13-56) on the HIP kernel k_cos_emb."""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _functional as F_
+from .base import LossBase
+
+
+class CosineEmbeddingLoss(LossBase):
+    def __init__(self, reduction: str = 'sum') -> None:
+        super().__init__()
+        assert reduction in ('sum', 'mean', 'none')
+        self._reduction = reduction
+
+    def lut_sum(self, input_: torch.Tensor, indices: torch.Tensor, lut: torch.Tensor
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
+        """planar [B,D,H,W] prediction, int indices [B,H,W] (0 = no target) and the
+        per-image LUT [B,L,D]: the gathers of task_helper/dense_visual_embedding.py:110-171
+        folded into the kernel.  -> (sum, number of valid px)"""
+        return F_.cosine_embedding_lut_sum(input_, indices, lut)
+
+    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor,
+                      target_similarity: Optional[torch.Tensor] = None):
+        if target_similarity is not None and not bool((target_similarity == 1).all()):
+            raise NotImplementedError('only similar pairs (label +1) are on the hot path')
+        n, d = input_.shape
+        if self._reduction != 'sum' or not input_.is_cuda or n == 0:
+            loss = torch.nn.functional.cosine_embedding_loss(
+                input_, target, torch.ones(n, device=input_.device), reduction='none')
+            if self._reduction == 'sum':
+                return loss.sum(), loss.numel()
+            if self._reduction == 'mean':
+                return loss.mean(), 1
+            return loss, input_.numel()
+        # rows (n, d): prediction planar (1, d, n, 1); the targets are their own LUT
+        x = input_.t().contiguous().view(1, d, n, 1)
+        idx = torch.arange(1, n + 1, dtype=torch.int32, device=input_.device).view(1, n, 1)
+        loss, _ = F_.cosine_embedding_lut_sum(x, idx, target.detach().view(1, n, d))
+        return loss, n

@@ -1,0 +1,39 @@
+"""`VonMisesLossBiternion` (reference loss/vonmises.py:18-51; Beyer et al., Biternion
+Nets, GCPR 2015) on the HIP kernels k_vm_fwd / k_vm_bwd."""
+from typing import Optional, Tuple
+
+import torch
+
+from . import _functional as F_
+from .base import LossBase
+
+
+class VonMisesLossBiternion(LossBase):
+    def __init__(self, reduction: str = 'sum', kappa: float = 1.0) -> None:
+        super().__init__()
+        assert reduction in ('sum', 'none')
+        self._kappa = kappa
+        self._reduction = reduction
+
+    def masked_sum(self, input_: torch.Tensor, target: torch.Tensor,
+                   mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+        """planar [B,2,H,W] prediction/target + [B,H,W] mask: the permute + boolean
+        gather of task_helper/instance.py:186-216 folded into the kernel."""
+        return F_.vonmises_sum(input_, target, mask, self._kappa)
+
+    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor):
+        if input_.ndim != 2 or target.ndim != 2:
+            raise ValueError(
+                "VonMisesLossBiternion does only support 2d inputs with shape (n, 2), you can "
+                "transpose your input to channels last and reshape to shape (b*h*w, c=2), "
+                "e.g., (b, c, h, w) -> (b, h, w, c) -> (b*h*w, c) with c = 2.")
+        n = input_.shape[0]
+        if self._reduction == 'none' or not input_.is_cuda or n == 0:
+            cos = (input_ * target).sum(dim=1, keepdim=True)
+            score = 1 - torch.exp(self._kappa * (cos - 1))
+            return (score.sum() if self._reduction == 'sum' else score), score.numel()
+        # rows (n, 2) -> planar (1, 2, n, 1) for the kernel (autograd carries the transpose)
+        x = input_.t().contiguous().view(1, 2, n, 1)
+        y = target.t().contiguous().view(1, 2, n, 1)
+        loss, _ = F_.vonmises_sum(x, y, None, self._kappa)
+        return loss, n
