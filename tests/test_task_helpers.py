@@ -1,0 +1,254 @@
+"""
+GPU tier: the task helpers (training_step / validation_step / validation_epoch_end) on a
+synthetic batch with multi-scale side outputs.  Loss-dict values are checked against the
+reference's formulas written with plain torch ops (fp64) in this file
+(task_helper/semantic.py:57-90, task_helper/instance.py:92-269, task_helper/base.py:161-182),
+the metric logs against the oracle.
+"""
+import numpy as np
+import pytest
+import torch
+
+from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _down(t, s):
+    return t[..., ::s, ::s].contiguous()
+
+
+def make_loss_batch(B=2, C=9, H=64, W=96, seed=0, with_orientation=True):
+    d = syn.make_loss_inputs(B, C, H, W, seed=seed)
+    t = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d.items()}
+    batch = {
+        'semantic': t['semantic_target'], 'instance_center': t['center_target'],
+        'instance_center_mask': t['center_mask'], 'instance_offset': t['offset_target'],
+        'instance_foreground': t['offset_mask'], 'orientation': t['orientation_target'],
+        'orientation_foreground': t['orientation_mask'],
+    }
+    for s in (2, 4):
+        batch[f'_down_{s}'] = {k: _down(v, s) for k, v in batch.items() if isinstance(v, torch.Tensor)}
+    main = (t['center_pred'].unsqueeze(1), t['offset_pred'], t['orientation_pred'])
+    if not with_orientation:
+        main = main[:2]
+    side = tuple(tuple(_down(x, s) * 0.9 for x in main) for s in (2, 4))
+    sem_side = tuple(_down(t['semantic_logits'], s) * 0.9 for s in (2, 4))
+    preds = {'semantic_output': t['semantic_logits'].requires_grad_(True),
+             'semantic_side_outputs': sem_side,
+             'instance_output': tuple(x.requires_grad_(True) for x in main),
+             'instance_side_outputs': side}
+    return batch, preds, t
+
+
+def ref_ce(x, t, w):
+    return torch.nn.functional.cross_entropy(x.double(), t.long() - 1, weight=w.double(),
+                                             reduction='sum', ignore_index=-1), (t > 0).sum()
+
+
+def test_semantic_task_helper_losses():
+    from nicr_mt_scene_analysis_amd.task_helper import SemanticTaskHelper
+    batch, preds, t = make_loss_batch()
+    helper = SemanticTaskHelper(n_classes=9, class_weights=t['class_weights'].cpu().numpy())
+    helper.initialize(torch.device('cuda'))
+    losses, logs = helper.training_step(batch, 0, preds)
+    assert set(losses) == {'semantic_loss_main', 'semantic_loss_down_2', 'semantic_loss_down_4',
+                           'semantic_total_loss'}
+    assert 'semantic_step_time' in logs and 'semantic_total_loss' in logs
+    tot_l, tot_n = 0, 0
+    for key, x, tg in (('main', preds['semantic_output'], batch['semantic']),
+                       ('down_2', preds['semantic_side_outputs'][0], batch['_down_2']['semantic']),
+                       ('down_4', preds['semantic_side_outputs'][1], batch['_down_4']['semantic'])):
+        l, n = ref_ce(x.detach(), tg, t['class_weights'])
+        np.testing.assert_allclose(float(losses[f'semantic_loss_{key}']), float(l / n), rtol=RTOL)
+        tot_l, tot_n = tot_l + l, tot_n + n
+    np.testing.assert_allclose(float(losses['semantic_total_loss']), float(tot_l / tot_n), rtol=RTOL)
+    losses['semantic_total_loss'].backward()
+    assert preds['semantic_output'].grad is not None
+
+
+def test_instance_task_helper_losses():
+    from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper
+    batch, preds, t = make_loss_batch()
+    helper = InstanceTaskHelper(semantic_n_classes=10, semantic_classes_is_thing=(False,) * 5 + (True,) * 5)
+    helper.initialize(torch.device('cuda'))
+    losses, _ = helper.training_step(batch, 0, preds)
+    want_keys = {f'instance_{k}_loss_{s}' for k in ('center', 'offset', 'orientation')
+                 for s in ('main', 'down_2', 'down_4')}
+    want_keys |= {f'instance_{k}_total_loss' for k in ('center', 'offset', 'orientation')}
+    assert set(losses) == want_keys
+
+    def scales(key_main, side_idx):
+        yield 'main', preds['instance_output'][side_idx], batch
+        for j, s in enumerate((2, 4)):
+            yield f'down_{s}', preds['instance_side_outputs'][j][side_idx], batch[f'_down_{s}']
+
+    sums = {k: [0, 0] for k in ('center', 'offset', 'orientation')}
+    for key, p, bt in scales('center', 0):
+        m = bt['instance_center_mask']
+        l = ((p.detach()[:, 0].double() * m) - bt['instance_center'].double()).pow(2).sum()
+        np.testing.assert_allclose(float(losses[f'instance_center_loss_{key}']), float(l / m.sum()), rtol=RTOL)
+        sums['center'][0] += l; sums['center'][1] += m.sum()
+    for key, p, bt in scales('offset', 1):
+        m = bt['instance_foreground']
+        l = ((p.detach().double() * m.unsqueeze(1)) - bt['instance_offset'].double()).abs().mean(1).sum()
+        np.testing.assert_allclose(float(losses[f'instance_offset_loss_{key}']), float(l / m.sum()), rtol=RTOL)
+        sums['offset'][0] += l; sums['offset'][1] += m.sum()
+    for key, p, bt in scales('orientation', 2):
+        m = bt['orientation_foreground']
+        dot = (p.detach().double() * bt['orientation'].double()).sum(1)
+        l = (1 - torch.exp(dot - 1))[m].sum()
+        n = max(int(m.sum()), 1)
+        np.testing.assert_allclose(float(losses[f'instance_orientation_loss_{key}']), float(l / n), rtol=RTOL)
+        sums['orientation'][0] += l; sums['orientation'][1] += n
+    for k, (l, n) in sums.items():
+        np.testing.assert_allclose(float(losses[f'instance_{k}_total_loss']), float(l / n), rtol=RTOL)
+    total = sum(losses[f'instance_{k}_total_loss'] for k in sums)
+    total.backward()
+    for x in preds['instance_output']:
+        assert x.grad is not None and torch.isfinite(x.grad).all()
+
+
+def test_panoptic_and_semantic_validation(oracle):
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    from nicr_mt_scene_analysis_amd.task_helper import PanopticTaskHelper, SemanticTaskHelper
+    from nicr_mt_scene_analysis_amd.data.preprocessing import APPLIED_PREPROCESSING_KEY
+    B, C, H, W = 3, 8, 96, 128
+    inp = syn.make_panoptic_inputs(B, C, H, W, n_centers=6, seed=2)
+    is_thing = tuple(bool(x) for x in inp['semantic_classes_is_thing'])
+    post = get_postprocessing_class('panoptic')(
+        semantic_postprocessing=get_postprocessing_class('semantic')(),
+        instance_postprocessing=get_postprocessing_class('instance')(),
+        semantic_classes_is_thing=is_thing, semantic_class_has_orientation=is_thing)
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+    rng = np.random.default_rng(0)
+    sem_gt = rng.integers(0, C + 1, (B, H, W)).astype(np.uint8)
+    batch = {'rgb_fullres': torch.zeros((B, 3, H, W)),
+             'semantic': dev(sem_gt), 'semantic_fullres': dev(sem_gt),
+             APPLIED_PREPROCESSING_KEY: [[{'type': 'Resize', 'valid_region_slice_y': slice(0, H),
+                                           'valid_region_slice_x': slice(0, W)}]] * B}
+    data = ((dev(inp['semantic_logits']), (dev(inp['instance_center']), dev(inp['instance_offset']))),
+            (None, None))
+    r = post.postprocess(data, batch, is_training=False)
+    pan = r['panoptic_segmentation_deeplab'].cpu().numpy()
+    pan_gt = np.roll(pan, (2, 3), axis=(1, 2))
+    pan_gt[:, :4] = 0
+    batch['panoptic_fullres'] = dev(pan_gt)
+    batch['panoptic_ids_to_instance_dict'] = [{} for _ in range(B)]
+
+    ph = PanopticTaskHelper(C + 1, (False,) + is_thing)
+    ph.initialize(torch.device('cuda'))
+    assert ph.training_step(batch, 0, r)[0] == {}
+    ph.validation_step(batch, 0, r)
+    artifacts, examples, logs = ph.validation_epoch_end()
+    for k in ('panoptic_all_deeplab_pq', 'panoptic_all_with_gt_deeplab_pq', 'panoptic_things_deeplab_rq',
+              'panoptic_stuff_deeplab_sq', 'panoptic_deeplab_semantic_miou', 'panoptic_epoch_end_time'):
+        assert k in logs, k
+    for k in ('panoptic_pq_per_class', 'panoptic_deeplab_semantic_cm',
+              'panoptic_deeplab_semantic_ious_per_class'):
+        assert k in artifacts, k
+    # against the oracle
+    state = None
+    cm = None
+    for b in range(B):
+        *state, _ = oracle.pq_compare_and_accumulate(pan[b], pan_gt[b], C + 1, 0, 1 << 16, 256 ** 3,
+                                                     state=state)
+        cm = oracle.confmat_update(pan[b] // 65536, sem_gt[b], C + 1, cm)
+    assert (artifacts['panoptic_deeplab_semantic_cm'].cpu().numpy() == cm).all()
+    miou, _ = oracle.miou_compute(cm, True)
+    np.testing.assert_allclose(float(logs['panoptic_deeplab_semantic_miou']), miou, rtol=1e-5)
+    sq = np.where(state[1] > 0, state[0] / np.maximum(state[1], 1), 0)
+    rq = np.where(state[1] + state[2] + state[3] > 0,
+                  state[1] / np.maximum(state[1] + .5 * state[2] + .5 * state[3], 1e-30), 0)
+    valid = (state[1] + state[2] + state[3]) != 0
+    valid[0] = False
+    np.testing.assert_allclose(float(logs['panoptic_all_deeplab_pq']), (sq * rq)[valid].mean(), rtol=1e-12)
+    # after epoch end the states are reset
+    assert float(ph._mae_pq_deeplab.tp_per_class.sum()) == 0
+
+    sh = SemanticTaskHelper(n_classes=C, disable_multiscale_supervision=True)
+    sh.initialize(torch.device('cuda'))
+    sh.validation_step(batch, 0, r)
+    art, _, logs = sh.validation_epoch_end()
+    idx = r['semantic_segmentation_idx_fullres'].cpu().numpy()
+    m = sem_gt != 0
+    cm2 = oracle.confmat_update(idx[m], sem_gt[m] - 1, C)
+    assert (art['semantic_cm'].cpu().numpy() == cm2).all()
+    np.testing.assert_allclose(float(logs['semantic_miou']), oracle.miou_compute(cm2)[0], rtol=1e-5)
+
+
+def test_instance_validation_step():
+    """instance quality with GT semantics (task_helper/instance.py:289-357): a perfect
+    prediction of GT-derived centers/offsets yields PQ == 1 for the thing classes."""
+    from nicr_mt_scene_analysis_amd.model.postprocessing import InstancePostprocessing
+    from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper
+    from nicr_mt_scene_analysis_amd.data.preprocessing import APPLIED_PREPROCESSING_KEY
+    B, H, W = 2, 64, 96
+    inst = np.zeros((B, H, W), np.int32)
+    sem = np.ones((B, H, W), np.uint8)                 # class 1 = stuff
+    heat = np.zeros((B, 1, H, W), np.float32)
+    off = np.zeros((B, 2, H, W), np.float32)
+    yy, xx = np.meshgrid(np.arange(H), np.arange(W), indexing='ij')
+    boxes = [(8, 8, 24, 30, 2), (30, 40, 60, 90, 3), (10, 50, 26, 80, 2)]
+    for b in range(B):
+        for k, (y0, x0, y1, x1, cls) in enumerate(boxes[:2 + b]):
+            inst[b, y0:y1, x0:x1] = k + 1
+            sem[b, y0:y1, x0:x1] = cls
+            cy, cx = (y0 + y1) // 2, (x0 + x1) // 2
+            heat[b, 0, cy, cx] = 1.0
+            off[b, 0, y0:y1, x0:x1] = (cy - yy[y0:y1, x0:x1]) / H
+            off[b, 1, y0:y1, x0:x1] = (cx - xx[y0:y1, x0:x1]) / W
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()      # noqa: E731
+    pan_gt = sem.astype(np.int64) * 65536 + inst
+    fg = inst != 0
+    batch = {
+        'instance_foreground': dev(fg), 'instance_fullres': dev(inst), 'semantic_fullres': dev(sem),
+        'panoptic_fullres': dev(pan_gt), 'panoptic_ids_to_instance_dict': [{} for _ in range(B)],
+        'instance_center': dev(heat[:, 0]), 'instance_center_mask': dev(np.ones((B, H, W), bool)),
+        'instance_offset': dev(off),
+        APPLIED_PREPROCESSING_KEY: [[{'type': 'Resize', 'valid_region_slice_y': slice(0, H),
+                                      'valid_region_slice_x': slice(0, W)}]] * B}
+    post = InstancePostprocessing()
+    preds = post.postprocess(((dev(heat), dev(off)), (None,)), batch, is_training=False)
+    helper = InstanceTaskHelper(4, (False, False, True, True), disable_multiscale_supervision=True)
+    helper.initialize(torch.device('cuda'))
+    losses, _ = helper.validation_step(batch, 0, preds)
+    assert float(losses['instance_center_total_loss']) == 0.0
+    assert float(losses['instance_offset_total_loss']) == 0.0
+    _, _, logs = helper.validation_epoch_end()
+    assert float(logs['instance_things_deeplab_pq']) == 1.0
+    assert float(logs['instance_all_deeplab_rq']) == 1.0
+    assert int(logs['instance_things_deeplab_num_categories']) == 2
+
+
+def test_dve_task_helper_loss():
+    from nicr_mt_scene_analysis_amd.task_helper import DenseVisualEmbeddingTaskHelper
+    d = syn.make_loss_inputs(2, 5, 24, 32, seed=3, embedding_dim=16, n_lut=7)
+    pred = torch.from_numpy(d['embedding_pred']).cuda().requires_grad_(True)
+    idx = torch.from_numpy(d['embedding_indices']).cuda()
+    luts = [torch.from_numpy(d['embedding_lut'][b]).cuda() for b in range(2)]
+    batch = {'dense_visual_embedding_lut': luts, 'dense_visual_embedding_indices': idx}
+    helper = DenseVisualEmbeddingTaskHelper(n_classes=5, disable_multiscale_supervision=True)
+    helper.initialize(torch.device('cuda'))
+    losses, _ = helper.training_step(batch, 0, {'dense_visual_embedding_output': pred})
+    valid = idx != 0
+    rows = pred.detach().permute(0, 2, 3, 1)[valid].double()
+    b_idx = torch.where(valid)[0]
+    tgt = torch.stack(luts)[b_idx, (idx[valid] - 1).long()].double()
+    ref = torch.nn.functional.cosine_embedding_loss(rows, tgt, torch.ones(len(rows), device='cuda'),
+                                                    reduction='sum') / len(rows)
+    np.testing.assert_allclose(float(losses['dense_visual_embedding_total_loss']), float(ref), rtol=RTOL)
+    np.testing.assert_allclose(float(losses['dense_visual_embedding_loss_main']), float(ref), rtol=RTOL)
+    losses['dense_visual_embedding_total_loss'].backward()
+    assert torch.isfinite(pred.grad).all()
+
+
+def test_accumulate_losses_zero_elements_warns():
+    from nicr_mt_scene_analysis_amd.task_helper import SemanticTaskHelper
+    h = SemanticTaskHelper(3)
+    with pytest.warns(UserWarning):
+        out = h.accumulate_losses([torch.zeros(())], [0])
+    assert float(out) == 0.0
+    out = h.accumulate_losses([torch.zeros((), device='cuda')], [torch.zeros((), dtype=torch.int64, device='cuda')])
+    assert float(out) == 0.0
