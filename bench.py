@@ -163,6 +163,8 @@ def main():
     fused_bytes = fused_bytes_px * B * H * W
     achieved = fused_bytes / (fused_ms * 1e-3) / 1e9
     pipeline_bytes_px = esize * C + 4 + 8 + 8 + 1           # 181 B/px at f32, C=40
+    if metrics is not None:
+        pipeline_bytes_px += 8 + 8 + 1                      # + pred pan, target pan, target sem
     roofline = {
         'bound': 'hbm', 'kernel': 'k_panoptic_fused',
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

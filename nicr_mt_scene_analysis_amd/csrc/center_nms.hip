@@ -85,6 +85,93 @@ __global__ __launch_bounds__(256) void k_nms_candidates(
     }
 }
 
+// Fast path (W % 32 == 0, ksize <= 9): a workgroup owns a strip of R full rows.  The
+// strip (+ halo rows) is staged in LDS with 16-B loads; every wave then covers 64
+// consecutive pixels of one row, so the survivors of a wave are ONE ballot and the
+// candidate words are written whole — no atomics, no memset of the bitmask.
+template <int PAD>
+__global__ __launch_bounds__(256) void k_nms_strip(
+    const float* __restrict__ center, uint32_t* __restrict__ cand_bits,
+    int H, int W, int R, int words_per_image, float thr)
+{
+    extern __shared__ float strip[];                 // [(R + 2 PAD)][W + 2 PAD]
+    const int b = blockIdx.y;
+    const int y0 = blockIdx.x * R;
+    const int rows = min(R, H - y0);
+    const float* img = center + (size_t)b * H * W;
+    const int tw = W + 2 * PAD;
+    const int trows = rows + 2 * PAD;
+
+    // ---- stage: thresholded values, -1 outside the image ---------------------------
+    if ((W & 3) == 0) {
+        const int w4 = W >> 2;
+        for (int i = threadIdx.x; i < trows * w4; i += 256) {
+            const int r = i / w4, c4 = i - r * w4;
+            const int gy = y0 - PAD + r;
+            float4 v = make_float4(-1.f, -1.f, -1.f, -1.f);
+            if (gy >= 0 && gy < H) {
+                v = *(const float4*)(img + (size_t)gy * W + 4 * c4);
+                v.x = threshold_m1(v.x, thr); v.y = threshold_m1(v.y, thr);
+                v.z = threshold_m1(v.z, thr); v.w = threshold_m1(v.w, thr);
+            }
+            float* dst = strip + r * tw + PAD + 4 * c4;
+            dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+        }
+    } else {
+        for (int i = threadIdx.x; i < trows * W; i += 256) {
+            const int r = i / W, c = i - r * W;
+            const int gy = y0 - PAD + r;
+            strip[r * tw + PAD + c] = (gy >= 0 && gy < H) ? threshold_m1(img[(size_t)gy * W + c], thr) : -1.f;
+        }
+    }
+    if (PAD > 0)
+        for (int i = threadIdx.x; i < trows * 2 * PAD; i += 256) {
+            const int r = i / (2 * PAD), k = i - r * 2 * PAD;
+            strip[r * tw + (k < PAD ? k : W + k)] = -1.f;
+        }
+    __syncthreads();
+
+    uint32_t* bits = cand_bits + (size_t)b * words_per_image;
+    for (int r = 0; r < rows; ++r) {
+        const int y = y0 + r;
+        const float* row = strip + (r + PAD) * tw + PAD;
+        for (int xb = 0; xb < W; xb += 256) {
+            const int x = xb + threadIdx.x;
+            bool cand = false;
+            if (x < W) {
+                const int self = y * W + x;
+                const float h = row[x];
+                bool survive;
+                if (y < PAD || y >= H - PAD || x < PAD || x >= W - PAD) {
+                    survive = (self == 0) && (h == 0.0f);          // zero-padded pool output
+                } else {
+                    float pooled = -INFINITY;
+                    int pidx = -1;
+#pragma unroll
+                    for (int dy = -PAD; dy <= PAD; ++dy)
+#pragma unroll
+                        for (int dx = -PAD; dx <= PAD; ++dx) {
+                            const float v = row[dy * tw + x + dx];
+                            if (v > pooled || v != v) { pooled = v; pidx = (dy + PAD) * (2 * PAD + 1) + dx + PAD; }
+                        }
+                    // window argmax is the centre element  <=>  pooling index == own index
+                    survive = (pidx == PAD * (2 * PAD + 1) + PAD) && (h == pooled);
+                }
+                cand = survive && h >= 0.0f;
+            }
+            const unsigned long long m = __ballot(cand);
+            if (lane_id() == 0) {
+                const int x_wave = xb + (int)(threadIdx.x & ~63u);
+                if (x_wave < W) {
+                    const int word = (y * W + x_wave) >> 5;        // W % 32 == 0: word-aligned
+                    bits[word] = (uint32_t)m;
+                    if (x_wave + 32 < W) bits[word + 1] = (uint32_t)(m >> 32);
+                }
+            }
+        }
+    }
+}
+
 // ---- block-wide helpers (1024 threads = 16 waves) ---------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v)
 {
@@ -268,20 +355,39 @@ extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
 
     const int words = (int)(((size_t)H * W + 31) / 32);
     uint32_t* bits = (uint32_t*)workspace;
-    int rc = check_hip(hipMemsetAsync(bits, 0, (size_t)B * words * sizeof(uint32_t), stream));
-    if (rc) return rc;
+    int rc;
     if (center_mask) {
         rc = check_hip(hipMemsetAsync(center_mask, 0, (size_t)B * H * W, stream));
         if (rc) return rc;
     }
     const int pad = (ksize - 1) / 2;
-    dim3 grid((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH, B);
-    if (pad <= NMS_PAD_MAX)
-        hipLaunchKernelGGL(k_nms_candidates<true>, grid, dim3(256), 0, stream,
-                           center, bits, H, W, words, threshold, pad);
-    else
-        hipLaunchKernelGGL(k_nms_candidates<false>, grid, dim3(256), 0, stream,
-                           center, bits, H, W, words, threshold, pad);
+    // strip fast path: whole candidate words per wave (needs W % 32 == 0)
+    int R = 4;
+    while (R > 1 && (size_t)(R + 2 * pad) * (W + 2 * pad) * sizeof(float) > 48 * 1024) R >>= 1;
+    const size_t strip_lds = (size_t)(R + 2 * pad) * (W + 2 * pad) * sizeof(float);
+    if ((W % 32) == 0 && pad <= NMS_PAD_MAX && strip_lds <= 64 * 1024) {
+        dim3 grid((H + R - 1) / R, B);
+#define NMSA_STRIP(PADV) hipLaunchKernelGGL(k_nms_strip<PADV>, grid, dim3(256), strip_lds, stream, \
+                                            center, bits, H, W, R, words, threshold)
+        switch (pad) {
+            case 0: NMSA_STRIP(0); break;
+            case 1: NMSA_STRIP(1); break;
+            case 2: NMSA_STRIP(2); break;
+            case 3: NMSA_STRIP(3); break;
+            default: NMSA_STRIP(4); break;
+        }
+#undef NMSA_STRIP
+    } else {
+        rc = check_hip(hipMemsetAsync(bits, 0, (size_t)B * words * sizeof(uint32_t), stream));
+        if (rc) return rc;
+        dim3 grid((W + NMS_TW - 1) / NMS_TW, (H + NMS_TH - 1) / NMS_TH, B);
+        if (pad <= NMS_PAD_MAX)
+            hipLaunchKernelGGL(k_nms_candidates<true>, grid, dim3(256), 0, stream,
+                               center, bits, H, W, words, threshold, pad);
+        else
+            hipLaunchKernelGGL(k_nms_candidates<false>, grid, dim3(256), 0, stream,
+                               center, bits, H, W, words, threshold, pad);
+    }
     rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(k_select_compact, dim3(B), dim3(SEL_THREADS), 0, stream,

@@ -274,6 +274,14 @@ __global__ __launch_bounds__(256) void k_pq_init(unsigned char* __restrict__ ws)
 
 constexpr int PQ_UNROLL = 4;      // 16-B loads in flight per lane and map (2 px each)
 
+typedef long long i64x2_t __attribute__((ext_vector_type(2)));
+// both maps are read exactly once: streaming (non-temporal) 16-B loads
+__device__ __forceinline__ longlong2 ld_i64x2_stream(const int64_t* p)
+{
+    const i64x2_t v = __builtin_nontemporal_load((const i64x2_t*)p);
+    return make_longlong2(v.x, v.y);
+}
+
 __global__ __launch_bounds__(256) void k_pq_count(
     const int64_t* __restrict__ pred, const int64_t* __restrict__ target,
     int P, int64_t offset, int px_per_block,
@@ -334,8 +342,8 @@ __global__ __launch_bounds__(256) void k_pq_count(
             for (int u = 0; u < PQ_UNROLL; ++u) {
                 const int i = base + (u * blockDim.x + threadIdx.x) * 2;
                 ok[u] = i < end;                                // end is even on this path
-                tv[u] = ok[u] ? *(const longlong2*)(tg + i) : make_longlong2(0, 0);
-                pv[u] = ok[u] ? *(const longlong2*)(pr + i) : make_longlong2(0, 0);
+                tv[u] = ok[u] ? ld_i64x2_stream(tg + i) : make_longlong2(0, 0);
+                pv[u] = ok[u] ? ld_i64x2_stream(pr + i) : make_longlong2(0, 0);
             }
 #pragma unroll
             for (int u = 0; u < PQ_UNROLL; ++u) {

@@ -25,6 +25,7 @@
 //    float with sqrt_rn(U) == d_min (from the exact fp64 square of the
 //    rounding midpoint); pass 2 (descending i) takes the lowest i with
 //    s_i <= U.  Both passes are branch-free compare/select.
+#include <stdlib.h>
 #include "nmsa_common.hpp"
 
 namespace nmsa {
@@ -34,12 +35,20 @@ constexpr int PX_PER_THREAD = 4;
 constexpr int PX_PER_ITER = FUSED_THREADS * PX_PER_THREAD;   // 1024
 
 // ---- typed 4-pixel loads -------------------------------------------------------
-template <int DTYPE, bool VEC>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
+
+template <int DTYPE, bool VEC, bool NT = false>
 __device__ __forceinline__ float4 load_px4(const void* base, size_t elem_off, int nvalid)
 {
     float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
     if (DTYPE == NMSA_F32) {
         const float* p = (const float*)base + elem_off;
+        if (VEC && NT) {
+            // streamed once: non-temporal hint (no reuse -> do not keep the lines)
+            const f32x4_t v = __builtin_nontemporal_load((const f32x4_t*)p);
+            return make_float4(v.x, v.y, v.z, v.w);
+        }
         if (VEC) return *(const float4*)p;
         if (nvalid > 0) r.x = p[0];
         if (nvalid > 1) r.y = p[1];
@@ -49,7 +58,10 @@ __device__ __forceinline__ float4 load_px4(const void* base, size_t elem_off, in
     } else {
         const uint16_t* p = (const uint16_t*)base + elem_off;
         uint16_t h[4] = {0, 0, 0, 0};
-        if (VEC) {
+        if (VEC && NT) {
+            const u16x4_t u = __builtin_nontemporal_load((const u16x4_t*)p);
+            h[0] = u.x; h[1] = u.y; h[2] = u.z; h[3] = u.w;
+        } else if (VEC) {
             const ushort4 u = *(const ushort4*)p;
             h[0] = u.x; h[1] = u.y; h[2] = u.z; h[3] = u.w;
         } else {
@@ -148,7 +160,7 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
 // fused: argmax + fg + grouping + class votes
 // dynamic LDS: float2 centers[max_centers] | u32 hist[lds_rows * NC] | u8 thing[256]
 // =================================================================================
-template <int DTYPE, bool VEC, bool WITH_SCORE>
+template <int DTYPE, bool VEC, bool WITH_SCORE, int UNROLL = 8, bool NT = true>
 __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
     const void* __restrict__ logits, const float* __restrict__ offset,
     const int32_t* __restrict__ centers_yx, const int32_t* __restrict__ n_centers,
@@ -193,13 +205,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
 #pragma unroll
         for (int j = 0; j < 4; ++j) { st.m[j] = -INFINITY; st.am[j] = 0; st.se[j] = 0.f; st.bad[j] = false; }
         int c = 0;
-        for (; c + 8 <= C; c += 8) {
-            float4 v[8];
+        for (; c + UNROLL <= C; c += UNROLL) {
+            float4 v[UNROLL];
 #pragma unroll
-            for (int u = 0; u < 8; ++u)
-                v[u] = load_px4<DTYPE, VEC>(logits, img_logits + (size_t)(c + u) * P + p0, nvalid);
+            for (int u = 0; u < UNROLL; ++u)
+                v[u] = load_px4<DTYPE, VEC, NT>(logits, img_logits + (size_t)(c + u) * P + p0, nvalid);
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
+            for (int u = 0; u < UNROLL; ++u) {
                 argmax_step<WITH_SCORE>(st, 0, v[u].x, c + u);
                 argmax_step<WITH_SCORE>(st, 1, v[u].y, c + u);
                 argmax_step<WITH_SCORE>(st, 2, v[u].z, c + u);
@@ -207,7 +219,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
             }
         }
         for (; c < C; ++c) {
-            const float4 v = load_px4<DTYPE, VEC>(logits, img_logits + (size_t)c * P + p0, nvalid);
+            const float4 v = load_px4<DTYPE, VEC, NT>(logits, img_logits + (size_t)c * P + p0, nvalid);
             argmax_step<WITH_SCORE>(st, 0, v.x, c);
             argmax_step<WITH_SCORE>(st, 1, v.y, c);
             argmax_step<WITH_SCORE>(st, 2, v.z, c);
@@ -230,8 +242,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
         // ---- a3: offset grouping ------------------------------------------------------
         uint32_t id[4] = {0u, 0u, 0u, 0u};
         if (any_fg && n > 0) {
-            const float4 oy = load_px4<NMSA_F32, VEC>(offy, (size_t)p0, nvalid);
-            const float4 ox = load_px4<NMSA_F32, VEC>(offx, (size_t)p0, nvalid);
+            const float4 oy = load_px4<NMSA_F32, VEC, NT>(offy, (size_t)p0, nvalid);
+            const float4 ox = load_px4<NMSA_F32, VEC, NT>(offx, (size_t)p0, nvalid);
             const float oyv[4] = {oy.x, oy.y, oy.z, oy.w};
             const float oxv[4] = {ox.x, ox.y, ox.z, ox.w};
             float ly[4], lx[4];
@@ -653,12 +665,19 @@ using namespace nmsa;
 // ---------------------------------------------------------------------------------
 namespace {
 
+int env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return v ? atoi(v) : dflt;
+}
+
 int fused_iters(int P)
 {
-    // 2 x 1024 px per workgroup: 150 workgroups per 640x480 image -> >= 4800 at B=32,
-    // >> 256 CUs x 8 resident, so the last partial wave of blocks is < 3 % of the grid
+    // 1024 px per workgroup: 300 workgroups per 640x480 image -> 9600 at B=32, >> 256 CUs x 8
+    // resident (measured on MI355X, profiles/r01_tune_fused.txt: 1 < 2 < 4 iterations)
     (void)P;
-    return 2;
+    static const int it = env_int("NMSA_FUSED_ITERS", 1);     // tuning knob
+    return it > 0 ? it : 1;
 }
 
 template <int DTYPE>
@@ -689,8 +708,22 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     hipLaunchKernelGGL((k_panoptic_fused<DTYPE, V, S>), grid, block, lds, stream, logits,    \
                        offset, centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, \
                        sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows)
-    if (vec) { if (score) NMSA_LAUNCH_FUSED(true, true); else NMSA_LAUNCH_FUSED(true, false); }
+    // tuning variants of the headline instantiation (f32, vector path, no score)
+    static const int unroll = env_int("NMSA_FUSED_UNROLL", 8);
+    static const int nt = env_int("NMSA_FUSED_NT", 1);
+#define NMSA_LAUNCH_FUSED_V(U, N)                                                              \
+    hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, U, N>), grid, block, lds, stream, \
+                       logits, offset, centers_yx, n_centers, is_thing, C, H, W, max_centers,  \
+                       iters, sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows)
+    if (vec && !score && DTYPE == NMSA_F32 && (unroll != 8 || !nt)) {
+        if (unroll == 4 && !nt) NMSA_LAUNCH_FUSED_V(4, false);
+        else if (unroll == 10 && !nt) NMSA_LAUNCH_FUSED_V(10, false);
+        else if (unroll == 4) NMSA_LAUNCH_FUSED_V(4, true);
+        else if (unroll == 10) NMSA_LAUNCH_FUSED_V(10, true);
+        else NMSA_LAUNCH_FUSED_V(8, false);
+    } else if (vec) { if (score) NMSA_LAUNCH_FUSED(true, true); else NMSA_LAUNCH_FUSED(true, false); }
     else { if (score) NMSA_LAUNCH_FUSED(false, true); else NMSA_LAUNCH_FUSED(false, false); }
+#undef NMSA_LAUNCH_FUSED_V
 #undef NMSA_LAUNCH_FUSED
     return check_launch();
 }
