@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument('--centers', type=int, default=24)
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-metrics', action='store_true')
+    ap.add_argument('--no-side-stream', action='store_true',
+                    help='enqueue the metric kernels on the main stream (no overlap)')
     ap.add_argument('--cpu-sample-images', type=int, default=32)
     return ap.parse_args()
 
@@ -96,14 +98,21 @@ def main():
     from nicr_mt_scene_analysis_amd import ops
     from nicr_mt_scene_analysis_amd.testing import synthetic as syn
 
-    torch.cuda.set_device(local_rank)
-    dev = torch.device('cuda', local_rank)
+    n_dev = torch.cuda.device_count()
+    dev_index = local_rank % max(n_dev, 1)       # rehearsal: several ranks may share one GPU
+    torch.cuda.set_device(dev_index)
+    dev = torch.device('cuda', dev_index)
     dist = None
     if world > 1:
         import torch.distributed as dist_
         dist = dist_
-        dist.init_process_group('nccl', rank=rank, world_size=world,
-                                device_id=dev)
+        # 'nccl' == RCCL on ROCm.  NMSA_BENCH_BACKEND=gloo is only for rehearsing the
+        # multi-rank path on a box with fewer GPUs than ranks (RCCL refuses shared devices).
+        backend = os.environ.get('NMSA_BENCH_BACKEND', 'nccl')
+        if backend == 'nccl':
+            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     B, C, H, W = args.batch_per_gpu, args.classes, args.height, args.width
     inp = syn.make_panoptic_inputs_torch(B, C, H, W, n_centers=args.centers,
@@ -116,7 +125,8 @@ def main():
     if not args.no_metrics:
         try:
             from nicr_mt_scene_analysis_amd.metric import bench_support
-            metrics = bench_support.MetricAccumulators(C + 1, dev, inp, rank)
+            metrics = bench_support.MetricAccumulators(C + 1, dev, inp, rank, world_size=world,
+                                                       side_stream=not args.no_side_stream)
         except ImportError:
             metrics = None
 
@@ -126,8 +136,7 @@ def main():
         r = ops.panoptic_pipeline(logits, center, offset, is_thing,
                                   fused_kernel_events=events if record else None)
         if metrics is not None:
-            metrics.update(r['panoptic'])
-            metrics.all_reduce(dist)
+            metrics.update_and_reduce(r['panoptic'], dist)
         return r
 
     for _ in range(args.warmup):
@@ -139,6 +148,8 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r = step(True)
+    if metrics is not None:
+        metrics.wait()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -146,7 +157,8 @@ def main():
     elapsed = time.perf_counter() - t0
 
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64,
+                         device=dev if dist.get_backend() == 'nccl' else 'cpu')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -165,10 +177,28 @@ def main():
     pipeline_bytes_px = esize * C + 4 + 8 + 8 + 1           # 181 B/px at f32, C=40
     if metrics is not None:
         pipeline_bytes_px += 8 + 8 + 1                      # + pred pan, target pan, target sem
+    # the same kernel without the metric kernels overlapping on the side stream (untimed)
+    iso_events = []
+    for _ in range(20):
+        ops.panoptic_pipeline(logits, center, offset, is_thing, fused_kernel_events=iso_events)
+    torch.cuda.synchronize()
+    iso_ms = float(np.mean([a.elapsed_time(b) for a, b in iso_events[2:]]))
+    # HBM bytes per launch from the committed PMC passes of this command (separate
+    # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 wide-stream correction applied by
+    # tools/summarize_profile.py); null when the workload differs from the profiled one
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
+    if os.path.exists(tpath) and (B, C, H, W) == (32, 40, 480, 640) and esize == 4:
+        with open(tpath) as f:
+            traffic = json.load(f).get('k_panoptic_fused', {}).get('hbm_bytes_per_launch')
     roofline = {
         'bound': 'hbm', 'kernel': 'k_panoptic_fused',
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': None,
+        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
+        'traffic_source': 'profiles/latest_traffic.json (rocprofv3 --pmc, per launch)' if traffic else None,
+        'algorithmic_bytes_per_launch': fused_bytes,
+        'kernel_ms_isolated': round(iso_ms, 4),
+        'frac_isolated': round(fused_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
         'kernel_ms': round(fused_ms, 4), 'algorithmic_bytes_per_px': fused_bytes_px,
         'pipeline_algorithmic_bytes_per_px': pipeline_bytes_px,
         'pipeline_frac': round(pipeline_bytes_px * B * H * W / (ms_per_step * 1e-3) / 1e9

@@ -131,31 +131,48 @@ __global__ __launch_bounds__(256) void k_nms_strip(
         }
     __syncthreads();
 
+    // A pixel survives iff it is the FIRST maximum of its window in row-major scan order
+    // and the window holds no NaN (ATen takes `v > max || isnan(v)`):  every element before
+    // it is strictly smaller, every element after it is <= (NaN fails both tests).
+    // Each thread walks one column down the strip and keeps the (2 PAD + 1) window rows in
+    // registers: (2 PAD + 1) LDS reads per pixel instead of (2 PAD + 1)^2.
     uint32_t* bits = cand_bits + (size_t)b * words_per_image;
-    for (int r = 0; r < rows; ++r) {
-        const int y = y0 + r;
-        const float* row = strip + (r + PAD) * tw + PAD;
-        for (int xb = 0; xb < W; xb += 256) {
-            const int x = xb + threadIdx.x;
+    constexpr int K = 2 * PAD + 1;
+    for (int xb = 0; xb < W; xb += 256) {
+        const int x = xb + threadIdx.x;
+        const bool in_x = x < W;
+        const int xc = in_x ? x : 0;
+        float win[K][K];
+#pragma unroll
+        for (int i = 0; i < K - 1; ++i)
+#pragma unroll
+            for (int j = 0; j < K; ++j)
+                win[i + 1][j] = strip[i * tw + xc + j];            // strip rows 0 .. K-2
+        for (int r = 0; r < rows; ++r) {
+            const int y = y0 + r;
+#pragma unroll
+            for (int i = 0; i < K - 1; ++i)
+#pragma unroll
+                for (int j = 0; j < K; ++j) win[i][j] = win[i + 1][j];
+#pragma unroll
+            for (int j = 0; j < K; ++j) win[K - 1][j] = strip[(r + K - 1) * tw + xc + j];
             bool cand = false;
-            if (x < W) {
-                const int self = y * W + x;
-                const float h = row[x];
+            if (in_x) {
+                const float h = win[PAD][PAD];
                 bool survive;
                 if (y < PAD || y >= H - PAD || x < PAD || x >= W - PAD) {
-                    survive = (self == 0) && (h == 0.0f);          // zero-padded pool output
+                    survive = (y * W + x == 0) && (h == 0.0f);     // zero-padded pool output
                 } else {
-                    float pooled = -INFINITY;
-                    int pidx = -1;
+                    survive = true;
 #pragma unroll
-                    for (int dy = -PAD; dy <= PAD; ++dy)
+                    for (int i = 0; i < K; ++i)
 #pragma unroll
-                        for (int dx = -PAD; dx <= PAD; ++dx) {
-                            const float v = row[dy * tw + x + dx];
-                            if (v > pooled || v != v) { pooled = v; pidx = (dy + PAD) * (2 * PAD + 1) + dx + PAD; }
+                        for (int j = 0; j < K; ++j) {
+                            if (i == PAD && j == PAD) continue;
+                            const bool before = (i < PAD) || (i == PAD && j < PAD);
+                            survive = survive && (before ? (win[i][j] < h) : (win[i][j] <= h));
                         }
-                    // window argmax is the centre element  <=>  pooling index == own index
-                    survive = (pidx == PAD * (2 * PAD + 1) + PAD) && (h == pooled);
+                    survive = survive && (h == h);
                 }
                 cand = survive && h >= 0.0f;
             }

@@ -18,6 +18,7 @@
 //                  fp64, per-class sums accumulated in that order -> the fp64
 //                  state is bit-identical to the reference's.
 // k_pq_accumulate: state += per-image results, in image order (deterministic).
+#include <stdlib.h>
 #include "nmsa_common.hpp"
 
 namespace nmsa {
@@ -62,44 +63,36 @@ __device__ __forceinline__ int64_t floormod64(int64_t a, int64_t b)
 // pred_div: preds are raw / pred_div (panoptic id // max_instances, panoptic.py:123)
 // =================================================================================
 constexpr int CM_LDS_BINS = 24 * 1024;     // 96 KB of u32 (n <= 156)
-constexpr int CM_CHUNK = 8;                // consecutive elements per lane and load group
+constexpr int CM_UNROLL = 4;               // 2-element loads in flight per lane and map
 
-// 8 consecutive elements starting at i (i % 8 == 0) as int64; VEC = one or a few
-// 8/16-B loads (pointer suitably aligned, chunk fully inside the array)
+// two consecutive elements starting at i (i even) as int64; VEC = one 2/4/8/16-B load
 template <int DT, bool VEC>
-__device__ __forceinline__ void load8(const void* p, int64_t i, int64_t n, int64_t out[CM_CHUNK])
+__device__ __forceinline__ void load2(const void* p, int64_t i, int64_t n, int64_t& a, int64_t& b)
 {
-    if (VEC && i + CM_CHUNK <= n) {
+    if (VEC && i + 2 <= n) {
         if (DT == NMSA_U8) {
-            const uint2 v = *(const uint2*)((const uint8_t*)p + i);
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { out[j] = (v.x >> (8 * j)) & 0xFF; out[4 + j] = (v.y >> (8 * j)) & 0xFF; }
+            const uint16_t v = *(const uint16_t*)((const uint8_t*)p + i);
+            a = v & 0xFF; b = v >> 8;
         } else if (DT == NMSA_I16) {
-            const int4 v = *(const int4*)((const int16_t*)p + i);
-            const int w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { out[2 * j] = (int16_t)(w[j] & 0xFFFF); out[2 * j + 1] = (int16_t)(w[j] >> 16); }
+            const uint32_t v = *(const uint32_t*)((const int16_t*)p + i);
+            a = (int16_t)(v & 0xFFFF); b = (int16_t)(v >> 16);
         } else if (DT == NMSA_I32) {
-            const int4 a = *(const int4*)((const int32_t*)p + i);
-            const int4 c = *(const int4*)((const int32_t*)p + i + 4);
-            out[0] = a.x; out[1] = a.y; out[2] = a.z; out[3] = a.w;
-            out[4] = c.x; out[5] = c.y; out[6] = c.z; out[7] = c.w;
+            const int2 v = *(const int2*)((const int32_t*)p + i);
+            a = v.x; b = v.y;
         } else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const longlong2 v = *(const longlong2*)((const int64_t*)p + i + 2 * j);
-                out[2 * j] = v.x; out[2 * j + 1] = v.y;
-            }
+            const longlong2 v = *(const longlong2*)((const int64_t*)p + i);
+            a = v.x; b = v.y;
         }
     } else {
-#pragma unroll
-        for (int j = 0; j < CM_CHUNK; ++j) out[j] = (i + j < n) ? load_int_m(p, DT, (size_t)(i + j)) : 0;
+        a = (i < n) ? load_int_m(p, DT, (size_t)i) : 0;
+        b = (i + 1 < n) ? load_int_m(p, DT, (size_t)(i + 1)) : 0;
     }
 }
 
-// Every lane owns 8 CONSECUTIVE elements per step: label maps are coherent along a row,
-// so the lane run-length-encodes its 8 bins in registers and issues one LDS atomic per
-// run (no cross-lane traffic at all); two steps are kept in flight for latency hiding.
+// Lanes of a wave hold consecutive element pairs (coalesced loads: every wave-instruction
+// reads one contiguous run).  Label maps are coherent along a row, so the wave is cut into
+// RUNS of equal bins and every run head issues ONE LDS atomic with the run length; with
+// incoherent labels every lane is a head and the atomics simply run in parallel.
 template <int PD, int TD, bool VEC>
 __global__ __launch_bounds__(256) void k_confmat(
     const void* __restrict__ preds, int64_t pred_div, const void* __restrict__ target,
@@ -114,49 +107,48 @@ __global__ __launch_bounds__(256) void k_confmat(
         __syncthreads();
     }
     bool bad = false;
-    auto bump = [&](int key, uint32_t len) {
-        if (key < 0) return;
-        if (use_lds) atomicAdd(&cm_hist[key], len);
-        else atomicAdd(&confmat[key], (unsigned long long)len);
+    auto bin_of = [&](int64_t t, int64_t p, bool valid) -> int {
+        if (!valid) return -1;
+        if (p < 0) bad = true;                              // bincount rejects negatives
+        if (pred_div != 1) p = p / pred_div;               // torch `//` on non-negative ids
+        if (mode == 1) { if (t == 0) return -1; t -= 1; }
+        const int64_t bin = t * n + p;                      // miou.py:50
+        if (t < 0 || p < 0 || bin >= nbins || bin < 0) { bad = true; return -1; }
+        return (int)bin;
     };
-    auto consume = [&](int64_t i0, const int64_t tv[CM_CHUNK], const int64_t pv[CM_CHUNK]) {
-        int run_key = -1;
-        uint32_t run_len = 0;
-#pragma unroll
-        for (int j = 0; j < CM_CHUNK; ++j) {
-            int key = -1;
-            if (i0 + j < n_px) {
-                int64_t t = tv[j], p = pv[j];
-                if (p < 0) bad = true;                          // bincount rejects negatives
-                if (pred_div != 1) p = p / pred_div;           // torch `//` on non-negative ids
-                bool skip = false;
-                if (mode == 1) { skip = (t == 0); t -= 1; }
-                if (!skip) {
-                    const int64_t bin = t * n + p;              // miou.py:50
-                    if (t < 0 || p < 0 || bin >= nbins || bin < 0) bad = true;
-                    else key = (int)bin;
-                }
-            }
-            if (key == run_key) ++run_len;
-            else { bump(run_key, run_len); run_key = key; run_len = 1; }
+    auto wave_runs = [&](int key, uint32_t weight) {
+        const int prev = __shfl_up(key, 1);
+        const bool head = key >= 0 && (lane_id() == 0 || prev != key);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long gaps = __ballot(key < 0);
+        if (head) {
+            const int l = lane_id();
+            const unsigned long long stop = (heads | gaps) & ~((2ull << l) - 1ull);
+            const int nxt = stop ? (__ffsll((long long)stop) - 1) : 64;
+            const uint32_t len = weight * (uint32_t)(nxt - l);
+            if (use_lds) atomicAdd(&cm_hist[key], len);
+            else atomicAdd(&confmat[key], (unsigned long long)len);
         }
-        bump(run_key, run_len);
     };
 
-    const int64_t n_chunks = (n_px + CM_CHUNK - 1) / CM_CHUNK;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; c < n_chunks; c += 2 * stride) {
-        const int64_t i0 = c * CM_CHUNK, i1 = (c + stride) * CM_CHUNK;
-        const bool second = (c + stride) < n_chunks;
-        int64_t t0[CM_CHUNK], p0[CM_CHUNK], t1[CM_CHUNK], p1[CM_CHUNK];
-        load8<TD, VEC>(target, i0, n_px, t0);
-        load8<PD, VEC>(preds, i0, n_px, p0);
-        if (second) {
-            load8<TD, VEC>(target, i1, n_px, t1);
-            load8<PD, VEC>(preds, i1, n_px, p1);
+    const int64_t tile = (int64_t)blockDim.x * 2 * CM_UNROLL;
+    const int64_t n_tiles = (n_px + tile - 1) / tile;
+    for (int64_t tl = blockIdx.x; tl < n_tiles; tl += gridDim.x) {
+        int64_t ta[CM_UNROLL], tb[CM_UNROLL], pa[CM_UNROLL], pb[CM_UNROLL];
+#pragma unroll
+        for (int u = 0; u < CM_UNROLL; ++u) {
+            const int64_t i = tl * tile + ((int64_t)u * blockDim.x + threadIdx.x) * 2;
+            load2<TD, VEC>(target, i, n_px, ta[u], tb[u]);
+            load2<PD, VEC>(preds, i, n_px, pa[u], pb[u]);
         }
-        consume(i0, t0, p0);
-        if (second) consume(i1, t1, p1);
+#pragma unroll
+        for (int u = 0; u < CM_UNROLL; ++u) {
+            const int64_t i = tl * tile + ((int64_t)u * blockDim.x + threadIdx.x) * 2;
+            const int k0 = bin_of(ta[u], pa[u], i < n_px);
+            const int k1 = bin_of(tb[u], pb[u], i + 1 < n_px);
+            if (__all(k0 == k1)) wave_runs(k0, 2u);
+            else { wave_runs(k0, 1u); wave_runs(k1, 1u); }
+        }
     }
     if (bad) atomicOr(status, ST_VALUE_RANGE);
     if (use_lds) {
@@ -403,21 +395,12 @@ __device__ __forceinline__ int block_incl_scan_i(int v, int* scratch, int* total
 
 constexpr int PQ_MATCH_THREADS = 1024;
 constexpr int PQ_MAX_CATEGORIES = 1024;
-constexpr int PQ_TP_CAP = 2048;             // matched pairs per image
+constexpr int PQ_TP_CAP = 1024;             // matched pairs per image
 
-__device__ __forceinline__ int64_t sorted_lookup(const int64_t* keys, const uint32_t* cnts,
-                                                 int n, int64_t key)
-{
-    int lo = 0, hi = n - 1;
-    while (lo <= hi) {
-        const int mid = (lo + hi) >> 1;
-        const int64_t k = keys[mid];
-        if (k == key) return cnts[mid];
-        if (k < key) lo = mid + 1; else hi = mid - 1;
-    }
-    return 0;
-}
-
+// One workgroup per image.  The intersection table is copied into LDS as it is (same
+// hash layout -> O(1) probes instead of sorted searches); only the MATCHED pairs (a few
+// dozen) are put in ascending-id order, which is all the reference's fp64 summation
+// order depends on.
 __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     unsigned char* __restrict__ ws, int num_categories, int64_t ignored_label,
     int64_t max_inst, int64_t offset, int64_t void_segment_id,
@@ -425,76 +408,38 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     int64_t* __restrict__ matches /* [B,match_cap,2] or null */, int match_cap,
     int32_t* __restrict__ n_matches, int* __restrict__ status)
 {
-    __shared__ int64_t sKey[PQ_I_CAP];          // intersection ids, sorted ascending
-    __shared__ uint32_t sCnt[PQ_I_CAP];
-    __shared__ int16_t sCat[PQ_I_CAP];          // category of a TP entry, -1 otherwise
+    __shared__ int64_t iK[PQ_I_CAP];                   // intersection table (hash layout)
+    __shared__ uint32_t iC[PQ_I_CAP];
     __shared__ int64_t kT[PQ_T_CAP], kP[PQ_P_CAP];     // segment-area tables (marginals)
     __shared__ uint32_t cT[PQ_T_CAP], cP[PQ_P_CAP];
     __shared__ uint8_t fT[PQ_T_CAP], fP[PQ_P_CAP];     // matched flags
-    __shared__ double tpIou[PQ_TP_CAP];         // TP entries compacted in id order
-    __shared__ int16_t tpCat[PQ_TP_CAP];
-    __shared__ uint16_t tpIdx[PQ_TP_CAP];
+    __shared__ int64_t tpKey[PQ_TP_CAP], tpKeyS[PQ_TP_CAP];   // TP list: unordered / sorted
+    __shared__ double tpIou[PQ_TP_CAP], tpIouS[PQ_TP_CAP];
+    __shared__ int16_t tpCat[PQ_TP_CAP], tpCatS[PQ_TP_CAP];
     __shared__ int fnI[PQ_MAX_CATEGORIES], fpI[PQ_MAX_CATEGORIES];
     __shared__ int64_t ignKeys[64];
-    __shared__ int nIgn;
-    __shared__ int scratch[32];
+    __shared__ int nIgn, nTPs;
 
     const int b = blockIdx.x, tid = threadIdx.x;
     const int64_t* gk = pq_keys(ws, b);
     const uint32_t* gc = pq_cnts(ws, b);
     int st = 0;
 
+    for (int i = tid; i < PQ_I_CAP; i += PQ_MATCH_THREADS) { iK[i] = gk[i]; iC[i] = gc[i]; }
     for (int i = tid; i < PQ_T_CAP; i += PQ_MATCH_THREADS) {
         fT[i] = 0; fP[i] = 0; kT[i] = KEY_EMPTY; kP[i] = KEY_EMPTY; cT[i] = 0; cP[i] = 0;
     }
     for (int i = tid; i < num_categories; i += PQ_MATCH_THREADS) { fnI[i] = 0; fpI[i] = 0; }
-    if (tid == 0) nIgn = 0;
-
-    // ---- 1. compact the intersection table --------------------------------------------
-    const int per = PQ_I_CAP / PQ_MATCH_THREADS;      // 4 slots / thread
-    int64_t myk[per];
-    uint32_t myc[per];
-    int mine = 0;
-#pragma unroll
-    for (int j = 0; j < per; ++j) {
-        myk[j] = gk[tid * per + j];
-        myc[j] = gc[tid * per + j];
-        mine += (myk[j] != KEY_EMPTY);
-    }
-    int nI;
-    int pos = block_incl_scan_i(mine, scratch, &nI) - mine;
-#pragma unroll
-    for (int j = 0; j < per; ++j)
-        if (myk[j] != KEY_EMPTY) { sKey[pos] = myk[j]; sCnt[pos] = myc[j]; ++pos; }
-    int n2 = 1;
-    while (n2 < nI) n2 <<= 1;
-    for (int i = nI + tid; i < n2; i += PQ_MATCH_THREADS) { sKey[i] = INT64_MAX; sCnt[i] = 0; }
+    if (tid == 0) { nIgn = 0; nTPs = 0; }
     __syncthreads();
 
-    // ---- 2. bitonic sort, ascending id (= reference dict iteration order) ---------------
-    for (int k = 2; k <= n2; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < n2; i += PQ_MATCH_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const bool up = (i & k) == 0;
-                    const int64_t a = sKey[i], c = sKey[ixj];
-                    if ((a > c) == up) {
-                        sKey[i] = c; sKey[ixj] = a;
-                        const uint32_t ca = sCnt[i]; sCnt[i] = sCnt[ixj]; sCnt[ixj] = ca;
-                    }
-                }
-            }
-            __syncthreads();
-        }
-    }
-
-    // ---- 3. segment areas = marginals of the intersection table (pq.py:83-84) ------------
-    for (int e = tid; e < nI; e += PQ_MATCH_THREADS) {
-        const int64_t iid = sKey[e];
+    // ---- 1. segment areas = marginals of the intersection table (pq.py:83-84) ------------
+    for (int s = tid; s < PQ_I_CAP; s += PQ_MATCH_THREADS) {
+        const int64_t iid = iK[s];
+        if (iid == KEY_EMPTY) continue;
         const int64_t gt = floordiv64(iid, offset), pr = floormod64(iid, offset);
-        if (!table_add(kT, cT, PQ_T_CAP - 1, gt, sCnt[e], PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
-        if (!table_add(kP, cP, PQ_P_CAP - 1, pr, sCnt[e], PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
+        if (!table_add(kT, cT, PQ_T_CAP - 1, gt, iC[s], PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
+        if (!table_add(kP, cP, PQ_P_CAP - 1, pr, iC[s], PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
     }
     __syncthreads();
     // ignored segments: target ids whose category is the ignored label (pq.py:89-93)
@@ -506,73 +451,55 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
         }
     }
 
-    // ---- 4. TP decision per intersection (pq.py:119-153) ----------------------------------
-    auto entry_iou = [&](int e, int* sT_out, int* sP_out) -> double {
-        const int64_t iid = sKey[e];
+    // ---- 2. TP decision per intersection (pq.py:119-153), unordered TP list --------------
+    for (int s = tid; s < PQ_I_CAP; s += PQ_MATCH_THREADS) {
+        const int64_t iid = iK[s];
+        if (iid == KEY_EMPTY || iid == void_segment_id) continue;          // :120-121
         const int64_t gt = floordiv64(iid, offset), pr = floormod64(iid, offset);
+        const int64_t gcat = floordiv64(gt, max_inst), pcat = floordiv64(pr, max_inst);
+        if (gcat != pcat) continue;                                         // :128-129
         // prediction_void_overlap (pq.py:35-44)
         const int64_t vid = (int64_t)((uint64_t)void_segment_id * (uint64_t)offset + (uint64_t)pr);
-        const int64_t r = sorted_lookup(sKey, sCnt, nI, vid);
+        const int sV = table_find(iK, PQ_I_CAP - 1, vid);
+        const int64_t r = sV >= 0 ? (int64_t)iC[sV] : 0;
         const int sT = table_find(kT, PQ_T_CAP - 1, gt);
         const int sP = table_find(kP, PQ_P_CAP - 1, pr);
-        *sT_out = sT; *sP_out = sP;
-        if (sT < 0 || sP < 0) return -1.0;
-        const int64_t ia = sCnt[e];
-        const int64_t uni = (int64_t)cT[sT] + (int64_t)cP[sP] - ia - r;       // :143
-        return (double)ia / (double)uni;                                       // :145
-    };
-    for (int e = tid; e < nI; e += PQ_MATCH_THREADS) {
-        int16_t cat = -1;
-        const int64_t iid = sKey[e];
-        if (iid != void_segment_id) {                                          // :120-121
-            const int64_t gcat = floordiv64(floordiv64(iid, offset), max_inst);
-            const int64_t pcat = floordiv64(floormod64(iid, offset), max_inst);
-            if (gcat == pcat) {                                                // :128-129
-                int sT, sP;
-                const double iou = entry_iou(e, &sT, &sP);
-                if (sT < 0 || sP < 0) st |= ST_MISSING_KEY;
-                else if (iou > 0.5) {                                          // :147
-                    if (gcat < 0 || gcat >= num_categories) st |= ST_CATEGORY_RANGE;
-                    else { cat = (int16_t)gcat; fT[sT] = 1; fP[sP] = 1; }
-                }
-            }
+        if (sT < 0 || sP < 0) { st |= ST_MISSING_KEY; continue; }
+        const int64_t ia = iC[s];
+        const int64_t uni = (int64_t)cT[sT] + (int64_t)cP[sP] - ia - r;     // :143
+        const double iou = (double)ia / (double)uni;                        // :145
+        if (iou > 0.5) {                                                    // :147
+            if (gcat < 0 || gcat >= num_categories) { st |= ST_CATEGORY_RANGE; continue; }
+            fT[sT] = 1; fP[sP] = 1;
+            const int at = atomicAdd(&nTPs, 1);
+            if (at < PQ_TP_CAP) { tpKey[at] = iid; tpIou[at] = iou; tpCat[at] = (int16_t)gcat; }
         }
-        sCat[e] = cat;
+    }
+    __syncthreads();
+    const int nTP = nTPs;
+    if (nTP > PQ_TP_CAP) st |= ST_TABLE_OVERFLOW;
+    const int nTPc = min(nTP, PQ_TP_CAP);
+
+    // ---- 3. rank sort of the TP list by id (= reference dict iteration order) --------------
+    for (int i = tid; i < nTPc; i += PQ_MATCH_THREADS) {
+        const int64_t k = tpKey[i];
+        int rank = 0;
+        for (int j = 0; j < nTPc; ++j) rank += (tpKey[j] < k);              // ids are distinct
+        tpKeyS[rank] = k; tpIouS[rank] = tpIou[i]; tpCatS[rank] = tpCat[i];
     }
     __syncthreads();
 
-    // ---- 5. ordered compaction of the TP entries, then per-class TP / IoU sums in
-    //         ascending-id order (bit-exact fp64: same operand order as the reference) ----
-    int nTP;
-    {
-        const int chunk = (nI + PQ_MATCH_THREADS - 1) / PQ_MATCH_THREADS;
-        const int e0 = min(tid * chunk, nI), e1 = min(e0 + chunk, nI);
-        int m = 0;
-        for (int e = e0; e < e1; ++e) m += (sCat[e] >= 0);
-        int at = block_incl_scan_i(m, scratch, &nTP) - m;
-        for (int e = e0; e < e1; ++e) {
-            if (sCat[e] < 0) continue;
-            if (at < PQ_TP_CAP) {
-                int sT, sP;
-                tpCat[at] = sCat[e]; tpIdx[at] = (uint16_t)e;
-                tpIou[at] = entry_iou(e, &sT, &sP);
-            }
-            ++at;
-        }
-        if (nTP > PQ_TP_CAP) st |= ST_TABLE_OVERFLOW;
-    }
-    __syncthreads();
+    // ---- 4. per-class TP / IoU sums in ascending-id order (bit-exact fp64) ------------------
     double* out = img_state + (size_t)b * 4 * num_categories;
-    const int nTPc = min(nTP, PQ_TP_CAP);
     for (int c = tid; c < num_categories; c += PQ_MATCH_THREADS) {
         double iou = 0.0, tp = 0.0;
         for (int e = 0; e < nTPc; ++e)
-            if (tpCat[e] == c) { tp += 1.0; iou += tpIou[e]; }
+            if (tpCatS[e] == c) { tp += 1.0; iou += tpIouS[e]; }
         out[0 * num_categories + c] = iou;
         out[1 * num_categories + c] = tp;
     }
 
-    // ---- 6. false negatives (pq.py:155-163) -----------------------------------------------
+    // ---- 5. false negatives (pq.py:155-163) -----------------------------------------------
     for (int s = tid; s < PQ_T_CAP; s += PQ_MATCH_THREADS) {
         const int64_t k = kT[s];
         if (k == KEY_EMPTY || fT[s]) continue;
@@ -581,16 +508,18 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
         if (cat < 0 || cat >= num_categories) { st |= ST_CATEGORY_RANGE; continue; }
         atomicAdd(&fnI[cat], 1);
     }
-    // ---- 7. false positives (pq.py:165-177) -------------------------------------------------
+    // ---- 6. false positives (pq.py:165-177) -------------------------------------------------
     const int n_ign = nIgn;
     if (n_ign > 64) st |= ST_TABLE_OVERFLOW;
     for (int s = tid; s < PQ_P_CAP; s += PQ_MATCH_THREADS) {
         const int64_t k = kP[s];
         if (k == KEY_EMPTY || fP[s]) continue;
         int64_t pio = 0;                                  // prediction_ignored_overlap :47-57
-        for (int q = 0; q < min(n_ign, 64); ++q)
-            pio += sorted_lookup(sKey, sCnt, nI,
-                                 (int64_t)((uint64_t)ignKeys[q] * (uint64_t)offset + (uint64_t)k));
+        for (int q = 0; q < min(n_ign, 64); ++q) {
+            const int sI = table_find(iK, PQ_I_CAP - 1,
+                                      (int64_t)((uint64_t)ignKeys[q] * (uint64_t)offset + (uint64_t)k));
+            if (sI >= 0) pio += iC[sI];
+        }
         if ((double)pio / (double)cP[s] > 0.5) continue;
         const int64_t cat = floordiv64(k, max_inst);
         if (cat < 0 || cat >= num_categories) { st |= ST_CATEGORY_RANGE; continue; }
@@ -602,12 +531,11 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
         out[3 * num_categories + c] = (double)fpI[c];
     }
 
-    // ---- 8. matched (gt, pred) pairs in id order (for the orientation MAE) -------------------
+    // ---- 7. matched (gt, pred) pairs in id order (for the orientation MAE) -------------------
     if (matches) {
         for (int i = tid; i < nTPc && i < match_cap; i += PQ_MATCH_THREADS) {
-            const int64_t iid = sKey[tpIdx[i]];
-            matches[((size_t)b * match_cap + i) * 2 + 0] = floordiv64(iid, offset);
-            matches[((size_t)b * match_cap + i) * 2 + 1] = floormod64(iid, offset);
+            matches[((size_t)b * match_cap + i) * 2 + 0] = floordiv64(tpKeyS[i], offset);
+            matches[((size_t)b * match_cap + i) * 2 + 1] = floormod64(tpKeyS[i], offset);
         }
     }
     if (tid == 0 && n_matches) n_matches[b] = nTP;
@@ -675,10 +603,11 @@ extern "C" int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pr
     const int nbins = n_classes * n_classes;
     const int use_lds = nbins <= CM_LDS_BINS;
     const size_t lds = use_lds ? (size_t)nbins * 4 : 0;
-    const int64_t n_chunks = (n_px + CM_CHUNK - 1) / CM_CHUNK;
+    const int64_t n_chunks = (n_px + 2 * CM_UNROLL - 1) / (2 * CM_UNROLL);     // per-thread work items
     // >= 4 workgroups per CU for latency hiding; a big LDS histogram allows only one
-    int64_t blocks = (lds > 40 * 1024) ? 256 : CM_MAX_BLOCKS;
-    const int64_t need = (n_chunks + 2 * 256 - 1) / (2 * 256);
+    static const int blocks_env = getenv("NMSA_CM_BLOCKS") ? atoi(getenv("NMSA_CM_BLOCKS")) : 0;
+    int64_t blocks = (lds > 40 * 1024) ? 256 : (blocks_env > 0 && blocks_env <= CM_MAX_BLOCKS ? blocks_env : CM_MAX_BLOCKS);
+    const int64_t need = (n_chunks + 256 - 1) / 256;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;
     const bool vec = (((uintptr_t)preds | (uintptr_t)target) & 15) == 0;
@@ -748,7 +677,8 @@ extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B,
     hipLaunchKernelGGL(k_pq_init, dim3(2, B), dim3(256), 0, stream, ws);
     int rc = check_launch();
     if (rc) return rc;
-    const int px_per_block = 4096;
+    static const int px_per_block_env = getenv("NMSA_PQ_PXB") ? atoi(getenv("NMSA_PQ_PXB")) : 0;
+    const int px_per_block = px_per_block_env > 0 ? (px_per_block_env & ~1) : 8192;     // tuning knob (profiles/r01_tune_notes.md)
     hipLaunchKernelGGL(k_pq_count, dim3((P + px_per_block - 1) / px_per_block, B), dim3(256), 0, stream,
                        pred, target, P, offset, px_per_block, ws, status);
     rc = check_launch();

@@ -1,11 +1,15 @@
 """Streaming metric accumulation for bench.py (BASELINE.json configs[3]).
 
-Every step each rank updates step-local accumulators from its shard of the
-batch (HIP kernels), sums them over the ranks with ONE all-reduce per dtype
-(RCCL over xGMI: the int64 confusion matrix, the float64 PQ vectors — ~15 KB,
-the only collective on the path) and adds the result to the replicated running
-totals.  Mirrors `dist_reduce_fx='sum'` of reference metric/miou.py:21-25 and
-metric/pq.py:228-246.
+Every step each rank updates accumulators from its shard of the batch (HIP kernels).
+With more than one rank the step-local accumulators are summed over the ranks with ONE
+all-reduce per dtype (RCCL over xGMI: the int64 confusion matrix, the float64 PQ vectors —
+~15 KB, the only collective on the path) and added to the replicated running totals;
+with a single rank the kernels accumulate into the totals directly.  Mirrors
+`dist_reduce_fx='sum'` of reference metric/miou.py:21-25 and metric/pq.py:228-246.
+
+The metric kernels are enqueued on a side HIP stream: they only depend on the panoptic
+map of their own step, so the latency-bound per-image kernels (matching, accumulation,
+all-reduce) overlap with the next step's streaming kernels.
 """
 import torch
 
@@ -16,16 +20,21 @@ from .pq import PanopticQuality
 
 class MetricAccumulators:
     def __init__(self, n_classes_with_void: int, device, inputs, rank: int = 0,
-                 max_instances_per_category: int = 1 << 16) -> None:
+                 max_instances_per_category: int = 1 << 16, world_size: int = 1,
+                 side_stream: bool = True) -> None:
         self.max_inst = max_instances_per_category
+        self.world_size = world_size
         n = n_classes_with_void
         is_thing = [False] + [bool(x) for x in inputs['semantic_classes_is_thing'].cpu().tolist()]
-        self.step_miou = MeanIntersectionOverUnion(n, ignore_first_class=True, device=device)
-        self.step_pq = PanopticQuality(n, 0, self.max_inst, 256 ** 3, is_thing, device=device)
-        # running totals: one flat buffer per step-metric (same packing as Metric._pack)
-        self._step_flat = [next(iter(self.step_miou._pack().values())),
-                           next(iter(self.step_pq._pack().values()))]
-        self._total_flat = [torch.zeros_like(f) for f in self._step_flat]
+        self.miou = MeanIntersectionOverUnion(n, ignore_first_class=True, device=device)
+        self.pq = PanopticQuality(n, 0, self.max_inst, 256 ** 3, is_thing, device=device)
+        # flat state buffers (same packing as Metric._pack); totals only when all-reducing
+        self._step_flat = [next(iter(self.miou._pack().values())),
+                           next(iter(self.pq._pack().values()))]
+        self._total_flat = [torch.zeros_like(f) for f in self._step_flat] \
+            if world_size > 1 else self._step_flat
+        self.stream = torch.cuda.Stream(device=device) if side_stream else None
+        self._ready = torch.cuda.Event()
         # synthetic ground truth: the prediction shifted by 3 px with a
         # void band, and uniformly random semantic labels
         r = ops.panoptic_pipeline(inputs['semantic_logits'], inputs['instance_center'],
@@ -37,25 +46,38 @@ class MetricAccumulators:
         g = torch.Generator(device=device).manual_seed(99 + rank)
         self.target_semantic = torch.randint(0, n, pan.shape, device=device, generator=g,
                                              dtype=torch.int64).to(torch.uint8)
+        torch.cuda.synchronize(device)
 
-    def update(self, panoptic_pred: torch.Tensor) -> None:
-        self.step_miou.zero_()
-        self.step_pq.zero_()
-        # miou.update(pan // max_inst, semantic target)   (task_helper/panoptic.py:123-126)
-        self.step_miou.update_from_panoptic(panoptic_pred, self.target_semantic, self.max_inst)
-        # pq.update(pan, panoptic target)                  (task_helper/panoptic.py:111-118)
-        self.step_pq.update(panoptic_pred, self.target_panoptic)
+    def update_and_reduce(self, panoptic_pred: torch.Tensor, dist=None) -> None:
+        cur = torch.cuda.current_stream(panoptic_pred.device)
+        stream = self.stream if self.stream is not None else cur
+        if stream is not cur:
+            self._ready.record(cur)
+            stream.wait_event(self._ready)
+            panoptic_pred.record_stream(stream)       # caching allocator: used on the side stream
+        with torch.cuda.stream(stream):
+            if self.world_size > 1:
+                self.miou.zero_()
+                self.pq.zero_()
+            # miou.update(pan // max_inst, semantic target)   (task_helper/panoptic.py:123-126)
+            self.miou.update_from_panoptic(panoptic_pred, self.target_semantic, self.max_inst)
+            # pq.update(pan, panoptic target)                  (task_helper/panoptic.py:111-118)
+            self.pq.update(panoptic_pred, self.target_panoptic)
+            if self.world_size > 1:
+                if dist is not None:
+                    self.miou.sync()
+                    self.pq.sync()
+                for tot, stp in zip(self._total_flat, self._step_flat):
+                    tot += stp
 
-    def all_reduce(self, dist=None) -> None:
-        if dist is not None:
-            self.step_miou.sync()
-            self.step_pq.sync()
-        for tot, stp in zip(self._total_flat, self._step_flat):
-            tot += stp
+    def wait(self) -> None:
+        """make the current stream wait for everything enqueued on the side stream"""
+        if self.stream is not None:
+            torch.cuda.current_stream().wait_stream(self.stream)
 
     @property
     def total_confmat(self) -> torch.Tensor:
-        return self._total_flat[0].view_as(self.step_miou.confmat)
+        return self._total_flat[0].view_as(self.miou.confmat)
 
     @property
     def total_pq(self) -> torch.Tensor:
