@@ -173,6 +173,24 @@ int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* ins, int ins
                         int64_t* pan, int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
                         nmsa_stream_t stream);
 
+/* Same merge for instance ids beyond uint8 (ground-truth maps: uint16 ids stored as
+ * int32, e.g. > 256 instances per image; task_helper/instance.py:61).  Ids 0..65535
+ * are ranked per image first (ascending order preserved), at most max_segments
+ * (<= 4096) distinct thing ids per image.
+ *   ids_pan / ids_ins  i64 [B, cap] with cap = max_segments rounded up to 1024
+ *   status  i32 [1]: NMSA_ST_TABLE_OVERFLOW (more ids than max_segments),
+ *                    32 = instance id outside [0, 65535]
+ */
+size_t nmsa_panoptic_merge_wide_workspace_bytes(int B, int n_classes, int max_segments);
+int nmsa_panoptic_merge_wide(const void* sem, int sem_dtype, const void* ins, int ins_dtype,
+                             const uint8_t* thing_seg, const uint8_t* is_thing_class,
+                             int B, int n_classes, int H, int W,
+                             int64_t max_instances_per_category, int64_t void_label,
+                             int max_segments,
+                             int64_t* pan, int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
+                             int32_t* status, void* workspace, size_t workspace_bytes,
+                             nmsa_stream_t stream);
+
 /* ---------------------------------------------------------------------------
  * next-1  InstancePostprocessing._get_instance_orientation
  *     model/postprocessing/instance.py:271-319

@@ -255,6 +255,40 @@ def panoptic_merge(
     return {'panoptic': pan, 'ids_pan': ids_pan, 'ids_ins': ids_ins, 'n_ids': n_ids}
 
 
+def panoptic_merge_wide(
+    semantic: torch.Tensor,
+    instance: torch.Tensor,
+    thing_seg: torch.Tensor,
+    is_thing_class: torch.Tensor,
+    max_instances_per_category: int,
+    void_label: int = 0,
+    max_segments: int = 1024,
+) -> Dict[str, torch.Tensor]:
+    """deeplab_merge_batch for instance ids 0..65535 (ground-truth maps)."""
+    sem = L.require_device_tensor(semantic, 'semantic')
+    ins = L.require_device_tensor(instance, 'instance')
+    B, H, W = sem.shape
+    dev = sem.device
+    thing = _u8(thing_seg)
+    lut = _u8(is_thing_class)
+    n_classes = int(lut.numel())
+    cap = ((max_segments + 1023) // 1024) * 1024
+    pan = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    ids_pan = torch.empty((B, cap), dtype=torch.int64, device=dev)
+    ids_ins = torch.empty((B, cap), dtype=torch.int64, device=dev)
+    n_ids = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws_bytes = L.lib().nmsa_panoptic_merge_wide_workspace_bytes(B, n_classes, max_segments)
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+    L.check(L.lib().nmsa_panoptic_merge_wide(
+        L.ptr(sem), L.int_dtype_code(sem), L.ptr(ins), L.int_dtype_code(ins), L.ptr(thing),
+        L.ptr(lut), B, n_classes, H, W, int(max_instances_per_category), int(void_label),
+        int(max_segments), L.ptr(pan), L.ptr(ids_pan), L.ptr(ids_ins), L.ptr(n_ids), L.ptr(status),
+        L.ptr(ws), ws_bytes, L.stream_ptr(dev)), 'nmsa_panoptic_merge_wide')
+    return {'panoptic': pan, 'ids_pan': ids_pan, 'ids_ins': ids_ins, 'n_ids': n_ids,
+            'status': status}
+
+
 # ------------------------------------------------------------------------- next-1
 def instance_orientation_sums(
     orientation: torch.Tensor,

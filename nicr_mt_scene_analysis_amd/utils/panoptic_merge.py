@@ -57,12 +57,6 @@ def deeplab_merge_batch(
     if sem.ndim != 3 or ins.shape != sem.shape or fg.shape != sem.shape:
         raise ValueError('expected three tensors of shape (B, H, W)')
 
-    # value-range checks: one small reduction (ids are uint8 on the prediction path)
-    if ins.dtype not in (torch.uint8, torch.bool):
-        if int(ins.max()) > _MAX_INSTANCE_ID:
-            raise NotImplementedError(
-                f'instance ids > {_MAX_INSTANCE_ID} are not supported by the HIP merge yet '
-                '(the prediction path produces uint8 ids, reference instance.py:236)')
     if n_classes is None:
         n_classes = int(sem.max()) + 1
     thing_list = [int(t) for t in thing_ids]
@@ -71,8 +65,24 @@ def deeplab_merge_batch(
     for t in thing_list:
         if 0 <= t < n_classes:
             lut[t] = 1
-    r = ops.panoptic_merge(sem, ins, fg, lut.to(dev), int(max_instances_per_category),
-                           int(void_label))
+    lut = lut.to(dev)
+    if ins.dtype in (torch.uint8, torch.bool):
+        # prediction path: uint8 ids (reference instance.py:236), direct-indexed kernels
+        r = ops.panoptic_merge(sem, ins, fg, lut, int(max_instances_per_category),
+                               int(void_label))
+    else:
+        # ground-truth maps: ids 0..65535, ranked per image on the device
+        for max_segments in (1024, 4096):
+            r = ops.panoptic_merge_wide(sem, ins, fg, lut, int(max_instances_per_category),
+                                        int(void_label), max_segments=max_segments)
+            st = int(r['status'].item())
+            if st & 32:
+                raise NotImplementedError('instance ids outside [0, 65535] are not supported '
+                                          '(dataset instance maps are uint16)')
+            if not (st & 1):
+                break
+        else:
+            raise NotImplementedError('more than 4096 distinct instance ids in one image')
     dicts = _ids_to_dicts(r['ids_pan'], r['ids_ins'], r['n_ids'])
     pan = r['panoptic']
     if in_device.type != 'cuda':

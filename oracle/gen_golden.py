@@ -324,7 +324,7 @@ def gen_merge(ref):
         pan, dicts = pm.deeplab_merge_batch(
             torch.from_numpy(sem), torch.from_numpy(ins), torch.from_numpy(thing),
             max_inst, thing_ids, void)
-        n, k, v = ids_to_arrays(dicts, cap=512)
+        n, k, v = ids_to_arrays(dicts, cap=2048)
         out.update({f'{name}__sem': sem, f'{name}__ins': ins, f'{name}__thing': thing,
                     f'{name}__params': jdump(dict(max_inst=max_inst,
                                                   thing_ids=[int(t) for t in thing_ids],
@@ -353,6 +353,15 @@ def gen_merge(ref):
     thing2 = rng.random(sem.shape) < 0.5
     run('mask_mismatch', sem, ins, thing2, 256, [1, 2, 6], 0)
     run('void_label_7', sem, ins, thing, 100, [3, 4], 7)
+    # ground-truth style ids beyond uint8: 300 distinct ids up to 60000, and 1500 distinct ids
+    # (more than the first table size of the HIP path)
+    for nm, n_ids, hi in (('wide_ids', 300, 60000), ('many_ids', 1500, 65535)):
+        ids = np.sort(rng.choice(np.arange(1, hi + 1), size=n_ids, replace=False))
+        cells = rng.integers(0, n_ids + 1, size=(2, H // 2, W // 2))      # 0 = no instance
+        ins_w = np.where(cells > 0, ids[np.maximum(cells - 1, 0)], 0)
+        ins_w = np.repeat(np.repeat(ins_w, 2, axis=1), 2, axis=2).astype(np.int32)
+        sem_w = blobs(C + 1, 2).astype(np.int64)
+        run(nm, sem_w, ins_w, ins_w != 0, 1 << 16, [3, 4, 5], 0)
     # everything stuff / everything void
     run('all_stuff', sem, np.zeros_like(ins), np.zeros_like(thing), 1 << 16, [], 0)
     run('all_void', np.zeros_like(sem), ins, thing, 1 << 16, [1], 0)

@@ -190,8 +190,14 @@ def test_merge_cases(ops):
         for t in p['thing_ids']:
             if t < n_classes:
                 lut[t] = 1
-        r = ops.panoptic_merge(dev(sem), dev(ins), dev(g[f'{name}__thing']), dev(lut),
-                               p['max_inst'], p['void'])
+        if ins.dtype == np.uint8:
+            r = ops.panoptic_merge(dev(sem), dev(ins), dev(g[f'{name}__thing']), dev(lut),
+                                   p['max_inst'], p['void'])
+        else:       # ground-truth style ids (int32, up to 65535): ranked on the device
+            r = ops.panoptic_merge_wide(dev(sem), dev(ins), dev(g[f'{name}__thing']), dev(lut),
+                                        p['max_inst'], p['void'],
+                                        max_segments=4096 if name == 'many_ids' else 1024)
+            assert int(r['status'].item()) == 0
         torch.cuda.synchronize()
         assert (r['panoptic'].cpu().numpy() == g[f'{name}__pan']).all(), name
         got = ids_from_arrays(r['n_ids'].cpu().numpy(), r['ids_pan'].cpu().numpy(),
