@@ -51,6 +51,9 @@ __device__ __forceinline__ float4 ld4(const void* base, size_t off, int nvalid, 
     return r;
 }
 
+typedef float f32x4_s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_s __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint16_t f32_to_bf16(float f)
 {
     // round-to-nearest-even via the hardware conversion (keeps NaN a NaN)
@@ -139,69 +142,159 @@ __global__ __launch_bounds__(256) void k_loss_finalize(
 //   per px (t = label-1 >= 0):  (1-ls)*w_t*(lse - x_t) + (ls/C)*(lse*W - sum_c w_c x_c)
 //   outputs: sum, n = #non-void px, aux = sum_px w_t  (divisor of the ESANet
 //   "weighted_reduction", ce.py:57-68)
+//
+// PXT pixels per lane: 4 for f32, 8 for bf16 / f16 — always 16-B loads.  The class loop
+// works in groups of U planes: group maximum with v_max3, ONE rescale of the running sum
+// per group, then 3 VALU per element (fma into the base-2 domain, v_exp_f32, add).  The
+// target logit x_t is fetched with one gather per pixel after the loop (the tile was just
+// streamed, the gather hits L2) instead of a compare/select per class.
 // =================================================================================
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+template <int DTYPE, int PXT, bool NT = true>
+__device__ __forceinline__ void ldpx(const void* base, size_t off, int nvalid, bool vec, float out[PXT])
+{
+    if (DTYPE == NMSA_F32) {
+        const float* p = (const float*)base + off;
+        if (vec) {
+            const f32x4_s v = NT ? __builtin_nontemporal_load((const f32x4_s*)p) : *(const f32x4_s*)p;
+            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+        } else {
+            for (int j = 0; j < PXT; ++j) out[j] = (j < nvalid) ? p[j] : 0.f;
+        }
+    } else {
+        const uint16_t* p = (const uint16_t*)base + off;
+        uint16_t h[PXT];
+        if (vec) {
+            const u32x4_s v = NT ? __builtin_nontemporal_load((const u32x4_s*)p) : *(const u32x4_s*)p;
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[2 * j] = (uint16_t)(w[j] & 0xFFFF); h[2 * j + 1] = (uint16_t)(w[j] >> 16); }
+        } else {
+            for (int j = 0; j < PXT; ++j) h[j] = (j < nvalid) ? p[j] : 0;
+        }
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) out[j] = (DTYPE == NMSA_BF16) ? bf16_to_f32(h[j]) : f16_to_f32(h[j]);
+    }
+}
+
+template <int DTYPE, int PXT>
+__device__ __forceinline__ void stpx(void* base, size_t off, int nvalid, bool vec, const float v[PXT])
+{
+    if (DTYPE == NMSA_F32) {
+        float* p = (float*)base + off;
+        if (vec) *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        else for (int j = 0; j < nvalid; ++j) p[j] = v[j];
+    } else {
+        uint16_t* p = (uint16_t*)base + off;
+        uint16_t h[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) h[j] = (DTYPE == NMSA_BF16) ? f32_to_bf16(v[j]) : f32_to_f16(v[j]);
+        if (vec) {
+            uint4 w;
+            w.x = h[0] | ((uint32_t)h[1] << 16); w.y = h[2] | ((uint32_t)h[3] << 16);
+            w.z = h[4] | ((uint32_t)h[5] << 16); w.w = h[6] | ((uint32_t)h[7] << 16);
+            *(uint4*)p = w;
+        } else {
+            for (int j = 0; j < nvalid; ++j) p[j] = h[j];
+        }
+    }
+}
+
 template <int DTYPE>
+__device__ __forceinline__ float ld_scalar(const void* base, size_t off)
+{
+    if (DTYPE == NMSA_F32) return ((const float*)base)[off];
+    const uint16_t h = ((const uint16_t*)base)[off];
+    return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
+}
+
+// streaming max / sum-of-exp2 over the classes for PXT pixels; SMOOTH adds sum_c w_c x_c
+template <int DTYPE, int PXT, int U, bool SMOOTH, bool TRACK_T, bool NT>
+__device__ __forceinline__ void ce_scan(const void* logits, size_t img, int P, int p0, int nvalid,
+                                        bool vec, int C, const float* s_w, const int t[PXT],
+                                        float m[PXT], float s[PXT], float swx[PXT], float xt[PXT])
+{
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) { m[j] = -INFINITY; s[j] = 0.f; swx[j] = 0.f; xt[j] = 0.f; }
+    int c = 0;
+    for (; c + U <= C; c += U) {
+        float v[U][PXT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) ldpx<DTYPE, PXT, NT>(logits, img + (size_t)(c + u) * P + p0, nvalid, vec, v[u]);
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const int tj = TRACK_T ? t[j] - c : 0;
+            float g = v[0][j];
+#pragma unroll
+            for (int u = 1; u < U; ++u) g = fmaxf(g, v[u][j]);
+            const float mn = fmaxf(m[j], g);
+            const float k = -mn * LOG2E;
+            float acc = s[j] * __builtin_amdgcn_exp2f(fmaf(m[j], LOG2E, k));        // rescale once per group
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                acc += __builtin_amdgcn_exp2f(fmaf(v[u][j], LOG2E, k));
+                if (SMOOTH) swx[j] = fmaf(s_w[c + u], v[u][j], swx[j]);
+                if (TRACK_T) xt[j] = (tj == u) ? v[u][j] : xt[j];
+            }
+            s[j] = acc; m[j] = mn;
+        }
+    }
+    for (; c < C; ++c) {
+        float v[PXT];
+        ldpx<DTYPE, PXT, NT>(logits, img + (size_t)c * P + p0, nvalid, vec, v);
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const float mn = fmaxf(m[j], v[j]);
+            const float k = -mn * LOG2E;
+            s[j] = s[j] * __builtin_amdgcn_exp2f(fmaf(m[j], LOG2E, k)) + __builtin_amdgcn_exp2f(fmaf(v[j], LOG2E, k));
+            m[j] = mn;
+            if (SMOOTH) swx[j] = fmaf(s_w[c], v[j], swx[j]);
+            if (TRACK_T) xt[j] = (t[j] == c) ? v[j] : xt[j];
+        }
+    }
+}
+
+template <int DTYPE, int PXT, bool SMOOTH>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
     LossPartial* __restrict__ partials, int* __restrict__ status)
 {
     extern __shared__ float s_w[];
-    float wsum = 0.f;
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
-    for (int c = 0; c < C; ++c) wsum += s_w[c];
+    float wsum = 0.f;
+    if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
     const int b = blockIdx.y;
     const size_t img = (size_t)b * C * P;
     double acc = 0.0, accw = 0.0;
     long long cnt = 0;
     bool bad = false;
-    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * LOSS_THREADS * 4) {
-        const int nvalid = min(4, P - p0);
-        int t[4];
-        for (int j = 0; j < 4; ++j) t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;   // ce.py:46
-        float m[4], s[4], xt[4], swx[4];
-        for (int j = 0; j < 4; ++j) { m[j] = -INFINITY; s[j] = 0.f; xt[j] = 0.f; swx[j] = 0.f; }
-        int c = 0;
-        for (; c + 8 <= C; c += 8) {
-            float4 v[8];
+    constexpr int U = (PXT == 4) ? 8 : 4;
+    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * PXT; p0 < P;
+         p0 += gridDim.x * LOSS_THREADS * PXT) {
+        const int nvalid = min(PXT, P - p0);
+        float m[PXT], s[PXT], swx[PXT], xts[PXT];
+        int tt[PXT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ld4<DTYPE>(logits, img + (size_t)(c + u) * P + p0, nvalid, vec);
-#pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                const float w = s_w[c + u];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float e = __expf(-fabsf(x[j] - m[j]));       // online logsumexp
-                    s[j] = (x[j] > m[j]) ? fmaf(s[j], e, 1.0f) : (s[j] + e);
-                    m[j] = fmaxf(m[j], x[j]);
-                    if (t[j] == c + u) xt[j] = x[j];
-                    swx[j] = fmaf(w, x[j], swx[j]);
-                }
-            }
-        }
-        for (; c < C; ++c) {
-            const float4 v = ld4<DTYPE>(logits, img + (size_t)c * P + p0, nvalid, vec);
-            const float x[4] = {v.x, v.y, v.z, v.w};
-            const float w = s_w[c];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float e = __expf(-fabsf(x[j] - m[j]));
-                s[j] = (x[j] > m[j]) ? fmaf(s[j], e, 1.0f) : (s[j] + e);
-                m[j] = fmaxf(m[j], x[j]);
-                if (t[j] == c) xt[j] = x[j];
-                swx[j] = fmaf(w, x[j], swx[j]);
-            }
-        }
+        for (int j = 0; j < PXT; ++j)
+            tt[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;       // ce.py:46
+        ce_scan<DTYPE, PXT, U, SMOOTH, true, true>(logits, img, P, p0, nvalid, vec, C, s_w, tt,
+                                                   m, s, swx, xts);
         float part = 0.f, partw = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (t[j] < 0) continue;                                  // void: ignore_index
-            if (t[j] >= C) { bad = true; continue; }
-            const float lse = m[j] + __logf(s[j]);
-            const float wt = s_w[t[j]];
-            part += (1.0f - ls) * wt * (lse - xt[j]) + (ls / C) * (lse * wsum - swx[j]);
+        for (int j = 0; j < PXT; ++j) {
+            const int t = tt[j];
+            if (t < 0) continue;                                            // void: ignore_index
+            if (t >= C) { bad = true; continue; }
+            const float xt = xts[j];
+            const float lse = fmaf(__log2f(s[j]), LN2, m[j]);
+            const float wt = s_w[t];
+            float l = (1.0f - ls) * wt * (lse - xt);
+            if (SMOOTH) l += (ls / C) * (lse * wsum - swx[j]);
+            part += l;
             partw += wt;
             ++cnt;
         }
@@ -213,72 +306,55 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
 
 // d loss_sum / d logits, times the upstream gradient *gscale  (ce.py via autograd)
 //   grad_j = g * [ (a + bsum) p_j - a [j == t] - b_j ],  a = (1-ls) w_t, b_j = (ls/C) w_j
-template <int DTYPE>
+// pass 1: max / sum (as forward); pass 2 re-reads the tile (L2) and writes
+// g*((a+bsum) p_j - b_j); the "- a" at the target class is one read-modify-write per px.
+template <int DTYPE, int PXT, bool SMOOTH>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
     const float* __restrict__ gscale, void* __restrict__ grad)
 {
     extern __shared__ float s_w[];
-    float wsum = 0.f;
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
-    for (int c = 0; c < C; ++c) wsum += s_w[c];
+    float wsum = 0.f;
+    if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
     const float g = *gscale;
     const int b = blockIdx.y;
     const size_t img = (size_t)b * C * P;
-    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * LOSS_THREADS * 4) {
-        const int nvalid = min(4, P - p0);
-        int t[4];
-        for (int j = 0; j < 4; ++j) t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;
-        float m[4], s[4];
-        for (int j = 0; j < 4; ++j) { m[j] = -INFINITY; s[j] = 0.f; }
-        int c = 0;
-        for (; c + 8 <= C; c += 8) {
-            float4 v[8];
+    constexpr int U = (PXT == 4) ? 8 : 4;
+    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * PXT; p0 < P;
+         p0 += gridDim.x * LOSS_THREADS * PXT) {
+        const int nvalid = min(PXT, P - p0);
+        float m[PXT], s[PXT], swx[PXT], xts[PXT];
+        int t[PXT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = ld4<DTYPE>(logits, img + (size_t)(c + u) * P + p0, nvalid, vec);
+        for (int j = 0; j < PXT; ++j)
+            t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;
+        // pass 1 with regular loads (the tile stays in L2 for pass 2)
+        ce_scan<DTYPE, PXT, U, false, false, false>(logits, img, P, p0, nvalid, vec, C, s_w, t,
+                                                    m, s, swx, xts);
+        float ag[PXT], abg[PXT], k0[PXT];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) {
-                const float x[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float e = __expf(-fabsf(x[j] - m[j]));
-                    s[j] = (x[j] > m[j]) ? fmaf(s[j], e, 1.0f) : (s[j] + e);
-                    m[j] = fmaxf(m[j], x[j]);
-                }
-            }
-        }
-        for (; c < C; ++c) {
-            const float4 v = ld4<DTYPE>(logits, img + (size_t)c * P + p0, nvalid, vec);
-            const float x[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float e = __expf(-fabsf(x[j] - m[j]));
-                s[j] = (x[j] > m[j]) ? fmaf(s[j], e, 1.0f) : (s[j] + e);
-                m[j] = fmaxf(m[j], x[j]);
-            }
-        }
-        float a[4], ab[4], inv[4];
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < PXT; ++j) {
             const bool on = t[j] >= 0 && t[j] < C;
-            a[j] = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
-            ab[j] = on ? a[j] + (ls / C) * wsum : 0.f;
-            inv[j] = 1.0f / s[j];
+            const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
+            ag[j] = g * a;
+            abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
+            k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));            // p = 2^(x log2e + k0)
         }
-        // second pass over the classes: the tile was just read, it is served from L2
-        for (c = 0; c < C; ++c) {
-            const float4 v = ld4<DTYPE>(logits, img + (size_t)c * P + p0, nvalid, vec);
-            const float x[4] = {v.x, v.y, v.z, v.w};
-            const float bj = (ls / C) * s_w[c];
-            float o[4];
+        for (int c = 0; c < C; ++c) {
+            float v[PXT], o[PXT];
+            ldpx<DTYPE, PXT, true>(logits, img + (size_t)c * P + p0, nvalid, vec, v);
+            const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const bool on = t[j] >= 0 && t[j] < C;
-                const float pj = __expf(x[j] - m[j]) * inv[j];
-                o[j] = on ? g * (ab[j] * pj - (t[j] == c ? a[j] : 0.f) - bj) : 0.f;
+            for (int j = 0; j < PXT; ++j) {
+                const float pj = __builtin_amdgcn_exp2f(fmaf(v[j], LOG2E, k0[j]));
+                float r = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
+                r -= (t[j] == c) ? ag[j] : 0.f;
+                o[j] = r;
             }
-            st4<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
+            stpx<DTYPE, PXT>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
         }
     }
 }
@@ -527,13 +603,20 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
     if (bad_shape(B, H, W) || C <= 0 || C > 4096) return NMSA_ERR_ARG;
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
-    const int vec = (P % 4 == 0) && ((((uintptr_t)logits | (uintptr_t)target) & 15) == 0);
-    const int gx = grid_x(P, 4);
+    const int pxt = (dtype == NMSA_F32) ? 4 : 8;
+    const int vec = (P % pxt == 0) && ((((uintptr_t)logits) & 15) == 0);
+    const int gx = grid_x(P, pxt);
+    const bool smooth = label_smoothing != 0.0f;
     LossPartial* partials = (LossPartial*)workspace;
-#define CALL(DT) hipLaunchKernelGGL((k_ce_fwd<DT>), dim3(gx, B), dim3(LOSS_THREADS), C * sizeof(float), \
-                                    stream, logits, target, weights, C, P, label_smoothing, vec, partials, status)
-    NMSA_DISPATCH_DTYPE(dtype, CALL)
-#undef CALL
+#define CE_FWD(DT, PX, SM) hipLaunchKernelGGL((k_ce_fwd<DT, PX, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
+        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, partials, status)
+    switch (dtype) {
+        case NMSA_F32: if (smooth) CE_FWD(NMSA_F32, 4, true); else CE_FWD(NMSA_F32, 4, false); break;
+        case NMSA_BF16: if (smooth) CE_FWD(NMSA_BF16, 8, true); else CE_FWD(NMSA_BF16, 8, false); break;
+        case NMSA_F16: if (smooth) CE_FWD(NMSA_F16, 8, true); else CE_FWD(NMSA_F16, 8, false); break;
+        default: return NMSA_ERR_ARG;
+    }
+#undef CE_FWD
     int rc = check_launch();
     if (rc) return rc;
     return finalize(partials, gx * B, loss_sum, weight_sum, n_elements, stream);
@@ -548,13 +631,19 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
     if (!logits || !target || !grad_scale || !grad_logits) return NMSA_ERR_ARG;
     if (bad_shape(B, H, W) || C <= 0 || C > 4096) return NMSA_ERR_ARG;
     const int P = H * W;
-    const int vec = (P % 4 == 0) &&
-                    ((((uintptr_t)logits | (uintptr_t)target | (uintptr_t)grad_logits) & 15) == 0);
-    const int gx = grid_x(P, 4);
-#define CALL(DT) hipLaunchKernelGGL((k_ce_bwd<DT>), dim3(gx, B), dim3(LOSS_THREADS), C * sizeof(float), \
-                                    stream, logits, target, weights, C, P, label_smoothing, vec, grad_scale, grad_logits)
-    NMSA_DISPATCH_DTYPE(dtype, CALL)
-#undef CALL
+    const int pxt = (dtype == NMSA_F32) ? 4 : 8;
+    const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 15) == 0);
+    const int gx = grid_x(P, pxt);
+    const bool smooth = label_smoothing != 0.0f;
+#define CE_BWD(DT, PX, SM) hipLaunchKernelGGL((k_ce_bwd<DT, PX, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
+        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, grad_scale, grad_logits)
+    switch (dtype) {
+        case NMSA_F32: if (smooth) CE_BWD(NMSA_F32, 4, true); else CE_BWD(NMSA_F32, 4, false); break;
+        case NMSA_BF16: if (smooth) CE_BWD(NMSA_BF16, 8, true); else CE_BWD(NMSA_BF16, 8, false); break;
+        case NMSA_F16: if (smooth) CE_BWD(NMSA_F16, 8, true); else CE_BWD(NMSA_F16, 8, false); break;
+        default: return NMSA_ERR_ARG;
+    }
+#undef CE_BWD
     return check_launch();
 }
 
