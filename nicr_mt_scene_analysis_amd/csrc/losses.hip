@@ -547,6 +547,129 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_cos_emb(
     }
 }
 
+// ---- LDS-resident LUT variant (the fast path) ---------------------------------------
+// The per-image LUT [L, D] (<= ~150 KB as fp32) is staged once per workgroup in LDS with a
+// row stride of D+1 words: lanes that need different rows at the same d then hit different
+// banks, lanes that need the same row are a broadcast.  Each lane owns PXT consecutive
+// pixels (16-B plane loads, U planes in flight); the only global traffic is the prediction.
+constexpr int COS_THREADS = 1024;
+
+template <int DTYPE, int PXT, bool BWD>
+__global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
+    const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
+    int D, int P, int L, int px_per_block, int vec,
+    const float* __restrict__ gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials, int* __restrict__ status)
+{
+    extern __shared__ float s_lut[];                   // [L][D + 1], then yy[L]
+    const int b = blockIdx.y;
+    const int ld = D + 1;
+    float* s_yy = s_lut + (size_t)L * ld;
+    const float* lut_b = lut + (size_t)b * L * D;
+    for (int i = threadIdx.x; i < L * D; i += COS_THREADS) {
+        const int r = i / D, d = i - r * D;
+        s_lut[r * ld + d] = lut_b[i];
+    }
+    __syncthreads();
+    for (int r = threadIdx.x; r < L; r += COS_THREADS) {
+        float yy = 0.f;
+        for (int d = 0; d < D; ++d) yy = fmaf(s_lut[r * ld + d], s_lut[r * ld + d], yy);
+        s_yy[r] = yy;
+    }
+    __syncthreads();
+
+    const float EPS = 1e-12f;
+    const float g = BWD ? *gscale : 0.f;
+    const size_t img = (size_t)b * D * P;
+    double acc = 0.0; long long cnt = 0;
+    bool bad = false;
+    constexpr int U = (PXT == 4) ? 8 : 4;
+    const int start = blockIdx.x * px_per_block;
+    const int end = min(start + px_per_block, P);
+    for (int p0 = start + threadIdx.x * PXT; p0 < end; p0 += COS_THREADS * PXT) {
+        const int nvalid = min(PXT, end - p0);
+        int row[PXT];
+        bool on[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const int ix = (j < nvalid) ? indices[(size_t)b * P + p0 + j] : 0;
+            if (ix < 0 || ix > L) bad = true;
+            on[j] = ix > 0 && ix <= L;
+            row[j] = (on[j] ? ix - 1 : 0) * ld;
+        }
+        float xy[PXT], xx[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) { xy[j] = 0.f; xx[j] = 0.f; }
+        int d = 0;
+        for (; d + U <= D; d += U) {
+            float v[U][PXT];
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+                ldpx<DTYPE, PXT, !BWD>(pred, img + (size_t)(d + u) * P + p0, nvalid, vec, v[u]);
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    xy[j] = fmaf(v[u][j], s_lut[row[j] + d + u], xy[j]);
+                    xx[j] = fmaf(v[u][j], v[u][j], xx[j]);
+                }
+        }
+        for (; d < D; ++d) {
+            float v[PXT];
+            ldpx<DTYPE, PXT, !BWD>(pred, img + (size_t)d * P + p0, nvalid, vec, v);
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                xy[j] = fmaf(v[j], s_lut[row[j] + d], xy[j]);
+                xx[j] = fmaf(v[j], v[j], xx[j]);
+            }
+        }
+        if (!BWD) {
+            float part = 0.f;
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                if (!on[j]) continue;
+                const float den = sqrtf((xx[j] + EPS) * (s_yy[row[j] / ld] + EPS));
+                part += 1.0f - xy[j] / den;
+                ++cnt;
+            }
+            acc += part;
+        } else {
+            // d/dx (1 - xy/den) = -y/den + xy x / ((xx + eps) den); second pass re-reads the tile (L2)
+            float k1[PXT], k2[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const float den = sqrtf((xx[j] + EPS) * (s_yy[row[j] / ld] + EPS));
+                k1[j] = on[j] ? -g / den : 0.f;
+                k2[j] = on[j] ? g * xy[j] / ((xx[j] + EPS) * den) : 0.f;
+            }
+            for (d = 0; d < D; ++d) {
+                float v[PXT], o[PXT];
+                ldpx<DTYPE, PXT, true>(pred, img + (size_t)d * P + p0, nvalid, vec, v);
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) o[j] = fmaf(k2[j], v[j], k1[j] * s_lut[row[j] + d]);
+                stpx<DTYPE, PXT>(grad, img + (size_t)d * P + p0, nvalid, vec, o);
+            }
+        }
+    }
+    if (!BWD) {
+        if (bad) atomicOr(status, 8);
+        // block_partial() is written for LOSS_THREADS; reduce the 16 waves here
+        __shared__ double r_sum[COS_THREADS / 64];
+        __shared__ long long r_cnt[COS_THREADS / 64];
+        acc = wave_reduce_sum(acc);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+        if (lane_id() == 0) { r_sum[threadIdx.x >> 6] = acc; r_cnt[threadIdx.x >> 6] = cnt; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double a = 0; long long c = 0;
+            for (int k = 0; k < COS_THREADS / 64; ++k) { a += r_sum[k]; c += r_cnt[k]; }
+            LossPartial pr; pr.sum = a; pr.aux = 0; pr.count = c; pr.pad = 0;
+            partials[blockIdx.y * gridDim.x + blockIdx.x] = pr;
+        }
+    }
+}
+
 }  // namespace nmsa
 
 using namespace nmsa;
@@ -733,6 +856,22 @@ extern "C" int nmsa_loss_vonmises_bwd(const void* pred, int dtype, const float* 
     return check_launch();
 }
 
+namespace {
+
+// workgroups per image for the LDS-LUT kernels: ~2 per CU over the whole batch
+int cos_blocks_per_image(int B, int P, int pxt)
+{
+    int per_img = (512 + B - 1) / B;
+    const int max_useful = (P + COS_THREADS * pxt - 1) / (COS_THREADS * pxt);
+    if (per_img > max_useful) per_img = max_useful;
+    if (per_img < 1) per_img = 1;
+    return per_img;
+}
+
+size_t cos_lds_bytes(int L, int D) { return ((size_t)L * (D + 1) + L) * sizeof(float); }
+
+}  // namespace
+
 extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t* indices,
                                      const float* lut, int B, int D, int H, int W, int L,
                                      double* loss_sum, int64_t* n_rows, int32_t* status,
@@ -743,8 +882,29 @@ extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t*
     if (bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
-    const int gx = grid_x(P, 1);
     LossPartial* partials = (LossPartial*)workspace;
+    const size_t lds = cos_lds_bytes(L, D);
+    if (lds <= 150 * 1024) {
+        const int pxt = (dtype == NMSA_F32) ? 4 : 8;
+        const int per_img = cos_blocks_per_image(B, P, pxt);
+        int ppb = (P + per_img - 1) / per_img;
+        ppb = ((ppb + pxt - 1) / pxt) * pxt;                      // keep 16-B alignment of block starts
+        const int gx = (P + ppb - 1) / ppb;
+        const int vec = (P % pxt == 0) && ((((uintptr_t)pred) & 15) == 0);
+#define COS_FWD(DT, PX) hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, false>), dim3(gx, B), dim3(COS_THREADS), lds, \
+        stream, pred, indices, lut, D, P, L, ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status)
+        switch (dtype) {
+            case NMSA_F32: COS_FWD(NMSA_F32, 4); break;
+            case NMSA_BF16: COS_FWD(NMSA_BF16, 8); break;
+            case NMSA_F16: COS_FWD(NMSA_F16, 8); break;
+            default: return NMSA_ERR_ARG;
+        }
+#undef COS_FWD
+        int rc = check_launch();
+        if (rc) return rc;
+        return finalize(partials, gx * B, loss_sum, nullptr, n_rows, stream);
+    }
+    const int gx = grid_x(P, 1);
 #define CALL(DT) hipLaunchKernelGGL((k_cos_emb<DT, false>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, \
                                     pred, indices, lut, D, P, L, (const float*)nullptr, (void*)nullptr, partials, status)
     NMSA_DISPATCH_DTYPE(dtype, CALL)
@@ -762,6 +922,25 @@ extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t*
     if (!pred || !indices || !lut || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
     if (bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
     const int P = H * W;
+    const size_t lds = cos_lds_bytes(L, D);
+    if (lds <= 150 * 1024) {
+        const int pxt = (dtype == NMSA_F32) ? 4 : 8;
+        const int per_img = cos_blocks_per_image(B, P, pxt);
+        int ppb = (P + per_img - 1) / per_img;
+        ppb = ((ppb + pxt - 1) / pxt) * pxt;
+        const int gx = (P + ppb - 1) / ppb;
+        const int vec = (P % pxt == 0) && ((((uintptr_t)pred | (uintptr_t)grad_pred) & 15) == 0);
+#define COS_BWD(DT, PX) hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, true>), dim3(gx, B), dim3(COS_THREADS), lds, \
+        stream, pred, indices, lut, D, P, L, ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr)
+        switch (dtype) {
+            case NMSA_F32: COS_BWD(NMSA_F32, 4); break;
+            case NMSA_BF16: COS_BWD(NMSA_BF16, 8); break;
+            case NMSA_F16: COS_BWD(NMSA_F16, 8); break;
+            default: return NMSA_ERR_ARG;
+        }
+#undef COS_BWD
+        return check_launch();
+    }
     const int gx = grid_x(P, 1);
 #define CALL(DT) hipLaunchKernelGGL((k_cos_emb<DT, true>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, \
                                     pred, indices, lut, D, P, L, grad_scale, grad_pred,                \
