@@ -48,6 +48,8 @@ def parse_args():
     ap.add_argument('--no-side-stream', action='store_true',
                     help='enqueue the metric kernels on the main stream (no overlap)')
     ap.add_argument('--cpu-sample-images', type=int, default=32)
+    ap.add_argument('--streams', type=int, default=2,
+                    help='batches in flight: consecutive steps alternate over this many HIP streams')
     return ap.parse_args()
 
 
@@ -131,25 +133,28 @@ def main():
             metrics = None
 
     events = []
+    # consecutive batches are independent: they alternate over `--streams` HIP streams so that
+    # the latency-bound per-image kernels of one batch (top-k select, class/rank assignment,
+    # PQ matching) overlap with the streaming kernels of the next one
+    streams = [torch.cuda.Stream(device=dev) for _ in range(max(args.streams, 1))]
 
-    def step(record):
-        r = ops.panoptic_pipeline(logits, center, offset, is_thing,
-                                  fused_kernel_events=events if record else None)
-        if metrics is not None:
-            metrics.update_and_reduce(r['panoptic'], dist)
+    def step(i, record):
+        with torch.cuda.stream(streams[i % len(streams)]):
+            r = ops.panoptic_pipeline(logits, center, offset, is_thing,
+                                      fused_kernel_events=events if record else None)
+            if metrics is not None:
+                metrics.update_and_reduce(r['panoptic'], dist)
         return r
 
-    for _ in range(args.warmup):
-        r = step(False)
+    for i in range(args.warmup):
+        r = step(i, False)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r = step(True)
-    if metrics is not None:
-        metrics.wait()
+    for i in range(args.steps):
+        r = step(i, True)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -215,6 +220,7 @@ def main():
                                + (' + mIoU/PQ accumulators (configs[3])' if metrics else ''),
                    'batch_per_gpu': B, 'global_batch': B * world, 'classes': C,
                    'height': H, 'width': W, 'centers_per_image': args.centers,
+                   'batches_in_flight': len(streams),
                    'parallelism': f'dp{world} (images sharded, accumulators all-reduced)'},
         'roofline': roofline,
     }

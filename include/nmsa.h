@@ -118,8 +118,9 @@ int nmsa_semantic_softmax(const void* logits, int logits_dtype,
  *   inst       u8 [B,H,W]
  *   fg_out     u8 [B,H,W] or NULL ('panoptic_foreground_mask')
  *   score      f32 [B,H,W] or NULL
- *   votes      u32 [B,256,C+1]  zeroed by this call; votes[b,id,c] = #px of
- *              instance id whose (class+1) == c
+ *   votes      u32 [B,256,C+1]; votes[b,id,c] = #px of instance id whose (class+1) == c.
+ *              Zeroed by this call unless votes_are_zero != 0 (the caller keeps a
+ *              persistent table that nmsa_panoptic_assign(clear_votes=1) left clean)
  *   vote_rows_hint  expected #instance ids + 1 (e.g. top_k_instances + 1): rows
  *              privatised in LDS; larger ids still count (global atomics). 0 = auto
  * nmsa_panoptic_assign: per instance: class = mode (smallest on ties), running
@@ -139,10 +140,10 @@ int nmsa_panoptic_fused(const void* logits, int logits_dtype, const float* offse
                         float scale_y, float scale_x,
                         int use_dist_thr, float dist_thr,
                         uint8_t* sem_u8, uint8_t* inst, uint8_t* fg_out, float* score,
-                        uint32_t* votes, int vote_rows_hint,
+                        uint32_t* votes, int votes_are_zero, int vote_rows_hint,
                         nmsa_stream_t stream);
 
-int nmsa_panoptic_assign(const uint32_t* votes, int B, int n_vote_classes,
+int nmsa_panoptic_assign(uint32_t* votes, int B, int n_vote_classes, int clear_votes,
                          int64_t max_instances_per_category, int64_t void_label,
                          int64_t* pan_of_inst, int32_t* area,
                          int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
@@ -239,6 +240,9 @@ int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pred_div,
  *   status       : i32 [1] device word, OR-ed with NMSA_ST_* bits
  *   limits       : <= 2048 distinct ids per image and side, <= 4096 distinct
  *                  intersections per image, num_categories <= 1024
+ *   workspace_is_clean : non-zero when `workspace` was last used by a completed
+ *                  nmsa_pq_update of the same B (which leaves the tables empty); the
+ *                  per-call table initialisation is then skipped
  * ------------------------------------------------------------------------- */
 size_t nmsa_pq_workspace_bytes(int B, int num_categories);
 int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int W,
@@ -249,7 +253,7 @@ int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int
                    double* fn_per_class, double* fp_per_class,
                    int64_t* matches, int match_capacity, int32_t* n_matches,
                    int32_t* status, void* workspace, size_t workspace_bytes,
-                   nmsa_stream_t stream);
+                   int workspace_is_clean, nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * a6-a10  per-pixel multi-task losses (forward + backward)

@@ -58,8 +58,8 @@ _SIGNATURES = {
     'nmsa_semantic_argmax': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'nmsa_semantic_softmax': (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp]),
     'nmsa_panoptic_fused': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i,
-                                 _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
-    'nmsa_panoptic_assign': (_i, [_vp, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
+                                 _f, _f, _i, _f, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'nmsa_panoptic_assign': (_i, [_vp, _i, _i, _i, _i64, _i64, _vp, _vp, _vp, _vp, _vp, _vp]),
     'nmsa_panoptic_paint': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64,
                                  _vp, _vp, _vp]),
     'nmsa_panoptic_merge': (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i64, _i64,
@@ -81,7 +81,7 @@ _SIGNATURES = {
     'nmsa_loss_cos_emb_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'nmsa_pq_workspace_bytes': (_sz, [_i, _i]),
     'nmsa_pq_update': (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64,
-                            _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+                            _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp]),
 }
 
 _lib = None

@@ -18,6 +18,7 @@
 // Why "value >= 0 candidates only": everything kept must pass `>= clamp(kth, 0)`,
 // so negative survivors never matter, and for v >= 0 the IEEE bit pattern is a
 // monotone unsigned key (with -0.0 mapped to key 0).
+#include <stdlib.h>
 #include "nmsa_common.hpp"
 
 namespace nmsa {
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(256) void k_nms_candidates(
 // consecutive pixels of one row, so the survivors of a wave are ONE ballot and the
 // candidate words are written whole — no atomics, no memset of the bitmask.
 template <int PAD>
-__global__ __launch_bounds__(256) void k_nms_strip(
+__global__ __launch_bounds__(1024) void k_nms_strip(
     const float* __restrict__ center, uint32_t* __restrict__ cand_bits,
     int H, int W, int R, int words_per_image, float thr)
 {
@@ -105,7 +106,7 @@ __global__ __launch_bounds__(256) void k_nms_strip(
     // ---- stage: thresholded values, -1 outside the image ---------------------------
     if ((W & 3) == 0) {
         const int w4 = W >> 2;
-        for (int i = threadIdx.x; i < trows * w4; i += 256) {
+        for (int i = threadIdx.x; i < trows * w4; i += blockDim.x) {
             const int r = i / w4, c4 = i - r * w4;
             const int gy = y0 - PAD + r;
             float4 v = make_float4(-1.f, -1.f, -1.f, -1.f);
@@ -118,14 +119,14 @@ __global__ __launch_bounds__(256) void k_nms_strip(
             dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
         }
     } else {
-        for (int i = threadIdx.x; i < trows * W; i += 256) {
+        for (int i = threadIdx.x; i < trows * W; i += blockDim.x) {
             const int r = i / W, c = i - r * W;
             const int gy = y0 - PAD + r;
             strip[r * tw + PAD + c] = (gy >= 0 && gy < H) ? threshold_m1(img[(size_t)gy * W + c], thr) : -1.f;
         }
     }
     if (PAD > 0)
-        for (int i = threadIdx.x; i < trows * 2 * PAD; i += 256) {
+        for (int i = threadIdx.x; i < trows * 2 * PAD; i += blockDim.x) {
             const int r = i / (2 * PAD), k = i - r * 2 * PAD;
             strip[r * tw + (k < PAD ? k : W + k)] = -1.f;
         }
@@ -138,7 +139,7 @@ __global__ __launch_bounds__(256) void k_nms_strip(
     // registers: (2 PAD + 1) LDS reads per pixel instead of (2 PAD + 1)^2.
     uint32_t* bits = cand_bits + (size_t)b * words_per_image;
     constexpr int K = 2 * PAD + 1;
-    for (int xb = 0; xb < W; xb += 256) {
+    for (int xb = 0; xb < W; xb += blockDim.x) {
         const int x = xb + threadIdx.x;
         const bool in_x = x < W;
         const int xc = in_x ? x : 0;
@@ -379,12 +380,16 @@ extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
     }
     const int pad = (ksize - 1) / 2;
     // strip fast path: whole candidate words per wave (needs W % 32 == 0)
-    int R = 4;
+    static const int rows_env = getenv("NMSA_NMS_ROWS") ? atoi(getenv("NMSA_NMS_ROWS")) : 0;
+    int R = rows_env > 0 ? rows_env : 4;
     while (R > 1 && (size_t)(R + 2 * pad) * (W + 2 * pad) * sizeof(float) > 48 * 1024) R >>= 1;
     const size_t strip_lds = (size_t)(R + 2 * pad) * (W + 2 * pad) * sizeof(float);
     if ((W % 32) == 0 && pad <= NMS_PAD_MAX && strip_lds <= 64 * 1024) {
         dim3 grid((H + R - 1) / R, B);
-#define NMSA_STRIP(PADV) hipLaunchKernelGGL(k_nms_strip<PADV>, grid, dim3(256), strip_lds, stream, \
+        // one thread per column when the row fits a workgroup (every wave fully used)
+        static const int thr_env = getenv("NMSA_NMS_THREADS") ? atoi(getenv("NMSA_NMS_THREADS")) : 0;
+        const int strip_threads = thr_env > 0 ? thr_env : 256;      // W threads measured equal
+#define NMSA_STRIP(PADV) hipLaunchKernelGGL(k_nms_strip<PADV>, grid, dim3(strip_threads), strip_lds, stream, \
                                             center, bits, H, W, R, words, threshold)
         switch (pad) {
             case 0: NMSA_STRIP(0); break;

@@ -421,11 +421,16 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     __shared__ int nIgn, nTPs;
 
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int64_t* gk = pq_keys(ws, b);
-    const uint32_t* gc = pq_cnts(ws, b);
+    int64_t* gk = pq_keys(ws, b);
+    uint32_t* gc = pq_cnts(ws, b);
     int st = 0;
 
-    for (int i = tid; i < PQ_I_CAP; i += PQ_MATCH_THREADS) { iK[i] = gk[i]; iC[i] = gc[i]; }
+    // take the image's table into LDS and leave the global copy empty for the next call
+    for (int i = tid; i < PQ_I_CAP; i += PQ_MATCH_THREADS) {
+        const int64_t k = gk[i];
+        iK[i] = k; iC[i] = gc[i];
+        if (k != KEY_EMPTY) { gk[i] = KEY_EMPTY; gc[i] = 0; }
+    }
     for (int i = tid; i < PQ_T_CAP; i += PQ_MATCH_THREADS) {
         fT[i] = 0; fP[i] = 0; kT[i] = KEY_EMPTY; kP[i] = KEY_EMPTY; cT[i] = 0; cP[i] = 0;
     }
@@ -659,7 +664,7 @@ extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B,
                               double* fn_per_class, double* fp_per_class,
                               int64_t* matches, int match_capacity, int32_t* n_matches,
                               int32_t* status, void* workspace, size_t workspace_bytes,
-                              nmsa_stream_t stream_)
+                              int workspace_is_clean, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !target || !iou_per_class || !tp_per_class || !fn_per_class || !fp_per_class ||
@@ -674,9 +679,11 @@ extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B,
     unsigned char* ws = (unsigned char*)workspace;
     double* img_state = (double*)(ws + (size_t)B * pq_image_bytes());
 
-    hipLaunchKernelGGL(k_pq_init, dim3(2, B), dim3(256), 0, stream, ws);
-    int rc = check_launch();
-    if (rc) return rc;
+    int rc;
+    if (!workspace_is_clean) {
+        hipLaunchKernelGGL(k_pq_init, dim3(2, B), dim3(256), 0, stream, ws);
+        if ((rc = check_launch())) return rc;
+    }
     static const int px_per_block_env = getenv("NMSA_PQ_PXB") ? atoi(getenv("NMSA_PQ_PXB")) : 0;
     const int px_per_block = px_per_block_env > 0 ? (px_per_block_env & ~1) : 8192;     // tuning knob (profiles/r01_tune_notes.md)
     hipLaunchKernelGGL(k_pq_count, dim3((P + px_per_block - 1) / px_per_block, B), dim3(256), 0, stream,

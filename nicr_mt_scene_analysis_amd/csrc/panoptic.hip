@@ -468,14 +468,14 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
 // a5: per-instance class (mode, smallest on ties) + running per-class counter
 // =================================================================================
 __global__ __launch_bounds__(256) void k_assign(
-    const uint32_t* __restrict__ votes, int NC, int64_t max_inst, int64_t void_label,
+    uint32_t* __restrict__ votes, int NC, int clear_votes, int64_t max_inst, int64_t void_label,
     int64_t* __restrict__ pan_of_inst, int32_t* __restrict__ area,
     int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins, int32_t* __restrict__ n_ids)
 {
     __shared__ int s_vcls[256];          // classes of the valid instances, ascending id
     __shared__ int s_wcnt[4];
     const int b = blockIdx.x, t = threadIdx.x;
-    const uint32_t* row = votes + ((size_t)b * 256 + t) * NC;
+    uint32_t* row = votes + ((size_t)b * 256 + t) * NC;
     uint32_t total = 0;
     int64_t bestc = -1;
     int cls = 0;
@@ -484,6 +484,8 @@ __global__ __launch_bounds__(256) void k_assign(
         total += v;
         if ((int64_t)v > bestc) { bestc = v; cls = c; }      // torch.mode: smallest value on ties
     }
+    // leave the table zeroed for the next call (saves the caller a memset per step)
+    if (clear_votes && total) for (int c = 0; c < NC; ++c) row[c] = 0;
     // skip id 0, empty masks (panoptic_merge.py:195-200) and void majority (:203-204)
     const bool valid = (t > 0) && (total > 0) && (cls != 0);
     // order-preserving compaction of the valid instances (ballot + popcount)
@@ -874,14 +876,17 @@ extern "C" int nmsa_panoptic_fused(const void* logits, int logits_dtype, const f
                                    float scale_y, float scale_x,
                                    int use_dist_thr, float dist_thr,
                                    uint8_t* sem_u8, uint8_t* inst, uint8_t* fg_out, float* score,
-                                   uint32_t* votes, int vote_rows_hint, nmsa_stream_t stream_)
+                                   uint32_t* votes, int votes_are_zero, int vote_rows_hint,
+                                   nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!logits || !offset || !centers_yx || !n_centers || !is_thing || !sem_u8 || !inst || !votes)
         return NMSA_ERR_ARG;
     if (bad_dims(B, H, W) || C <= 0 || C > 256 || max_centers <= 0) return NMSA_ERR_ARG;
-    int rc = check_hip(hipMemsetAsync(votes, 0, (size_t)B * 256 * (C + 1) * sizeof(uint32_t), stream));
-    if (rc) return rc;
+    if (!votes_are_zero) {
+        int rc = check_hip(hipMemsetAsync(votes, 0, (size_t)B * 256 * (C + 1) * sizeof(uint32_t), stream));
+        if (rc) return rc;
+    }
     switch (logits_dtype) {
         case NMSA_F32:
             return launch_fused<NMSA_F32>(logits, offset, centers_yx, n_centers, is_thing, B, C, H, W,
@@ -899,7 +904,7 @@ extern "C" int nmsa_panoptic_fused(const void* logits, int logits_dtype, const f
     }
 }
 
-extern "C" int nmsa_panoptic_assign(const uint32_t* votes, int B, int n_vote_classes,
+extern "C" int nmsa_panoptic_assign(uint32_t* votes, int B, int n_vote_classes, int clear_votes,
                                     int64_t max_instances_per_category, int64_t void_label,
                                     int64_t* pan_of_inst, int32_t* area,
                                     int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
@@ -908,7 +913,7 @@ extern "C" int nmsa_panoptic_assign(const uint32_t* votes, int B, int n_vote_cla
     hipStream_t stream = (hipStream_t)stream_;
     if (!votes || !pan_of_inst || !ids_pan || !ids_ins || !n_ids) return NMSA_ERR_ARG;
     if (B <= 0 || n_vote_classes <= 0) return NMSA_ERR_ARG;
-    hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_vote_classes,
+    hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_vote_classes, clear_votes,
                        max_instances_per_category, void_label, pan_of_inst, area,
                        ids_pan, ids_ins, n_ids);
     return check_launch();
@@ -968,7 +973,7 @@ extern "C" int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* i
                        thing_seg, n_classes, P, votes);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_classes,
+    hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_classes, 0,
                        max_instances_per_category, void_label, pan_of_inst, (int32_t*)nullptr,
                        ids_pan, ids_ins, n_ids);
     rc = check_launch();

@@ -55,10 +55,12 @@ class PanopticQuality(Metric):
                            dist_reduce_fx='sum')
         self._status = torch.zeros((1,), dtype=torch.int32, device=self.device)
         self._match_capacity = 1024
+        self._workspaces = {}
 
     def to(self, device, *args, **kwargs):
         super().to(device)
         self._status = self._status.to(self.device)
+        self._workspaces = {}
         return self
 
     def reset(self) -> None:
@@ -80,7 +82,14 @@ class PanopticQuality(Metric):
         B, H, W = p.shape
         lib = L.lib()
         ws_bytes = lib.nmsa_pq_workspace_bytes(B, self.num_categories)
-        ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+        # persistent workspace per (batch size, stream): a completed update leaves the hash
+        # tables empty, so only the first use pays for the initialisation
+        ws_key = (B, torch.cuda.current_stream(dev).cuda_stream)
+        ws = self._workspaces.get(ws_key)
+        clean = ws is not None
+        if ws is None:
+            ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=dev)
+            self._workspaces[ws_key] = ws
         matches = n_matches = None
         if want_matches:
             matches = torch.empty((B, self._match_capacity, 2), dtype=torch.int64, device=dev)
@@ -90,7 +99,8 @@ class PanopticQuality(Metric):
             int(self.max_instances_per_category), int(self.offset), int(self.void_segment_id),
             L.ptr(self.iou_per_class), L.ptr(self.tp_per_class), L.ptr(self.fn_per_class),
             L.ptr(self.fp_per_class), L.ptr(matches), self._match_capacity, L.ptr(n_matches),
-            L.ptr(self._status), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), 'nmsa_pq_update')
+            L.ptr(self._status), L.ptr(ws), ws_bytes, int(clean), L.stream_ptr(dev)),
+            'nmsa_pq_update')
         if want_matches:
             return matches, n_matches
         return None

@@ -13,6 +13,20 @@ from . import _lib as L
 
 DEFAULT_MAX_CENTERS = 256
 
+# persistent, always-zero vote tables (one per device / shape): nmsa_panoptic_assign clears
+# the rows it read, so the next step needs no memset.  Keyed by stream as well, so that
+# concurrent pipelines on different streams never share a table.
+_VOTE_TABLES: Dict[tuple, torch.Tensor] = {}
+
+
+def _vote_table(dev: torch.device, B: int, n_cols: int) -> torch.Tensor:
+    key = (dev, B, n_cols, torch.cuda.current_stream(dev).cuda_stream)
+    t = _VOTE_TABLES.get(key)
+    if t is None:
+        t = torch.zeros((B, 256, n_cols), dtype=torch.int32, device=dev)
+        _VOTE_TABLES[key] = t
+    return t
+
 
 def _u8(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
     """bool / uint8 tensor viewed as uint8 (torch.bool storage is one byte)."""
@@ -176,7 +190,8 @@ def panoptic_pipeline(
     inst = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
     fg = torch.empty((B, H, W), dtype=torch.uint8, device=dev) if want_foreground else None
     score = torch.empty((B, H, W), dtype=torch.float32, device=dev) if want_score else None
-    votes = torch.empty((B, 256, Cn + 1), dtype=torch.int32, device=dev)
+    votes = _vote_table(dev, B, Cn + 1)
+    vote_key = (dev, B, Cn + 1, torch.cuda.current_stream(dev).cuda_stream)
     sy, sx = (float(H), float(W)) if normalized_offset else (1.0, 1.0)
     if fused_kernel_events is not None:
         ev0 = torch.cuda.Event(enable_timing=True)
@@ -187,7 +202,7 @@ def panoptic_pipeline(
         L.ptr(cen['n_centers']), L.ptr(thing), B, Cn, H, W, int(max_centers), sy, sx,
         0 if distance_threshold is None else 1,
         0.0 if distance_threshold is None else float(distance_threshold),
-        L.ptr(sem_u8), L.ptr(inst), L.ptr(fg), L.ptr(score), L.ptr(votes),
+        L.ptr(sem_u8), L.ptr(inst), L.ptr(fg), L.ptr(score), L.ptr(votes), 1,
         int(top_k) + 1, st), 'nmsa_panoptic_fused')
     if fused_kernel_events is not None:
         ev1.record(torch.cuda.current_stream(dev))
@@ -198,10 +213,14 @@ def panoptic_pipeline(
     ids_pan = torch.empty((B, 256), dtype=torch.int64, device=dev)
     ids_ins = torch.empty((B, 256), dtype=torch.int64, device=dev)
     n_ids = torch.empty((B,), dtype=torch.int32, device=dev)
-    L.check(lib.nmsa_panoptic_assign(
-        L.ptr(votes), B, Cn + 1, int(max_instances_per_category), int(void_label),
-        L.ptr(pan_of_inst), L.ptr(area), L.ptr(ids_pan), L.ptr(ids_ins), L.ptr(n_ids), st),
-        'nmsa_panoptic_assign')
+    try:
+        L.check(lib.nmsa_panoptic_assign(
+            L.ptr(votes), B, Cn + 1, 1, int(max_instances_per_category), int(void_label),
+            L.ptr(pan_of_inst), L.ptr(area), L.ptr(ids_pan), L.ptr(ids_ins), L.ptr(n_ids), st),
+            'nmsa_panoptic_assign')
+    except Exception:
+        _VOTE_TABLES.pop(vote_key, None)          # the table was written but not cleared
+        raise
 
     pan = torch.empty((B, H, W), dtype=torch.int64, device=dev)
     pan_sem = torch.empty((B, H, W), dtype=torch.int64, device=dev) \
@@ -218,7 +237,7 @@ def panoptic_pipeline(
         'centers_yx': cen['centers_yx'], 'n_centers': cen['n_centers'],
         'center_scores': cen['scores'], 'area': area,
         'ids_pan': ids_pan, 'ids_ins': ids_ins, 'n_ids': n_ids,
-        'pan_of_inst': pan_of_inst, 'votes': votes,
+        'pan_of_inst': pan_of_inst,
     }
 
 
