@@ -83,16 +83,43 @@ struct ArgmaxState {
     float m[4];
     int am[4];
     float se[4];     // running sum of exp(x - m) (only when WITH_SCORE)
-    bool bad[4];
+    float nf[4];     // stays 0 while every logit is finite, NaN as soon as one is NaN / +-inf
 };
+
+__device__ __forceinline__ void argmax_init(ArgmaxState& s)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { s.m[j] = -INFINITY; s.am[j] = 0; s.se[j] = 0.f; s.nf[j] = 0.f; }
+}
+
+// Exact rule for a column that holds a non-finite logit (rare, re-reads the column):
+// softmax of a column with a NaN, a +inf, or nothing but -inf is all-NaN and torch.max then
+// returns index 0 (semantic.py:52-53); a column with some -inf entries is an ordinary one.
+template <int DTYPE>
+__device__ __noinline__ bool column_degenerate(const void* logits, size_t col0, int P, int C)
+{
+    bool nan_or_pinf = false, any_finite = false;
+    for (int c = 0; c < C; ++c) {
+        float v;
+        if (DTYPE == NMSA_F32) v = ((const float*)logits)[col0 + (size_t)c * P];
+        else {
+            const uint16_t h = ((const uint16_t*)logits)[col0 + (size_t)c * P];
+            v = (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
+        }
+        if (v != v || v == INFINITY) nan_or_pinf = true;
+        if (fabsf(v) < INFINITY) any_finite = true;
+    }
+    return nan_or_pinf || !any_finite;
+}
 
 template <bool WITH_SCORE>
 __device__ __forceinline__ void argmax_step(ArgmaxState& s, int j, float v, int c)
 {
-    s.bad[j] = s.bad[j] || (v != v);
+    s.nf[j] = fmaf(v, 0.0f, s.nf[j]);          // finite: += +-0 ; NaN / inf: NaN
     if (WITH_SCORE) {
         // online softmax denominator: one exp per class
-        const float e = __expf(-fabsf(v - s.m[j]));
+        // (-inf logits contribute exp(-inf) = 0; avoid the NaN of -inf - -inf)
+        const float e = (v == -INFINITY) ? 0.f : __expf(-fabsf(v - s.m[j]));
         s.se[j] = (v > s.m[j]) ? fmaf(s.se[j], e, 1.0f) : (s.se[j] + e);
     }
     if (v > s.m[j]) { s.m[j] = v; s.am[j] = c; }
@@ -123,35 +150,57 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
                                        const bool act[4], int use_thr, float thr,
                                        uint32_t id[4])
 {
-    float smin[4];
+    // pass 1: first index of the smallest squared distance, and `prev` = the smallest
+    // squared distance among the centers BEFORE that index (= the running minimum at the
+    // moment of the last update)
+    float smin[4], prev[4];
+    int imin[4];
     {
         const float2 c0 = cen[0];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) smin[j] = sqdist(c0.x, c0.y, ly[j], lx[j]);
+        for (int j = 0; j < 4; ++j) {
+            smin[j] = sqdist(c0.x, c0.y, ly[j], lx[j]);
+            prev[j] = INFINITY;
+            imin[j] = 0;
+        }
     }
     for (int i = 1; i < n; ++i) {
         const float2 c = cen[i];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) smin[j] = fminf(smin[j], sqdist(c.x, c.y, ly[j], lx[j]));
+        for (int j = 0; j < 4; ++j) {
+            const float s = sqdist(c.x, c.y, ly[j], lx[j]);
+            const bool upd = s < smin[j];
+            prev[j] = upd ? smin[j] : prev[j];
+            imin[j] = upd ? i : imin[j];
+            smin[j] = upd ? s : smin[j];
+        }
     }
-    float U[4], dmin[4];
-    int best[4];
+    // The reference compares d = sqrt_rn(s) and takes the LOWEST index among equal d.
+    // imin is already that index unless an earlier center has s in (smin, U], U = largest
+    // float with the same rounded square root.  U <= smin (1 + 2^-22); test a superset
+    // with one fma and only then pay for the exact tie interval and the second pass.
+    bool maybe_tie = false;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        dmin[j] = sqrtf(smin[j]);          // correctly rounded (no fast-math)
-        U[j] = sqrt_tie_upper(dmin[j]);
-        best[j] = 0;
-    }
-    for (int i = n - 1; i >= 0; --i) {
-        const float2 c = cen[i];
+    for (int j = 0; j < 4; ++j)
+        maybe_tie = maybe_tie || (act[j] && !(prev[j] > fmaf(smin[j], 4.8e-7f, smin[j])));
+    int best[4] = {imin[0], imin[1], imin[2], imin[3]};
+    if (__any(maybe_tie)) {
+        float U[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (sqdist(c.x, c.y, ly[j], lx[j]) <= U[j]) best[j] = i;
+        for (int j = 0; j < 4; ++j) U[j] = sqrt_tie_upper(sqrtf(smin[j]));
+        for (int i = n - 1; i >= 0; --i) {
+            const float2 c = cen[i];
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (sqdist(c.x, c.y, ly[j], lx[j]) <= U[j]) best[j] = i;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) best[j] = (smin[j] != smin[j]) ? 0 : best[j];    // NaN loc -> index 0
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         uint32_t v = (uint32_t)(best[j] + 1) & 0xFFu;               // uint8 wrap (instance.py:236)
-        if (use_thr && dmin[j] > thr) v = 0;                        // instance.py:246-247
+        if (use_thr && sqrtf(smin[j]) > thr) v = 0;                 // instance.py:246-247
         id[j] = act[j] ? v : 0u;
     }
 }
@@ -202,8 +251,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
 
         // ---- a1: argmax over classes (first index of the maximum) --------------------
         ArgmaxState st;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { st.m[j] = -INFINITY; st.am[j] = 0; st.se[j] = 0.f; st.bad[j] = false; }
+        argmax_init(st);
         int c = 0;
         for (; c + UNROLL <= C; c += UNROLL) {
             float4 v[UNROLL];
@@ -232,7 +280,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
         for (int j = 0; j < 4; ++j) {
             // softmax of a column with a NaN / +inf / all -inf is all-NaN and
             // torch.max then returns index 0 (semantic.py:52-53)
-            const bool degenerate = st.bad[j] || !(fabsf(st.m[j]) < INFINITY);
+            bool degenerate = false;
+            if (st.nf[j] != st.nf[j] && j < nvalid)     // some non-finite logit: exact re-check
+                degenerate = column_degenerate<DTYPE>(logits, img_logits + p0 + j, P, C);
             cls[j] = degenerate ? 0 : st.am[j];
             if (WITH_SCORE) st.se[j] = degenerate ? __int_as_float(0x7fc00000) : (1.0f / st.se[j]);
             fg[j] = (j < nvalid) && (thing[cls[j]] != 0);               // panoptic.py:123-127
@@ -315,8 +365,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_argmax(
     const int nvalid = min(4, P - p0);
     const size_t img = (size_t)b * C * P;
     ArgmaxState st;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { st.m[j] = -INFINITY; st.am[j] = 0; st.se[j] = 0.f; st.bad[j] = false; }
+    argmax_init(st);
     int c = 0;
     for (; c + 8 <= C; c += 8) {
         float4 v[8];
@@ -339,7 +388,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_argmax(
         argmax_step<WITH_SCORE>(st, 3, v.w, c);
     }
     for (int j = 0; j < nvalid; ++j) {
-        const bool degenerate = st.bad[j] || !(fabsf(st.m[j]) < INFINITY);
+        bool degenerate = false;
+        if (st.nf[j] != st.nf[j]) degenerate = column_degenerate<DTYPE>(logits, img + p0 + j, P, C);
         const int cls = degenerate ? 0 : st.am[j];
         const size_t o = (size_t)b * P + p0 + j;
         if (idx_u8) idx_u8[o] = (uint8_t)cls;

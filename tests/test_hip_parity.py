@@ -122,6 +122,36 @@ def test_bf16_logits_vs_oracle(ops, oracle):
     np.testing.assert_allclose(r['semantic_score'].cpu().numpy(), score, rtol=1e-5, atol=1e-7)
 
 
+def test_nonfinite_logits_vs_oracle(ops, oracle):
+    """NaN / +inf / -inf logits: softmax-then-max semantics (index 0 for degenerate columns,
+    -inf entries alone are ordinary), checked against the oracle; f32 and bf16."""
+    inp = syn.make_panoptic_inputs(2, 9, 32, 48, n_centers=4, seed=8)
+    lg = inp['semantic_logits'].copy()
+    lg[0, 3, 2, 2] = np.nan                  # NaN -> index 0
+    lg[0, 5, 4, 7] = np.inf                  # +inf -> index 0
+    lg[0, 2, 6, 1] = -np.inf                 # a single -inf: ordinary column
+    lg[0, :, 8, 8] = -np.inf                 # all -inf -> index 0
+    lg[1, 0, 3, 3] = -np.inf
+    lg[1, 8, 3, 3] = np.inf                  # both infinities -> index 0
+    lg[1, :, 10, 10] = -np.inf
+    lg[1, 4, 10, 10] = 1.0                   # all but one -inf: that one wins
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.from_numpy(lg).to(dt)
+        idx, score = oracle.semantic_argmax(x.float().numpy())
+        r = ops.semantic_argmax(x.cuda(), want_u8=True, want_i64=True, want_score=True)
+        torch.cuda.synchronize()
+        assert (r['idx'].cpu().numpy() == idx).all()
+        assert (r['idx_u8'].cpu().numpy() == idx).all()
+        np.testing.assert_allclose(r['score'].cpu().numpy(), score, rtol=1e-5, atol=1e-7,
+                                   equal_nan=True)
+        p = ops.panoptic_pipeline(x.cuda(), dev(inp['instance_center']), dev(inp['instance_offset']),
+                                  dev(inp['semantic_classes_is_thing']))
+        torch.cuda.synchronize()
+        assert (p['semantic_idx_u8'].cpu().numpy() == idx).all()
+    assert idx[0, 2, 2] == 0 and idx[0, 4, 7] == 0 and idx[0, 8, 8] == 0 and idx[1, 3, 3] == 0
+    assert idx[1, 10, 10] == 4 and idx[0, 6, 1] != 2
+
+
 def test_centers_adversarial(ops):
     g = load('centers_adversarial')
     for name in jload(g['names']):
