@@ -239,6 +239,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
+        dist.barrier()              # rank 0 may still be timing the CPU baseline
         dist.destroy_process_group()
 
 

@@ -808,7 +808,12 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, U, N>), grid, block, lds, stream, \
                        logits, offset, centers_yx, n_centers, is_thing, C, H, W, max_centers,  \
                        iters, sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows)
-    if (vec && !score && DTYPE == NMSA_F32 && (unroll != 8 || !nt)) {
+    static const int unroll16 = env_int("NMSA_FUSED_UNROLL16", 8);     // 16-bit logits
+    if (vec && !score && DTYPE != NMSA_F32 && unroll16 != 8) {
+        if (unroll16 == 16) NMSA_LAUNCH_FUSED_V(16, true);
+        else if (unroll16 == 20) NMSA_LAUNCH_FUSED_V(20, true);
+        else NMSA_LAUNCH_FUSED_V(10, true);
+    } else if (vec && !score && DTYPE == NMSA_F32 && (unroll != 8 || !nt)) {
         if (unroll == 4 && !nt) NMSA_LAUNCH_FUSED_V(4, false);
         else if (unroll == 10 && !nt) NMSA_LAUNCH_FUSED_V(10, false);
         else if (unroll == 4) NMSA_LAUNCH_FUSED_V(4, true);
