@@ -41,6 +41,8 @@ enum {
 enum { NMSA_F32 = 0, NMSA_BF16 = 1, NMSA_F16 = 2 };
 /* integer element types of label / id tensors */
 enum { NMSA_U8 = 0, NMSA_I16 = 1, NMSA_I32 = 2, NMSA_I64 = 3 };
+/* nmsa_resize_nearest also moves f32 maps (scores): */
+#define NMSA_ELEM_F32 8
 
 #define NMSA_MAX_INSTANCE_IDS 256 /* instance ids are uint8 in the reference (instance.py:236) */
 
@@ -191,6 +193,36 @@ int nmsa_panoptic_merge_wide(const void* sem, int sem_dtype, const void* ins, in
                              int64_t* pan, int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
                              int32_t* status, void* workspace, size_t workspace_bytes,
                              nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * f2  DensePostprocessingBase._crop_to_valid_region_and_resize_prediction
+ *     model/postprocessing/dense_base.py:15-58   (the full-resolution step)
+ * Every plane of `src` ([planes,Hs,Ws], planes = B or B*C) is cropped to the valid
+ * region [y0:y0+h, x0:x0+w] and resized to [Ho,Wo]; dst is [planes,Ho,Wo].
+ * The arithmetic is bit-for-bit the one of ATen's CPU kernels (see csrc/resize.hip):
+ *   nearest : src = min(int(floorf(dst * float(in)/float(out))), in-1); i32 / i64 maps
+ *             take the reference's float32 round trip (dense_base.py:38-40, :52)
+ *   bilinear: align_corners=False, width first; dst has the dtype of src
+ *   elem_type: NMSA_U8 (also bool) | NMSA_I16 | NMSA_I32 | NMSA_I64 | NMSA_ELEM_F32
+ * ------------------------------------------------------------------------- */
+int nmsa_resize_nearest(const void* src, int elem_type, int planes, int Hs, int Ws,
+                        int y0, int x0, int h, int w, int Ho, int Wo, void* dst,
+                        nmsa_stream_t stream);
+int nmsa_resize_bilinear(const void* src, int dtype, int planes, int Hs, int Ws,
+                         int y0, int x0, int h, int w, int Ho, int Wo, void* dst,
+                         nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
+ * f2  SemanticPostprocessing full-resolution argmax   model/postprocessing/semantic.py:61-80
+ * crop + bilinear resize + argmax + max-softmax score of the logits in ONE pass; the
+ * [B,C,Ho,Wo] full-resolution logits are not materialised (nmsa_resize_bilinear makes
+ * them when `semantic_output_fullres` itself is read).  Same outputs / NULL rules as
+ * nmsa_semantic_argmax; logits [B,C,Hs,Ws].
+ * ------------------------------------------------------------------------- */
+int nmsa_semantic_argmax_resized(const void* logits, int logits_dtype, int B, int C,
+                                 int Hs, int Ws, int y0, int x0, int h, int w, int Ho, int Wo,
+                                 uint8_t* idx_u8, int64_t* idx_i64, float* score,
+                                 nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * next-1  InstancePostprocessing._get_instance_orientation

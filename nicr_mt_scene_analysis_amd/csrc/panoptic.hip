@@ -27,6 +27,7 @@
 //    s_i <= U.  Both passes are branch-free compare/select.
 #include <stdlib.h>
 #include "nmsa_common.hpp"
+#include "argmax_state.hpp"
 
 namespace nmsa {
 
@@ -78,20 +79,6 @@ __device__ __forceinline__ float4 load_px4(const void* base, size_t elem_off, in
     }
 }
 
-// ---- per-pixel class argmax state ---------------------------------------------
-struct ArgmaxState {
-    float m[4];
-    int am[4];
-    float se[4];     // running sum of exp(x - m) (only when WITH_SCORE)
-    float nf[4];     // stays 0 while every logit is finite, NaN as soon as one is NaN / +-inf
-};
-
-__device__ __forceinline__ void argmax_init(ArgmaxState& s)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) { s.m[j] = -INFINITY; s.am[j] = 0; s.se[j] = 0.f; s.nf[j] = 0.f; }
-}
-
 // Exact rule for a column that holds a non-finite logit (rare, re-reads the column):
 // softmax of a column with a NaN, a +inf, or nothing but -inf is all-NaN and torch.max then
 // returns index 0 (semantic.py:52-53); a column with some -inf entries is an ordinary one.
@@ -110,19 +97,6 @@ __device__ __noinline__ bool column_degenerate(const void* logits, size_t col0, 
         if (fabsf(v) < INFINITY) any_finite = true;
     }
     return nan_or_pinf || !any_finite;
-}
-
-template <bool WITH_SCORE>
-__device__ __forceinline__ void argmax_step(ArgmaxState& s, int j, float v, int c)
-{
-    s.nf[j] = fmaf(v, 0.0f, s.nf[j]);          // finite: += +-0 ; NaN / inf: NaN
-    if (WITH_SCORE) {
-        // online softmax denominator: one exp per class
-        // (-inf logits contribute exp(-inf) = 0; avoid the NaN of -inf - -inf)
-        const float e = (v == -INFINITY) ? 0.f : __expf(-fabsf(v - s.m[j]));
-        s.se[j] = (v > s.m[j]) ? fmaf(s.se[j], e, 1.0f) : (s.se[j] + e);
-    }
-    if (v > s.m[j]) { s.m[j] = v; s.am[j] = c; }
 }
 
 // ---- exact nearest-center search for 4 pixels -----------------------------------

@@ -1,16 +1,17 @@
 """`DensePostprocessingBase` (reference model/postprocessing/dense_base.py:14-58).
 
-Crop to the valid region and resize to the dataset resolution.  This is the
-"full-resolution step either side of the merge" that SURVEY.md §8(f) ranks as
-next after the hot path: it stays a torch (ATen, on-device) call here —
-integer maps take the same float32 round-trip as the reference so that the
-nearest-neighbour source pixel is chosen identically.
+Crop to the valid region and resize to the dataset resolution — the
+"full-resolution step either side of the merge" (SURVEY.md §8 f2).  The crop is
+folded into the HIP resize kernels (csrc/resize.hip: `nmsa_resize_nearest`,
+`nmsa_resize_bilinear`), whose index / weight arithmetic reproduces the ATen
+CPU kernels the reference's evaluation path runs, including the float32 round
+trip the reference takes for integer maps.
 """
 from typing import Tuple
 
 import torch
-import torch.nn.functional as F
 
+from ... import ops
 from .base import PostprocessingBase
 
 
@@ -23,19 +24,14 @@ class DensePostprocessingBase(PostprocessingBase):
         mode: str = 'nearest'
     ) -> torch.Tensor:
         sl_h, sl_w = valid_region_slices
-        out = prediction[..., sl_h, sl_w]
+        cropped = prediction[..., sl_h, sl_w]
         h, w = shape
-        if tuple(out.shape[-2:]) == (h, w):
-            return out
+        if tuple(cropped.shape[-2:]) == (h, w):
+            return cropped              # nothing to resize (dense_base.py:28-31)
 
-        squeeze = out.ndim == 3
-        if squeeze:
-            out = out.unsqueeze(1)          # interpolate wants BCHW
-        orig_dtype = out.dtype
-        if not out.is_floating_point():
-            out = out.to(torch.float32)
-        extra = {} if mode == 'nearest' else {'align_corners': False}
-        out = F.interpolate(out, size=(h, w), mode=mode, **extra).to(orig_dtype)
-        if squeeze:
-            out = out.squeeze(1)
-        return out
+        if mode == 'nearest':
+            return ops.resize_nearest(prediction, (h, w), valid_region_slices)
+        if mode == 'bilinear':
+            return ops.resize_bilinear(prediction, (h, w), valid_region_slices)
+        raise NotImplementedError(
+            f"resize mode '{mode}' (the reference only uses 'nearest' and 'bilinear')")

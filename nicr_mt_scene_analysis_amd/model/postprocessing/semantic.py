@@ -35,14 +35,25 @@ class SemanticPostprocessing(DensePostprocessingBase):
         r['semantic_segmentation_score' + suffix] = am['score']
         r['semantic_segmentation_idx' + suffix] = am['idx']
 
-    def _fullres_entries(self, r: LazyDict, output: torch.Tensor, batch: BatchType,
-                         same_resolution_source: str = '') -> None:
+    def _fullres_entries(self, r: LazyDict, output: torch.Tensor, batch: BatchType) -> None:
+        """semantic.py:61-80.  With a real resize, idx / score come from ONE fused pass over the
+        network-resolution logits (`nmsa_semantic_argmax_resized`); the full-resolution logits
+        and their softmax are produced only when somebody reads them."""
         crop, shape = get_valid_region_slices_and_fullres_shape(batch, 'semantic')
-        output_fullres = self._crop_to_valid_region_and_resize_prediction(
-            output, valid_region_slices=crop, shape=shape, mode='bilinear')
-        r[get_fullres_key('semantic_output')] = output_fullres
-        if output_fullres.shape == output.shape and \
-                output_fullres.data_ptr() == output.data_ptr():
+        cropped = output[..., crop[0], crop[1]]
+        k_out, k_sm, k_score, k_idx = (get_fullres_key(k) for k in (
+            'semantic_output', 'semantic_softmax_scores', 'semantic_segmentation_score',
+            'semantic_segmentation_idx'))
+        if tuple(cropped.shape[-2:]) != tuple(shape):
+            r.set_lazy(k_out, lambda: ops.resize_bilinear(output, shape, crop))
+            r.set_lazy(k_sm, lambda: ops.semantic_softmax(r[k_out]))
+            am = ops.semantic_argmax_resized(output, shape, crop,
+                                             want_u8=False, want_i64=True, want_score=True)
+            r[k_score] = am['score']
+            r[k_idx] = am['idx']
+            return
+        r[k_out] = cropped
+        if cropped.shape == output.shape:
             # nothing was cropped or resized: the fullres entries are the same
             # functions of the same logits -> share them (bit-identical)
             for k in ('semantic_softmax_scores', 'semantic_segmentation_score',
@@ -52,7 +63,7 @@ class SemanticPostprocessing(DensePostprocessingBase):
                 else:
                     r[get_fullres_key(k)] = r[k]
         else:
-            self._argmax_entries(r, output_fullres.contiguous(), suffix='_fullres')
+            self._argmax_entries(r, cropped.contiguous(), suffix='_fullres')
 
     def _postprocess_inference(
         self, data: DecoderRawOutputType, batch: BatchType

@@ -5,7 +5,7 @@ synchronisation.  These are thin argument marshallers over include/nmsa.h; the
 reference-shaped classes (model/postprocessing, utils/panoptic_merge, metric,
 loss) are built on top of them.
 """
-from typing import Dict, Optional
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -106,6 +106,75 @@ def group_offsets(
         0.0 if distance_threshold is None else float(distance_threshold),
         L.ptr(inst), L.ptr(area), L.stream_ptr(dev)), 'nmsa_group_offsets')
     return {'instance': inst, 'area': area}
+
+
+# ----------------------------------------------------------------------------- f2
+NMSA_ELEM_F32 = 8
+
+
+def _crop_geometry(t: torch.Tensor, crop) -> Tuple[int, int, int, int, int, int]:
+    Hs, Ws = int(t.shape[-2]), int(t.shape[-1])
+    if crop is None:
+        return Hs, Ws, 0, 0, Hs, Ws
+    sl_h, sl_w = crop
+    y0, y1, st_y = sl_h.indices(Hs)
+    x0, x1, st_x = sl_w.indices(Ws)
+    if st_y != 1 or st_x != 1 or y1 <= y0 or x1 <= x0:
+        raise ValueError(f'unsupported valid-region slices {crop}')
+    return Hs, Ws, y0, x0, y1 - y0, x1 - x0
+
+
+def resize_nearest(maps: torch.Tensor, size: Tuple[int, int], crop=None) -> torch.Tensor:
+    """crop `maps[..., crop]` and F.interpolate(mode='nearest') to `size`, bit-identical to the
+    reference's `_crop_to_valid_region_and_resize_prediction` (dense_base.py:15-58),
+    including its float32 round trip for int32 / int64 maps."""
+    x = L.require_device_tensor(maps, 'maps')
+    code = NMSA_ELEM_F32 if x.dtype == torch.float32 else L.int_dtype_code(x)
+    Hs, Ws, y0, x0, h, w = _crop_geometry(x, crop)
+    Ho, Wo = int(size[0]), int(size[1])
+    planes = x.numel() // (Hs * Ws)
+    out = torch.empty(tuple(x.shape[:-2]) + (Ho, Wo), dtype=x.dtype, device=x.device)
+    L.check(L.lib().nmsa_resize_nearest(
+        L.ptr(x), code, planes, Hs, Ws, y0, x0, h, w, Ho, Wo, L.ptr(out),
+        L.stream_ptr(x.device)), 'nmsa_resize_nearest')
+    return out
+
+
+def resize_bilinear(maps: torch.Tensor, size: Tuple[int, int], crop=None) -> torch.Tensor:
+    """crop + F.interpolate(mode='bilinear', align_corners=False) (dense_base.py:15-58)."""
+    x = L.require_device_tensor(maps, 'maps')
+    Hs, Ws, y0, x0, h, w = _crop_geometry(x, crop)
+    Ho, Wo = int(size[0]), int(size[1])
+    planes = x.numel() // (Hs * Ws)
+    out = torch.empty(tuple(x.shape[:-2]) + (Ho, Wo), dtype=x.dtype, device=x.device)
+    L.check(L.lib().nmsa_resize_bilinear(
+        L.ptr(x), L.float_dtype_code(x), planes, Hs, Ws, y0, x0, h, w, Ho, Wo, L.ptr(out),
+        L.stream_ptr(x.device)), 'nmsa_resize_bilinear')
+    return out
+
+
+def semantic_argmax_resized(
+    logits: torch.Tensor,
+    size: Tuple[int, int],
+    crop=None,
+    want_u8: bool = False,
+    want_i64: bool = True,
+    want_score: bool = True,
+) -> Dict[str, torch.Tensor]:
+    """reference: semantic.py:61-80 — crop + bilinear resize + softmax + max at the dataset
+    resolution, in one pass over the network-resolution logits."""
+    x = L.require_device_tensor(logits, 'logits')
+    B, Cn = int(x.shape[0]), int(x.shape[1])
+    Hs, Ws, y0, x0, h, w = _crop_geometry(x, crop)
+    Ho, Wo = int(size[0]), int(size[1])
+    dev = x.device
+    u8 = torch.empty((B, Ho, Wo), dtype=torch.uint8, device=dev) if want_u8 else None
+    i64 = torch.empty((B, Ho, Wo), dtype=torch.int64, device=dev) if want_i64 else None
+    sc = torch.empty((B, Ho, Wo), dtype=torch.float32, device=dev) if want_score else None
+    L.check(L.lib().nmsa_semantic_argmax_resized(
+        L.ptr(x), L.float_dtype_code(x), B, Cn, Hs, Ws, y0, x0, h, w, Ho, Wo,
+        L.ptr(u8), L.ptr(i64), L.ptr(sc), L.stream_ptr(dev)), 'nmsa_semantic_argmax_resized')
+    return {'idx_u8': u8, 'idx': i64, 'score': sc}
 
 
 # ----------------------------------------------------------------------------- a1

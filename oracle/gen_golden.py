@@ -550,6 +550,92 @@ def gen_orientation(ref):
          mask=mask, **res)
 
 
+def gen_fullres(ref):
+    """f2: crop to the valid region + resize to the dataset resolution
+    (dense_base.py:15-58, semantic.py:61-80, panoptic.py:240-290)."""
+    print('full-resolution step (reference _crop_to_valid_region_and_resize_prediction)')
+    from oracle import oracle as orc
+    post = ref.post_semantic.SemanticPostprocessing()
+    rng = np.random.default_rng(31)
+    Hs, Ws = 96, 128
+    geoms = {                       # name -> (crop, out shape)
+        'up_crop': ((slice(4, 92), slice(0, 128)), (150, 200)),
+        'up_crop_xy': ((slice(0, 96), slice(7, 121)), (171, 203)),
+        'down': ((slice(0, 96), slice(0, 128)), (70, 90)),
+        'double': ((slice(0, 96), slice(0, 128)), (192, 256)),
+        'odd': ((slice(3, 90), slice(5, 126)), (131, 197)),
+    }
+    out = {'geoms': jdump({k: [[c[0].start, c[0].stop, c[1].start, c[1].stop], list(sz)]
+                           for k, (c, sz) in geoms.items()})}
+    maps = {
+        'u8': rng.integers(0, 256, (1, Hs, Ws)).astype(np.uint8),
+        'bool': rng.random((1, Hs, Ws)) < 0.5,
+        'i32': rng.integers(-5, 1 << 20, (1, Hs, Ws)).astype(np.int32),
+        # panoptic ids; a few beyond 2^24 to pin the float32 round trip of the reference
+        'i64': np.where(rng.random((1, Hs, Ws)) < 0.05,
+                        rng.integers(1 << 24, 1 << 28, (1, Hs, Ws)),
+                        rng.integers(0, 40 * 65536, (1, Hs, Ws))).astype(np.int64),
+        'f32': rng.random((1, Hs, Ws)).astype(np.float32),
+    }
+    logits = (rng.standard_normal((1, 3, Hs, Ws)) * 3).astype(np.float32)
+    for k, v in maps.items():
+        out[f'in__{k}'] = v
+    out['in__logits'] = logits
+    for name, (crop, size) in geoms.items():
+        for k, v in maps.items():
+            r = post._crop_to_valid_region_and_resize_prediction(
+                torch.from_numpy(v), valid_region_slices=crop, shape=size, mode='nearest').numpy()
+            assert np.array_equal(r, orc.resize_nearest(v, size, crop)), (name, k)
+            if name in ('up_crop', 'odd') or k in ('u8', 'i64'):     # keep the file small
+                out[f'{name}__nearest_{k}'] = r
+        r = post._crop_to_valid_region_and_resize_prediction(
+            torch.from_numpy(logits), valid_region_slices=crop, shape=size, mode='bilinear').numpy()
+        mine = orc.resize_bilinear(logits, size, crop)
+        # bit-exact, NaN-free inputs (the committed vectors are the reference's)
+        assert np.array_equal(r, mine), (name, float(np.abs(r - mine).max()))
+        out[f'{name}__bilinear'] = r
+    save('fullres_cases', **out)
+
+    # ---- end to end: the reference panoptic postprocessing with a real fullres step ----
+    inp = syn.make_panoptic_inputs(2, n_classes=40, height=Hs, width=Ws, n_centers=9, seed=77)
+    is_thing = tuple(bool(x) for x in inp['semantic_classes_is_thing'])
+    pan = ref.post_panoptic.PanopticPostprocessing(
+        semantic_postprocessing=ref.post_semantic.SemanticPostprocessing(),
+        instance_postprocessing=ref.post_instance.InstancePostprocessing(),
+        semantic_classes_is_thing=is_thing, semantic_class_has_orientation=is_thing)
+    crop, size = geoms['up_crop']
+    batch = {
+        'rgb_fullres': torch.zeros((2, 3) + size),
+        ref.APPLIED_PREPROCESSING_KEY: [[{
+            'type': 'Resize', 'valid_region_slice_y': crop[0], 'valid_region_slice_x': crop[1],
+        }]] * 2,
+    }
+    data = ((torch.from_numpy(inp['semantic_logits']),
+             (torch.from_numpy(inp['instance_center']), torch.from_numpy(inp['instance_offset']))),
+            (None, None))
+    r = pan.postprocess(data, batch, is_training=False)
+    e2e = dict(input_digest=jdump(syn.input_digest(inp['semantic_logits'], inp['instance_center'],
+                                                    inp['instance_offset'])),
+               crop=np.array([crop[0].start, crop[0].stop, crop[1].start, crop[1].stop], np.int32),
+               size=np.array(size, np.int32))
+    for k, v in r.items():
+        if not (k.endswith('_fullres') and torch.is_tensor(v)):
+            continue
+        a = v.numpy()
+        if k == 'semantic_output_fullres':
+            a = a[:, ::13]                                   # 4 of 40 classes
+        elif k == 'semantic_softmax_scores_fullres':
+            continue                                          # = softmax of the entry above
+        e2e[k] = a
+        print('   ', k, a.dtype, a.shape)
+    # the argmax boundary (argmax of logits vs max of softmax) is documented; make sure the
+    # committed vector does not sit on it
+    lf = orc.resize_bilinear(inp['semantic_logits'], size, crop)
+    idx, _ = orc.semantic_argmax(lf)
+    assert np.array_equal(idx, e2e['semantic_segmentation_idx_fullres'])
+    save('fullres_panoptic', **e2e)
+
+
 def main():
     ref = load_reference()
     only = set(sys.argv[1:])
@@ -572,6 +658,8 @@ def main():
         gen_losses(ref)
     if want('orientation'):
         gen_orientation(ref)
+    if want('fullres'):
+        gen_fullres(ref)
 
 
 if __name__ == '__main__':

@@ -773,3 +773,84 @@ int orc_loss_cosine_embedding(const float* pred /* [B,D,H,W] */, const int32_t* 
     *loss_sum = total; *n_rows = n;
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* f2  DensePostprocessingBase._crop_to_valid_region_and_resize_prediction     */
+/*     model/postprocessing/dense_base.py:15-58                                */
+/* crop [y0:y0+h, x0:x0+w] of every [Hs,Ws] plane, then F.interpolate to       */
+/* (Ho,Wo).  The index / weight arithmetic restates ATen's CPU kernels         */
+/* (aten/src/ATen/native/UpSample.h: nearest_idx, area_pixel_compute_source_   */
+/* index, compute_source_index_and_lambda; cpu/UpSampleKernel.cpp generic      */
+/* 2-d linear kernel) and is pinned bit-for-bit by tests/golden/fullres_*.npz. */
+/* ------------------------------------------------------------------------- */
+static int nearest_src(float scale, int dst, int in)
+{
+    int i = (int)floorf((float)dst * scale);
+    return i < in - 1 ? i : in - 1;
+}
+
+static void bilinear_src(float scale, int dst, int in, int* i0, int* i1, float* w0, float* w1)
+{
+    float s = fmaf(scale, (float)dst + 0.5f, -0.5f);
+    if (s < 0.f) s = 0.f;
+    *i0 = (int)s < in - 1 ? (int)s : in - 1;
+    *i1 = *i0 + 1 < in - 1 ? *i0 + 1 : in - 1;
+    float l = s - (float)*i0;
+    if (l < 0.f) l = 0.f;
+    if (l > 1.f) l = 1.f;
+    *w1 = l;
+    *w0 = 1.0f - l;
+}
+
+/* elem_bytes: 1, 2, 4, 8 (integer maps) or -4 (float32 maps).  Integer maps wider  */
+/* than 2 bytes go through float32 like the reference (dense_base.py:38-40, :52).    */
+int orc_resize_nearest(const void* src, int elem_bytes, int planes, int Hs, int Ws,
+                       int y0, int x0, int h, int w, int Ho, int Wo, void* dst)
+{
+    if (!src || !dst || planes <= 0 || h <= 0 || w <= 0 || Ho <= 0 || Wo <= 0) return ORC_ERR_ARG;
+    if (y0 < 0 || x0 < 0 || y0 + h > Hs || x0 + w > Ws) return ORC_ERR_ARG;
+    const float sy = (float)h / (float)Ho, sx = (float)w / (float)Wo;
+    for (int p = 0; p < planes; ++p)
+        for (int y = 0; y < Ho; ++y) {
+            const size_t srow = ((size_t)p * Hs + y0 + nearest_src(sy, y, h)) * Ws + x0;
+            const size_t drow = ((size_t)p * Ho + y) * Wo;
+            for (int x = 0; x < Wo; ++x) {
+                const size_t s = srow + nearest_src(sx, x, w), d = drow + x;
+                switch (elem_bytes) {
+                    case 1: ((uint8_t*)dst)[d] = ((const uint8_t*)src)[s]; break;
+                    case 2: ((int16_t*)dst)[d] = ((const int16_t*)src)[s]; break;
+                    case 4: ((int32_t*)dst)[d] = (int32_t)(float)((const int32_t*)src)[s]; break;
+                    case 8: ((int64_t*)dst)[d] = (int64_t)(float)((const int64_t*)src)[s]; break;
+                    case -4: ((float*)dst)[d] = ((const float*)src)[s]; break;
+                    default: return ORC_ERR_ARG;
+                }
+            }
+        }
+    return ORC_OK;
+}
+
+int orc_resize_bilinear(const float* src, int planes, int Hs, int Ws,
+                        int y0, int x0, int h, int w, int Ho, int Wo, float* dst)
+{
+    if (!src || !dst || planes <= 0 || h <= 0 || w <= 0 || Ho <= 0 || Wo <= 0) return ORC_ERR_ARG;
+    if (y0 < 0 || x0 < 0 || y0 + h > Hs || x0 + w > Ws) return ORC_ERR_ARG;
+    const float sy = (float)h / (float)Ho, sx = (float)w / (float)Wo;
+    for (int p = 0; p < planes; ++p)
+        for (int y = 0; y < Ho; ++y) {
+            int iy0, iy1;
+            float wy0, wy1;
+            bilinear_src(sy, y, h, &iy0, &iy1, &wy0, &wy1);
+            const float* r0 = src + ((size_t)p * Hs + y0 + iy0) * Ws + x0;
+            const float* r1 = src + ((size_t)p * Hs + y0 + iy1) * Ws + x0;
+            float* d = dst + ((size_t)p * Ho + y) * Wo;
+            for (int x = 0; x < Wo; ++x) {
+                int ix0, ix1;
+                float wx0, wx1;
+                bilinear_src(sx, x, w, &ix0, &ix1, &wx0, &wx1);
+                const float t0 = fmaf(r0[ix0], wx0, r0[ix1] * wx1);
+                const float t1 = fmaf(r1[ix0], wx0, r1[ix1] * wx1);
+                d[x] = fmaf(t0, wy0, t1 * wy1);
+            }
+        }
+    return ORC_OK;
+}

@@ -275,3 +275,39 @@ def loss_cosine_embedding(pred, indices, lut, want_grad=False):
         B, D, H, W, L, C.byref(s), C.byref(n), _p(grad, C.c_float)),
         'loss_cos_emb')
     return s.value, n.value, grad
+
+
+# -- f2: crop + resize (dense_base.py:15-58) -------------------------------------
+def _crop_args(shape, crop):
+    Hs, Ws = shape[-2:]
+    (ys, xs) = crop if crop is not None else (slice(0, Hs), slice(0, Ws))
+    y0, y1, _ = ys.indices(Hs)
+    x0, x1, _ = xs.indices(Ws)
+    return Hs, Ws, y0, x0, y1 - y0, x1 - x0
+
+
+def resize_nearest(maps, size, crop=None):
+    """maps [..., Hs, Ws] (uint8/bool/int16/int32/int64/float32) -> [..., Ho, Wo]."""
+    a = np.ascontiguousarray(maps)
+    code = {np.dtype(np.uint8): 1, np.dtype(np.bool_): 1, np.dtype(np.int16): 2,
+            np.dtype(np.int32): 4, np.dtype(np.int64): 8, np.dtype(np.float32): -4}[a.dtype]
+    Hs, Ws, y0, x0, h, w = _crop_args(a.shape, crop)
+    Ho, Wo = int(size[0]), int(size[1])
+    planes = int(np.prod(a.shape[:-2], dtype=np.int64))
+    out = np.empty(a.shape[:-2] + (Ho, Wo), a.dtype)
+    _chk(lib().orc_resize_nearest(a.ctypes.data_as(C.c_void_p), code, planes, Hs, Ws,
+                                  y0, x0, h, w, Ho, Wo, out.ctypes.data_as(C.c_void_p)),
+         'resize_nearest')
+    return out
+
+
+def resize_bilinear(maps, size, crop=None):
+    """float32 [..., Hs, Ws] -> [..., Ho, Wo], align_corners=False."""
+    a = _c(maps, np.float32)
+    Hs, Ws, y0, x0, h, w = _crop_args(a.shape, crop)
+    Ho, Wo = int(size[0]), int(size[1])
+    planes = int(np.prod(a.shape[:-2], dtype=np.int64))
+    out = np.empty(a.shape[:-2] + (Ho, Wo), np.float32)
+    _chk(lib().orc_resize_bilinear(_p(a, C.c_float), planes, Hs, Ws, y0, x0, h, w, Ho, Wo,
+                                   _p(out, C.c_float)), 'resize_bilinear')
+    return out

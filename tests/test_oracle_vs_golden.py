@@ -227,3 +227,55 @@ def test_losses(oracle):
     np.testing.assert_allclose(s, g['cos_emb__loss'], rtol=1e-5)
     assert n == g['cos_emb__n']
     np.testing.assert_allclose(grad, g['cos_emb__grad'], rtol=1e-4, atol=1e-6)
+
+
+# ---------------------------------------------------------------------------
+# f2: crop + resize to the dataset resolution (dense_base.py:15-58)
+def _fullres_geoms(g):
+    out = {}
+    for name, (c, size) in jload(g['geoms']).items():
+        out[name] = ((slice(c[0], c[1]), slice(c[2], c[3])), tuple(size))
+    return out
+
+
+def test_fullres_resize_cases(oracle):
+    g = load('fullres_cases')
+    n = 0
+    for name, (crop, size) in _fullres_geoms(g).items():
+        for k in ('u8', 'bool', 'i32', 'i64', 'f32'):
+            key = f'{name}__nearest_{k}'
+            if key not in g:
+                continue
+            got = oracle.resize_nearest(g[f'in__{k}'], size, crop)
+            assert got.dtype == g[key].dtype and np.array_equal(got, g[key]), key
+            n += 1
+        got = oracle.resize_bilinear(g['in__logits'], size, crop)
+        assert np.array_equal(got, g[f'{name}__bilinear']), name      # bit-exact
+        n += 1
+    assert n >= 20
+
+
+def test_fullres_panoptic(oracle):
+    """the reference's PanopticPostprocessing with a real crop + upscale (96x128 -> 150x200)"""
+    g = load('fullres_panoptic')
+    inp = syn.make_panoptic_inputs(2, n_classes=40, height=96, width=128, n_centers=9, seed=77)
+    if syn.input_digest(inp['semantic_logits'], inp['instance_center'],
+                        inp['instance_offset']) != jload(g['input_digest']):
+        pytest.skip('synthetic inputs differ bit-wise on this host (numpy/libm)')
+    c = g['crop']
+    crop, size = (slice(int(c[0]), int(c[1])), slice(int(c[2]), int(c[3]))), tuple(g['size'])
+    r = _run_pipeline_oracle(oracle, inp['semantic_logits'], inp['instance_center'],
+                             inp['instance_offset'], inp['semantic_classes_is_thing'])
+    lf = oracle.resize_bilinear(inp['semantic_logits'], size, crop)
+    assert np.array_equal(lf[:, ::13], g['semantic_output_fullres'])
+    idx, score = oracle.semantic_argmax(lf)
+    assert np.array_equal(idx, g['semantic_segmentation_idx_fullres'])
+    np.testing.assert_allclose(score, g['semantic_segmentation_score_fullres'],
+                               rtol=1e-5, atol=1e-7)
+    assert np.array_equal(oracle.resize_nearest(r['pan'], size, crop),
+                          g['panoptic_segmentation_deeplab_fullres'])
+    assert np.array_equal(oracle.resize_nearest(r['inst'].astype(np.uint8), size, crop),
+                          g['panoptic_segmentation_deeplab_instance_idx_fullres'])
+    pan_sem = np.where(r['pan'] > 0, r['pan'] // (1 << 16), 0)
+    assert np.array_equal(oracle.resize_nearest(pan_sem.astype(np.int64), size, crop),
+                          g['panoptic_segmentation_deeplab_semantic_idx_fullres'])
