@@ -32,4 +32,23 @@ __device__ __forceinline__ void argmax_step(ArgmaxState& s, int j, float v, int 
     if (v > s.m[j]) { s.m[j] = v; s.am[j] = c; }
 }
 
+// Four classes c0..c0+3 of pixel j at once (values already in registers): one running-max
+// update and ONE rescale of the softmax denominator per group instead of per class.
+// No `nf` bookkeeping: a NaN / +inf logit, or a prefix of nothing but -inf, turns `se` into NaN,
+// and the caller re-evaluates such a column exactly (a superset of the degenerate columns).
+__device__ __forceinline__ void argmax_group4_score(ArgmaxState& s, int j, const float v[4], int c0)
+{
+    constexpr float kLog2e = 1.4426950408889634f;
+    const float gm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+    const float nm = fmaxf(s.m[j], gm);
+    const float rescale = __builtin_amdgcn_exp2f((s.m[j] - nm) * kLog2e);
+    float e = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) e += __builtin_amdgcn_exp2f((v[i] - nm) * kLog2e);
+    s.se[j] = fmaf(s.se[j], rescale, e);
+    const int first = (v[0] == gm) ? 0 : (v[1] == gm) ? 1 : (v[2] == gm) ? 2 : 3;
+    s.am[j] = (gm > s.m[j]) ? c0 + first : s.am[j];
+    s.m[j] = nm;
+}
+
 }  // namespace nmsa

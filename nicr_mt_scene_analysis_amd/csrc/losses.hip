@@ -21,7 +21,6 @@
 namespace nmsa {
 
 constexpr int LOSS_THREADS = 256;
-constexpr int LOSS_MAX_BLOCKS = 2048;
 
 struct LossPartial { double sum; double aux; long long count; long long pad; };
 

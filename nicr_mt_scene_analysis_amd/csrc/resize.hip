@@ -23,6 +23,7 @@
 //   for tiny outputs ATen switches to a 4-weight form that differs by <= 1 ulp.)
 // Integer maps take the reference's float32 round trip (dense_base.py:38-40), which is
 // the identity below 2^24 and reproduced above it.
+#include <stdlib.h>
 #include "nmsa_common.hpp"
 #include "argmax_state.hpp"
 
@@ -66,6 +67,27 @@ __device__ __forceinline__ float ld_elem(const void* p, size_t i)
     if (DTYPE == NMSA_F32) return ((const float*)p)[i];
     const uint16_t h = ((const uint16_t*)p)[i];
     return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
+}
+
+// the two horizontal neighbours (a = row[ix0], b = row[ix1]) with ONE load: ix1 == ix0 + 1
+// everywhere but on the clamped right edge, where both are the last pixel.  `xb` =
+// min(ix0, w - 2) is the pair's base, `edge` = (ix0 == w - 1).  Needs w >= 2.
+template <int DTYPE>
+__device__ __forceinline__ void ld_pair(const void* p, size_t i, bool edge, float& a, float& b)
+{
+    float lo, hi;
+    if (DTYPE == NMSA_F32) {
+        typedef float f32x2_t __attribute__((ext_vector_type(2), aligned(4)));
+        const f32x2_t v = *(const f32x2_t*)((const float*)p + i);
+        lo = v.x; hi = v.y;
+    } else {
+        typedef unsigned short u16x2_t __attribute__((ext_vector_type(2), aligned(2)));
+        const u16x2_t v = *(const u16x2_t*)((const uint16_t*)p + i);
+        lo = (DTYPE == NMSA_BF16) ? bf16_to_f32(v.x) : f16_to_f32(v.x);
+        hi = (DTYPE == NMSA_BF16) ? bf16_to_f32(v.y) : f16_to_f32(v.y);
+    }
+    a = edge ? hi : lo;
+    b = hi;
 }
 
 // round-to-nearest-even to the storage type of the logits (what the reference's
@@ -140,35 +162,13 @@ __global__ __launch_bounds__(256) void k_resize_nearest(
 // =================================================================================
 // bilinear (align_corners=False), output in the input's storage type
 // =================================================================================
+// One thread = 4 consecutive output pixels of one row, for RB_PLANES consecutive planes:
+// the index / weight arithmetic is paid once and reused for every plane.
+constexpr int RB_PLANES = 8;
+
 template <int DTYPE, bool VEC>
-__global__ __launch_bounds__(256) void k_resize_bilinear(
-    const void* __restrict__ src, void* __restrict__ dst, CropResize g, int planes)
+__device__ __forceinline__ void store_px4(void* dst, size_t o, const float v[4], int nvalid)
 {
-    const int Q = (g.Wo + 3) >> 2;
-    const long long total = (long long)planes * g.Ho * Q;
-    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= total) return;
-    const int q = (int)(t % Q);
-    const long long row = t / Q;
-    const int y = (int)(row % g.Ho);
-    const long long plane = row / g.Ho;
-    int iy0, iy1;
-    float wy0, wy1;
-    bilinear_src(g.sy, y, g.h, iy0, iy1, wy0, wy1);
-    const size_t r0 = ((size_t)plane * g.Hs + g.y0 + iy0) * g.Ws + g.x0;
-    const size_t r1 = ((size_t)plane * g.Hs + g.y0 + iy1) * g.Ws + g.x0;
-    float v[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int x = min(q * 4 + j, g.Wo - 1);
-        int ix0, ix1;
-        float wx0, wx1;
-        bilinear_src(g.sx, x, g.w, ix0, ix1, wx0, wx1);
-        v[j] = bilerp(ld_elem<DTYPE>(src, r0 + ix0), ld_elem<DTYPE>(src, r0 + ix1),
-                      ld_elem<DTYPE>(src, r1 + ix0), ld_elem<DTYPE>(src, r1 + ix1),
-                      wx0, wx1, wy0, wy1);
-    }
-    const size_t o = (size_t)row * g.Wo + q * 4;
     if (DTYPE == NMSA_F32) {
         float* d = (float*)dst + o;
         if (VEC) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(256) void k_resize_bilinear(
             __builtin_nontemporal_store(ov, (f32x4_t*)d);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (q * 4 + j < g.Wo) d[j] = v[j];
+            for (int j = 0; j < 4; ++j) if (j < nvalid) d[j] = v[j];
         }
     } else {
         uint16_t* d = (uint16_t*)dst + o;
@@ -191,11 +191,68 @@ __global__ __launch_bounds__(256) void k_resize_bilinear(
             typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
             u16x4_t ov;
             ov.x = hbits[0]; ov.y = hbits[1]; ov.z = hbits[2]; ov.w = hbits[3];
-            *(u16x4_t*)d = ov;
+            __builtin_nontemporal_store(ov, (u16x4_t*)d);
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) if (q * 4 + j < g.Wo) d[j] = hbits[j];
+            for (int j = 0; j < 4; ++j) if (j < nvalid) d[j] = hbits[j];
         }
+    }
+}
+
+template <int DTYPE, bool VEC, bool PAIR>
+__global__ __launch_bounds__(256) void k_resize_bilinear(
+    const void* __restrict__ src, void* __restrict__ dst, CropResize g, int planes)
+{
+    const int Q = (g.Wo + 3) >> 2;
+    const int plane_groups = (planes + RB_PLANES - 1) / RB_PLANES;
+    const long long total = (long long)plane_groups * g.Ho * Q;
+    const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= total) return;
+    const int q = (int)(t % Q);
+    const long long row = t / Q;
+    const int y = (int)(row % g.Ho);
+    const int p_begin = (int)(row / g.Ho) * RB_PLANES;
+    const int p_end = min(p_begin + RB_PLANES, planes);
+    int iy0, iy1;
+    float wy0, wy1;
+    bilinear_src(g.sy, y, g.h, iy0, iy1, wy0, wy1);
+    int xo[4], xo1[4];
+    bool edge[4];
+    float wx0[4], wx1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int x = min(q * 4 + j, g.Wo - 1);
+        int ix0, ix1;
+        bilinear_src(g.sx, x, g.w, ix0, ix1, wx0[j], wx1[j]);
+        edge[j] = PAIR && (ix0 == g.w - 1);
+        xo[j] = PAIR ? min(ix0, g.w - 2) : ix0;
+        xo1[j] = ix1;
+    }
+    const size_t plane_stride = (size_t)g.Hs * g.Ws;
+    size_t r0 = (size_t)p_begin * plane_stride + (size_t)(g.y0 + iy0) * g.Ws + g.x0;
+    size_t r1 = (size_t)p_begin * plane_stride + (size_t)(g.y0 + iy1) * g.Ws + g.x0;
+    size_t o = ((size_t)p_begin * g.Ho + y) * g.Wo + q * 4;
+    const int nvalid = min(4, g.Wo - q * 4);
+    for (int p = p_begin; p < p_end; ++p) {
+        float a[4], b[4], c[4], d[4], v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (PAIR) {
+                ld_pair<DTYPE>(src, r0 + xo[j], edge[j], a[j], b[j]);
+                ld_pair<DTYPE>(src, r1 + xo[j], edge[j], c[j], d[j]);
+            } else {
+                a[j] = ld_elem<DTYPE>(src, r0 + xo[j]);
+                b[j] = ld_elem<DTYPE>(src, r0 + xo1[j]);
+                c[j] = ld_elem<DTYPE>(src, r1 + xo[j]);
+                d[j] = ld_elem<DTYPE>(src, r1 + xo1[j]);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = bilerp(a[j], b[j], c[j], d[j], wx0[j], wx1[j], wy0, wy1);
+        store_px4<DTYPE, VEC>(dst, o, v, nvalid);
+        r0 += plane_stride;
+        r1 += plane_stride;
+        o += (size_t)g.Ho * g.Wo;
     }
 }
 
@@ -222,7 +279,7 @@ __device__ __noinline__ bool resized_column_degenerate(
     return nan_or_pinf || !any_finite;
 }
 
-template <int DTYPE, bool WITH_SCORE>
+template <int DTYPE, bool WITH_SCORE, bool PAIR>
 __global__ __launch_bounds__(RZ_TW * RZ_TH) void k_argmax_resized(
     const void* __restrict__ logits, CropResize g, int C, int tiles_x, int tiles_y,
     long long n_tiles,
@@ -248,6 +305,11 @@ __global__ __launch_bounds__(RZ_TW * RZ_TH) void k_argmax_resized(
     const size_t o01 = img + (size_t)(g.y0 + iy0) * g.Ws + g.x0 + ix1;
     const size_t o10 = img + (size_t)(g.y0 + iy1) * g.Ws + g.x0 + ix0;
     const size_t o11 = img + (size_t)(g.y0 + iy1) * g.Ws + g.x0 + ix1;
+    // PAIR: both horizontal neighbours with one load (see ld_pair)
+    const bool edge = PAIR && (ix0 == g.w - 1);
+    const int xb = PAIR ? min(ix0, g.w - 2) : 0;
+    const size_t q0 = img + (size_t)(g.y0 + iy0) * g.Ws + g.x0 + xb;
+    const size_t q1 = img + (size_t)(g.y0 + iy1) * g.Ws + g.x0 + xb;
 
     ArgmaxState st;
     argmax_init(st);
@@ -257,10 +319,15 @@ __global__ __launch_bounds__(RZ_TW * RZ_TH) void k_argmax_resized(
 #pragma unroll
         for (int u = 0; u < RZ_UNROLL; ++u) {
             const size_t pc = (size_t)(c + u) * plane_stride;
-            a[u] = ld_elem<DTYPE>(logits, pc + o00);
-            bb[u] = ld_elem<DTYPE>(logits, pc + o01);
-            cc[u] = ld_elem<DTYPE>(logits, pc + o10);
-            d[u] = ld_elem<DTYPE>(logits, pc + o11);
+            if (PAIR) {
+                ld_pair<DTYPE>(logits, pc + q0, edge, a[u], bb[u]);
+                ld_pair<DTYPE>(logits, pc + q1, edge, cc[u], d[u]);
+            } else {
+                a[u] = ld_elem<DTYPE>(logits, pc + o00);
+                bb[u] = ld_elem<DTYPE>(logits, pc + o01);
+                cc[u] = ld_elem<DTYPE>(logits, pc + o10);
+                d[u] = ld_elem<DTYPE>(logits, pc + o11);
+            }
         }
 #pragma unroll
         for (int u = 0; u < RZ_UNROLL; ++u)
@@ -284,6 +351,264 @@ __global__ __launch_bounds__(RZ_TW * RZ_TH) void k_argmax_resized(
     if (idx_u8) idx_u8[o] = (uint8_t)cls;
     if (idx_i64) idx_i64[o] = cls;
     if (WITH_SCORE) score[o] = degenerate ? __int_as_float(0x7fc00000) : (1.0f / st.se[0]);
+}
+
+// =================================================================================
+// LDS-staged tiles (upscaling, the common case: network 480x640 -> dataset resolution)
+// =================================================================================
+// The gather kernels above issue 4 scattered loads per output pixel and class and are bound
+// by the texture-address path, not by HBM.  When upscaling, a 64 x 16 output tile reads a
+// source footprint of at most ~(63*sx + 3) x (15*sy + 3) <= 67 x 19 pixels per class: stage
+// it once per chunk of 4 classes, then interpolate out of LDS.
+// Staging is LDS-DMA in 16-byte pieces (`global_load_lds_dwordx4`: no VGPR round trip, 1 KiB
+// per wave-instruction, ONE instruction per thread and class): the footprint window is
+// widened to whole pieces (P = 4 or 8 elements x ceil(SWt / ..)) and, at the right image
+// border, shifted left so that it never leaves the source row; piece e = row * (P/EPP) + q
+// lands at LDS byte 16*e — lane-linear per wave, as the DMA requires — so the LDS image is
+// the window itself with pitch P.  Two LDS buffers: chunk i+1 is in flight while chunk i is
+// interpolated, one barrier per chunk.  Lane = output x (conflict-free LDS reads), each
+// thread owns 4 consecutive output rows.
+constexpr int LT_TW = 64, LT_TH = 16, LT_THREADS = 256;
+constexpr int LT_CH = 4;                   // classes per chunk (x 2 LDS buffers)
+constexpr int LT_MODE_ARGMAX = 0, LT_MODE_ARGMAX_SCORE = 1, LT_MODE_MATERIALISE = 2;
+
+__device__ __forceinline__ void glds_piece(const void* gsrc, void* lds_wave_base)
+{
+    typedef const __attribute__((address_space(1))) void* gptr_t;
+    typedef __attribute__((address_space(3))) void* lptr_t;
+    __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_wave_base, 16, 0, 0);
+}
+
+template <int DTYPE>
+__device__ __forceinline__ float lds_elem(const void* plane, int i)
+{
+    if (DTYPE == NMSA_F32) return ((const float*)plane)[i];
+    const uint16_t h = ((const uint16_t*)plane)[i];
+    return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
+}
+
+// Exact re-evaluation of one output column (rare: the fast path's denominator came out NaN):
+// softmax-then-max semantics of semantic.py:74-75 incl. the degenerate columns.
+template <int DTYPE>
+__device__ __noinline__ void resized_column_exact(
+    const void* logits, size_t o00, size_t o01, size_t o10, size_t o11, size_t plane_stride,
+    int C, float wx0, float wx1, float wy0, float wy1, int& cls, float& score)
+{
+    bool nan_or_pinf = false, any_finite = false;
+    float m = -INFINITY;
+    int am = 0;
+    for (int c = 0; c < C; ++c) {
+        const size_t pc = (size_t)c * plane_stride;
+        const float v = round_to_storage<DTYPE>(bilerp(
+            ld_elem<DTYPE>(logits, pc + o00), ld_elem<DTYPE>(logits, pc + o01),
+            ld_elem<DTYPE>(logits, pc + o10), ld_elem<DTYPE>(logits, pc + o11),
+            wx0, wx1, wy0, wy1));
+        if (v != v || v == INFINITY) nan_or_pinf = true;
+        if (fabsf(v) < INFINITY) any_finite = true;
+        if (v > m) { m = v; am = c; }
+    }
+    if (nan_or_pinf || !any_finite) { cls = 0; score = __int_as_float(0x7fc00000); return; }
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const size_t pc = (size_t)c * plane_stride;
+        const float v = round_to_storage<DTYPE>(bilerp(
+            ld_elem<DTYPE>(logits, pc + o00), ld_elem<DTYPE>(logits, pc + o01),
+            ld_elem<DTYPE>(logits, pc + o10), ld_elem<DTYPE>(logits, pc + o11),
+            wx0, wx1, wy0, wy1));
+        se += (v == -INFINITY) ? 0.f : __expf(v - m);
+    }
+    cls = am;
+    score = 1.0f / se;
+}
+
+template <int DTYPE, int MODE, int K16>
+__global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
+    const void* __restrict__ src, CropResize g, int planes, int group, int tiles_x, int tiles_y,
+    long long n_tiles,
+    uint8_t* __restrict__ idx_u8, int64_t* __restrict__ idx_i64, float* __restrict__ score,
+    void* __restrict__ dst)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    constexpr int ESZ = (DTYPE == NMSA_F32) ? 4 : 2;   // bytes per element
+    constexpr int EPP = 16 / ESZ;                      // elements per 16-byte piece
+    constexpr int PLANE = K16 * LT_THREADS * EPP;      // elements per staged class plane
+    const long long tile = xcd_contiguous_tile(blockIdx.x, n_tiles);
+    if (tile >= n_tiles) return;                       // block-uniform
+    const int tx = (int)(tile % tiles_x);
+    const long long rr = tile / tiles_x;
+    const int ty = (int)(rr % tiles_y);
+    const int grp = (int)(rr / tiles_y);
+    const int p_begin = grp * group;
+    const int C = min(group, planes - p_begin);        // planes (classes) of this tile
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+
+    // ---- tile footprint in the source (block-uniform) --------------------------------------
+    int xs0, xs1, ys0, ys1, ti;
+    float tf0, tf1;
+    bilinear_src(g.sx, min(tx * LT_TW, g.Wo - 1), g.w, xs0, ti, tf0, tf1);
+    bilinear_src(g.sx, min(tx * LT_TW + LT_TW - 1, g.Wo - 1), g.w, ti, xs1, tf0, tf1);
+    bilinear_src(g.sy, min(ty * LT_TH, g.Ho - 1), g.h, ys0, ti, tf0, tf1);
+    bilinear_src(g.sy, min(ty * LT_TH + LT_TH - 1, g.Ho - 1), g.h, ti, ys1, tf0, tf1);
+    const int SHt = ys1 - ys0 + 1;
+    const int PR = (xs1 - xs0 + EPP) / EPP;            // pieces per window row
+    const int P = PR * EPP;                            // window width = LDS pitch (elements)
+    const int xa = min(xs0, g.Ws - g.x0 - P);          // window start: never past the row end
+    const int n_pieces = PR * SHt;                     // <= K16 * 256 (host-checked bound)
+
+    // ---- this thread's 4 output pixels ---------------------------------------------------------
+    const int x = tx * LT_TW + lane;
+    int ix0, ix1;
+    float wx0, wx1;
+    bilinear_src(g.sx, min(x, g.Wo - 1), g.w, ix0, ix1, wx0, wx1);
+    const int cx0 = ix0 - xa, cx1 = ix1 - xa;
+    int r0[4], r1[4], yy[4];
+    float wy0[4], wy1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        yy[j] = ty * LT_TH + wv * 4 + j;
+        int iy0, iy1;
+        bilinear_src(g.sy, min(yy[j], g.Ho - 1), g.h, iy0, iy1, wy0[j], wy1[j]);
+        r0[j] = (iy0 - ys0) * P;
+        r1[j] = (iy1 - ys0) * P;
+    }
+    auto corner = [&](const void* L, int cc, int j, int which) -> float {
+        // which: 0 a (row0,x0)  1 b (row0,x1)  2 c (row1,x0)  3 d (row1,x1); cc * PLANE folds
+        // into the ds_read immediate offset
+        const int i = ((which & 2) ? r1[j] : r0[j]) + ((which & 1) ? cx1 : cx0);
+        return lds_elem<DTYPE>(L, cc * PLANE + i);
+    };
+
+    // ---- staging slots: piece e of the window -> source offset (the tail lanes of the last
+    //      slot re-load the last piece into the padding of the LDS plane) -----------------------
+    int goff[K16];
+#pragma unroll
+    for (int k = 0; k < K16; ++k) {
+        const int e = min((int)threadIdx.x + k * LT_THREADS, n_pieces - 1);
+        const int r = e / PR, q = e - r * PR;
+        goff[k] = r * g.Ws + q * EPP;
+    }
+    const size_t plane_stride = (size_t)g.Hs * g.Ws;
+    const size_t base = (size_t)p_begin * plane_stride + (size_t)(g.y0 + ys0) * g.Ws + g.x0 + xa;
+    unsigned char* wave_lds = lds_raw + (size_t)wv * 64 * 16;
+    const int k_used = (n_pieces + LT_THREADS - 1) / LT_THREADS;
+
+    // two LDS buffers of LT_CH classes: chunk i+1 is in flight (LDS-DMA) while chunk i is
+    // interpolated; ONE barrier per chunk
+    auto stage = [&](int c0, int buf) {
+        const int nch = min(LT_CH, C - c0);
+        for (int cc = 0; cc < nch; ++cc) {
+            const size_t pb = base + (size_t)(c0 + cc) * plane_stride;
+            unsigned char* L = wave_lds + (size_t)(buf * LT_CH + cc) * PLANE * ESZ;
+#pragma unroll
+            for (int k = 0; k < K16; ++k)
+                if (k < k_used)
+                    glds_piece((const unsigned char*)src + (pb + goff[k]) * ESZ,
+                               L + (size_t)k * LT_THREADS * 16);
+        }
+    };
+    ArgmaxState st;
+    argmax_init(st);
+    stage(0, 0);
+    int buf = 0;
+    for (int c0 = 0; c0 < C; c0 += LT_CH, buf ^= 1) {
+        const int nch = min(LT_CH, C - c0);
+        __syncthreads();          // vmcnt(0) + barrier: chunk c0 has landed, the other buffer is free
+        if (c0 + LT_CH < C) stage(c0 + LT_CH, buf ^ 1);
+        const void* L = lds_raw + (size_t)buf * LT_CH * PLANE * ESZ;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float v[LT_CH];
+#pragma unroll
+            for (int cc = 0; cc < LT_CH; ++cc) {
+                const float val = round_to_storage<DTYPE>(bilerp(
+                    corner(L, cc, j, 0), corner(L, cc, j, 1), corner(L, cc, j, 2), corner(L, cc, j, 3),
+                    wx0, wx1, wy0[j], wy1[j]));
+                v[cc] = (cc < nch) ? val : -INFINITY;          // tail chunk: stale LDS, ignored
+            }
+            if (MODE == LT_MODE_MATERIALISE) {
+                if (x < g.Wo && yy[j] < g.Ho) {
+#pragma unroll
+                    for (int cc = 0; cc < LT_CH; ++cc) {
+                        if (cc >= nch) break;
+                        const size_t o = ((size_t)(p_begin + c0 + cc) * g.Ho + yy[j]) * g.Wo + x;
+                        if (DTYPE == NMSA_F32) __builtin_nontemporal_store(v[cc], (float*)dst + o);
+                        else if (DTYPE == NMSA_BF16) ((uint16_t*)dst)[o] = f32_to_bf16_bits(v[cc]);
+                        else ((uint16_t*)dst)[o] = __builtin_bit_cast(uint16_t, (_Float16)v[cc]);
+                    }
+                }
+            } else if (MODE == LT_MODE_ARGMAX_SCORE) {
+                static_assert(LT_CH == 4, "argmax_group4_score");
+                argmax_group4_score(st, j, v, c0);
+            } else {
+#pragma unroll
+                for (int cc = 0; cc < LT_CH; ++cc)
+                    if (cc < nch) argmax_step<false>(st, j, v[cc], c0 + cc);
+            }
+        }
+    }
+    if (MODE == LT_MODE_MATERIALISE) return;
+    if (x >= g.Wo) return;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (yy[j] >= g.Ho) continue;
+        int cls = st.am[j];
+        float sc = 0.f;
+        const bool suspicious = (MODE == LT_MODE_ARGMAX_SCORE) ? (st.se[j] != st.se[j])
+                                                               : (st.nf[j] != st.nf[j]);
+        if (MODE == LT_MODE_ARGMAX_SCORE) sc = 1.0f / st.se[j];
+        if (suspicious) {
+            const size_t img = (size_t)p_begin * plane_stride;
+            const size_t q0 = img + (size_t)(g.y0 + ys0 + r0[j] / P) * g.Ws + g.x0;
+            const size_t q1 = img + (size_t)(g.y0 + ys0 + r1[j] / P) * g.Ws + g.x0;
+            resized_column_exact<DTYPE>(src, q0 + ix0, q0 + ix1, q1 + ix0, q1 + ix1, plane_stride, C,
+                                        wx0, wx1, wy0[j], wy1[j], cls, sc);
+        }
+        const size_t o = ((size_t)grp * g.Ho + yy[j]) * g.Wo + x;
+        if (idx_u8) idx_u8[o] = (uint8_t)cls;
+        if (idx_i64) idx_i64[o] = cls;
+        if (MODE == LT_MODE_ARGMAX_SCORE) score[o] = sc;
+    }
+}
+
+// Staging slots per thread and class (K16 = 1 or 2 pieces of 16 bytes) for this resize; 0 when
+// the gather kernels must be used (downscaling: the footprint of a tile does not fit the
+// staging slots; or a source row narrower than one window).
+int plan_tiles(const CropResize& g, int elem_bytes)
+{
+    if (getenv("NMSA_RESIZE_NO_LDS")) return 0;
+    // ix1(last) - ix0(first) + 1 <= 63*sx + 3 (+1 slack for the float rounding of the indices)
+    const long long sw = (long long)(63.0f * g.sx) + 4, sh = (long long)((LT_TH - 1) * g.sy) + 4;
+    const int epp = 16 / elem_bytes;
+    const long long pr = (sw + epp - 1) / epp;
+    if (pr * sh > 2 * LT_THREADS) return 0;
+    if ((long long)g.Ws - g.x0 < pr * epp) return 0;
+    return pr * sh > LT_THREADS ? 2 : 1;
+}
+
+template <int DTYPE, int MODE, int K16>
+int launch_tile_k(const void* src, const CropResize& g, int planes, int group,
+                  uint8_t* idx_u8, int64_t* idx_i64, float* score, void* dst, hipStream_t stream)
+{
+    const int tiles_x = (g.Wo + LT_TW - 1) / LT_TW;
+    const int tiles_y = (g.Ho + LT_TH - 1) / LT_TH;
+    const int groups = (planes + group - 1) / group;
+    const long long n_tiles = (long long)tiles_x * tiles_y * groups;
+    const long long blocks = ((n_tiles + 7) / 8) * 8;       // see xcd_contiguous_tile
+    if (blocks > 0x7fffffffLL) return NMSA_ERR_ARG;
+    const size_t lds_bytes = (size_t)K16 * LT_THREADS * 16 * LT_CH * 2;
+    hipLaunchKernelGGL((k_resized_tile<DTYPE, MODE, K16>), dim3((unsigned)blocks), dim3(LT_THREADS),
+                       lds_bytes, stream, src, g, planes, group, tiles_x, tiles_y, n_tiles,
+                       idx_u8, idx_i64, score, dst);
+    return check_launch();
+}
+
+template <int DTYPE, int MODE>
+int launch_tile(const void* src, const CropResize& g, int k16, int planes, int group,
+                uint8_t* idx_u8, int64_t* idx_i64, float* score, void* dst, hipStream_t stream)
+{
+    if (k16 == 1)
+        return launch_tile_k<DTYPE, MODE, 1>(src, g, planes, group, idx_u8, idx_i64, score, dst, stream);
+    return launch_tile_k<DTYPE, MODE, 2>(src, g, planes, group, idx_u8, idx_i64, score, dst, stream);
 }
 
 bool bad_geometry(int planes, int Hs, int Ws, int y0, int x0, int h, int w, int Ho, int Wo)
@@ -320,15 +645,23 @@ int launch_nearest(const void* src, void* dst, const CropResize& g, int planes, 
 template <int DTYPE>
 int launch_bilinear(const void* src, void* dst, const CropResize& g, int planes, hipStream_t stream)
 {
-    const long long total = (long long)planes * g.Ho * ((g.Wo + 3) / 4);
+    const int tile_k = plan_tiles(g, DTYPE == NMSA_F32 ? 4 : 2);
+    if (tile_k > 0)
+        return launch_tile<DTYPE, LT_MODE_MATERIALISE>(src, g, tile_k, planes, planes < 32 ? planes : 32,
+                                                       nullptr, nullptr, nullptr, dst, stream);
+    const long long groups = (planes + RB_PLANES - 1) / RB_PLANES;
+    const long long total = groups * g.Ho * ((g.Wo + 3) / 4);
     const long long blocks = (total + 255) / 256;
     if (blocks > 0x7fffffffLL) return NMSA_ERR_ARG;
     const size_t esz = (DTYPE == NMSA_F32) ? 4 : 2;
     const bool vec = (g.Wo % 4 == 0) && ((uintptr_t)dst % (4 * esz) == 0);
-    if (vec) hipLaunchKernelGGL((k_resize_bilinear<DTYPE, true>), dim3((unsigned)blocks), dim3(256),
-                                0, stream, src, dst, g, planes);
-    else hipLaunchKernelGGL((k_resize_bilinear<DTYPE, false>), dim3((unsigned)blocks), dim3(256),
-                            0, stream, src, dst, g, planes);
+    const bool pair = g.w >= 2;
+#define NMSA_LAUNCH_RB(V, PR)                                                                \
+    hipLaunchKernelGGL((k_resize_bilinear<DTYPE, V, PR>), dim3((unsigned)blocks), dim3(256), \
+                       0, stream, src, dst, g, planes)
+    if (vec) { if (pair) NMSA_LAUNCH_RB(true, true); else NMSA_LAUNCH_RB(true, false); }
+    else { if (pair) NMSA_LAUNCH_RB(false, true); else NMSA_LAUNCH_RB(false, false); }
+#undef NMSA_LAUNCH_RB
     return check_launch();
 }
 
@@ -336,17 +669,26 @@ template <int DTYPE>
 int launch_argmax_resized(const void* logits, const CropResize& g, int B, int C,
                           uint8_t* idx_u8, int64_t* idx_i64, float* score, hipStream_t stream)
 {
+    const int tile_k = plan_tiles(g, DTYPE == NMSA_F32 ? 4 : 2);
+    if (tile_k > 0) {
+        if (score) return launch_tile<DTYPE, LT_MODE_ARGMAX_SCORE>(logits, g, tile_k, B * C, C, idx_u8,
+                                                                    idx_i64, score, nullptr, stream);
+        return launch_tile<DTYPE, LT_MODE_ARGMAX>(logits, g, tile_k, B * C, C, idx_u8, idx_i64, score,
+                                                  nullptr, stream);
+    }
     const int tiles_x = (g.Wo + RZ_TW - 1) / RZ_TW;
     const int tiles_y = (g.Ho + RZ_TH - 1) / RZ_TH;
     const long long n_tiles = (long long)tiles_x * tiles_y * B;
     const long long blocks = ((n_tiles + 7) / 8) * 8;       // see xcd_contiguous_tile
     if (blocks > 0x7fffffffLL) return NMSA_ERR_ARG;
-    if (score) hipLaunchKernelGGL((k_argmax_resized<DTYPE, true>), dim3((unsigned)blocks),
-                                  dim3(RZ_TW * RZ_TH), 0, stream, logits, g, C, tiles_x, tiles_y,
-                                  n_tiles, idx_u8, idx_i64, score);
-    else hipLaunchKernelGGL((k_argmax_resized<DTYPE, false>), dim3((unsigned)blocks),
-                            dim3(RZ_TW * RZ_TH), 0, stream, logits, g, C, tiles_x, tiles_y,
-                            n_tiles, idx_u8, idx_i64, score);
+    const bool pair = g.w >= 2 && g.sx > 1.0f;    // paired loads pay off only when downscaling
+#define NMSA_LAUNCH_RZ(S, PR)                                                               \
+    hipLaunchKernelGGL((k_argmax_resized<DTYPE, S, PR>), dim3((unsigned)blocks),            \
+                       dim3(RZ_TW * RZ_TH), 0, stream, logits, g, C, tiles_x, tiles_y,      \
+                       n_tiles, idx_u8, idx_i64, score)
+    if (score) { if (pair) NMSA_LAUNCH_RZ(true, true); else NMSA_LAUNCH_RZ(true, false); }
+    else { if (pair) NMSA_LAUNCH_RZ(false, true); else NMSA_LAUNCH_RZ(false, false); }
+#undef NMSA_LAUNCH_RZ
     return check_launch();
 }
 
