@@ -225,6 +225,33 @@ int nmsa_semantic_argmax_resized(const void* logits, int logits_dtype, int B, in
                                  nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * f3  PanopticPostprocessing `compute_scores` branch   model/postprocessing/panoptic.py:171-239
+ * Dense semantic / instance / panoptic score maps and the per-instance mean semantic score,
+ * without the [B,C,H,W] softmax tensor and without the per-instance Python loop.
+ *   logits      f32|bf16|f16 [B,C,H,W]
+ *   sem_idx     u8  [B,H,W]  argmax class (nmsa_panoptic_fused / nmsa_semantic_argmax)
+ *   sem_prob    f32 [B,H,W]  its softmax probability (the `score` output of the same calls)
+ *   inst        u8  [B,H,W]; pan i64 [B,H,W] = class_value * max_instances_per_category + k
+ *   pan_of_inst i64 [B,256]  panoptic id of every instance id (nmsa_panoptic_assign)
+ *   inst_score_tab f32 [B,256]  instance score by instance id (meta 'score'; entry 0 unused)
+ * outputs (f32 [B,H,W]):
+ *   semantic score = softmax probability of the pixel's PANOPTIC class (0 on void),
+ *   instance score = the instance's score on its painted pixels, else 0,
+ *   panoptic score = mean semantic score of the instance x instance score on painted pixels,
+ *                    else the semantic score;
+ *   mean_semantic_score f32 [B,256] (meta 'semantic_score'; NaN for unused ids), may be NULL
+ * ------------------------------------------------------------------------- */
+size_t nmsa_panoptic_scores_workspace_bytes(int B);
+int nmsa_panoptic_scores(const void* logits, int logits_dtype,
+                         const uint8_t* sem_idx, const float* sem_prob,
+                         const uint8_t* inst, const int64_t* pan,
+                         const int64_t* pan_of_inst, const float* inst_score_tab,
+                         int B, int C, int H, int W, int64_t max_instances_per_category,
+                         float* out_semantic_score, float* out_instance_score,
+                         float* out_panoptic_score, float* mean_semantic_score,
+                         void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * next-1  InstancePostprocessing._get_instance_orientation
  *     model/postprocessing/instance.py:271-319
  *   orientation f32 [B,2,H,W]; inst u8; mask u8 or NULL

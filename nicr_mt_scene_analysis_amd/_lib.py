@@ -71,6 +71,9 @@ _SIGNATURES = {
     'nmsa_resize_bilinear': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp]),
     'nmsa_semantic_argmax_resized': (_i, [_vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i,
                                           _vp, _vp, _vp, _vp]),
+    'nmsa_panoptic_scores_workspace_bytes': (_sz, [_i]),
+    'nmsa_panoptic_scores': (_i, [_vp, _i, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i64,
+                                  _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_instance_orientation': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'nmsa_confmat_workspace_bytes': (_sz, [_i]),
     'nmsa_confmat_update': (_i, [_vp, _i, _i64, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -163,48 +163,30 @@ class PanopticPostprocessing(DensePostprocessingBase):
                     m[id_]['orientation'] = ori[b].get(id_, float('nan'))
         return r
 
-    # next-3: per-instance score maps of panoptic.py:171-239, vectorised
-    # on the device with torch segment reductions (no per-instance Python loops over
-    # full images); not part of the HIP-kernel rows yet.
+    # f3: score maps of panoptic.py:171-239 — two HIP kernels
+    # (`nmsa_panoptic_scores`), no softmax tensor, no per-instance loops over images.
     def _add_scores(self, r, p, panoptic_ids: List[dict], meta: List[dict]) -> None:
-        probs = r['semantic_softmax_scores']
-        pan_semantic = p['panoptic_semantic']
-        panoptic_seg = p['panoptic']
-        inst = p['instance'].long()
-        B = inst.shape[0]
-        void = pan_semantic == 0
-        idx = (pan_semantic - 1).clamp_(min=0).unsqueeze(1)
-        sem_score = torch.take_along_dim(probs, idx, dim=1).squeeze(1)
-        sem_score = sem_score.masked_fill(void, 0.0)
-        r['panoptic_segmentation_deeplab_semantic_score'] = sem_score
-
-        # pixels painted with an instance's panoptic id: inst > 0 and pan == pan_of_inst
-        pan_of_inst = p['pan_of_inst']                                    # [B,256]
-        painted = (inst > 0) & (panoptic_seg == torch.gather(pan_of_inst, 1, inst.flatten(1)).view_as(inst))
-        flat_key = (torch.arange(B, device=inst.device).view(B, 1, 1) * 256 + inst)[painted]
-        sums = torch.zeros((B * 256,), dtype=torch.float32, device=inst.device)
-        cnts = torch.zeros((B * 256,), dtype=torch.float32, device=inst.device)
-        sums.index_add_(0, flat_key, sem_score[painted])
-        cnts.index_add_(0, flat_key, torch.ones_like(sem_score[painted]))
-        mean_sem = (sums / cnts.clamp(min=1)).view(B, 256)
-        score_tab = torch.zeros((B, 256), dtype=torch.float32, device=inst.device)
+        B = p['instance'].shape[0]
+        dev = p['instance'].device
+        score_tab = torch.zeros((B, 256), dtype=torch.float32, device=dev)
         k = min(p['center_scores'].shape[1], 255)
         score_tab[:, 1:k + 1] = p['center_scores'][:, :k]
-        inst_score = torch.where(painted, torch.gather(score_tab, 1, inst.flatten(1)).view_as(inst),
-                                 torch.zeros((), device=inst.device))
-        pan_score = torch.where(
-            painted,
-            (torch.gather(mean_sem, 1, inst.flatten(1)) * torch.gather(score_tab, 1, inst.flatten(1))).view_as(inst),
-            sem_score)
-        r['panoptic_segmentation_deeplab_instance_score'] = inst_score
-        r['panoptic_segmentation_deeplab_panoptic_score'] = pan_score
+        sc = ops.panoptic_scores(
+            r['semantic_output'], p['semantic_idx_u8'], p['semantic_score'], p['instance'],
+            p['panoptic'], p['pan_of_inst'], score_tab, self._max_instances_per_category)
+        r['panoptic_segmentation_deeplab_semantic_score'] = sc['semantic_score']
+        r['panoptic_segmentation_deeplab_instance_score'] = sc['instance_score']
+        r['panoptic_segmentation_deeplab_panoptic_score'] = sc['panoptic_score']
 
-        mean_host = mean_sem.cpu().tolist()
-        sem_of_inst = (pan_of_inst // self._max_instances_per_category).cpu().tolist()
+        # ONE small D2H copy for the meta dicts (panoptic.py:214-232)
+        host = torch.cat([sc['mean_semantic_score'].double(),
+                          (p['pan_of_inst'] // self._max_instances_per_category).double()],
+                         dim=1).cpu().tolist()
         for b in range(B):
             for pan_id, ins_id in panoptic_ids[b].items():
                 m = meta[b][ins_id]
-                m['semantic_score'] = mean_host[b][ins_id]
-                m['semantic_idx'] = sem_of_inst[b][ins_id]
-                m['panoptic_score'] = mean_host[b][ins_id] * m['score']
+                mean = float(np.float32(host[b][ins_id]))
+                m['semantic_score'] = mean
+                m['semantic_idx'] = int(host[b][256 + ins_id])
+                m['panoptic_score'] = float(np.float32(mean) * np.float32(m['score']))
                 m['panoptic_id'] = pan_id

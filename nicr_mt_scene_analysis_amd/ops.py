@@ -310,6 +310,43 @@ def panoptic_pipeline(
     }
 
 
+# ----------------------------------------------------------------------------- f3
+def panoptic_scores(
+    logits: torch.Tensor,
+    semantic_idx_u8: torch.Tensor,
+    semantic_prob: torch.Tensor,
+    instance: torch.Tensor,
+    panoptic: torch.Tensor,
+    pan_of_inst: torch.Tensor,
+    instance_score_table: torch.Tensor,
+    max_instances_per_category: int,
+) -> Dict[str, torch.Tensor]:
+    """reference: the `compute_scores` branch of PanopticPostprocessing (panoptic.py:171-239)"""
+    x = L.require_device_tensor(logits, 'logits')
+    B, Cn, H, W = x.shape
+    dev = x.device
+    sem = L.require_device_tensor(semantic_idx_u8, 'semantic_idx_u8')
+    prob = L.require_device_tensor(semantic_prob, 'semantic_prob')
+    ins = L.require_device_tensor(instance, 'instance')
+    pan = L.require_device_tensor(panoptic, 'panoptic')
+    poi = L.require_device_tensor(pan_of_inst, 'pan_of_inst')
+    tab = L.require_device_tensor(instance_score_table, 'instance_score_table')
+    assert sem.dtype == torch.uint8 and ins.dtype == torch.uint8 and pan.dtype == torch.int64
+    assert prob.dtype == torch.float32 and tab.dtype == torch.float32 and poi.dtype == torch.int64
+    assert tuple(tab.shape) == (B, 256) and tuple(poi.shape) == (B, 256)
+    out = [torch.empty((B, H, W), dtype=torch.float32, device=dev) for _ in range(3)]
+    mean = torch.empty((B, 256), dtype=torch.float32, device=dev)
+    ws_bytes = L.lib().nmsa_panoptic_scores_workspace_bytes(B)
+    ws = torch.empty((ws_bytes // 8,), dtype=torch.float64, device=dev)
+    L.check(L.lib().nmsa_panoptic_scores(
+        L.ptr(x), L.float_dtype_code(x), L.ptr(sem), L.ptr(prob), L.ptr(ins), L.ptr(pan),
+        L.ptr(poi), L.ptr(tab), B, Cn, H, W, int(max_instances_per_category),
+        L.ptr(out[0]), L.ptr(out[1]), L.ptr(out[2]), L.ptr(mean), L.ptr(ws), ws_bytes,
+        L.stream_ptr(dev)), 'nmsa_panoptic_scores')
+    return {'semantic_score': out[0], 'instance_score': out[1], 'panoptic_score': out[2],
+            'mean_semantic_score': mean}
+
+
 # ----------------------------------------------------------------------------- a5
 def panoptic_merge(
     semantic: torch.Tensor,

@@ -636,6 +636,59 @@ def gen_fullres(ref):
     save('fullres_panoptic', **e2e)
 
 
+def gen_scores(ref):
+    """f3: the compute_scores branch of the reference's PanopticPostprocessing."""
+    print('compute_scores (reference panoptic.py:171-239)')
+    from oracle import oracle as orc
+    inp = syn.make_panoptic_inputs(2, n_classes=8, height=96, width=128, n_centers=7, seed=5)
+    is_thing = tuple(bool(x) for x in inp['semantic_classes_is_thing'])
+    pan = ref.post_panoptic.PanopticPostprocessing(
+        semantic_postprocessing=ref.post_semantic.SemanticPostprocessing(),
+        instance_postprocessing=ref.post_instance.InstancePostprocessing(),
+        semantic_classes_is_thing=is_thing, semantic_class_has_orientation=is_thing,
+        compute_scores=True)
+    logits = torch.from_numpy(inp['semantic_logits'])
+    data = ((logits, (torch.from_numpy(inp['instance_center']),
+                      torch.from_numpy(inp['instance_offset']))), (None, None))
+    r = pan.postprocess(data, make_batch(ref, 2, 96, 128), is_training=False)
+    meta = r['panoptic_segmentation_deeplab_instance_meta']
+    cap = 256
+    m_sem = np.full((2, cap), np.nan, np.float32)
+    m_pan = np.full((2, cap), np.nan, np.float32)
+    m_idx = np.full((2, cap), -1, np.int64)
+    m_pid = np.full((2, cap), -1, np.int64)
+    tab = np.zeros((2, 256), np.float32)
+    for b, md in enumerate(meta):
+        for i, m in md.items():
+            tab[b, i] = m['score']
+            if 'panoptic_id' in m:
+                m_sem[b, i] = m['semantic_score']
+                m_pan[b, i] = m['panoptic_score']
+                m_idx[b, i] = m['semantic_idx']
+                m_pid[b, i] = m['panoptic_id']
+    idn, idk, idv = ids_to_arrays(r['panoptic_segmentation_deeplab_ids'])
+    out = dict(
+        in_semantic_logits=inp['semantic_logits'], in_instance_center=inp['instance_center'],
+        in_instance_offset=inp['instance_offset'],
+        in_semantic_classes_is_thing=inp['semantic_classes_is_thing'],
+        panoptic=r['panoptic_segmentation_deeplab'].numpy(),
+        panoptic_semantic=r['panoptic_segmentation_deeplab_semantic_idx'].numpy(),
+        ids_n=idn, ids_pan=idk, ids_ins=idv, inst_score_by_id=tab,
+        semantic_score=r['panoptic_segmentation_deeplab_semantic_score'].numpy(),
+        instance_score=r['panoptic_segmentation_deeplab_instance_score'].numpy(),
+        panoptic_score=r['panoptic_segmentation_deeplab_panoptic_score'].numpy(),
+        meta_semantic_score=m_sem, meta_panoptic_score=m_pan, meta_semantic_idx=m_idx,
+        meta_panoptic_id=m_pid)
+    # generation-time check of the restatement
+    ids = [dict(zip(idk[b, :idn[b]].tolist(), idv[b, :idn[b]].tolist())) for b in range(2)]
+    sem, ins, pns, mean = orc.panoptic_scores(inp['semantic_logits'], out['panoptic_semantic'],
+                                              out['panoptic'], ids, tab)
+    np.testing.assert_allclose(sem, out['semantic_score'], rtol=1e-5, atol=1e-7)
+    assert np.array_equal(ins, out['instance_score'])
+    np.testing.assert_allclose(pns, out['panoptic_score'], rtol=1e-5, atol=1e-7)
+    save('scores_cases', **out)
+
+
 def main():
     ref = load_reference()
     only = set(sys.argv[1:])
@@ -660,6 +713,8 @@ def main():
         gen_orientation(ref)
     if want('fullres'):
         gen_fullres(ref)
+    if want('scores'):
+        gen_scores(ref)
 
 
 if __name__ == '__main__':

@@ -854,3 +854,63 @@ int orc_resize_bilinear(const float* src, int planes, int Hs, int Ws,
         }
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* f3  PanopticPostprocessing compute_scores   model/postprocessing/panoptic.py:171-239 */
+/* semantic score = softmax(logits)[panoptic class - 1] (0 on void, :176-195);            */
+/* per (pan_id -> ins_id) of the id dict, in dict order: mask = (pan == pan_id);          */
+/* instance score -> mask (:208-209); mean semantic score over mask (:213-215);           */
+/* panoptic score = mean * instance score (f32 product) -> mask (:225-227).               */
+/* ------------------------------------------------------------------------- */
+int orc_panoptic_scores(const float* logits, const int64_t* pan_sem, const int64_t* pan,
+                        const int64_t* ids_pan, const int64_t* ids_ins, const int32_t* n_ids,
+                        int cap, const float* inst_score_by_id /* [B,256] */,
+                        int B, int C, int H, int W,
+                        float* sem_score, float* inst_score, float* pan_score,
+                        float* mean_by_id /* [B,256], NaN where unused */)
+{
+    const int64_t P = (int64_t)H * W;
+    for (int b = 0; b < B; ++b) {
+        const float* x = logits + (size_t)b * C * P;
+        for (int64_t p = 0; p < P; ++p) {
+            const size_t o = (size_t)b * P + p;
+            const int64_t k = pan_sem[o];
+            float s = 0.f;
+            if (k > 0 && k <= C) {
+                float m = -INFINITY;
+                for (int c = 0; c < C; ++c) if (x[(size_t)c * P + p] > m) m = x[(size_t)c * P + p];
+                double se = 0.0;
+                int bad = 0;
+                for (int c = 0; c < C; ++c) {
+                    const float v = x[(size_t)c * P + p];
+                    if (v != v) bad = 1;
+                    se += exp((double)v - (double)m);
+                }
+                if (bad || !(m > -INFINITY) || m == INFINITY) s = NAN;
+                else s = (float)(exp((double)x[(size_t)(k - 1) * P + p] - (double)m) / se);
+            }
+            sem_score[o] = s;
+            inst_score[o] = 0.f;
+            pan_score[o] = s;
+        }
+        for (int i = 0; i < 256; ++i) mean_by_id[(size_t)b * 256 + i] = NAN;
+        for (int j = 0; j < n_ids[b]; ++j) {
+            const int64_t pid = ids_pan[(size_t)b * cap + j], iid = ids_ins[(size_t)b * cap + j];
+            if (iid < 0 || iid > 255) return ORC_ERR_RANGE;
+            const float is = inst_score_by_id[(size_t)b * 256 + iid];
+            double sum = 0.0;
+            int64_t n = 0;
+            for (int64_t p = 0; p < P; ++p)
+                if (pan[(size_t)b * P + p] == pid) { sum += sem_score[(size_t)b * P + p]; ++n; }
+            const float mean = n ? (float)(sum / (double)n) : NAN;
+            const float prod = mean * is;
+            mean_by_id[(size_t)b * 256 + iid] = mean;
+            for (int64_t p = 0; p < P; ++p)
+                if (pan[(size_t)b * P + p] == pid) {
+                    inst_score[(size_t)b * P + p] = is;
+                    pan_score[(size_t)b * P + p] = prod;
+                }
+        }
+    }
+    return ORC_OK;
+}

@@ -311,3 +311,32 @@ def resize_bilinear(maps, size, crop=None):
     _chk(lib().orc_resize_bilinear(_p(a, C.c_float), planes, Hs, Ws, y0, x0, h, w, Ho, Wo,
                                    _p(out, C.c_float)), 'resize_bilinear')
     return out
+
+
+# -- f3: compute_scores (panoptic.py:171-239) -------------------------------------
+def panoptic_scores(logits, pan_sem, pan, ids, inst_score_by_id):
+    """ids: list (per image) of dict pan_id -> ins_id in insertion order."""
+    logits = _c(logits, np.float32)
+    B, Cn, H, W = logits.shape
+    pan_sem = _c(pan_sem, np.int64)
+    pan = _c(pan, np.int64)
+    cap = max(1, max(len(d) for d in ids))
+    ids_pan = np.zeros((B, cap), np.int64)
+    ids_ins = np.zeros((B, cap), np.int64)
+    n_ids = np.zeros((B,), np.int32)
+    for b, d in enumerate(ids):
+        n_ids[b] = len(d)
+        for j, (k, v) in enumerate(d.items()):
+            ids_pan[b, j], ids_ins[b, j] = k, v
+    tab = _c(inst_score_by_id, np.float32)
+    assert tab.shape == (B, 256)
+    sem = np.empty((B, H, W), np.float32)
+    ins = np.empty((B, H, W), np.float32)
+    pns = np.empty((B, H, W), np.float32)
+    mean = np.empty((B, 256), np.float32)
+    _chk(lib().orc_panoptic_scores(
+        _p(logits, C.c_float), _p(pan_sem, C.c_int64), _p(pan, C.c_int64),
+        _p(ids_pan, C.c_int64), _p(ids_ins, C.c_int64), _p(n_ids, C.c_int32), cap,
+        _p(tab, C.c_float), B, Cn, H, W, _p(sem, C.c_float), _p(ins, C.c_float),
+        _p(pns, C.c_float), _p(mean, C.c_float)), 'panoptic_scores')
+    return sem, ins, pns, mean

@@ -258,3 +258,63 @@ def test_many_centers_regrow_table():
     for i in want[0]:
         assert meta[0][i]['center_yx'] == want[0][i]['center_yx']
         assert meta[0][i]['area'] == want[0][i]['area']
+
+
+def test_compute_scores_vs_golden():
+    """f3: score maps + meta of the reference's compute_scores branch (panoptic.py:171-239),
+    produced by `nmsa_panoptic_scores`, against the reference's own output."""
+    g = load('scores_cases')
+    post = build_panoptic(g['in_semantic_classes_is_thing'], None, compute_scores=True)
+    logits, center, offset = (dev(g['in_semantic_logits']), dev(g['in_instance_center']),
+                              dev(g['in_instance_offset']))
+    B, _, H, W = logits.shape
+    r = post.postprocess(((logits, (center, offset)), (None, None)), make_batch(B, H, W),
+                         is_training=False)
+    assert (r['panoptic_segmentation_deeplab'].cpu().numpy() == g['panoptic']).all()
+    for key, name in (('semantic_score', 'panoptic_segmentation_deeplab_semantic_score'),
+                      ('instance_score', 'panoptic_segmentation_deeplab_instance_score'),
+                      ('panoptic_score', 'panoptic_segmentation_deeplab_panoptic_score')):
+        got = r[name]
+        assert got.dtype == torch.float32 and got.is_cuda
+        np.testing.assert_allclose(got.cpu().numpy(), g[key], rtol=1e-5, atol=1e-7, err_msg=key)
+        np.testing.assert_allclose(r[name + '_fullres'].cpu().numpy(), g[key], rtol=1e-5, atol=1e-7)
+    assert (r['panoptic_segmentation_deeplab_instance_score'].cpu().numpy() == g['instance_score']).all()
+    meta = r['panoptic_segmentation_deeplab_instance_meta']
+    for b in range(B):
+        used = np.where(g['meta_panoptic_id'][b] >= 0)[0]
+        assert sorted(i for i, m in meta[b].items() if 'panoptic_id' in m) == list(used)
+        for i in used:
+            m = meta[b][int(i)]
+            assert m['panoptic_id'] == g['meta_panoptic_id'][b, i]
+            assert m['semantic_idx'] == g['meta_semantic_idx'][b, i]
+            assert abs(m['semantic_score'] - g['meta_semantic_score'][b, i]) <= 1e-5 * abs(g['meta_semantic_score'][b, i])
+            assert abs(m['panoptic_score'] - g['meta_panoptic_score'][b, i]) <= 1e-5 * abs(g['meta_panoptic_score'][b, i])
+
+
+def test_panoptic_scores_vs_oracle(oracle):
+    """nmsa_panoptic_scores through ops on a larger random case incl. bf16 logits"""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+    inp = syn.make_panoptic_inputs(3, n_classes=19, height=120, width=160, n_centers=12, seed=11)
+    for dt in (torch.float32, torch.bfloat16):
+        x = torch.from_numpy(inp['semantic_logits']).to(dt)
+        p = ops.panoptic_pipeline(x.cuda(), dev(inp['instance_center']), dev(inp['instance_offset']),
+                                  dev(inp['semantic_classes_is_thing']), want_score=True,
+                                  want_panoptic_semantic=True)
+        tab = torch.zeros((3, 256), dtype=torch.float32, device='cuda')
+        tab[:, 1:] = p['center_scores'][:, :255]
+        sc = ops.panoptic_scores(x.cuda(), p['semantic_idx_u8'], p['semantic_score'], p['instance'],
+                                 p['panoptic'], p['pan_of_inst'], tab, 1 << 16)
+        torch.cuda.synchronize()
+        ids = ids_from_arrays(p['n_ids'].cpu().numpy(), p['ids_pan'].cpu().numpy(),
+                              p['ids_ins'].cpu().numpy())
+        sem, ins, pns, mean = oracle.panoptic_scores(
+            x.float().numpy(), p['panoptic_semantic'].cpu().numpy(), p['panoptic'].cpu().numpy(),
+            ids, tab.cpu().numpy())
+        np.testing.assert_allclose(sc['semantic_score'].cpu().numpy(), sem, rtol=1e-5, atol=1e-7)
+        assert np.array_equal(sc['instance_score'].cpu().numpy(), ins)
+        np.testing.assert_allclose(sc['panoptic_score'].cpu().numpy(), pns, rtol=1e-5, atol=1e-7)
+        got_mean = sc['mean_semantic_score'].cpu().numpy()
+        for b, d in enumerate(ids):
+            for ins_id in d.values():
+                assert abs(got_mean[b, ins_id] - mean[b, ins_id]) <= 1e-5 * abs(mean[b, ins_id])

@@ -279,3 +279,21 @@ def test_fullres_panoptic(oracle):
     pan_sem = np.where(r['pan'] > 0, r['pan'] // (1 << 16), 0)
     assert np.array_equal(oracle.resize_nearest(pan_sem.astype(np.int64), size, crop),
                           g['panoptic_segmentation_deeplab_semantic_idx_fullres'])
+
+
+# ---------------------------------------------------------------------------
+# f3: compute_scores (panoptic.py:171-239)
+def test_scores_cases(oracle):
+    g = load('scores_cases')
+    ids = ids_from_arrays(g['ids_n'], g['ids_pan'], g['ids_ins'])
+    sem, ins, pns, mean = oracle.panoptic_scores(g['in_semantic_logits'], g['panoptic_semantic'],
+                                                 g['panoptic'], ids, g['inst_score_by_id'])
+    np.testing.assert_allclose(sem, g['semantic_score'], rtol=1e-5, atol=1e-7)
+    assert np.array_equal(ins, g['instance_score'])
+    np.testing.assert_allclose(pns, g['panoptic_score'], rtol=1e-5, atol=1e-7)
+    used = g['meta_panoptic_id'] >= 0
+    np.testing.assert_allclose(mean[used], g['meta_semantic_score'][used], rtol=1e-5)
+    # the pipeline feeding it is the pinned one
+    r = _run_pipeline_oracle(oracle, g['in_semantic_logits'], g['in_instance_center'],
+                             g['in_instance_offset'], g['in_semantic_classes_is_thing'])
+    assert np.array_equal(r['pan'], g['panoptic']) and r['ids'] == ids
