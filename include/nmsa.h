@@ -264,6 +264,60 @@ int nmsa_instance_orientation(const float* orientation, const uint8_t* inst,
                               double* sums, int32_t* count, nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * f4  ground-truth target generation on the device (per batch instead of per sample in the
+ *     dataloader workers).  Label maps in their on-wire dtypes (data/preprocessing/torch.py:60-66:
+ *     semantic uint8, instance uint16 -> int32); instance ids in [0, 65535], at most
+ *     `max_instances` (<= 4096) distinct ids per image.
+ *  status bits (OR-ed into *status): 1 too many distinct ids, 32 id out of range,
+ *     64 semantic label outside [0, n_classes), 128 id table (max_segments) overflow.
+ *  workspace: nmsa_targets_workspace_bytes(B, n_classes, max_instances), 8-byte aligned.
+ *
+ *  nmsa_instance_clear_stuff   InstanceClearStuffIDs._preprocess   data/preprocessing/instance.py:46-93
+ *     instance[is_stuff_class[semantic]] = 0, in place (is_stuff_class includes void)
+ *  nmsa_instance_targets       InstanceTargetGenerator._preprocess data/preprocessing/instance.py:157-286
+ *     is_thing_class u8 [n_classes] or NULL (every instance encoded); is_stuff_class u8 [n_classes]
+ *     or NULL (center mask = foreground); gauss_lut f32 [2*(3*sigma+1)^2 + 1]: heat-map value by
+ *     integer squared distance to the center, float32(exp(-d2 / (2 sigma^2)));
+ *     center f32 [B,H,W]; offset [B,2,H,W] (dy,dx): f32 divided by (H,W) when normalized_offset,
+ *     else i16; foreground / center_mask u8 [B,H,W] (center_mask may be NULL);
+ *     encoded_ids / skipped_ids i32 [B, cap] ascending (cap = max_instances rounded up to 1024),
+ *     n_encoded / n_skipped i32 [B]   (the reference's dynamic parameters; any may be NULL)
+ *  nmsa_panoptic_targets       PanopticTargetGenerator._preprocess data/preprocessing/panoptic.py:48-85
+ *                              = naive_merge_semantic_and_instance_np utils/panoptic_merge.py:43-107
+ *     panoptic i64 [B,H,W]; ids_pan / ids_ins i64 [B,max_segments] in the reference's dict order
+ *     (instance ascending, then class ascending), n_ids i32 [B]
+ *  nmsa_dve_targets            DenseVisualEmbeddingTargetGenerator  data/preprocessing/
+ *                              dense_visual_embedding.py:22-93
+ *     keys i64 [B,K] (first n_keys[b] valid), embeddings f32 [B,K,D], image_embedding f32 [B,D];
+ *     lut f32 [B,K,D] = normalise(embedding - diff_factor * image_embedding) (NULL: indices only);
+ *     indices i32 [B,H,W] = 1 + position of the pixel's panoptic id in keys (0 = none)
+ * ------------------------------------------------------------------------- */
+size_t nmsa_targets_workspace_bytes(int B, int n_classes, int max_instances);
+int nmsa_instance_clear_stuff(const void* semantic, int sem_dtype, void* instance, int ins_dtype,
+                              const uint8_t* is_stuff_class, int n_classes, int64_t n_px,
+                              nmsa_stream_t stream);
+int nmsa_instance_targets(const void* semantic, int sem_dtype, const void* instance, int ins_dtype,
+                          const uint8_t* is_thing_class, const uint8_t* is_stuff_class,
+                          int B, int n_classes, int H, int W,
+                          int sigma, const float* gauss_lut, int normalized_offset, int max_instances,
+                          float* center, void* offset, uint8_t* foreground, uint8_t* center_mask,
+                          int32_t* encoded_ids, int32_t* n_encoded,
+                          int32_t* skipped_ids, int32_t* n_skipped,
+                          int32_t* status, void* workspace, size_t workspace_bytes,
+                          nmsa_stream_t stream);
+int nmsa_panoptic_targets(const void* semantic, int sem_dtype, const void* instance, int ins_dtype,
+                          const uint8_t* is_thing_class, int B, int n_classes, int H, int W,
+                          int64_t max_instances_per_category, int64_t void_label,
+                          int max_instances, int max_segments,
+                          int64_t* panoptic, int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
+                          int32_t* status, void* workspace, size_t workspace_bytes,
+                          nmsa_stream_t stream);
+int nmsa_dve_targets(const int64_t* panoptic, const int64_t* keys, const int32_t* n_keys,
+                     const float* embeddings, const float* image_embedding, float diff_factor,
+                     int B, int K, int D, int H, int W,
+                     float* lut, int32_t* indices, nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * a11  MeanIntersectionOverUnion.update   metric/miou.py:44-56
  *   confmat[t, p] += 1 for every element (bincount(t*n + p, minlength=n*n)).
  *   preds / target: any integer dtype, n_px elements each.

@@ -9,23 +9,9 @@
 // ascending id order is preserved, which the running per-class counter of the merge
 // depends on), then the same vote / assign / paint scheme runs on the dense ranks.
 #include "nmsa_common.hpp"
+#include "id_rank.hpp"
 
 namespace nmsa {
-
-constexpr int MW_MAX_ID = 65535;
-constexpr int MW_WORDS = (MW_MAX_ID + 1) / 32;      // 2048 bitmap words per image
-constexpr int MW_ST_ID_RANGE = 32;                  // status bit: instance id outside [0, 65535]
-constexpr int MW_ST_OVERFLOW = 1;                   // more distinct ids than max_segments
-
-__device__ __forceinline__ int64_t mw_load(const void* p, int dtype, size_t i)
-{
-    switch (dtype) {
-        case NMSA_U8: return ((const uint8_t*)p)[i];
-        case NMSA_I16: return ((const int16_t*)p)[i];
-        case NMSA_I32: return ((const int32_t*)p)[i];
-        default: return ((const int64_t*)p)[i];
-    }
-}
 
 struct MwView {
     uint32_t* bitmap;      // [MW_WORDS]
@@ -79,33 +65,6 @@ __global__ __launch_bounds__(256) void k_mw_presence(
         wave_aggregate_add(key, [&](int id, uint32_t) { atomicOr(&v.bitmap[id >> 5], 1u << (id & 31)); });
     }
     if (bad) atomicOr(status, MW_ST_ID_RANGE);
-}
-
-__device__ __forceinline__ int mw_wave_scan(int x)
-{
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const int t = __shfl_up(x, o);
-        if (lane_id() >= o) x += t;
-    }
-    return x;
-}
-
-__device__ __forceinline__ int mw_block_scan(int v, int* scratch, int* total)
-{
-    const int w = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    const int incl = mw_wave_scan(v);
-    __syncthreads();
-    if (lane_id() == 63) scratch[w] = incl;
-    __syncthreads();
-    if (w == 0) {
-        int s = (lane_id() < nw) ? scratch[lane_id()] : 0;
-        s = mw_wave_scan(s);
-        if (lane_id() < nw) scratch[lane_id()] = s;
-    }
-    __syncthreads();
-    *total = scratch[nw - 1];
-    return incl + ((w == 0) ? 0 : scratch[w - 1]);
 }
 
 // one 1024-thread workgroup per image: rank = number of smaller present ids

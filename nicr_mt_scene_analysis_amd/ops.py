@@ -347,6 +347,151 @@ def panoptic_scores(
             'mean_semantic_score': mean}
 
 
+# ----------------------------------------------------------------------------- f4
+_GAUSS_LUTS: Dict[tuple, torch.Tensor] = {}
+
+
+def _gauss_lut(sigma: int, dev: torch.device) -> torch.Tensor:
+    """heat-map value by integer squared distance: the entries of the reference's precomputed
+    (6s+3)^2 patch (data/preprocessing/instance.py:147-154), same numpy float64 exp, rounded to
+    float32 exactly like `np.maximum(center_img, gauss)` stored into the float32 image does."""
+    key = (int(sigma), dev)
+    if key not in _GAUSS_LUTS:
+        import numpy as np
+        r = 3 * int(sigma) + 1
+        d2 = np.arange(2 * r * r + 1, dtype=np.float64)
+        lut = np.exp(-d2 / (2 * int(sigma) ** 2)).astype(np.float32)
+        _GAUSS_LUTS[key] = torch.from_numpy(lut).to(dev)
+    return _GAUSS_LUTS[key]
+
+
+def _targets_workspace(B: int, n_classes: int, max_instances: int, dev) -> Tuple[torch.Tensor, int]:
+    nbytes = L.lib().nmsa_targets_workspace_bytes(B, n_classes, max_instances)
+    if nbytes == 0:
+        raise ValueError('max_instances must be in [1, 4096]')
+    return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev), nbytes
+
+
+def instance_clear_stuff(semantic: torch.Tensor, instance: torch.Tensor,
+                         is_stuff_class: torch.Tensor) -> torch.Tensor:
+    """reference: InstanceClearStuffIDs (data/preprocessing/instance.py:46-93); in place."""
+    sem = L.require_device_tensor(semantic, 'semantic')
+    if not instance.is_cuda or not instance.is_contiguous():
+        raise L.NmsaError('instance must be a contiguous device tensor (modified in place)')
+    lut = _u8(is_stuff_class)
+    L.check(L.lib().nmsa_instance_clear_stuff(
+        L.ptr(sem), L.int_dtype_code(sem), L.ptr(instance), L.int_dtype_code(instance),
+        L.ptr(lut), int(lut.numel()), int(sem.numel()), L.stream_ptr(sem.device)),
+        'nmsa_instance_clear_stuff')
+    return instance
+
+
+def instance_targets(
+    semantic: torch.Tensor,
+    instance: torch.Tensor,
+    n_classes: int,
+    is_thing_class: Optional[torch.Tensor],
+    is_stuff_class: Optional[torch.Tensor],
+    sigma: int,
+    normalized_offset: bool = True,
+    max_instances: int = 1024,
+) -> Dict[str, torch.Tensor]:
+    """reference: InstanceTargetGenerator._preprocess (data/preprocessing/instance.py:157-286)
+    for a whole batch [B,H,W]."""
+    sem = L.require_device_tensor(semantic, 'semantic')
+    ins = L.require_device_tensor(instance, 'instance')
+    B, H, W = sem.shape
+    dev = sem.device
+    th = None if is_thing_class is None else _u8(is_thing_class)
+    st = None if is_stuff_class is None else _u8(is_stuff_class)
+    cap = ((int(max_instances) + 1023) // 1024) * 1024
+    center = torch.empty((B, H, W), dtype=torch.float32, device=dev)
+    offset = torch.empty((B, 2, H, W), dtype=torch.float32 if normalized_offset else torch.int16,
+                         device=dev)
+    fg = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    cm = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
+    enc = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    skp = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    n_enc = torch.empty((B,), dtype=torch.int32, device=dev)
+    n_skp = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws, ws_bytes = _targets_workspace(B, int(n_classes), int(max_instances), dev)
+    L.check(L.lib().nmsa_instance_targets(
+        L.ptr(sem), L.int_dtype_code(sem), L.ptr(ins), L.int_dtype_code(ins), L.ptr(th), L.ptr(st),
+        B, int(n_classes), H, W, int(sigma), L.ptr(_gauss_lut(sigma, dev)),
+        int(bool(normalized_offset)), int(max_instances),
+        L.ptr(center), L.ptr(offset), L.ptr(fg), L.ptr(cm), L.ptr(enc), L.ptr(n_enc),
+        L.ptr(skp), L.ptr(n_skp), L.ptr(status), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+        'nmsa_instance_targets')
+    return {'center': center, 'offset': offset, 'foreground': fg.view(torch.bool),
+            'center_mask': cm.view(torch.bool), 'encoded_ids': enc, 'n_encoded': n_enc,
+            'skipped_ids': skp, 'n_skipped': n_skp, 'status': status}
+
+
+def panoptic_targets(
+    semantic: torch.Tensor,
+    instance: torch.Tensor,
+    n_classes: int,
+    is_thing_class: Optional[torch.Tensor],
+    max_instances_per_category: int,
+    void_label: int = 0,
+    max_instances: int = 1024,
+    max_segments: int = 2048,
+) -> Dict[str, torch.Tensor]:
+    """reference: naive_merge_semantic_and_instance_np (utils/panoptic_merge.py:43-107) as
+    called by PanopticTargetGenerator (data/preprocessing/panoptic.py:48-85), per batch."""
+    sem = L.require_device_tensor(semantic, 'semantic')
+    ins = L.require_device_tensor(instance, 'instance')
+    B, H, W = sem.shape
+    dev = sem.device
+    th = None if is_thing_class is None else _u8(is_thing_class)
+    pan = torch.empty((B, H, W), dtype=torch.int64, device=dev)
+    ids_pan = torch.empty((B, int(max_segments)), dtype=torch.int64, device=dev)
+    ids_ins = torch.empty((B, int(max_segments)), dtype=torch.int64, device=dev)
+    n_ids = torch.empty((B,), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws, ws_bytes = _targets_workspace(B, int(n_classes), int(max_instances), dev)
+    L.check(L.lib().nmsa_panoptic_targets(
+        L.ptr(sem), L.int_dtype_code(sem), L.ptr(ins), L.int_dtype_code(ins), L.ptr(th),
+        B, int(n_classes), H, W, int(max_instances_per_category), int(void_label),
+        int(max_instances), int(max_segments), L.ptr(pan), L.ptr(ids_pan), L.ptr(ids_ins),
+        L.ptr(n_ids), L.ptr(status), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+        'nmsa_panoptic_targets')
+    return {'panoptic': pan, 'ids_pan': ids_pan, 'ids_ins': ids_ins, 'n_ids': n_ids,
+            'status': status}
+
+
+def dve_targets(
+    panoptic: torch.Tensor,
+    keys: torch.Tensor,
+    n_keys: torch.Tensor,
+    embeddings: Optional[torch.Tensor] = None,
+    image_embedding: Optional[torch.Tensor] = None,
+    diff_factor: float = 0.65,
+) -> Dict[str, torch.Tensor]:
+    """reference: DenseVisualEmbeddingTargetGenerator (dense_visual_embedding.py:22-93)."""
+    pan = L.require_device_tensor(panoptic, 'panoptic')
+    k = L.require_device_tensor(keys, 'keys')
+    nk = L.require_device_tensor(n_keys, 'n_keys')
+    assert pan.dtype == torch.int64 and k.dtype == torch.int64 and nk.dtype == torch.int32
+    B, H, W = pan.shape
+    K = int(k.shape[1])
+    dev = pan.device
+    idx = torch.empty((B, H, W), dtype=torch.int32, device=dev)
+    lut = None
+    D = 0
+    emb = img = None
+    if embeddings is not None:
+        emb = L.require_device_tensor(embeddings, 'embeddings').float()
+        img = L.require_device_tensor(image_embedding, 'image_embedding').float()
+        D = int(emb.shape[2])
+        lut = torch.empty((B, K, D), dtype=torch.float32, device=dev)
+    L.check(L.lib().nmsa_dve_targets(
+        L.ptr(pan), L.ptr(k), L.ptr(nk), L.ptr(emb), L.ptr(img), float(diff_factor),
+        B, K, D, H, W, L.ptr(lut), L.ptr(idx), L.stream_ptr(dev)), 'nmsa_dve_targets')
+    return {'indices': idx, 'lut': lut}
+
+
 # ----------------------------------------------------------------------------- a5
 def panoptic_merge(
     semantic: torch.Tensor,

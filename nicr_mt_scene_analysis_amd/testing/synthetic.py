@@ -178,6 +178,35 @@ def make_loss_inputs(
     return out
 
 
+def make_label_maps(batch_size, n_classes=41, height=480, width=640, n_instances=30, seed=0,
+                    max_id=65535, mixed_fraction=0.3):
+    """Ground-truth style label maps for the target generators.
+
+    semantic u8 [B,H,W] in [0, n_classes) (0 = void): blocky regions; instance int32 [B,H,W]:
+    `n_instances` random ellipses with sparse ids in [1, max_id] (uint16 range, as the datasets
+    store them), later ones painted over earlier ones.  A `mixed_fraction` of the instances keeps
+    the underlying (mixed) semantic labels, the others get one thing class painted in.
+    is_thing = class index >= n_classes // 2 (void and the lower half are stuff)."""
+    rng = np.random.default_rng(seed)
+    is_thing = np.arange(n_classes) >= max(1, n_classes // 2)
+    thing_ids = np.where(is_thing)[0]
+    sem = np.empty((batch_size, height, width), np.uint8)
+    ins = np.zeros((batch_size, height, width), np.int32)
+    yy, xx = np.mgrid[0:height, 0:width]
+    for b in range(batch_size):
+        coarse = rng.integers(0, n_classes, ((height + 31) // 32, (width + 31) // 32))
+        sem[b] = np.kron(coarse, np.ones((32, 32), np.int64))[:height, :width]
+        ids = rng.choice(np.arange(1, max_id + 1), size=n_instances, replace=False)
+        for k, iid in enumerate(ids):
+            cy, cx = rng.integers(0, height), rng.integers(0, width)
+            ry, rx = rng.integers(3, max(4, height // 5)), rng.integers(3, max(4, width // 5))
+            m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
+            ins[b][m] = iid
+            if rng.random() >= mixed_fraction:
+                sem[b][m] = rng.choice(thing_ids)
+    return {'semantic': sem, 'instance': ins, 'semantic_classes_is_thing': is_thing}
+
+
 def input_digest(*arrays: np.ndarray) -> str:
     h = hashlib.sha256()
     for a in arrays:

@@ -689,6 +689,100 @@ def gen_scores(ref):
     save('scores_cases', **out)
 
 
+def gen_targets(ref):
+    """f4: the reference's numpy target generators, sample by sample."""
+    print('target generation (reference data/preprocessing/{instance,panoptic,dense_visual_embedding}.py)')
+    from oracle import oracle as orc
+    B, NC, H, W = 3, 9, 96, 128
+    maps = syn.make_label_maps(B, NC, H, W, n_instances=14, seed=1)
+    is_thing = tuple(bool(x) for x in maps['semantic_classes_is_thing'])
+    out = dict(in_semantic=maps['semantic'], in_instance=maps['instance'],
+               in_is_thing=maps['semantic_classes_is_thing'])
+    clear = ref.prep_instance.InstanceClearStuffIDs(semantic_classes_is_thing=is_thing)
+    gens = {
+        's8n': ref.prep_instance.InstanceTargetGenerator(sigma=8, semantic_classes_is_thing=is_thing),
+        's3u': ref.prep_instance.InstanceTargetGenerator(sigma=3, semantic_classes_is_thing=is_thing,
+                                                         normalized_offset=False),
+        's5nothing': ref.prep_instance.InstanceTargetGenerator(sigma=5),
+    }
+    pgen = ref.prep_panoptic.PanopticTargetGenerator(semantic_classes_is_thing=is_thing)
+    dgen = ref.prep_dve.DenseVisualEmbeddingTargetGenerator(diff_factor=0.65)
+    rng = np.random.default_rng(3)
+    D, K = 16, 12
+    cleared = np.empty((B, H, W), np.int32)
+    res = {k: dict(center=[], offset=[], fg=[], cmask=[]) for k in gens}
+    pan, pan_ids = [], []
+    dve_keys = np.zeros((B, K), np.int64)
+    dve_n = np.zeros((B,), np.int32)
+    dve_emb = rng.standard_normal((B, K, D)).astype(np.float32)
+    dve_img = rng.standard_normal((B, D)).astype(np.float32)
+    dve_lut = np.zeros((B, K, D), np.float32)
+    dve_idx = np.zeros((B, H, W), np.int32)
+    enc = {k: [] for k in gens}
+    for b in range(B):
+        smp = clear({'semantic': maps['semantic'][b].copy(),
+                     'instance': maps['instance'][b].astype(np.uint16)})
+        cleared[b] = smp['instance']
+        for k, gen in gens.items():
+            sample = {'semantic': smp['semantic'].copy(), 'instance': smp['instance'].copy()}
+            r = gen(sample)
+            res[k]['center'].append(r['instance_center'])
+            res[k]['offset'].append(np.moveaxis(r['instance_offset'], -1, 0))      # HWC -> CHW
+            res[k]['fg'].append(r['instance_foreground'])
+            res[k]['cmask'].append(r['instance_center_mask'])
+        r = pgen({'semantic': smp['semantic'].copy(), 'instance': smp['instance'].copy()})
+        pan.append(r['panoptic'].astype(np.int64))
+        pan_ids.append(dict(r['panoptic_ids_to_instance_dict']))
+        present = [int(v) for v in np.unique(r['panoptic']) if v != 0]
+        keys = [present[i] for i in rng.permutation(len(present))[:K - 2]] + [123456789]
+        dve_n[b] = len(keys)
+        dve_keys[b, :len(keys)] = keys
+        smp_d = {'image_embedding': dve_img[b],
+                 'panoptic_embedding': {k_: dve_emb[b, i] for i, k_ in enumerate(keys)},
+                 'panoptic': r['panoptic']}
+        rd = dgen(smp_d)
+        dve_lut[b, :len(keys)] = rd['dense_visual_embedding_lut']
+        dve_idx[b] = rd['dense_visual_embedding_indices']
+    out['cleared_instance'] = cleared
+    for k in gens:
+        out[f'{k}__center'] = np.stack(res[k]['center'])
+        out[f'{k}__offset'] = np.stack(res[k]['offset'])
+        out[f'{k}__foreground'] = np.stack(res[k]['fg'])
+        out[f'{k}__center_mask'] = np.stack(res[k]['cmask'])
+    out['panoptic'] = np.stack(pan)
+    n, kk, vv = ids_to_arrays(pan_ids, cap=256)
+    out.update(pan_ids_n=n, pan_ids_pan=kk, pan_ids_ins=vv)
+    out.update(dve_keys=dve_keys, dve_n=dve_n, dve_emb=dve_emb, dve_img=dve_img, dve_lut=dve_lut,
+               dve_indices=dve_idx)
+    # the reference asserts when an instance is skipped (stuff majority) — record that it does
+    smp = {'semantic': maps['semantic'][0].copy(), 'instance': maps['instance'][0].astype(np.uint16)}
+    try:
+        gens['s8n'](smp)
+        out['uncleared_raises'] = np.int32(0)
+    except AssertionError:
+        out['uncleared_raises'] = np.int32(1)
+    print('    uncleared instance map raises AssertionError:', int(out['uncleared_raises']))
+
+    # generation-time check of the restatement
+    stuff = np.zeros((NC,), np.uint8)
+    stuff[np.where(~maps['semantic_classes_is_thing'])[0][1:]] = 1
+    o = orc.instance_targets(maps['semantic'], cleared, NC, maps['semantic_classes_is_thing'], stuff, 8, True)
+    assert np.array_equal(o['center'], out['s8n__center'])
+    assert np.array_equal(o['offset'], out['s8n__offset'])
+    assert np.array_equal(o['foreground'], out['s8n__foreground'])
+    assert np.array_equal(o['center_mask'], out['s8n__center_mask'])
+    o = orc.instance_targets(maps['semantic'], cleared, NC, maps['semantic_classes_is_thing'], stuff, 3, False)
+    assert np.array_equal(o['center'], out['s3u__center']) and np.array_equal(o['offset'], out['s3u__offset'])
+    o = orc.instance_targets(maps['semantic'], cleared, NC, None, None, 5, True)
+    assert np.array_equal(o['center'], out['s5nothing__center'])
+    assert np.array_equal(o['center_mask'], out['s5nothing__center_mask'])
+    p2, d2 = orc.naive_merge(maps['semantic'], cleared, 1 << 16, np.where(maps['semantic_classes_is_thing'])[0], 0)
+    assert np.array_equal(p2, out['panoptic'])
+    assert [list(d.items()) for d in d2] == [list(d.items()) for d in pan_ids]
+    assert np.array_equal(orc.dve_indices(out['panoptic'], [dve_keys[b, :dve_n[b]] for b in range(B)]), dve_idx)
+    save('target_cases', **out)
+
+
 def main():
     ref = load_reference()
     only = set(sys.argv[1:])
@@ -715,6 +809,8 @@ def main():
         gen_fullres(ref)
     if want('scores'):
         gen_scores(ref)
+    if want('targets'):
+        gen_targets(ref)
 
 
 if __name__ == '__main__':

@@ -914,3 +914,93 @@ int orc_panoptic_scores(const float* logits, const int64_t* pan_sem, const int64
     }
     return ORC_OK;
 }
+
+/* ------------------------------------------------------------------------- */
+/* f4  InstanceTargetGenerator._preprocess   data/preprocessing/instance.py:157-286 */
+/* one image; sem u8 [H,W], ins i32 [H,W] (uint16 ids).  Returns ORC_ERR_RANGE  */
+/* for ids outside [0,65535] / labels outside [0,n_classes).                    */
+/* encoded_ids / skipped_ids: ascending (np.unique order), capacity `cap`.      */
+/* ------------------------------------------------------------------------- */
+int orc_instance_targets(const uint8_t* sem, const int32_t* ins, int H, int W, int n_classes,
+                         const uint8_t* is_thing /* or NULL */, const uint8_t* is_stuff /* or NULL */,
+                         int sigma, int normalized,
+                         float* center, float* offset_f32 /* [2,H,W] or NULL */,
+                         int16_t* offset_i16 /* [2,H,W] or NULL */,
+                         uint8_t* fg, uint8_t* center_mask,
+                         int32_t* encoded_ids, int32_t* n_encoded,
+                         int32_t* skipped_ids, int32_t* n_skipped, int cap)
+{
+    const int64_t P = (int64_t)H * W;
+    uint8_t* present = (uint8_t*)calloc(65536, 1);
+    int64_t* hist = (int64_t*)malloc((size_t)n_classes * sizeof(int64_t));
+    int16_t* off = (int16_t*)calloc((size_t)2 * P, sizeof(int16_t));
+    int rc = ORC_OK;
+    for (int64_t p = 0; p < P; ++p) {
+        if (ins[p] < 0 || ins[p] > 65535 || sem[p] >= n_classes) { rc = ORC_ERR_RANGE; goto done; }
+        present[ins[p]] = 1;
+        center[p] = 0.f;
+        fg[p] = 0;
+    }
+    *n_encoded = 0;
+    *n_skipped = 0;
+    const int r = 3 * sigma + 1;
+    for (int id = 1; id < 65536; ++id) {                       /* np.unique: ascending (:191) */
+        if (!present[id]) continue;
+        memset(hist, 0, (size_t)n_classes * sizeof(int64_t));
+        int64_t n = 0, sy = 0, sx = 0;
+        for (int64_t p = 0; p < P; ++p)
+            if (ins[p] == id) { ++hist[sem[p]]; ++n; sy += p / W; sx += p % W; }
+        int cls = 0;
+        for (int c = 1; c < n_classes; ++c) if (hist[c] > hist[cls]) cls = c;   /* bincount.argmax (:207-209) */
+        if (is_thing && !is_thing[cls]) {                      /* :210-213 */
+            if (*n_skipped >= cap) { rc = ORC_ERR_CAPACITY; goto done; }
+            skipped_ids[(*n_skipped)++] = id;
+            continue;
+        }
+        if (*n_encoded >= cap) { rc = ORC_ERR_CAPACITY; goto done; }
+        encoded_ids[(*n_encoded)++] = id;
+        const int cy = (int)((double)sy / (double)n), cx = (int)((double)sx / (double)n);   /* :221-222 */
+        for (int y = cy - r; y <= cy + r; ++y) {               /* patch (:223-240) */
+            if (y < 0 || y >= H) continue;
+            for (int x = cx - r; x <= cx + r; ++x) {
+                if (x < 0 || x >= W) continue;
+                const double d2 = (double)((x - cx) * (x - cx) + (y - cy) * (y - cy));
+                const float g = (float)exp(-d2 / (double)(2 * sigma * sigma));
+                if (g > center[(int64_t)y * W + x]) center[(int64_t)y * W + x] = g;
+            }
+        }
+        for (int64_t p = 0; p < P; ++p)
+            if (ins[p] == id) {
+                fg[p] = 1;
+                off[p] = (int16_t)(cy - (int)(p / W));          /* :243-247 */
+                off[P + p] = (int16_t)(cx - (int)(p % W));
+            }
+    }
+    for (int64_t p = 0; p < P; ++p) {
+        if (offset_i16) { offset_i16[p] = off[p]; offset_i16[P + p] = off[P + p]; }
+        if (offset_f32) {
+            if (normalized) {                                   /* :249-253 */
+                offset_f32[p] = (float)off[p] / (float)H;
+                offset_f32[P + p] = (float)off[P + p] / (float)W;
+            } else {
+                offset_f32[p] = (float)off[p];
+                offset_f32[P + p] = (float)off[P + p];
+            }
+        }
+        if (center_mask) center_mask[p] = fg[p] || (is_stuff && is_stuff[sem[p]]);   /* :271-277 */
+    }
+done:
+    free(present); free(hist); free(off);
+    return rc;
+}
+
+/* f4  DenseVisualEmbeddingTargetGenerator._process_scale   dense_visual_embedding.py:22-45 */
+int orc_dve_indices(const int64_t* pan, int64_t n_px, const int64_t* keys, int n_keys, int32_t* indices)
+{
+    for (int64_t p = 0; p < n_px; ++p) {
+        int32_t idx = 0;
+        for (int k = 0; k < n_keys; ++k) if (keys[k] == pan[p]) idx = k + 1;    /* later key overwrites */
+        indices[p] = idx;
+    }
+    return ORC_OK;
+}

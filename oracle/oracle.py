@@ -340,3 +340,45 @@ def panoptic_scores(logits, pan_sem, pan, ids, inst_score_by_id):
         _p(tab, C.c_float), B, Cn, H, W, _p(sem, C.c_float), _p(ins, C.c_float),
         _p(pns, C.c_float), _p(mean, C.c_float)), 'panoptic_scores')
     return sem, ins, pns, mean
+
+
+# -- f4: target generation ----------------------------------------------------------
+def instance_targets(sem, ins, n_classes, is_thing=None, is_stuff=None, sigma=8,
+                     normalized=True, cap=4096):
+    """sem u8 [B,H,W], ins int32 [B,H,W] -> dict of batched targets (offset [B,2,H,W])."""
+    sem = _c(sem, np.uint8)
+    ins = _c(ins, np.int32)
+    B, H, W = sem.shape
+    th = None if is_thing is None else _c(is_thing, np.uint8)
+    st = None if is_stuff is None else _c(is_stuff, np.uint8)
+    center = np.empty((B, H, W), np.float32)
+    off_f = np.empty((B, 2, H, W), np.float32)
+    off_i = np.empty((B, 2, H, W), np.int16)
+    fg = np.empty((B, H, W), np.uint8)
+    cm = np.empty((B, H, W), np.uint8)
+    enc, skp = [], []
+    for b in range(B):
+        e = np.zeros((cap,), np.int32)
+        s = np.zeros((cap,), np.int32)
+        ne, ns = C.c_int32(0), C.c_int32(0)
+        _chk(lib().orc_instance_targets(
+            _p(sem[b], C.c_uint8), _p(ins[b], C.c_int32), H, W, int(n_classes),
+            _p(th, C.c_uint8), _p(st, C.c_uint8), int(sigma), int(bool(normalized)),
+            _p(center[b], C.c_float), _p(off_f[b], C.c_float), _p(off_i[b], C.c_int16),
+            _p(fg[b], C.c_uint8), _p(cm[b], C.c_uint8),
+            _p(e, C.c_int32), C.byref(ne), _p(s, C.c_int32), C.byref(ns), cap), 'instance_targets')
+        enc.append(e[:ne.value].tolist())
+        skp.append(s[:ns.value].tolist())
+    return dict(center=center, offset=off_f if normalized else off_i, foreground=fg.astype(bool),
+                center_mask=cm.astype(bool), encoded=enc, skipped=skp)
+
+
+def dve_indices(pan, keys):
+    """pan i64 [B,H,W], keys: list (per image) of panoptic ids -> int32 indices [B,H,W]."""
+    pan = _c(pan, np.int64)
+    out = np.empty(pan.shape, np.int32)
+    for b in range(pan.shape[0]):
+        k = _c(list(keys[b]), np.int64)
+        _chk(lib().orc_dve_indices(_p(pan[b], C.c_int64), pan[b].size, _p(k, C.c_int64), len(k),
+                                   _p(out[b], C.c_int32)), 'dve_indices')
+    return out

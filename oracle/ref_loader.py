@@ -140,6 +140,14 @@ def load_reference():
     ns.APPLIED_PREPROCESSING_KEY = \
         sys.modules[f'{PKG}.data.preprocessing.base'].APPLIED_PREPROCESSING_KEY
 
+    # --- target generators --------------------------------------
+    sys.modules[f'{PKG}.data'].CollateIgnoredDict = \
+        sys.modules[f'{PKG}.data._types'].CollateIgnoredDict
+    ns.prep_instance = _load('data.preprocessing.instance', 'data/preprocessing/instance.py')
+    ns.prep_panoptic = _load('data.preprocessing.panoptic', 'data/preprocessing/panoptic.py')
+    ns.prep_dve = _load('data.preprocessing.dense_visual_embedding',
+                        'data/preprocessing/dense_visual_embedding.py')
+
     # --- postprocessing ------------------------------------------------------
     _load('model.postprocessing.base', 'model/postprocessing/base.py')
     _load('model.postprocessing.dense_base', 'model/postprocessing/dense_base.py')

@@ -297,3 +297,37 @@ def test_scores_cases(oracle):
     r = _run_pipeline_oracle(oracle, g['in_semantic_logits'], g['in_instance_center'],
                              g['in_instance_offset'], g['in_semantic_classes_is_thing'])
     assert np.array_equal(r['pan'], g['panoptic']) and r['ids'] == ids
+
+
+# ---------------------------------------------------------------------------
+# f4: target generation (data/preprocessing/{instance,panoptic,dense_visual_embedding}.py)
+def _stuff_lut(is_thing):
+    st = np.zeros((len(is_thing),), np.uint8)
+    st[np.where(~is_thing)[0][1:]] = 1
+    return st
+
+
+def test_target_cases(oracle):
+    g = load('target_cases')
+    sem, ins, is_thing = g['in_semantic'], g['cleared_instance'], g['in_is_thing']
+    NC = len(is_thing)
+    for name, kw in (('s8n', dict(is_thing=is_thing, is_stuff=_stuff_lut(is_thing), sigma=8, normalized=True)),
+                     ('s3u', dict(is_thing=is_thing, is_stuff=_stuff_lut(is_thing), sigma=3, normalized=False)),
+                     ('s5nothing', dict(sigma=5, normalized=True))):
+        o = oracle.instance_targets(sem, ins, NC, **kw)
+        assert np.array_equal(o['center'], g[f'{name}__center']), name          # bit-exact
+        assert o['offset'].dtype == g[f'{name}__offset'].dtype
+        assert np.array_equal(o['offset'], g[f'{name}__offset']), name
+        assert np.array_equal(o['foreground'], g[f'{name}__foreground']), name
+        assert np.array_equal(o['center_mask'], g[f'{name}__center_mask']), name
+        assert all(len(s) == 0 for s in o['skipped'])
+    # an uncleared map has stuff-majority instances: the reference asserts, the oracle lists them
+    assert int(g['uncleared_raises']) == 1
+    o = oracle.instance_targets(sem, g['in_instance'], NC, is_thing=is_thing, sigma=8)
+    assert any(len(s) for s in o['skipped'])
+    pan, dicts = oracle.naive_merge(sem, ins, 1 << 16, np.where(is_thing)[0], 0)
+    assert np.array_equal(pan, g['panoptic'])
+    want = ids_from_arrays(g['pan_ids_n'], g['pan_ids_pan'], g['pan_ids_ins'])
+    assert [list(d.items()) for d in dicts] == [list(d.items()) for d in want]
+    keys = [g['dve_keys'][b, :g['dve_n'][b]] for b in range(len(sem))]
+    assert np.array_equal(oracle.dve_indices(g['panoptic'], keys), g['dve_indices'])

@@ -1,0 +1,131 @@
+"""
+GPU tier (pytest -m gpu): ground-truth target generation on the device
+through the C ABI (nmsa_instance_clear_stuff / nmsa_instance_targets / nmsa_panoptic_targets /
+nmsa_dve_targets) and the batch-level mirrors of the reference classes, against the reference's
+own numpy generators (tests/golden/target_cases.npz) and the C oracle.  Heat-maps, offsets,
+masks, panoptic ids and id dicts are bit-exact; the normalised embedding LUT is fp32 within
+rtol 1e-5 (numpy's pairwise float32 norm vs a wave reduction).
+"""
+import numpy as np
+import pytest
+import torch
+
+from _golden import load, ids_from_arrays
+from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def _stuff_lut(is_thing):
+    st = np.zeros((len(is_thing),), np.uint8)
+    st[np.where(~is_thing)[0][1:]] = 1
+    return st
+
+
+def test_targets_vs_golden():
+    from nicr_mt_scene_analysis_amd.data.preprocessing import (
+        DenseVisualEmbeddingTargetGenerator, InstanceClearStuffIDs, InstanceTargetGenerator,
+        PanopticTargetGenerator)
+    g = load('target_cases')
+    is_thing = tuple(bool(x) for x in g['in_is_thing'])
+    batch = {'semantic': dev(g['in_semantic']), 'instance': dev(g['in_instance'])}
+    with pytest.raises(AssertionError):            # like the reference on an uncleared map
+        InstanceTargetGenerator(sigma=8, semantic_classes_is_thing=is_thing)(dict(batch))
+    batch = InstanceClearStuffIDs(semantic_classes_is_thing=is_thing)(batch)
+    assert np.array_equal(batch['instance'].cpu().numpy(), g['cleared_instance'])
+    for name, gen in (
+            ('s8n', InstanceTargetGenerator(sigma=8, semantic_classes_is_thing=is_thing)),
+            ('s3u', InstanceTargetGenerator(sigma=3, semantic_classes_is_thing=is_thing,
+                                            normalized_offset=False)),
+            ('s5nothing', InstanceTargetGenerator(sigma=5))):
+        r = gen(dict(batch), n_classes=len(is_thing))
+        assert np.array_equal(r['instance_center'].cpu().numpy(), g[f'{name}__center']), name
+        off = r['instance_offset'].cpu().numpy()
+        assert off.dtype == g[f'{name}__offset'].dtype and np.array_equal(off, g[f'{name}__offset'])
+        assert r['instance_foreground'].dtype == torch.bool
+        assert np.array_equal(r['instance_foreground'].cpu().numpy(), g[f'{name}__foreground'])
+        assert np.array_equal(r['instance_center_mask'].cpu().numpy(), g[f'{name}__center_mask'])
+        enc = gen.last_dynamic_parameters['encoded_instances']
+        for b in range(len(enc)):
+            assert enc[b] == sorted(int(v) for v in np.unique(g['cleared_instance'][b]) if v != 0)
+    r = PanopticTargetGenerator(semantic_classes_is_thing=is_thing)(dict(batch))
+    assert r['panoptic'].dtype == torch.int64
+    assert np.array_equal(r['panoptic'].cpu().numpy(), g['panoptic'])
+    want = ids_from_arrays(g['pan_ids_n'], g['pan_ids_pan'], g['pan_ids_ins'])
+    assert [list(d.items()) for d in r['panoptic_ids_to_instance_dict']] == \
+        [list(d.items()) for d in want]
+    db = {'panoptic': r['panoptic'], 'panoptic_embedding_keys': dev(g['dve_keys']),
+          'panoptic_embedding_n': dev(g['dve_n']), 'panoptic_embedding': dev(g['dve_emb']),
+          'image_embedding': dev(g['dve_img'])}
+    rd = DenseVisualEmbeddingTargetGenerator(diff_factor=0.65)(db)
+    assert np.array_equal(rd['dense_visual_embedding_indices'].cpu().numpy(), g['dve_indices'])
+    lut = rd['dense_visual_embedding_lut'].cpu().numpy()
+    for b in range(lut.shape[0]):
+        n = int(g['dve_n'][b])
+        np.testing.assert_allclose(lut[b, :n], g['dve_lut'][b, :n], rtol=1e-5, atol=1e-7)
+
+
+@pytest.mark.parametrize('cfg', [
+    dict(B=2, NC=41, H=480, W=640, n=60, seed=4, sigma=8),       # dataset-sized
+    dict(B=3, NC=5, H=37, W=53, n=9, seed=5, sigma=2),           # ragged, patches clipped everywhere
+    dict(B=1, NC=151, H=96, W=128, n=1500, seed=6, sigma=4),     # > 1024 ids: table regrowth
+])
+def test_targets_vs_oracle(oracle, cfg):
+    from nicr_mt_scene_analysis_amd import ops
+    m = syn.make_label_maps(cfg['B'], cfg['NC'], cfg['H'], cfg['W'], cfg['n'], seed=cfg['seed'])
+    is_thing = m['semantic_classes_is_thing']
+    sem = m['semantic']
+    ins = m['instance'].copy()
+    ins[~is_thing[sem]] = 0                                       # InstanceClearStuffIDs
+    d_ins = dev(m['instance'])
+    stuff_incl_void = dev((~is_thing).astype(np.uint8))
+    ops.instance_clear_stuff(dev(sem), d_ins, stuff_incl_void)
+    assert np.array_equal(d_ins.cpu().numpy(), ins)
+    max_inst = 4096 if cfg['n'] > 1000 else 1024
+    r = ops.instance_targets(dev(sem), d_ins, cfg['NC'], dev(is_thing.astype(np.uint8)),
+                             dev(_stuff_lut(is_thing)), cfg['sigma'], True, max_instances=max_inst)
+    torch.cuda.synchronize()
+    assert int(r['status'].item()) == 0
+    o = oracle.instance_targets(sem, ins, cfg['NC'], is_thing, _stuff_lut(is_thing), cfg['sigma'], True)
+    assert np.array_equal(r['center'].cpu().numpy(), o['center'])
+    assert np.array_equal(r['offset'].cpu().numpy(), o['offset'])
+    assert np.array_equal(r['foreground'].cpu().numpy(), o['foreground'])
+    assert np.array_equal(r['center_mask'].cpu().numpy(), o['center_mask'])
+    n_enc = r['n_encoded'].cpu().numpy()
+    for b in range(cfg['B']):
+        assert r['encoded_ids'][b, :n_enc[b]].cpu().tolist() == o['encoded'][b]
+    if cfg['n'] > 1000:
+        small = ops.instance_targets(dev(sem), d_ins, cfg['NC'], None, None, cfg['sigma'], True,
+                                     max_instances=1024)
+        assert int(small['status'].item()) & 1                     # too many ids for this table
+    p = ops.panoptic_targets(dev(sem), d_ins, cfg['NC'], dev(is_thing.astype(np.uint8)), 1 << 16, 0,
+                             max_instances=max_inst, max_segments=8192)
+    assert int(p['status'].item()) == 0
+    pan, dicts = oracle.naive_merge(sem, ins, 1 << 16, np.where(is_thing)[0], 0)
+    assert np.array_equal(p['panoptic'].cpu().numpy(), pan)
+    got = ids_from_arrays(p['n_ids'].cpu().numpy(), p['ids_pan'].cpu().numpy(), p['ids_ins'].cpu().numpy())
+    assert [list(d.items()) for d in got] == [list(d.items()) for d in dicts]
+    # naive merge on the UNcleared map (instances over stuff / void, mixed labels)
+    p = ops.panoptic_targets(dev(sem), dev(m['instance']), cfg['NC'], dev(is_thing.astype(np.uint8)),
+                             1 << 16, 0, max_instances=max_inst, max_segments=8192)
+    pan, dicts = oracle.naive_merge(sem, m['instance'], 1 << 16, np.where(is_thing)[0], 0)
+    assert np.array_equal(p['panoptic'].cpu().numpy(), pan)
+    got = ids_from_arrays(p['n_ids'].cpu().numpy(), p['ids_pan'].cpu().numpy(), p['ids_ins'].cpu().numpy())
+    assert [list(d.items()) for d in got] == [list(d.items()) for d in dicts]
+
+
+def test_targets_status_bits():
+    from nicr_mt_scene_analysis_amd import ops
+    sem = torch.zeros((1, 8, 8), dtype=torch.uint8, device='cuda')
+    ins = torch.zeros((1, 8, 8), dtype=torch.int32, device='cuda')
+    ins[0, 0, 0] = 70000
+    r = ops.instance_targets(sem, ins, 4, None, None, 2)
+    assert int(r['status'].item()) & 32
+    ins[0, 0, 0] = 5
+    sem[0, 0, 0] = 9
+    r = ops.instance_targets(sem, ins, 4, None, None, 2)
+    assert int(r['status'].item()) & 64
