@@ -179,7 +179,7 @@ def make_loss_inputs(
 
 
 def make_label_maps(batch_size, n_classes=41, height=480, width=640, n_instances=30, seed=0,
-                    max_id=65535, mixed_fraction=0.3):
+                    max_id=65535, mixed_fraction=0.3, max_radius=None):
     """Ground-truth style label maps for the target generators.
 
     semantic u8 [B,H,W] in [0, n_classes) (0 = void): blocky regions; instance int32 [B,H,W]:
@@ -199,7 +199,8 @@ def make_label_maps(batch_size, n_classes=41, height=480, width=640, n_instances
         ids = rng.choice(np.arange(1, max_id + 1), size=n_instances, replace=False)
         for k, iid in enumerate(ids):
             cy, cx = rng.integers(0, height), rng.integers(0, width)
-            ry, rx = rng.integers(3, max(4, height // 5)), rng.integers(3, max(4, width // 5))
+            ry = rng.integers(3, max_radius or max(4, height // 5))
+            rx = rng.integers(3, max_radius or max(4, width // 5))
             m = ((yy - cy) / ry) ** 2 + ((xx - cx) / rx) ** 2 <= 1.0
             ins[b][m] = iid
             if rng.random() >= mixed_fraction:

@@ -143,9 +143,9 @@ def deeplab_merge(sem, ins, thing_seg, max_inst, thing_ids, void_label=0):
                   thing_ids, void_label)
 
 
-def naive_merge(sem, ins, max_inst, thing_ids, void_label=0):
+def naive_merge(sem, ins, max_inst, thing_ids, void_label=0, cap=1024):
     return _merge(lib().orc_naive_merge, sem, ins, None, max_inst,
-                  thing_ids, void_label)
+                  thing_ids, void_label, cap=cap)
 
 
 # -- orientation ----------------------------------------------------------------
