@@ -238,19 +238,19 @@ def test_batch_helpers():
         get_valid_region_slices({})
 
 
-def test_crop_and_resize_matches_reference_recipe():
-    """dense_base.py:15-58: nearest resize through float32, bilinear with align_corners=False"""
+def test_crop_and_resize_host_side():
+    """dense_base.py:15-58: no resize -> the cropped view itself; a real resize is HIP work
+    (tests/test_fullres.py) and a CPU tensor must fail loudly, not fall back"""
+    from nicr_mt_scene_analysis_amd._lib import NmsaError
     from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
     post = get_postprocessing_class('semantic')()
     ids = torch.arange(2 * 6 * 8).reshape(2, 6, 8) * 65536
-    out = post._crop_to_valid_region_and_resize_prediction(ids, (slice(1, 5), slice(0, 8)), (8, 16))
-    ref = torch.nn.functional.interpolate(ids[:, 1:5].unsqueeze(1).float(), size=(8, 16),
-                                          mode='nearest').long().squeeze(1)
-    assert out.dtype == ids.dtype and (out == ref).all()
     same = post._crop_to_valid_region_and_resize_prediction(ids, (slice(0, 6), slice(0, 8)), (6, 8))
     assert same.data_ptr() == ids.data_ptr()
-    x = torch.rand((1, 3, 4, 4))
-    out = post._crop_to_valid_region_and_resize_prediction(x, (slice(0, 4), slice(0, 4)), (8, 8),
-                                                           mode='bilinear')
-    assert torch.equal(out, torch.nn.functional.interpolate(x, size=(8, 8), mode='bilinear',
-                                                            align_corners=False))
+    crop = post._crop_to_valid_region_and_resize_prediction(ids, (slice(1, 5), slice(2, 8)), (4, 6))
+    assert torch.equal(crop, ids[:, 1:5, 2:8])
+    with pytest.raises(NmsaError):
+        post._crop_to_valid_region_and_resize_prediction(ids, (slice(1, 5), slice(0, 8)), (8, 16))
+    with pytest.raises(NotImplementedError):
+        post._crop_to_valid_region_and_resize_prediction(ids, (slice(1, 5), slice(0, 8)), (8, 16),
+                                                         mode='bicubic')
