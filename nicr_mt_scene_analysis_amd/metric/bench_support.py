@@ -2,9 +2,10 @@
 
 Every step each rank updates accumulators from its shard of the batch (HIP kernels).
 With more than one rank the step-local accumulators are summed over the ranks with ONE
-all-reduce per dtype (RCCL over xGMI: the int64 confusion matrix, the float64 PQ vectors —
-~15 KB, the only collective on the path) and added to the replicated running totals;
-with a single rank the kernels accumulate into the totals directly.  Mirrors
+all-reduce (RCCL over xGMI): the int64 confusion matrix (step-local counts < 2^53, exact in
+float64) and the float64 PQ vectors travel in one packed float64 buffer of ~15 KB — the only
+collective on the path — and are added to the replicated running totals; with a single rank
+the kernels accumulate into the totals directly.  Mirrors
 `dist_reduce_fx='sum'` of reference metric/miou.py:21-25 and metric/pq.py:228-246.
 
 The metric kernels are enqueued on a side HIP stream: they only depend on the panoptic
@@ -33,6 +34,10 @@ class MetricAccumulators:
                            next(iter(self.pq._pack().values()))]
         self._total_flat = [torch.zeros_like(f) for f in self._step_flat] \
             if world_size > 1 else self._step_flat
+        n_conf = self._step_flat[0].numel()
+        self._packed = torch.zeros((n_conf + self._step_flat[1].numel(),), dtype=torch.float64,
+                                   device=device) if world_size > 1 else None
+        self._n_conf = n_conf
         self.stream = torch.cuda.Stream(device=device) if side_stream else None
         self._ready = torch.cuda.Event()
         # synthetic ground truth: the prediction shifted by 3 px with a
@@ -64,11 +69,22 @@ class MetricAccumulators:
             # pq.update(pan, panoptic target)                  (task_helper/panoptic.py:111-118)
             self.pq.update(panoptic_pred, self.target_panoptic)
             if self.world_size > 1:
+                n = self._n_conf
+                self._packed[:n].copy_(self._step_flat[0])            # i64 -> f64, exact
+                self._packed[n:].copy_(self._step_flat[1])
                 if dist is not None:
-                    self.miou.sync()
-                    self.pq.sync()
-                for tot, stp in zip(self._total_flat, self._step_flat):
-                    tot += stp
+                    self._all_reduce(dist, self._packed)
+                self._total_flat[0] += self._packed[:n].to(torch.int64)
+                self._total_flat[1] += self._packed[n:]
+
+    @staticmethod
+    def _all_reduce(dist, buf: torch.Tensor) -> None:
+        if dist.get_backend() == 'nccl':
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        else:                                   # gloo rehearsal with device states
+            host = buf.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            buf.copy_(host)
 
     def wait(self) -> None:
         """make the current stream wait for everything enqueued on the side stream"""

@@ -352,3 +352,25 @@ def test_pq_with_orientation_mae():
     np.testing.assert_allclose(float(r['mae_deeplab_rad']), 0.5, rtol=1e-6)
     assert int(pq.n_elements) == 1
     assert float(r['all_deeplab_pq']) == 1.0
+
+
+@gpu
+def test_bench_accumulators_packed_reduce_path():
+    """bench.py's MetricAccumulators: the multi-rank path (step-local states -> one packed
+    float64 buffer -> [all-reduce] -> totals) gives the same totals as direct accumulation."""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.metric.bench_support import MetricAccumulators
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+    inp = syn.make_panoptic_inputs_torch(2, 8, 96, 128, n_centers=6, seed=3, device='cuda')
+    a = MetricAccumulators(9, torch.device('cuda'), inp, world_size=1, side_stream=False)
+    b = MetricAccumulators(9, torch.device('cuda'), inp, world_size=2, side_stream=True)
+    pan = ops.panoptic_pipeline(inp['semantic_logits'], inp['instance_center'],
+                                inp['instance_offset'], inp['semantic_classes_is_thing'])['panoptic']
+    for _ in range(3):
+        a.update_and_reduce(pan)
+        b.update_and_reduce(pan, dist=None)
+    b.wait()
+    torch.cuda.synchronize()
+    assert a.total_confmat.sum() > 0
+    assert torch.equal(a.total_confmat, b.total_confmat)
+    assert torch.equal(a.total_pq, b.total_pq)
