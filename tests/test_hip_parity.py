@@ -111,6 +111,37 @@ def test_pipeline_vs_oracle(ops, oracle, shape, quant):
         assert list(a.items()) == list(b.items())
 
 
+def test_cfg5_shape_vs_oracle(ops, oracle):
+    """BASELINE configs[4] shape: 1024x768, 150 classes, 48 centers, bf16 logits — one full-size
+    image end to end against the C oracle (ids bit-exact)."""
+    B, C, H, W = 1, 150, 768, 1024
+    dinp = syn.make_panoptic_inputs_torch(B, C, H, W, n_centers=48, seed=31, device='cuda',
+                                          logits_dtype=torch.bfloat16)
+    lb = dinp['semantic_logits']
+    assert lb.dtype == torch.bfloat16
+    r = ops.panoptic_pipeline(lb, dinp['instance_center'], dinp['instance_offset'],
+                              dinp['semantic_classes_is_thing'], want_score=True,
+                              want_panoptic_semantic=True)
+    torch.cuda.synchronize()
+    r = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in r.items()}
+    inp = {k: v.float().cpu().numpy() if v.is_floating_point() else v.cpu().numpy()
+           for k, v in dinp.items() if isinstance(v, torch.Tensor)}
+    is_thing = inp['semantic_classes_is_thing'].astype(bool)
+    idx, score = oracle.semantic_argmax(inp['semantic_logits'])
+    fg = is_thing[idx]
+    cyx, n, _, _ = oracle.center_nms_topk(inp['instance_center'], max_centers=256)
+    inst, area = oracle.group_offsets(inp['instance_offset'], fg, cyx, n, scale_y=H, scale_x=W)
+    pan, ids = oracle.deeplab_merge(idx + 1, inst, fg, 1 << 16, np.where(is_thing)[0] + 1, 0)
+    assert (r['semantic_idx_u8'] == idx).all()
+    np.testing.assert_allclose(r['semantic_score'], score, rtol=1e-5, atol=1e-7)
+    assert (r['n_centers'] == n).all() and (r['centers_yx'][0, :n[0]] == cyx[0, :n[0]]).all()
+    assert (r['instance'] == inst).all()
+    assert (r['panoptic'] == pan).all()
+    assert (r['panoptic_semantic'] == pan // 65536).all()
+    got = ids_from_arrays(r['n_ids'], r['ids_pan'], r['ids_ins'])
+    assert list(got[0].items()) == list(ids[0].items())
+
+
 def test_bf16_logits_vs_oracle(ops, oracle):
     inp = syn.make_panoptic_inputs(2, 40, 96, 128, n_centers=7, seed=5)
     lb = torch.from_numpy(inp['semantic_logits']).to(torch.bfloat16)
