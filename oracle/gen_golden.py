@@ -175,6 +175,25 @@ def gen_panoptic(ref):
              digest=jdump(digest), **panoptic_outputs(r, score_stride=8))
 
 
+def gen_edges(ref):
+    """degenerate images: no centers, no foreground, all foreground with one center, a tight
+    distance threshold that un-assigns most pixels."""
+    print('panoptic pipeline edge cases (reference PanopticPostprocessing.postprocess)')
+    inp = syn.make_panoptic_inputs(4, n_classes=6, height=48, width=64, n_centers=4, seed=13)
+    lg = inp['semantic_logits']
+    is_thing = inp['semantic_classes_is_thing']
+    inp['instance_center'][0] = 0.0                       # image 0: no centers at all
+    lg[1, np.where(is_thing)[0]] -= 100.0                 # image 1: every pixel is stuff
+    lg[2, np.where(~is_thing)[0]] -= 100.0                # image 2: every pixel is a thing ...
+    heat = inp['instance_center'][2]
+    heat[:] = 0.0
+    heat[0, 20, 30] = 0.9                                 # ... and exactly one center
+    for name, kw in (('plain', None), ('thr', dict(offset_distance_threshold=6))):
+        r = run_panoptic(ref, inp, heatmap_kwargs=kw)
+        save(f'panoptic_edges_{name}', kwargs=jdump(kw or {}),
+             **{f'in_{k}': v for k, v in inp.items()}, **panoptic_outputs(r))
+
+
 def gen_centers(ref):
     print('center NMS / top-k adversarial cases (reference _get_instance_centers)')
     rng = np.random.default_rng(7)
@@ -793,6 +812,8 @@ def main():
         check_norm_formula(ref)
     if want('panoptic'):
         gen_panoptic(ref)
+    if want('edges'):
+        gen_edges(ref)
     if want('centers'):
         gen_centers(ref)
     if want('grouping'):

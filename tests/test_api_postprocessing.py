@@ -136,7 +136,8 @@ def build_panoptic(is_thing, kw=None, compute_scores=False):
         compute_scores=compute_scores)
 
 
-@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_small_kwargs'])
+@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_small_kwargs',
+                                  'panoptic_edges_plain', 'panoptic_edges_thr'])
 def test_panoptic_postprocess_vs_golden(name):
     g = load(name)
     kw = jload(g['kwargs']) if 'kwargs' in g else None

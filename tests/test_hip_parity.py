@@ -61,7 +61,8 @@ def check_against_golden(g, r):
         assert list(a.items()) == list(b.items())
 
 
-@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_small_kwargs'])
+@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_small_kwargs',
+                                  'panoptic_edges_plain', 'panoptic_edges_thr'])
 def test_pipeline_small_vs_golden(ops, name):
     g = load(name)
     kw = jload(g['kwargs']) if 'kwargs' in g else None

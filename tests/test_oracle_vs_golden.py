@@ -51,7 +51,8 @@ def _check_pipeline(g, r):
         assert list(rd.items()) == list(gd.items())      # insertion order too
 
 
-@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_small_kwargs'])
+@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_small_kwargs',
+                                  'panoptic_edges_plain', 'panoptic_edges_thr'])
 def test_pipeline_small(oracle, name):
     g = load(name)
     kw = jload(g['kwargs']) if 'kwargs' in g else None
