@@ -131,3 +131,27 @@ def test_targets_status_bits():
     sem[0, 0, 0] = 9
     r = ops.instance_targets(sem, ins, 4, None, None, 2)
     assert int(r['status'].item()) & 64
+
+
+def test_reference_property_checks():
+    """the properties the reference's own tests assert (tests/test_preprocessing.py:145-216):
+    after InstanceClearStuffIDs every stuff pixel has id 0; the target generator's foreground
+    is exactly the set of thing-class pixels that carry an instance."""
+    from nicr_mt_scene_analysis_amd.data.preprocessing import InstanceClearStuffIDs, InstanceTargetGenerator
+    m = syn.make_label_maps(2, 41, 120, 160, 25, seed=8)
+    thing_classes = [1, 2, 3]
+    is_thing = tuple(i in thing_classes for i in range(41))
+    m['semantic'][m['semantic'] > 6] = 0          # keep a few classes, lots of void
+    batch = {'semantic': dev(m['semantic']), 'instance': dev(m['instance'])}
+    batch = InstanceClearStuffIDs(semantic_classes_is_thing=is_thing)(batch)
+    sem, ins = batch['semantic'].cpu().numpy(), batch['instance'].cpu().numpy()
+    for c in range(41):
+        if not is_thing[c]:
+            assert (ins[sem == c] == 0).all()
+    assert (ins[np.isin(sem, thing_classes)] == m['instance'][np.isin(sem, thing_classes)]).all()
+    r = InstanceTargetGenerator(sigma=8, semantic_classes_is_thing=is_thing)(batch)
+    for k in ('instance_center', 'instance_offset', 'instance_foreground', 'instance_center_mask'):
+        assert k in r
+    fg = r['instance_foreground'].cpu().numpy()
+    assert np.array_equal(fg, np.isin(sem, thing_classes) & (ins > 0))
+    assert float(r['instance_center'].max()) == 1.0 and float(r['instance_center'].min()) >= 0.0
