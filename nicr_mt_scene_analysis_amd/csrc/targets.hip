@@ -82,25 +82,137 @@ __device__ __forceinline__ int wave_reduce_sum_i(int v)
     return v;
 }
 
+// ---- labels of 4 consecutive pixels ---------------------------------------------------------
+// FAST = the on-wire dtypes (semantic uint8, instance int32) with 16-byte aligned rows of 4:
+// one 16-B and one 4-B load per thread.  Everything else takes the generic per-element loader.
+template <bool FAST>
+__device__ __forceinline__ void load_ins4(const void* ins, int ins_dtype, size_t o, int nvalid,
+                                          int64_t out[4])
+{
+    if (FAST) {
+        const int4 v = *(const int4*)((const int32_t*)ins + o);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = (j < nvalid) ? mw_load(ins, ins_dtype, o + j) : 0;
+    }
+}
+
+template <bool FAST>
+__device__ __forceinline__ void load_sem4(const void* sem, int sem_dtype, size_t o, int nvalid,
+                                          int64_t out[4])
+{
+    if (FAST) {
+        const uchar4 v = *(const uchar4*)((const uint8_t*)sem + o);
+        out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) out[j] = (j < nvalid) ? mw_load(sem, sem_dtype, o + j) : 0;
+    }
+}
+
+// wave_aggregate_add with a wave-uniform weight per contributing lane
+template <typename AddFn>
+__device__ __forceinline__ void wave_aggregate_add_w(int key, uint32_t weight, AddFn add)
+{
+    unsigned long long todo = __ballot(key >= 0);
+    while (todo) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const int k = __shfl(key, leader);
+        const unsigned long long same = __ballot(key == k) & todo;
+        if (lane_id() == leader) add(k, (uint32_t)__popcll(same) * weight);
+        todo &= ~same;
+    }
+}
+
+constexpr int TG_PX_PER_BLOCK = 256 * 4;
+
+// Lanes hold consecutive pixel groups, so equal keys come in RUNS: every run head learns its
+// run's length and last lane from two ballots — all heads then act in parallel (one atomic per
+// run), with no leader-serial loop over the distinct keys.  key < 0 = gap.  Wave-uniform call.
+__device__ __forceinline__ bool wave_run_head(int key, int& len, int& last)
+{
+    const int prev = __shfl_up(key, 1);
+    const int l = lane_id();
+    const bool head = key >= 0 && (l == 0 || prev != key);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long gaps = __ballot(key < 0);
+    const unsigned long long stop = (heads | gaps) & ~((2ull << l) - 1ull);
+    const int nxt = stop ? (__ffsll((long long)stop) - 1) : 64;
+    len = nxt - l;
+    last = nxt - 1;
+    return head;
+}
+
+// A 1024-pixel workgroup meets only a handful of instances, but a big instance is met by
+// hundreds of workgroups: accumulate in small LDS hash tables (linear probing, 4 tries, global
+// atomic as the fallback) and flush each used slot with ONE global atomic per workgroup.
+constexpr int TG_H1 = 64;       // slots keyed by dense instance id: sum of y, sum of x
+constexpr int TG_H2 = 256;      // slots keyed by (dense id, class): votes
+
+struct TgLdsTables {
+    int k1[TG_H1];
+    unsigned long long sy[TG_H1], sx[TG_H1];
+    int k2[TG_H2];
+    uint32_t cnt[TG_H2];
+};
+
+__device__ __forceinline__ int tg_slot(int* keys, int n, int key)
+{
+    int slot = (int)(((uint32_t)key * 2654435761u) >> 16) & (n - 1);
+    for (int t = 0; t < 4; ++t) {
+        const int old = atomicCAS(&keys[slot], -1, key);
+        if (old == -1 || old == key) return slot;
+        slot = (slot + 1) & (n - 1);
+    }
+    return -1;
+}
+
 // ---- presence of every non-zero instance id ------------------------------------------------
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_tg_presence(
     const void* __restrict__ ins, int ins_dtype, int P, int cap, int NC,
     unsigned char* __restrict__ ws, int* __restrict__ status)
 {
+    __shared__ int s_ids[TG_H1];
     const int b = blockIdx.y;
     TgView v = tg_view(ws, b, cap, NC);
-    const int stride = gridDim.x * blockDim.x;
-    const int trips = (P + stride - 1) / stride;
+    if (threadIdx.x < TG_H1) s_ids[threadIdx.x] = -1;
+    __syncthreads();
     bool bad = false;
-    for (int k = 0; k < trips; ++k) {
-        const int p = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-        int key = -1;
-        if (p < P) {
-            const int64_t i = mw_load(ins, ins_dtype, (size_t)b * P + p);
-            if (i < 0 || i > MW_MAX_ID) bad = true;
-            else if (i > 0) key = (int)i;
+    for (int p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 - (int)threadIdx.x * 4 < P;
+         p0 += gridDim.x * TG_PX_PER_BLOCK) {
+        int key[4] = {-1, -1, -1, -1};
+        if (p0 < P) {
+            int64_t id[4];
+            load_ins4<FAST>(ins, ins_dtype, (size_t)b * P + p0, min(4, P - p0), id);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (id[j] < 0 || id[j] > MW_MAX_ID) bad = true;
+                else if (id[j] > 0) key[j] = (int)id[j];
+            }
         }
-        wave_aggregate_add(key, [&](int id, uint32_t) { atomicOr(&v.bitmap[id >> 5], 1u << (id & 31)); });
+        // lanes whose 4 pixels agree (instance maps are coherent: almost all) are cut into runs,
+        // one atomic per run head; a boundary lane sets its own few bits
+        const bool same4 = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
+        int rl, rlast;
+        const int k4 = same4 ? key[0] : -1;
+        // big instances would hammer one bitmap word with thousands of same-address atomics:
+        // collect the workgroup's ids in a small LDS set, one global atomic per id at the end
+        auto set_bit = [&](int id) {
+            if (tg_slot(s_ids, TG_H1, id) < 0) atomicOr(&v.bitmap[id >> 5], 1u << (id & 31));
+        };
+        if (wave_run_head(k4, rl, rlast)) set_bit(k4);
+        if (!same4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (key[j] >= 0 && (j == 0 || key[j] != key[j - 1])) set_bit(key[j]);
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TG_H1 && s_ids[threadIdx.x] >= 0) {
+        const int id = s_ids[threadIdx.x];
+        atomicOr(&v.bitmap[id >> 5], 1u << (id & 31));
     }
     if (bad) atomicOr(status, TG_ST_ID_RANGE);
 }
@@ -135,50 +247,93 @@ __global__ __launch_bounds__(1024) void k_tg_rank(unsigned char* __restrict__ ws
 }
 
 // ---- per-instance statistics: class histogram, sum of y, sum of x --------------------------------
-template <bool WITH_MOMENTS>
+template <bool WITH_MOMENTS, bool FAST>
 __global__ __launch_bounds__(256) void k_tg_stats(
     const void* __restrict__ sem, int sem_dtype, const void* __restrict__ ins, int ins_dtype,
     int P, int W, int cap, int NC, unsigned char* __restrict__ ws, int* __restrict__ status)
 {
+    __shared__ TgLdsTables T;
     const int b = blockIdx.y;
     TgView v = tg_view(ws, b, cap, NC);
-    const int stride = gridDim.x * blockDim.x;
-    const int trips = (P + stride - 1) / stride;
+    for (int i = threadIdx.x; i < TG_H2; i += 256) {
+        T.k2[i] = -1; T.cnt[i] = 0;
+        if (i < TG_H1) { T.k1[i] = -1; T.sy[i] = 0; T.sx[i] = 0; }
+    }
+    __syncthreads();
+    auto add_vote = [&](int key, uint32_t n) {
+        const int slot = tg_slot(T.k2, TG_H2, key);
+        if (slot >= 0) atomicAdd(&T.cnt[slot], n);
+        else atomicAdd(&v.votes[key], n);
+    };
+    auto add_moments = [&](int dd, unsigned long long ay, unsigned long long ax) {
+        const int slot = tg_slot(T.k1, TG_H1, dd);
+        if (slot >= 0) { atomicAdd(&T.sy[slot], ay); atomicAdd(&T.sx[slot], ax); }
+        else { atomicAdd(&v.sum_y[dd], ay); atomicAdd(&v.sum_x[dd], ax); }
+    };
     bool bad = false;
-    for (int k = 0; k < trips; ++k) {
-        const int p = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-        int d = -1, vote_key = -1, y = 0, x = 0;
-        if (p < P) {
-            const size_t o = (size_t)b * P + p;
-            const int64_t i = mw_load(ins, ins_dtype, o);
-            if (i > 0 && i <= MW_MAX_ID) {
-                const int dd = id_rank_dense(v.bitmap, v.prefix, (int)i);
-                if (dd < cap) {
-                    d = dd;
-                    const int64_t s = mw_load(sem, sem_dtype, o);
-                    if (s < 0 || s >= NC) bad = true;
-                    else vote_key = dd * NC + (int)s;
-                    y = p / W;
-                    x = p - y * W;
+    for (int p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 - (int)threadIdx.x * 4 < P;
+         p0 += gridDim.x * TG_PX_PER_BLOCK) {
+        int d[4] = {-1, -1, -1, -1}, vote_key[4] = {-1, -1, -1, -1};
+        int y0 = 0, x0 = 0;
+        if (p0 < P) {
+            const int nvalid = min(4, P - p0);
+            int64_t id[4], sm[4];
+            load_ins4<FAST>(ins, ins_dtype, (size_t)b * P + p0, nvalid, id);
+            load_sem4<FAST>(sem, sem_dtype, (size_t)b * P + p0, nvalid, sm);
+            y0 = p0 / W;
+            x0 = p0 - y0 * W;
+            int dd_prev = -1;
+            int64_t id_prev = -1;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (id[j] <= 0 || id[j] > MW_MAX_ID) continue;
+                const int dd = (id[j] == id_prev) ? dd_prev : id_rank_dense(v.bitmap, v.prefix, (int)id[j]);
+                id_prev = id[j];
+                dd_prev = dd;
+                if (dd >= cap) continue;
+                d[j] = dd;
+                if (sm[j] < 0 || sm[j] >= NC) bad = true;
+                else vote_key[j] = dd * NC + (int)sm[j];
+            }
+        }
+        // class votes: lanes whose 4 pixels agree (the usual case) share ONE wave-aggregated
+        // round of weight 4; a boundary lane adds its own pixels
+        const bool votes_same = vote_key[0] == vote_key[1] && vote_key[1] == vote_key[2] &&
+                                vote_key[2] == vote_key[3];
+        int rl, rlast;
+        const int vk = votes_same ? vote_key[0] : -1;
+        if (wave_run_head(vk, rl, rlast)) add_vote(vk, 4u * (uint32_t)rl);
+        if (!votes_same) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (vote_key[j] >= 0) add_vote(vote_key[j], 1u);
+        }
+        if (WITH_MOMENTS) {
+            // same split for the coordinate sums: a lane with one instance in one row contributes
+            // (4y, 4x + 6); the sum over a run is a difference of two wave prefix sums
+            const bool lane_uniform = d[0] == d[1] && d[1] == d[2] && d[2] == d[3] && x0 + 3 < W;
+            const int dj = lane_uniform ? d[0] : -1;
+            const int ly = dj >= 0 ? 4 * y0 : 0, lx = dj >= 0 ? 4 * x0 + 6 : 0;
+            const int cy = mw_wave_scan(ly), cx = mw_wave_scan(lx);           // inclusive
+            const bool head = wave_run_head(dj, rl, rlast);
+            const int ey = __shfl(cy, rlast), ex = __shfl(cx, rlast);
+            if (head)
+                add_moments(dj, (unsigned long long)(ey - cy + ly), (unsigned long long)(ex - cx + lx));
+            if (!lane_uniform) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (d[j] < 0) continue;
+                    const int pj = x0 + j;
+                    add_moments(d[j], (unsigned long long)(y0 + pj / W), (unsigned long long)(pj % W));
                 }
             }
         }
-        wave_aggregate_add(vote_key, [&](int kk, uint32_t cnt) { atomicAdd(&v.votes[kk], cnt); });
-        if (WITH_MOMENTS) {
-            unsigned long long todo = __ballot(d >= 0);
-            while (todo) {
-                const int leader = __ffsll((long long)todo) - 1;
-                const int kd = __shfl(d, leader);
-                const bool mine = (d == kd);
-                const unsigned long long same = __ballot(mine) & todo;
-                const int sy = wave_reduce_sum_i(mine ? y : 0);
-                const int sx = wave_reduce_sum_i(mine ? x : 0);
-                if (lane_id() == 0) {       // __shfl_down reductions land in lane 0
-                    atomicAdd(&v.sum_y[kd], (unsigned long long)sy);
-                    atomicAdd(&v.sum_x[kd], (unsigned long long)sx);
-                }
-                todo &= ~same;
-            }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TG_H2; i += 256) {
+        if (T.k2[i] >= 0 && T.cnt[i]) atomicAdd(&v.votes[T.k2[i]], T.cnt[i]);
+        if (WITH_MOMENTS && i < TG_H1 && T.k1[i] >= 0) {
+            atomicAdd(&v.sum_y[T.k1[i]], T.sy[i]);
+            atomicAdd(&v.sum_x[T.k1[i]], T.sx[i]);
         }
     }
     if (bad) atomicOr(status, TG_ST_CLASS_RANGE);
@@ -250,7 +405,7 @@ constexpr int TGP_THREADS = 256;
 constexpr int TGP_PX = 1024;                 // consecutive pixels per workgroup
 constexpr int TGP_LUT_LDS = 4096;            // heat-map table entries kept in LDS (sigma <= 14)
 
-template <bool NORMALIZED>
+template <bool NORMALIZED, bool FAST>
 __global__ __launch_bounds__(TGP_THREADS) void k_tg_paint(
     const void* __restrict__ sem, int sem_dtype, const void* __restrict__ ins, int ins_dtype,
     const uint8_t* __restrict__ is_stuff_class, const float* __restrict__ gauss_lut, int lut_n,
@@ -298,44 +453,94 @@ __global__ __launch_bounds__(TGP_THREADS) void k_tg_paint(
     const int n_cand = s_n;
     const float* lut = lut_in_lds ? s_lut : gauss_lut;
 
-    for (int p = p_begin + threadIdx.x; p < p_end; p += TGP_THREADS) {
-        const int y = p / W, x = p - y * W;
-        const size_t o = (size_t)b * P + p;
-        // heat-map: max over the patches that cover this pixel (instance.py:213-229)
-        float hm = 0.f;
-        for (int i = 0; i < n_cand; ++i) {
-            const int dy = y - s_cand[2 * i], dx = x - s_cand[2 * i + 1];
-            if (abs(dy) <= radius && abs(dx) <= radius) hm = fmaxf(hm, lut[dy * dy + dx * dx]);
+    const int p0 = p_begin + threadIdx.x * 4;             // 4 consecutive pixels per thread
+    if (p0 >= p_end) return;
+    const int nvalid = min(4, p_end - p0);
+    const size_t o = (size_t)b * P + p0;
+    int yy[4], xx[4];
+    {
+        int y = p0 / W, x = p0 - y * W;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            yy[j] = y; xx[j] = x;
+            if (++x == W) { x = 0; ++y; }
         }
-        center[o] = hm;
-        // offsets / foreground (instance.py:201-206,232-237)
-        const int64_t id = mw_load(ins, ins_dtype, o);
-        bool fg = false;
-        int oy = 0, ox = 0;
-        if (id > 0 && id <= MW_MAX_ID) {
-            const int d = id_rank_dense(v.bitmap, v.prefix, (int)id);
+    }
+    // heat-map: max over the patches that cover the pixel (instance.py:213-229)
+    float hm[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < n_cand; ++i) {
+        const int cy = s_cand[2 * i], cx = s_cand[2 * i + 1];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int dy = yy[j] - cy, dx = xx[j] - cx;
+            if (abs(dy) <= radius && abs(dx) <= radius) hm[j] = fmaxf(hm[j], lut[dy * dy + dx * dx]);
+        }
+    }
+    // offsets / foreground (instance.py:201-206,232-237)
+    int64_t id[4], sm[4] = {0, 0, 0, 0};
+    load_ins4<FAST>(ins, ins_dtype, o, nvalid, id);
+    if (center_mask && is_stuff_class) load_sem4<FAST>(sem, sem_dtype, o, nvalid, sm);
+    uint8_t fg[4], cm[4];
+    int oy[4], ox[4];
+    int64_t id_prev = -1;
+    int d_prev = -1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        fg[j] = 0; oy[j] = 0; ox[j] = 0;
+        if (id[j] > 0 && id[j] <= MW_MAX_ID) {
+            const int d = (id[j] == id_prev) ? d_prev : id_rank_dense(v.bitmap, v.prefix, (int)id[j]);
+            id_prev = id[j];
+            d_prev = d;
             if (d < cap && v.enc[d]) {
-                fg = true;
-                oy = (int)(int16_t)(v.center_yx[2 * d] - y);        // int16 image (instance.py:180)
-                ox = (int)(int16_t)(v.center_yx[2 * d + 1] - x);
+                fg[j] = 1;
+                oy[j] = (int)(int16_t)(v.center_yx[2 * d] - yy[j]);       // int16 image (instance.py:180)
+                ox[j] = (int)(int16_t)(v.center_yx[2 * d + 1] - xx[j]);
             }
         }
-        const size_t oo = (size_t)b * 2 * P + p;
+        cm[j] = fg[j];
+        if (center_mask && is_stuff_class && sm[j] >= 0 && sm[j] < NC && is_stuff_class[sm[j]])
+            cm[j] = 1;                                                     // instance.py:263-269
+    }
+    const size_t oo = (size_t)b * 2 * P + p0;
+    if (FAST) {
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        typedef short i16x4_t __attribute__((ext_vector_type(4)));
+        typedef unsigned char u8x4_t __attribute__((ext_vector_type(4)));
+        f32x4_t h4; h4.x = hm[0]; h4.y = hm[1]; h4.z = hm[2]; h4.w = hm[3];
+        *(f32x4_t*)(center + o) = h4;
         if (NORMALIZED) {
-            ((float*)offset)[oo] = __fdiv_rn((float)oy, (float)H);   // instance.py:239-243
-            ((float*)offset)[oo + P] = __fdiv_rn((float)ox, (float)W);
+            f32x4_t a, c;                                                  // instance.py:239-243
+            a.x = __fdiv_rn((float)oy[0], (float)H); a.y = __fdiv_rn((float)oy[1], (float)H);
+            a.z = __fdiv_rn((float)oy[2], (float)H); a.w = __fdiv_rn((float)oy[3], (float)H);
+            c.x = __fdiv_rn((float)ox[0], (float)W); c.y = __fdiv_rn((float)ox[1], (float)W);
+            c.z = __fdiv_rn((float)ox[2], (float)W); c.w = __fdiv_rn((float)ox[3], (float)W);
+            *(f32x4_t*)((float*)offset + oo) = a;
+            *(f32x4_t*)((float*)offset + oo + P) = c;
         } else {
-            ((int16_t*)offset)[oo] = (int16_t)oy;
-            ((int16_t*)offset)[oo + P] = (int16_t)ox;
+            i16x4_t a, c;
+            a.x = (short)oy[0]; a.y = (short)oy[1]; a.z = (short)oy[2]; a.w = (short)oy[3];
+            c.x = (short)ox[0]; c.y = (short)ox[1]; c.z = (short)ox[2]; c.w = (short)ox[3];
+            *(i16x4_t*)((int16_t*)offset + oo) = a;
+            *(i16x4_t*)((int16_t*)offset + oo + P) = c;
         }
-        foreground[o] = fg;
+        u8x4_t f4; f4.x = fg[0]; f4.y = fg[1]; f4.z = fg[2]; f4.w = fg[3];
+        *(u8x4_t*)(foreground + o) = f4;
         if (center_mask) {
-            bool cm = fg;
-            if (is_stuff_class) {
-                const int64_t s = mw_load(sem, sem_dtype, o);
-                if (s >= 0 && s < NC && is_stuff_class[s]) cm = true;   // instance.py:263-269
+            u8x4_t c4; c4.x = cm[0]; c4.y = cm[1]; c4.z = cm[2]; c4.w = cm[3];
+            *(u8x4_t*)(center_mask + o) = c4;
+        }
+    } else {
+        for (int j = 0; j < nvalid; ++j) {
+            center[o + j] = hm[j];
+            if (NORMALIZED) {
+                ((float*)offset)[oo + j] = __fdiv_rn((float)oy[j], (float)H);
+                ((float*)offset)[oo + P + j] = __fdiv_rn((float)ox[j], (float)W);
+            } else {
+                ((int16_t*)offset)[oo + j] = (int16_t)oy[j];
+                ((int16_t*)offset)[oo + P + j] = (int16_t)ox[j];
             }
-            center_mask[o] = cm;
+            foreground[o + j] = fg[j];
+            if (center_mask) center_mask[o + j] = cm[j];
         }
     }
 }
@@ -391,6 +596,7 @@ __global__ __launch_bounds__(1024) void k_tg_naive_ranks(
     }
 }
 
+template <bool FAST>
 __global__ __launch_bounds__(256) void k_tg_naive_paint(
     const void* __restrict__ sem, int sem_dtype, const void* __restrict__ ins, int ins_dtype,
     const uint8_t* __restrict__ is_thing_class, int P, int cap, int NC, int64_t max_inst,
@@ -398,24 +604,42 @@ __global__ __launch_bounds__(256) void k_tg_naive_paint(
 {
     const int b = blockIdx.y;
     TgView v = tg_view(ws, b, cap, NC);
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const size_t o = (size_t)b * P + p;
-        const int64_t i = mw_load(ins, ins_dtype, o);
-        const int64_t s = mw_load(sem, sem_dtype, o);
-        int64_t r = void_label;
-        if (s > 0 && s < NC) {
-            if (i > 0 && i <= MW_MAX_ID) {
-                const int d = id_rank_dense(v.bitmap, v.prefix, (int)i);
-                if (d < cap) r = s * max_inst + v.votes[(size_t)d * NC + s];
-            } else if (i == 0 && !(is_thing_class && is_thing_class[s])) {
-                r = s * max_inst;                          // stuff paste (:90-101)
+    for (int p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * TG_PX_PER_BLOCK) {
+        const int nvalid = min(4, P - p0);
+        const size_t o = (size_t)b * P + p0;
+        int64_t id[4], sm[4], r[4];
+        load_ins4<FAST>(ins, ins_dtype, o, nvalid, id);
+        load_sem4<FAST>(sem, sem_dtype, o, nvalid, sm);
+        int64_t id_prev = -1;
+        int d_prev = -1;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = void_label;
+            const int64_t i = id[j], c = sm[j];
+            if (c > 0 && c < NC) {
+                if (i > 0 && i <= MW_MAX_ID) {
+                    const int d = (i == id_prev) ? d_prev : id_rank_dense(v.bitmap, v.prefix, (int)i);
+                    id_prev = i;
+                    d_prev = d;
+                    if (d < cap) r[j] = c * max_inst + v.votes[(size_t)d * NC + c];
+                } else if (i == 0 && !(is_thing_class && is_thing_class[c])) {
+                    r[j] = c * max_inst;                       // stuff paste (:90-101)
+                }
             }
         }
-        pan[o] = r;
+        if (FAST) {
+            typedef long i64x4_t __attribute__((ext_vector_type(4)));
+            i64x4_t q; q.x = r[0]; q.y = r[1]; q.z = r[2]; q.w = r[3];
+            *(i64x4_t*)(pan + o) = q;
+        } else {
+            for (int j = 0; j < nvalid; ++j) pan[o + j] = r[j];
+        }
     }
 }
 
 // ---- dense visual embedding targets -----------------------------------------------------------
+// The keys are searched by the WAVE, not per pixel: for every distinct panoptic id among the
+// wave's pixels (1-3 in practice) lane l compares key l, one ballot finds the last match.
 __global__ __launch_bounds__(256) void k_dve_indices(
     const int64_t* __restrict__ pan, const int64_t* __restrict__ keys, const int32_t* __restrict__ n_keys,
     int K, int P, int32_t* __restrict__ indices)
@@ -425,11 +649,44 @@ __global__ __launch_bounds__(256) void k_dve_indices(
     const int n = min(n_keys[b], K);
     for (int i = threadIdx.x; i < n; i += blockDim.x) s_keys[i] = keys[(size_t)b * K + i];
     __syncthreads();
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const int64_t id = pan[(size_t)b * P + p];
-        int idx = 0;
-        for (int i = 0; i < n; ++i) idx = (s_keys[i] == id) ? i + 1 : idx;   // last match wins
-        indices[(size_t)b * P + p] = idx;
+    const bool vec = (P % 4 == 0) && ((uintptr_t)pan % 32 == 0) && ((uintptr_t)indices % 16 == 0);
+    for (int p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 - (int)threadIdx.x * 4 < P;
+         p0 += gridDim.x * TG_PX_PER_BLOCK) {
+        const int nvalid = max(0, min(4, P - p0));
+        const size_t o = (size_t)b * P + p0;
+        int64_t id[4] = {0, 0, 0, 0};
+        if (nvalid == 4 && vec) {
+            typedef long i64x4_t __attribute__((ext_vector_type(4)));
+            const i64x4_t q = *(const i64x4_t*)(pan + o);
+            id[0] = q.x; id[1] = q.y; id[2] = q.z; id[3] = q.w;
+        } else {
+            for (int j = 0; j < nvalid; ++j) id[j] = pan[o + j];
+        }
+        int idx[4] = {0, 0, 0, 0};
+        for (int j = 0; j < 4; ++j) {
+            const bool repeat = j > 0 && id[j] == id[j - 1];
+            if (repeat) idx[j] = idx[j - 1];
+            if (__all(repeat || j >= nvalid)) continue;
+            unsigned long long todo = __ballot(!repeat && j < nvalid);
+            while (todo) {
+                const int leader = __ffsll((long long)todo) - 1;
+                const long long want = __shfl((long long)id[j], leader);
+                int found = 0;
+                for (int c0 = 0; c0 < n; c0 += 64) {
+                    const int i = c0 + lane_id();
+                    const unsigned long long m = __ballot(i < n && s_keys[i] == want);
+                    if (m) found = c0 + 64 - __clzll((long long)m);       // last match wins
+                }
+                const bool mine = !repeat && j < nvalid && id[j] == want;
+                if (mine) idx[j] = found;
+                todo &= ~__ballot(mine);
+            }
+        }
+        if (nvalid == 4 && vec) {
+            *(int4*)(indices + o) = make_int4(idx[0], idx[1], idx[2], idx[3]);
+        } else {
+            for (int j = 0; j < nvalid; ++j) indices[o + j] = idx[j];
+        }
     }
 }
 
@@ -469,25 +726,42 @@ __global__ __launch_bounds__(256) void k_clear_stuff(
 
 int tg_cap(int max_instances) { return ((max_instances + 1023) / 1024) * 1024; }
 
+// the vectorised label loaders apply to the on-wire dtypes with 4-pixel aligned images
+bool tg_fast(const void* sem, int sem_dtype, const void* ins, int ins_dtype, int P)
+{
+    return sem_dtype == NMSA_U8 && ins_dtype == NMSA_I32 && P % 4 == 0 &&
+           (uintptr_t)sem % 4 == 0 && (uintptr_t)ins % 16 == 0;
+}
+
+int tg_grid_x(int P)
+{
+    int gx = (P + TG_PX_PER_BLOCK - 1) / TG_PX_PER_BLOCK;
+    return gx > 1024 ? 1024 : gx;
+}
+
 int tg_common(const void* sem, int sem_dtype, const void* ins, int ins_dtype, int B, int NC, int P,
               int W, int cap, bool moments, unsigned char* ws, size_t need, int32_t* status,
               hipStream_t stream)
 {
     int rc = check_hip(hipMemsetAsync(ws, 0, need, stream));
     if (rc) return rc;
-    int gx = (P + 255) / 256;
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_tg_presence, dim3(gx, B), dim3(256), 0, stream, ins, ins_dtype, P, cap, NC, ws,
-                       status);
+    const int gx = tg_grid_x(P);
+    const bool fast = tg_fast(sem, sem_dtype, ins, ins_dtype, P);
+    if (fast)
+        hipLaunchKernelGGL(k_tg_presence<true>, dim3(gx, B), dim3(256), 0, stream, ins, ins_dtype, P, cap,
+                           NC, ws, status);
+    else
+        hipLaunchKernelGGL(k_tg_presence<false>, dim3(gx, B), dim3(256), 0, stream, ins, ins_dtype, P, cap,
+                           NC, ws, status);
     if ((rc = check_launch())) return rc;
     hipLaunchKernelGGL(k_tg_rank, dim3(B), dim3(1024), 0, stream, ws, cap, NC, status);
     if ((rc = check_launch())) return rc;
-    if (moments)
-        hipLaunchKernelGGL(k_tg_stats<true>, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins,
-                           ins_dtype, P, W, cap, NC, ws, status);
-    else
-        hipLaunchKernelGGL(k_tg_stats<false>, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins,
-                           ins_dtype, P, W, cap, NC, ws, status);
+#define NMSA_LAUNCH_STATS(M, F)                                                                     \
+    hipLaunchKernelGGL((k_tg_stats<M, F>), dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins,  \
+                       ins_dtype, P, W, cap, NC, ws, status)
+    if (moments) { if (fast) NMSA_LAUNCH_STATS(true, true); else NMSA_LAUNCH_STATS(true, false); }
+    else { if (fast) NMSA_LAUNCH_STATS(false, true); else NMSA_LAUNCH_STATS(false, false); }
+#undef NMSA_LAUNCH_STATS
     return check_launch();
 }
 
@@ -541,14 +815,16 @@ extern "C" int nmsa_instance_targets(const void* semantic, int sem_dtype, const 
     const int lut_n = 2 * radius * radius + 1;
     const size_t lds = (size_t)cap * 2 * sizeof(int) + (lut_n <= TGP_LUT_LDS ? (size_t)lut_n * 4 : 0);
     dim3 grid((P + TGP_PX - 1) / TGP_PX, B);
-    if (normalized_offset)
-        hipLaunchKernelGGL(k_tg_paint<true>, grid, dim3(TGP_THREADS), lds, stream, semantic, sem_dtype,
-                           instance, ins_dtype, is_stuff_class, gauss_lut, lut_n, radius, H, W, cap,
-                           n_classes, ws, center, offset, foreground, center_mask);
-    else
-        hipLaunchKernelGGL(k_tg_paint<false>, grid, dim3(TGP_THREADS), lds, stream, semantic, sem_dtype,
-                           instance, ins_dtype, is_stuff_class, gauss_lut, lut_n, radius, H, W, cap,
-                           n_classes, ws, center, offset, foreground, center_mask);
+    const bool fast = tg_fast(semantic, sem_dtype, instance, ins_dtype, P) &&
+                      (uintptr_t)center % 16 == 0 && (uintptr_t)offset % 16 == 0 &&
+                      (uintptr_t)foreground % 4 == 0 && (uintptr_t)center_mask % 4 == 0;
+#define NMSA_LAUNCH_TGP(N, F)                                                                          \
+    hipLaunchKernelGGL((k_tg_paint<N, F>), grid, dim3(TGP_THREADS), lds, stream, semantic, sem_dtype,  \
+                       instance, ins_dtype, is_stuff_class, gauss_lut, lut_n, radius, H, W, cap,       \
+                       n_classes, ws, center, offset, foreground, center_mask)
+    if (normalized_offset) { if (fast) NMSA_LAUNCH_TGP(true, true); else NMSA_LAUNCH_TGP(true, false); }
+    else { if (fast) NMSA_LAUNCH_TGP(false, true); else NMSA_LAUNCH_TGP(false, false); }
+#undef NMSA_LAUNCH_TGP
     return check_launch();
 }
 
@@ -581,11 +857,15 @@ extern "C" int nmsa_panoptic_targets(const void* semantic, int sem_dtype, const 
     hipLaunchKernelGGL(k_tg_naive_ranks, dim3(B), dim3(1024), 0, stream, ws, cap, n_classes, max_segments,
                        max_instances_per_category, ids_pan, ids_ins, n_ids, status);
     if ((rc = check_launch())) return rc;
-    int gx = (P + 255) / 256;
-    if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_tg_naive_paint, dim3(gx, B), dim3(256), 0, stream, semantic, sem_dtype, instance,
-                       ins_dtype, is_thing_class, P, cap, n_classes, max_instances_per_category, void_label,
-                       ws, panoptic);
+    const int gx = tg_grid_x(P);
+    if (tg_fast(semantic, sem_dtype, instance, ins_dtype, P) && (uintptr_t)panoptic % 32 == 0)
+        hipLaunchKernelGGL(k_tg_naive_paint<true>, dim3(gx, B), dim3(256), 0, stream, semantic, sem_dtype,
+                           instance, ins_dtype, is_thing_class, P, cap, n_classes,
+                           max_instances_per_category, void_label, ws, panoptic);
+    else
+        hipLaunchKernelGGL(k_tg_naive_paint<false>, dim3(gx, B), dim3(256), 0, stream, semantic, sem_dtype,
+                           instance, ins_dtype, is_thing_class, P, cap, n_classes,
+                           max_instances_per_category, void_label, ws, panoptic);
     return check_launch();
 }
 
@@ -600,8 +880,7 @@ extern "C" int nmsa_dve_targets(const int64_t* panoptic, const int64_t* keys, co
         (int64_t)H * W > ((int64_t)1 << 30))
         return NMSA_ERR_ARG;
     const int P = H * W;
-    int gx = (P + 255) / 256;
-    if (gx > 1024) gx = 1024;
+    const int gx = tg_grid_x(P);
     hipLaunchKernelGGL(k_dve_indices, dim3(gx, B), dim3(256), (size_t)K * sizeof(int64_t), stream,
                        panoptic, keys, n_keys, K, P, indices);
     int rc = check_launch();
