@@ -46,8 +46,11 @@ __global__ __launch_bounds__(256) void k_mw_presence(
     const void* __restrict__ ins, int ins_dtype, const uint8_t* __restrict__ thing_seg,
     int P, int cap, int NC, unsigned char* __restrict__ ws, int* __restrict__ status)
 {
+    __shared__ int s_ids[64];               // the workgroup's ids (lds_hash_slot), flushed once
     const int b = blockIdx.y;
     MwView v = mw_view(ws, b, cap, NC);
+    if (threadIdx.x < 64) s_ids[threadIdx.x] = -1;
+    __syncthreads();
     const int stride = gridDim.x * blockDim.x;
     const int trips = (P + stride - 1) / stride;
     bool bad = false;
@@ -62,7 +65,14 @@ __global__ __launch_bounds__(256) void k_mw_presence(
                 else key = (int)i;
             }
         }
-        wave_aggregate_add(key, [&](int id, uint32_t) { atomicOr(&v.bitmap[id >> 5], 1u << (id & 31)); });
+        wave_aggregate_add(key, [&](int id, uint32_t) {
+            if (lds_hash_slot(s_ids, 64, id) < 0) atomicOr(&v.bitmap[id >> 5], 1u << (id & 31));
+        });
+    }
+    __syncthreads();
+    if (threadIdx.x < 64 && s_ids[threadIdx.x] >= 0) {
+        const int id = s_ids[threadIdx.x];
+        atomicOr(&v.bitmap[id >> 5], 1u << (id & 31));
     }
     if (bad) atomicOr(status, MW_ST_ID_RANGE);
 }
@@ -103,8 +113,13 @@ __global__ __launch_bounds__(256) void k_mw_votes(
     const void* __restrict__ sem, int sem_dtype, const void* __restrict__ ins, int ins_dtype,
     const uint8_t* __restrict__ thing_seg, int P, int cap, int NC, unsigned char* __restrict__ ws)
 {
+    __shared__ int s_key[256];
+    __shared__ uint32_t s_cnt[256];
     const int b = blockIdx.y;
     MwView v = mw_view(ws, b, cap, NC);
+    s_key[threadIdx.x] = -1;
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
     const int stride = gridDim.x * blockDim.x;
     const int trips = (P + stride - 1) / stride;
     for (int k = 0; k < trips; ++k) {
@@ -119,8 +134,15 @@ __global__ __launch_bounds__(256) void k_mw_votes(
                 if (d < cap) key = d * NC + (int)s;
             }
         }
-        wave_aggregate_add(key, [&](int kk, uint32_t cnt) { atomicAdd(&v.votes[kk], cnt); });
+        wave_aggregate_add(key, [&](int kk, uint32_t cnt) {
+            const int slot = lds_hash_slot(s_key, 256, kk);
+            if (slot >= 0) atomicAdd(&s_cnt[slot], cnt);
+            else atomicAdd(&v.votes[kk], cnt);
+        });
     }
+    __syncthreads();
+    if (s_key[threadIdx.x] >= 0 && s_cnt[threadIdx.x])
+        atomicAdd(&v.votes[s_key[threadIdx.x]], s_cnt[threadIdx.x]);
 }
 
 // mode (smallest class on ties) + running per-class counter in ascending id order

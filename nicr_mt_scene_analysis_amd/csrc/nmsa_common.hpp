@@ -52,6 +52,22 @@ __device__ __forceinline__ void wave_aggregate_add(int key, AddFn add)
     }
 }
 
+// Slot of `key` in a small LDS hash set / table `keys[n]` (n a power of two, empty = -1): linear
+// probing, 4 tries, -1 when full there (callers then fall back to a global atomic).  Used to
+// privatise per-workgroup accumulators whose keys (instance ids, (instance, class) pairs) are
+// few per workgroup but shared by hundreds of workgroups — direct global atomics on them
+// serialise on a handful of addresses.
+__device__ __forceinline__ int lds_hash_slot(int* keys, int n, int key)
+{
+    int slot = (int)(((uint32_t)key * 2654435761u) >> 16) & (n - 1);
+    for (int t = 0; t < 4; ++t) {
+        const int old = atomicCAS(&keys[slot], -1, key);
+        if (old == -1 || old == key) return slot;
+        slot = (slot + 1) & (n - 1);
+    }
+    return -1;
+}
+
 __device__ __forceinline__ float wave_reduce_sum(float v)
 {
 #pragma unroll

@@ -373,6 +373,32 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_argmax(
 }
 
 // softmax over the class axis, f32 out (semantic.py:52 'semantic_softmax_scores')
+// ATen's max reduction propagates NaN; fmaxf drops it
+__device__ __forceinline__ float max_nan(float m, float v)
+{
+    return (v != v) ? v : ((m != m) ? m : fmaxf(m, v));
+}
+
+// exact three-pass column (max, sum of exp, normalise): the arithmetic of F.softmax incl. its
+// NaN results for columns with a NaN, a +inf or nothing but -inf
+template <int DTYPE>
+__device__ __noinline__ void softmax_column_3pass(const void* logits, size_t col0, int P, int C,
+                                                  float* probs)
+{
+    auto ld = [&](int c) -> float {
+        if (DTYPE == NMSA_F32) return ((const float*)logits)[col0 + (size_t)c * P];
+        const uint16_t h = ((const uint16_t*)logits)[col0 + (size_t)c * P];
+        return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
+    };
+    float m = -INFINITY, sum = 0.f;
+    for (int c = 0; c < C; ++c) m = max_nan(m, ld(c));
+    for (int c = 0; c < C; ++c) sum += __expf(ld(c) - m);
+    for (int c = 0; c < C; ++c) probs[col0 + (size_t)c * P] = __expf(ld(c) - m) / sum;
+}
+
+// generic: TWO passes over the logits (online max / sum of exp, then normalise) = 3 x 4C bytes
+// per pixel instead of the 4 x 4C of max / sum / normalise.  Columns holding a non-finite logit
+// (rare) are redone by the exact three-pass routine.
 template <int DTYPE, bool VEC>
 __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_softmax(
     const void* __restrict__ logits, int C, int P, float* __restrict__ probs)
@@ -383,28 +409,74 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_softmax(
     const int nvalid = min(4, P - p0);
     const size_t img = (size_t)b * C * P;
     float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    float sum[4] = {0.f, 0.f, 0.f, 0.f}, nf[4] = {0.f, 0.f, 0.f, 0.f};
     for (int c = 0; c < C; ++c) {
-        const float4 v = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
-        // fmaxf drops NaN; propagate it explicitly like ATen's max reduction
-        m[0] = (v.x != v.x) ? v.x : ((m[0] != m[0]) ? m[0] : fmaxf(m[0], v.x));
-        m[1] = (v.y != v.y) ? v.y : ((m[1] != m[1]) ? m[1] : fmaxf(m[1], v.y));
-        m[2] = (v.z != v.z) ? v.z : ((m[2] != m[2]) ? m[2] : fmaxf(m[2], v.z));
-        m[3] = (v.w != v.w) ? v.w : ((m[3] != m[3]) ? m[3] : fmaxf(m[3], v.w));
+        const float4 v4 = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
+        const float v[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            nf[j] = fmaf(v[j], 0.0f, nf[j]);                      // NaN once a logit is not finite
+            const float e = __expf(-fabsf(v[j] - m[j]));
+            sum[j] = (v[j] > m[j]) ? fmaf(sum[j], e, 1.0f) : (sum[j] + e);
+            m[j] = fmaxf(m[j], v[j]);
+        }
     }
-    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    float inv[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) inv[j] = 1.0f / sum[j];
     for (int c = 0; c < C; ++c) {
-        const float4 v = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
-        s[0] += expf(v.x - m[0]); s[1] += expf(v.y - m[1]);
-        s[2] += expf(v.z - m[2]); s[3] += expf(v.w - m[3]);
-    }
-    for (int c = 0; c < C; ++c) {
-        const float4 v = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
-        const float r[4] = {expf(v.x - m[0]) / s[0], expf(v.y - m[1]) / s[1],
-                            expf(v.z - m[2]) / s[2], expf(v.w - m[3]) / s[3]};
+        const float4 v4 = load_px4<DTYPE, VEC>(logits, img + (size_t)c * P + p0, nvalid);
+        const float r[4] = {__expf(v4.x - m[0]) * inv[0], __expf(v4.y - m[1]) * inv[1],
+                            __expf(v4.z - m[2]) * inv[2], __expf(v4.w - m[3]) * inv[3]};
         float* o = probs + img + (size_t)c * P + p0;
-        if (VEC) *(float4*)o = make_float4(r[0], r[1], r[2], r[3]);
-        else for (int j = 0; j < nvalid; ++j) o[j] = r[j];
+        if (VEC) {
+            f32x4_t q; q.x = r[0]; q.y = r[1]; q.z = r[2]; q.w = r[3];
+            __builtin_nontemporal_store(q, (f32x4_t*)o);
+        } else {
+            for (int j = 0; j < nvalid; ++j) o[j] = r[j];
+        }
     }
+    for (int j = 0; j < nvalid; ++j)
+        if (nf[j] != nf[j]) softmax_column_3pass<DTYPE>(logits, img + p0 + j, P, C, probs);
+}
+
+// C <= CMAX: the whole column of 4 pixels stays in registers — ONE read and one write of the
+// tensor (2 x 4C bytes per pixel).  The arithmetic is the plain max / sum / normalise, so the
+// non-finite cases need no special handling.
+template <int DTYPE, int CMAX>
+__global__ __launch_bounds__(FUSED_THREADS) void k_semantic_softmax_reg(
+    const void* __restrict__ logits, int C, int P, float* __restrict__ probs)
+{
+    const int b = blockIdx.y;
+    const int p0 = (blockIdx.x * FUSED_THREADS + threadIdx.x) * PX_PER_THREAD;
+    if (p0 >= P) return;
+    const size_t img = (size_t)b * C * P;
+    float4 v[CMAX];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) v[c] = load_px4<DTYPE, true, true>(logits, img + (size_t)c * P + p0, 4);
+    float m[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            m[0] = max_nan(m[0], v[c].x); m[1] = max_nan(m[1], v[c].y);
+            m[2] = max_nan(m[2], v[c].z); m[3] = max_nan(m[3], v[c].w);
+        }
+    float sum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            v[c].x = __expf(v[c].x - m[0]); v[c].y = __expf(v[c].y - m[1]);
+            v[c].z = __expf(v[c].z - m[2]); v[c].w = __expf(v[c].w - m[3]);
+            sum[0] += v[c].x; sum[1] += v[c].y; sum[2] += v[c].z; sum[3] += v[c].w;
+        }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+            f32x4_t q;
+            q.x = v[c].x / sum[0]; q.y = v[c].y / sum[1]; q.z = v[c].z / sum[2]; q.w = v[c].w / sum[3];
+            __builtin_nontemporal_store(q, (f32x4_t*)(probs + img + (size_t)c * P + p0));
+        }
 }
 
 // =================================================================================
@@ -645,29 +717,92 @@ __device__ __forceinline__ int64_t load_int(const void* p, int dtype, size_t i)
     }
 }
 
+// 4 consecutive integer labels; VEC = 4-element aligned rows (one wide load per tensor)
+template <bool VEC>
+__device__ __forceinline__ void load_int4(const void* p, int dtype, size_t o, int nvalid, int64_t out[4])
+{
+    if (VEC) {
+        switch (dtype) {
+            case NMSA_U8: {
+                const uchar4 v = *(const uchar4*)((const uint8_t*)p + o);
+                out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+                return;
+            }
+            case NMSA_I16: {
+                const short4 v = *(const short4*)((const int16_t*)p + o);
+                out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+                return;
+            }
+            case NMSA_I32: {
+                const int4 v = *(const int4*)((const int32_t*)p + o);
+                out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
+                return;
+            }
+            default: {
+                const longlong2 a = *(const longlong2*)((const int64_t*)p + o);
+                const longlong2 c = *(const longlong2*)((const int64_t*)p + o + 2);
+                out[0] = a.x; out[1] = a.y; out[2] = c.x; out[3] = c.y;
+                return;
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) out[j] = (j < nvalid) ? load_int(p, dtype, o + j) : 0;
+}
+
+constexpr int MG_PX_PER_BLOCK = 256 * 4;
+
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_merge_votes(
     const void* __restrict__ sem, int sem_dtype, const void* __restrict__ ins, int ins_dtype,
     const uint8_t* __restrict__ thing_seg, int NC, int P, uint32_t* __restrict__ votes)
 {
+    // per-workgroup (instance, class) counters in an LDS hash table, one global atomic per used
+    // slot at the end (see lds_hash_slot)
+    __shared__ int s_key[256];
+    __shared__ uint32_t s_cnt[256];
     const int b = blockIdx.y;
-    const int stride = gridDim.x * blockDim.x;
     uint32_t* votes_b = votes + (size_t)b * 256 * NC;
-    // uniform trip count so that every lane reaches the wave-level aggregation
-    const int trips = (P + stride - 1) / stride;
-    for (int k = 0; k < trips; ++k) {
-        const int p = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
-        int key = -1;
-        if (p < P) {
-            const size_t o = (size_t)b * P + p;
-            const int64_t i = load_int(ins, ins_dtype, o);
-            const int64_t s = load_int(sem, sem_dtype, o);
-            // is_thing = (ins > 0) & thing_seg  (panoptic_merge.py:182,198)
-            if (i > 0 && i < 256 && thing_seg[o] && s >= 0 && s < NC) key = (int)(i * NC + s);
+    s_key[threadIdx.x] = -1;
+    s_cnt[threadIdx.x] = 0;
+    __syncthreads();
+    auto add = [&](int kk, uint32_t cnt) {
+        const int slot = lds_hash_slot(s_key, 256, kk);
+        if (slot >= 0) atomicAdd(&s_cnt[slot], cnt);
+        else atomicAdd(&votes_b[kk], cnt);
+    };
+    // block-uniform trip count so that every lane reaches the wave-level aggregation
+    for (int p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 - (int)threadIdx.x * 4 < P;
+         p0 += gridDim.x * MG_PX_PER_BLOCK) {
+        int key[4] = {-1, -1, -1, -1};
+        if (p0 < P) {
+            const int nvalid = min(4, P - p0);
+            const size_t o = (size_t)b * P + p0;
+            int64_t i4[4], s4[4], t4[4];
+            load_int4<VEC>(ins, ins_dtype, o, nvalid, i4);
+            load_int4<VEC>(sem, sem_dtype, o, nvalid, s4);
+            load_int4<VEC>(thing_seg, NMSA_U8, o, nvalid, t4);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                // is_thing = (ins > 0) & thing_seg  (panoptic_merge.py:182,198)
+                if (j < nvalid && i4[j] > 0 && i4[j] < 256 && t4[j] && s4[j] >= 0 && s4[j] < NC)
+                    key[j] = (int)(i4[j] * NC + s4[j]);
         }
-        wave_aggregate_add(key, [&](int kk, uint32_t cnt) { atomicAdd(&votes_b[kk], cnt); });
+        // lanes whose 4 pixels agree share one aggregated round of weight 4; boundary lanes add
+        // their own pixels
+        const bool same4 = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
+        wave_aggregate_add(same4 ? key[0] : -1, [&](int kk, uint32_t cnt) { add(kk, 4u * cnt); });
+        if (!same4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) if (key[j] >= 0) add(key[j], 1u);
+        }
     }
+    __syncthreads();
+    if (s_key[threadIdx.x] >= 0 && s_cnt[threadIdx.x])
+        atomicAdd(&votes_b[s_key[threadIdx.x]], s_cnt[threadIdx.x]);
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_merge_paint(
     const void* __restrict__ sem, int sem_dtype, const void* __restrict__ ins, int ins_dtype,
     const uint8_t* __restrict__ thing_seg, const uint8_t* __restrict__ is_thing_class,
@@ -678,23 +813,35 @@ __global__ __launch_bounds__(256) void k_merge_paint(
     const int b = blockIdx.y;
     s_inst[threadIdx.x] = pan_of_inst[(size_t)b * 256 + threadIdx.x];
     __syncthreads();
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const size_t o = (size_t)b * P + p;
-        const int64_t i = load_int(ins, ins_dtype, o);
-        const int64_t s = load_int(sem, sem_dtype, o);
-        int64_t r = void_label;
-        if (i != 0) {
-            if (i > 0 && i < 256 && thing_seg[o]) r = s_inst[i];
-        } else if (s > 0 && s < NC && !is_thing_class[s]) {
-            r = s * max_inst;                                  // panoptic_merge.py:222-223
+    for (int p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * MG_PX_PER_BLOCK) {
+        const int nvalid = min(4, P - p0);
+        const size_t o = (size_t)b * P + p0;
+        int64_t i4[4], s4[4], t4[4], r[4];
+        load_int4<VEC>(ins, ins_dtype, o, nvalid, i4);
+        load_int4<VEC>(sem, sem_dtype, o, nvalid, s4);
+        load_int4<VEC>(thing_seg, NMSA_U8, o, nvalid, t4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            r[j] = void_label;
+            if (i4[j] != 0) {
+                if (i4[j] > 0 && i4[j] < 256 && t4[j]) r[j] = s_inst[i4[j]];
+            } else if (s4[j] > 0 && s4[j] < NC && !is_thing_class[s4[j]]) {
+                r[j] = s4[j] * max_inst;                       // panoptic_merge.py:222-223
+            }
         }
-        pan[o] = r;
+        if (VEC) {
+            *(longlong2*)(pan + o) = make_longlong2(r[0], r[1]);
+            *(longlong2*)(pan + o + 2) = make_longlong2(r[2], r[3]);
+        } else {
+            for (int j = 0; j < nvalid; ++j) pan[o + j] = r[j];
+        }
     }
 }
 
 // =================================================================================
 // next-1: per-instance biternion sums (instance.py:300-313)
 // =================================================================================
+template <bool VEC>
 __global__ __launch_bounds__(256) void k_orientation_sums(
     const float* __restrict__ orientation, const uint8_t* __restrict__ inst,
     const uint8_t* __restrict__ mask, int P, double* __restrict__ sums, int32_t* __restrict__ count)
@@ -707,14 +854,57 @@ __global__ __launch_bounds__(256) void k_orientation_sums(
     __syncthreads();
     const float* o0 = orientation + (size_t)b * 2 * P;
     const float* o1 = o0 + P;
-    for (int p = blockIdx.x * blockDim.x + threadIdx.x; p < P; p += gridDim.x * blockDim.x) {
-        const size_t o = (size_t)b * P + p;
-        const uint8_t id = inst[o];
-        if (!id) continue;
-        if (mask && !mask[o]) continue;
-        atomicAdd(&s_sum[id * 2 + 0], (double)o0[p]);
-        atomicAdd(&s_sum[id * 2 + 1], (double)o1[p]);
-        atomicAdd(&s_cnt[id], 1);
+    // 4 consecutive pixels per lane.  A lane whose pixels belong to one instance contributes its
+    // partial sums to ONE wave round: per distinct id (1-3 per wave) the wave sums its lanes in
+    // fp64 and lane 0 adds to the LDS table; boundary lanes add their pixels on their own.
+    for (int p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 - (int)threadIdx.x * 4 < P;
+         p0 += gridDim.x * MG_PX_PER_BLOCK) {
+        int id[4] = {0, 0, 0, 0};
+        float a[4] = {0.f, 0.f, 0.f, 0.f}, c[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p0 < P) {
+            const int nvalid = min(4, P - p0);
+            const size_t o = (size_t)b * P + p0;
+            int64_t i4[4], m4[4] = {1, 1, 1, 1};
+            load_int4<VEC>(inst, NMSA_U8, o, nvalid, i4);
+            if (mask) load_int4<VEC>(mask, NMSA_U8, o, nvalid, m4);
+            if (VEC) {
+                const float4 x = *(const float4*)(o0 + p0), y = *(const float4*)(o1 + p0);
+                a[0] = x.x; a[1] = x.y; a[2] = x.z; a[3] = x.w;
+                c[0] = y.x; c[1] = y.y; c[2] = y.z; c[3] = y.w;
+            } else {
+                for (int j = 0; j < nvalid; ++j) { a[j] = o0[p0 + j]; c[j] = o1[p0 + j]; }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) id[j] = (j < nvalid && m4[j]) ? (int)i4[j] : 0;
+        }
+        const bool same4 = id[0] == id[1] && id[1] == id[2] && id[2] == id[3];
+        const int lid = same4 ? id[0] : 0;
+        const double l0 = (double)a[0] + (double)a[1] + (double)a[2] + (double)a[3];
+        const double l1 = (double)c[0] + (double)c[1] + (double)c[2] + (double)c[3];
+        unsigned long long todo = __ballot(lid != 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int kid = __shfl(lid, leader);
+            const bool mine = (lid == kid);
+            const unsigned long long same = __ballot(mine) & todo;
+            const double r0 = wave_reduce_sum(mine ? l0 : 0.0);
+            const double r1 = wave_reduce_sum(mine ? l1 : 0.0);
+            if (lane_id() == 0) {
+                atomicAdd(&s_sum[kid * 2 + 0], r0);
+                atomicAdd(&s_sum[kid * 2 + 1], r1);
+                atomicAdd(&s_cnt[kid], 4 * (int)__popcll(same));
+            }
+            todo &= ~same;
+        }
+        if (!same4) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (!id[j]) continue;
+                atomicAdd(&s_sum[id[j] * 2 + 0], (double)a[j]);
+                atomicAdd(&s_sum[id[j] * 2 + 1], (double)c[j]);
+                atomicAdd(&s_cnt[id[j]], 1);
+            }
+        }
     }
     __syncthreads();
     const int t = threadIdx.x;
@@ -820,7 +1010,9 @@ int launch_softmax(const void* logits, int B, int C, int P, float* probs, hipStr
 {
     const bool vec = (P % 4 == 0) && (((uintptr_t)logits | (uintptr_t)probs) % 16 == 0);
     dim3 grid((P + PX_PER_ITER - 1) / PX_PER_ITER, B), block(FUSED_THREADS);
-    if (vec) hipLaunchKernelGGL((k_semantic_softmax<DTYPE, true>), grid, block, 0, stream, logits, C, P, probs);
+    if (vec && C <= 48 && getenv("NMSA_SOFTMAX_2PASS") == nullptr)
+        hipLaunchKernelGGL((k_semantic_softmax_reg<DTYPE, 48>), grid, block, 0, stream, logits, C, P, probs);
+    else if (vec) hipLaunchKernelGGL((k_semantic_softmax<DTYPE, true>), grid, block, 0, stream, logits, C, P, probs);
     else hipLaunchKernelGGL((k_semantic_softmax<DTYPE, false>), grid, block, 0, stream, logits, C, P, probs);
     return check_launch();
 }
@@ -996,10 +1188,16 @@ extern "C" int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* i
     const int P = H * W;
     int rc = check_hip(hipMemsetAsync(votes, 0, (size_t)B * 256 * n_classes * sizeof(uint32_t), stream));
     if (rc) return rc;
-    int gx = (P + 255) / 256;
+    int gx = (P + MG_PX_PER_BLOCK - 1) / MG_PX_PER_BLOCK;
     if (gx > 1024) gx = 1024;
-    hipLaunchKernelGGL(k_merge_votes, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins, ins_dtype,
-                       thing_seg, n_classes, P, votes);
+    const size_t esz[4] = {1, 2, 4, 8};
+    const bool vec = P % 4 == 0 && (uintptr_t)sem % (4 * esz[sem_dtype]) == 0 &&
+                     (uintptr_t)ins % (4 * esz[ins_dtype]) == 0 && (uintptr_t)thing_seg % 4 == 0 &&
+                     (uintptr_t)pan % 16 == 0;
+    if (vec) hipLaunchKernelGGL(k_merge_votes<true>, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins,
+                                ins_dtype, thing_seg, n_classes, P, votes);
+    else hipLaunchKernelGGL(k_merge_votes<false>, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins,
+                            ins_dtype, thing_seg, n_classes, P, votes);
     rc = check_launch();
     if (rc) return rc;
     hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_classes, 0,
@@ -1007,9 +1205,12 @@ extern "C" int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* i
                        ids_pan, ids_ins, n_ids);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_merge_paint, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins, ins_dtype,
-                       thing_seg, is_thing_class, pan_of_inst, n_classes, P,
-                       max_instances_per_category, void_label, pan);
+    if (vec) hipLaunchKernelGGL(k_merge_paint<true>, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins,
+                                ins_dtype, thing_seg, is_thing_class, pan_of_inst, n_classes, P,
+                                max_instances_per_category, void_label, pan);
+    else hipLaunchKernelGGL(k_merge_paint<false>, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins,
+                            ins_dtype, thing_seg, is_thing_class, pan_of_inst, n_classes, P,
+                            max_instances_per_category, void_label, pan);
     return check_launch();
 }
 
@@ -1024,8 +1225,12 @@ extern "C" int nmsa_instance_orientation(const float* orientation, const uint8_t
     if (rc) return rc;
     rc = check_hip(hipMemsetAsync(count, 0, (size_t)B * 256 * sizeof(int32_t), stream));
     if (rc) return rc;
-    int gx = (P + 4095) / 4096;
-    hipLaunchKernelGGL(k_orientation_sums, dim3(gx, B), dim3(256), 0, stream, orientation, inst, mask,
-                       P, sums, count);
+    const int gx = (P + 4 * MG_PX_PER_BLOCK - 1) / (4 * MG_PX_PER_BLOCK);
+    const bool vec = P % 4 == 0 && (uintptr_t)orientation % 16 == 0 && (uintptr_t)inst % 4 == 0 &&
+                     (uintptr_t)mask % 4 == 0;
+    if (vec) hipLaunchKernelGGL(k_orientation_sums<true>, dim3(gx, B), dim3(256), 0, stream, orientation,
+                                inst, mask, P, sums, count);
+    else hipLaunchKernelGGL(k_orientation_sums<false>, dim3(gx, B), dim3(256), 0, stream, orientation,
+                            inst, mask, P, sums, count);
     return check_launch();
 }

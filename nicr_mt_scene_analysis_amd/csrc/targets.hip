@@ -157,17 +157,6 @@ struct TgLdsTables {
     uint32_t cnt[TG_H2];
 };
 
-__device__ __forceinline__ int tg_slot(int* keys, int n, int key)
-{
-    int slot = (int)(((uint32_t)key * 2654435761u) >> 16) & (n - 1);
-    for (int t = 0; t < 4; ++t) {
-        const int old = atomicCAS(&keys[slot], -1, key);
-        if (old == -1 || old == key) return slot;
-        slot = (slot + 1) & (n - 1);
-    }
-    return -1;
-}
-
 // ---- presence of every non-zero instance id ------------------------------------------------
 template <bool FAST>
 __global__ __launch_bounds__(256) void k_tg_presence(
@@ -200,7 +189,7 @@ __global__ __launch_bounds__(256) void k_tg_presence(
         // big instances would hammer one bitmap word with thousands of same-address atomics:
         // collect the workgroup's ids in a small LDS set, one global atomic per id at the end
         auto set_bit = [&](int id) {
-            if (tg_slot(s_ids, TG_H1, id) < 0) atomicOr(&v.bitmap[id >> 5], 1u << (id & 31));
+            if (lds_hash_slot(s_ids, TG_H1, id) < 0) atomicOr(&v.bitmap[id >> 5], 1u << (id & 31));
         };
         if (wave_run_head(k4, rl, rlast)) set_bit(k4);
         if (!same4) {
@@ -261,12 +250,12 @@ __global__ __launch_bounds__(256) void k_tg_stats(
     }
     __syncthreads();
     auto add_vote = [&](int key, uint32_t n) {
-        const int slot = tg_slot(T.k2, TG_H2, key);
+        const int slot = lds_hash_slot(T.k2, TG_H2, key);
         if (slot >= 0) atomicAdd(&T.cnt[slot], n);
         else atomicAdd(&v.votes[key], n);
     };
     auto add_moments = [&](int dd, unsigned long long ay, unsigned long long ax) {
-        const int slot = tg_slot(T.k1, TG_H1, dd);
+        const int slot = lds_hash_slot(T.k1, TG_H1, dd);
         if (slot >= 0) { atomicAdd(&T.sy[slot], ay); atomicAdd(&T.sx[slot], ax); }
         else { atomicAdd(&v.sum_y[dd], ay); atomicAdd(&v.sum_x[dd], ax); }
     };

@@ -62,6 +62,16 @@ def main():
         'group_offsets': (lambda: ops.group_offsets(inp['instance_offset'], r['foreground'],
                                                     r['centers_yx'], r['n_centers'], H, W), 10),
     }
+    sem_i64 = (r['semantic_idx_u8'].long() + 1)
+    lut = torch.zeros((C + 1,), dtype=torch.uint8, device=dev)
+    lut[1:] = inp['semantic_classes_is_thing'].to(torch.uint8)
+    ins_i32 = r['instance'].int() * 37          # sparse "ground-truth" ids
+    tests['merge_u8'] = (lambda: ops.panoptic_merge(sem_i64, r['instance'], r['foreground'], lut,
+                                                    1 << 16, 0), 8 + 1 + 1 + 8)
+    tests['merge_wide'] = (lambda: ops.panoptic_merge_wide(sem_i64, ins_i32, r['foreground'], lut,
+                                                           1 << 16, 0), 8 + 4 + 1 + 8)
+    tests['orientation'] = (lambda: ops.instance_orientation_sums(
+        inp['instance_offset'], r['instance'], r['foreground']), 8 + 1 + 1)
     want = sys.argv[1:] or list(tests)
     for name in want:
         fn, bpp = tests[name]
