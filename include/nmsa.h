@@ -382,7 +382,10 @@ int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int
  * nmsa_loss_ce_*       CrossEntropyLossSemantic._compute_loss  loss/ce.py:40-68
  *     target u8 [B,H,W], 0 = void (ignored); weights f32 [C] or NULL;
  *     weight_sum (f64, may be NULL) = sum over non-void px of w[label]: the divisor
- *     of the ESANet `weighted_reduction` (ce.py:57-68)
+ *     of the ESANet `weighted_reduction` (ce.py:57-68);
+ *     lse2 f32 [B,H,W] (optional, NULL = off): the forward pass stores -log2(sum_c exp(x_c))
+ *     per pixel and the backward pass, given the same buffer, reads the logits ONCE
+ *     instead of twice (what autograd's saved log_softmax buys the reference)
  * nmsa_loss_masked_*   MSELoss / L1Loss (reduction='sum') loss/mse.py:21-41, l1.py:21-41
  *     with the masking of task_helper/instance.py:129-139,154-167:
  *     sum_px mean_c f(pred*mask - target), n = sum(mask); mask u8 [B,H,W] or NULL;
@@ -396,11 +399,12 @@ int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int
 size_t nmsa_loss_workspace_bytes(int B, int H, int W);
 int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* target, const float* weights,
                      int B, int C, int H, int W, float label_smoothing,
-                     double* loss_sum, int64_t* n_elements, double* weight_sum, int32_t* status,
-                     void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+                     double* loss_sum, int64_t* n_elements, double* weight_sum, float* lse2_out,
+                     int32_t* status, void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
 int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* target, const float* weights,
                      int B, int C, int H, int W, float label_smoothing,
-                     const float* grad_scale, void* grad_logits, nmsa_stream_t stream);
+                     const float* grad_scale, const float* lse2, void* grad_logits,
+                     nmsa_stream_t stream);
 int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
                          int B, int C, int H, int W, int kind,
                          double* loss_sum, int64_t* n_mask,

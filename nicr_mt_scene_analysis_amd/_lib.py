@@ -85,8 +85,9 @@ _SIGNATURES = {
     'nmsa_confmat_workspace_bytes': (_sz, [_i]),
     'nmsa_confmat_update': (_i, [_vp, _i, _i64, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_loss_workspace_bytes': (_sz, [_i, _i, _i]),
-    'nmsa_loss_ce_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'nmsa_loss_ce_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp]),
+    'nmsa_loss_ce_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                              _vp]),
+    'nmsa_loss_ce_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'nmsa_loss_masked_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_loss_masked_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'nmsa_loss_vonmises_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -259,7 +259,7 @@ template <int DTYPE, int PXT, bool SMOOTH>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
-    LossPartial* __restrict__ partials, int* __restrict__ status)
+    LossPartial* __restrict__ partials, int* __restrict__ status, float* __restrict__ lse2_out)
 {
     extern __shared__ float s_w[];
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
@@ -282,6 +282,21 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
             tt[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;       // ce.py:46
         ce_scan<DTYPE, PXT, U, SMOOTH, true, true>(logits, img, P, p0, nvalid, vec, C, s_w, tt,
                                                    m, s, swx, xts);
+        if (lse2_out) {
+            // log2-domain log-sum-exp per pixel, kept for the backward pass (one read of the
+            // logits there instead of two)
+            float k0[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));
+            float* q = lse2_out + (size_t)b * P + p0;
+            if (vec && nvalid == PXT) {
+#pragma unroll
+                for (int j = 0; j < PXT; j += 4)
+                    *(float4*)(q + j) = make_float4(k0[j], k0[j + 1], k0[j + 2], k0[j + 3]);
+            } else {
+                for (int j = 0; j < nvalid; ++j) q[j] = k0[j];
+            }
+        }
         float part = 0.f, partw = 0.f;
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
@@ -311,7 +326,7 @@ template <int DTYPE, int PXT, bool SMOOTH>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
-    const float* __restrict__ gscale, void* __restrict__ grad)
+    const float* __restrict__ gscale, void* __restrict__ grad, const float* __restrict__ lse2)
 {
     extern __shared__ float s_w[];
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
@@ -330,17 +345,34 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
 #pragma unroll
         for (int j = 0; j < PXT; ++j)
             t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;
-        // pass 1 with regular loads (the tile stays in L2 for pass 2)
-        ce_scan<DTYPE, PXT, U, false, false, false>(logits, img, P, p0, nvalid, vec, C, s_w, t,
-                                                    m, s, swx, xts);
         float ag[PXT], abg[PXT], k0[PXT];
+        if (lse2) {
+            // the forward pass left -log2(sum exp) per pixel: no first pass over the logits
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) k0[j] = 0.f;
+            const float* q = lse2 + (size_t)b * P + p0;
+            if (vec && nvalid == PXT) {
+#pragma unroll
+                for (int j = 0; j < PXT; j += 4) {
+                    const float4 f = *(const float4*)(q + j);
+                    k0[j] = f.x; k0[j + 1] = f.y; k0[j + 2] = f.z; k0[j + 3] = f.w;
+                }
+            } else {
+                for (int j = 0; j < nvalid; ++j) k0[j] = q[j];
+            }
+        } else {
+            // pass 1 with regular loads (the tile may still be in L2 / MALL for pass 2)
+            ce_scan<DTYPE, PXT, U, false, false, false>(logits, img, P, p0, nvalid, vec, C, s_w, t,
+                                                        m, s, swx, xts);
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));
+        }
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
             const bool on = t[j] >= 0 && t[j] < C;
             const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
             ag[j] = g * a;
-            abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
-            k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));            // p = 2^(x log2e + k0)
+            abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;   // p = 2^(x log2e + k0)
         }
         for (int c = 0; c < C; ++c) {
             float v[PXT], o[PXT];
@@ -717,6 +749,7 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
                                 const float* weights, int B, int C, int H, int W,
                                 float label_smoothing,
                                 double* loss_sum, int64_t* n_elements, double* weight_sum,
+                                float* lse2_out,
                                 int32_t* status, void* workspace, size_t workspace_bytes,
                                 nmsa_stream_t stream_)
 {
@@ -726,12 +759,13 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
     const int pxt = (dtype == NMSA_F32) ? 4 : 8;
-    const int vec = (P % pxt == 0) && ((((uintptr_t)logits) & 15) == 0);
+    const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)lse2_out) & 15) == 0);
     const int gx = grid_x(P, pxt);
     const bool smooth = label_smoothing != 0.0f;
     LossPartial* partials = (LossPartial*)workspace;
 #define CE_FWD(DT, PX, SM) hipLaunchKernelGGL((k_ce_fwd<DT, PX, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
-        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, partials, status)
+        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, partials, status, \
+        lse2_out)
     switch (dtype) {
         case NMSA_F32: if (smooth) CE_FWD(NMSA_F32, 4, true); else CE_FWD(NMSA_F32, 4, false); break;
         case NMSA_BF16: if (smooth) CE_FWD(NMSA_BF16, 8, true); else CE_FWD(NMSA_BF16, 8, false); break;
@@ -746,19 +780,21 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
 
 extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* target,
                                 const float* weights, int B, int C, int H, int W,
-                                float label_smoothing, const float* grad_scale, void* grad_logits,
-                                nmsa_stream_t stream_)
+                                float label_smoothing, const float* grad_scale, const float* lse2,
+                                void* grad_logits, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!logits || !target || !grad_scale || !grad_logits) return NMSA_ERR_ARG;
     if (bad_shape(B, H, W) || C <= 0 || C > 4096) return NMSA_ERR_ARG;
     const int P = H * W;
     const int pxt = (dtype == NMSA_F32) ? 4 : 8;
-    const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 15) == 0);
+    const int vec = (P % pxt == 0) &&
+                    ((((uintptr_t)logits | (uintptr_t)grad_logits | (uintptr_t)lse2) & 15) == 0);
     const int gx = grid_x(P, pxt);
     const bool smooth = label_smoothing != 0.0f;
 #define CE_BWD(DT, PX, SM) hipLaunchKernelGGL((k_ce_bwd<DT, PX, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
-        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, grad_scale, grad_logits)
+        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, grad_scale, \
+        grad_logits, lse2)
     switch (dtype) {
         case NMSA_F32: if (smooth) CE_BWD(NMSA_F32, 4, true); else CE_BWD(NMSA_F32, 4, false); break;
         case NMSA_BF16: if (smooth) CE_BWD(NMSA_BF16, 8, true); else CE_BWD(NMSA_BF16, 8, false); break;

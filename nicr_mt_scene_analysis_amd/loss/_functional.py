@@ -53,11 +53,17 @@ class CrossEntropyFunction(torch.autograd.Function):
         wsum = torch.empty((1,), dtype=torch.float64, device=dev)
         status = torch.zeros((1,), dtype=torch.int32, device=dev)
         ws, nbytes = _workspace(B, H, W, dev)
+        # per-pixel log-sum-exp for the backward pass (4 B/px instead of a second read of the
+        # logits), only when a gradient can be asked for
+        lse2 = torch.empty((B, H, W), dtype=torch.float32, device=dev) \
+            if ctx.needs_input_grad[0] else None
         L.check(L.lib().nmsa_loss_ce_fwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(t), L.ptr(w), B, C, H, W,
-            float(label_smoothing), L.ptr(s), L.ptr(n), L.ptr(wsum), L.ptr(status), L.ptr(ws),
-            nbytes, L.stream_ptr(dev)), 'nmsa_loss_ce_fwd')
-        ctx.save_for_backward(x, t, w if w is not None else torch.empty(0, device=dev))
+            float(label_smoothing), L.ptr(s), L.ptr(n), L.ptr(wsum), L.ptr(lse2), L.ptr(status),
+            L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_ce_fwd')
+        ctx.save_for_backward(x, t, w if w is not None else torch.empty(0, device=dev),
+                              lse2 if lse2 is not None else torch.empty(0, device=dev))
+        ctx.has_lse = lse2 is not None
         ctx.has_w = w is not None
         ctx.ls = float(label_smoothing)
         loss = s[0].to(torch.float32)
@@ -68,14 +74,14 @@ class CrossEntropyFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, g_n, g_w):
-        x, t, w = ctx.saved_tensors
+        x, t, w, lse2 = ctx.saved_tensors
         B, C, H, W = x.shape
         grad = torch.empty_like(x)
         gs = _grad_scale(g_loss)
         L.check(L.lib().nmsa_loss_ce_bwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(t), L.ptr(w) if ctx.has_w else None,
-            B, C, H, W, ctx.ls, L.ptr(gs), L.ptr(grad), L.stream_ptr(x.device)),
-            'nmsa_loss_ce_bwd')
+            B, C, H, W, ctx.ls, L.ptr(gs), L.ptr(lse2) if ctx.has_lse else None, L.ptr(grad),
+            L.stream_ptr(x.device)), 'nmsa_loss_ce_bwd')
         return grad, None, None, None
 
 

@@ -68,10 +68,10 @@ def main():
 
     rows = [
         ('CE fwd', ce_fwd, es * C + 1),
-        ('CE fwd+bwd', ce_fwd_bwd, 2 * (es * C + 1) + es * C),
+        ('CE fwd+bwd', ce_fwd_bwd, 2 * (es * C + 1) + es * C + 8),      # + saved log-sum-exp w/r
         ('4 losses fwd', fwd_all, es * C + 1 + (es + 4 + 1) + 2 * (2 * es + 8 + 1)),
         ('4 losses fwd+bwd', fwd_bwd_all,
-         2 * (es * C + 1 + (es + 4 + 1) + 2 * (2 * es + 8 + 1)) + es * C + es + 2 * es + 2 * es),
+         2 * (es * C + 1 + (es + 4 + 1) + 2 * (2 * es + 8 + 1)) + es * C + es + 2 * es + 2 * es + 8),
     ]
     for name, fn, bpp in rows:
         us = timeit(fn)
