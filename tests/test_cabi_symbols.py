@@ -30,3 +30,17 @@ def test_cpu_tensors_are_rejected_loudly():
     from nicr_mt_scene_analysis_amd import ops
     with pytest.raises(L.NmsaError):
         ops.semantic_argmax(torch.zeros((1, 3, 4, 4)))
+
+
+def test_header_is_plain_c99():
+    """include/nmsa.h is the FFI contract: it must compile as C (no C++ / HIP types)."""
+    import os
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        import pytest
+        pytest.skip('no gcc')
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    subprocess.check_call([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror',
+                           '-fsyntax-only', '-x', 'c', os.path.join(root, 'include', 'nmsa.h')])
