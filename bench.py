@@ -227,7 +227,7 @@ def main():
         'roofline': roofline,
     }
 
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # contract: rank 0 at N=1 only
         cb, (idx, inst, pan) = cpu_baseline(inp, args.cpu_sample_images, C, H, W, metrics)
         n = idx.shape[0]
         ok = bool((r['semantic_idx_u8'][:n].cpu().numpy() == idx).all()
@@ -241,7 +241,7 @@ def main():
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
-        dist.barrier()              # rank 0 may still be timing the CPU baseline
+        dist.barrier()
         dist.destroy_process_group()
 
 
