@@ -328,3 +328,34 @@ def test_full_size_properties(ops):
     # idempotence / determinism: a second run is bit-identical
     r2 = ops.panoptic_pipeline(logits, center, offset, is_thing)
     assert (r2['panoptic'] == pan).all() and (r2['instance'] == inst).all()
+
+
+def test_graphed_pipeline_matches_eager(ops):
+    """HIP-graph replay of the hot path (launch-bound small batches) == eager launches, also
+    after the bound inputs were overwritten in place."""
+    from nicr_mt_scene_analysis_amd.graph import GraphedPanopticPipeline
+    a = syn.make_panoptic_inputs(1, 12, 96, 128, n_centers=5, seed=41)
+    b = syn.make_panoptic_inputs(1, 12, 96, 128, n_centers=7, seed=42)
+    lg, ce, of = dev(a['semantic_logits']), dev(a['instance_center']), dev(a['instance_offset'])
+    th = dev(a['semantic_classes_is_thing'])
+    pipe = GraphedPanopticPipeline(lg, ce, of, th, want_score=True)
+    for inp in (a, b, a):
+        lg.copy_(dev(inp['semantic_logits']))
+        ce.copy_(dev(inp['instance_center']))
+        of.copy_(dev(inp['instance_offset']))
+        out = pipe.replay()
+        torch.cuda.synchronize()
+        got = {k: v.clone() for k, v in out.items() if isinstance(v, torch.Tensor)}
+        ref = ops.panoptic_pipeline(lg, ce, of, th, want_score=True)
+        torch.cuda.synchronize()
+        for k in ('panoptic', 'instance', 'semantic_idx_u8', 'semantic_score', 'n_centers',
+                  'centers_yx', 'ids_pan', 'ids_ins', 'n_ids', 'area'):
+            n = None
+            if k in ('centers_yx',):
+                n = int(ref['n_centers'][0])
+                assert torch.equal(got[k][:, :n], ref[k][:, :n]), k
+            elif k in ('ids_pan', 'ids_ins'):
+                n = int(ref['n_ids'][0])
+                assert torch.equal(got[k][:, :n], ref[k][:, :n]), k
+            else:
+                assert torch.equal(got[k], ref[k]), k
