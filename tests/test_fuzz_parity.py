@@ -1,0 +1,199 @@
+"""
+GPU tier (pytest -m gpu): randomised parity of the HIP hot path against the C oracle on small
+adversarial inputs — quantised logits / heat-maps / offsets so that EXACT ties (equal logits,
+plateaus in the heat-map, equidistant centers, equal top-k values) are common, odd shapes, tiny
+top-k, every heat-map kernel size, optional foreground masking and distance threshold.
+The oracle itself is pinned to the reference by tests/test_oracle_vs_golden.py.
+"""
+import numpy as np
+import pytest
+import torch
+
+from _golden import ids_from_arrays
+
+pytestmark = pytest.mark.gpu
+
+hypothesis = pytest.importorskip('hypothesis')
+from hypothesis import given, settings, strategies as st, HealthCheck   # noqa: E402
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+@st.composite
+def cases(draw):
+    B = draw(st.integers(1, 3))
+    C = draw(st.integers(2, 9))
+    H = draw(st.integers(6, 33))
+    W = draw(st.integers(6, 40))
+    seed = draw(st.integers(0, 2 ** 31 - 1))
+    levels = draw(st.sampled_from([2, 3, 5, 17]))            # few logit levels -> ties
+    heat_levels = draw(st.sampled_from([3, 6, 64]))
+    off_q = draw(st.sampled_from([1.0, 0.5, 0.125]))          # offsets on a px grid -> equal distances
+    ksize = draw(st.sampled_from([3, 5, 7]))
+    topk = draw(st.integers(1, 6))
+    thr = draw(st.sampled_from([0.0, 0.1, 0.34, 0.9]))
+    apply_fg = draw(st.booleans())
+    dist_thr = draw(st.sampled_from([None, 0.0, 2.0, 7.5]))
+    n_thing = draw(st.integers(0, C))
+    return dict(B=B, C=C, H=H, W=W, seed=seed, levels=levels, heat_levels=heat_levels, off_q=off_q,
+                ksize=ksize, topk=topk, thr=thr, apply_fg=apply_fg, dist_thr=dist_thr, n_thing=n_thing)
+
+
+def make_inputs(p):
+    rng = np.random.default_rng(p['seed'])
+    B, C, H, W = p['B'], p['C'], p['H'], p['W']
+    logits = rng.integers(0, p['levels'], (B, C, H, W)).astype(np.float32)
+    heat = (rng.integers(0, p['heat_levels'], (B, 1, H, W)) / (p['heat_levels'] - 1)).astype(np.float32)
+    # offsets: multiples of off_q pixels, normalised by (H, W) like the network head
+    off_px = rng.integers(-8, 9, (B, 2, H, W)) * p['off_q']
+    offset = np.stack([off_px[:, 0] / H, off_px[:, 1] / W], 1).astype(np.float32)
+    is_thing = np.zeros((C,), bool)
+    is_thing[rng.permutation(C)[:p['n_thing']]] = True
+    return logits, heat, offset, is_thing
+
+
+@settings(max_examples=300, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(p=cases())
+def test_fuzz_pipeline_vs_oracle(oracle, p):
+    from nicr_mt_scene_analysis_amd import ops
+    logits, heat, offset, is_thing = make_inputs(p)
+    B, C, H, W = logits.shape
+    r = ops.panoptic_pipeline(
+        dev(logits), dev(heat), dev(offset), dev(is_thing), threshold=p['thr'],
+        kernel_size=p['ksize'], top_k=p['topk'], apply_foreground_mask=p['apply_fg'],
+        distance_threshold=p['dist_thr'], want_score=True, want_panoptic_semantic=True,
+        max_centers=1024)
+    torch.cuda.synchronize()
+    r = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in r.items()}
+
+    idx, score = oracle.semantic_argmax(logits)
+    fg = is_thing[idx]
+    cyx, n, scores, _ = oracle.center_nms_topk(heat, fg=fg, threshold=p['thr'], ksize=p['ksize'],
+                                               topk=p['topk'], apply_fg=p['apply_fg'],
+                                               max_centers=1024)
+    assert (r['semantic_idx_u8'] == idx).all(), p
+    np.testing.assert_allclose(r['semantic_score'], score, rtol=1e-5, atol=1e-7)
+    assert (r['foreground'] == fg).all(), p
+    assert (r['n_centers'] == n).all(), p
+    for b in range(B):
+        assert (r['centers_yx'][b, :n[b]] == cyx[b, :n[b]]).all(), p
+        assert (r['center_scores'][b, :n[b]] == scores[b, :n[b]]).all(), p
+    if n.max() > 255:
+        return                      # uint8 wrap of the ids is pinned by the golden fixture only
+    inst, area = oracle.group_offsets(offset, fg, cyx, n, scale_y=H, scale_x=W, dist_thr=p['dist_thr'])
+    assert (r['instance'] == inst).all(), p
+    pan, ids = oracle.deeplab_merge(idx + 1, inst, fg, 1 << 16, np.where(is_thing)[0] + 1, 0)
+    assert (r['panoptic'] == pan).all(), p
+    got = ids_from_arrays(r['n_ids'], r['ids_pan'], r['ids_ins'])
+    assert [list(d.items()) for d in got] == [list(d.items()) for d in ids], p
+
+
+@settings(max_examples=150, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(4, 30), W=st.integers(4, 37),
+       n_cat=st.integers(2, 7), n_seg=st.integers(1, 9))
+def test_fuzz_metrics_vs_oracle(oracle, seed, B, H, W, n_cat, n_seg):
+    """random blocky panoptic maps: PQ states and confusion matrix bit-exact vs the oracle"""
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
+    rng = np.random.default_rng(seed)
+
+    def pan_map():
+        out = np.zeros((B, H, W), np.int64)
+        for b in range(B):
+            for _ in range(n_seg):
+                y0, x0 = rng.integers(0, H), rng.integers(0, W)
+                y1, x1 = rng.integers(y0, H) + 1, rng.integers(x0, W) + 1
+                cat = rng.integers(0, n_cat)
+                out[b, y0:y1, x0:x1] = cat * 65536 + (rng.integers(0, 4) if cat else 0)
+        return out
+    pred, tgt = pan_map(), pan_map()
+    is_thing = [False] + [bool(rng.integers(0, 2)) for _ in range(n_cat - 1)]
+    pq = PanopticQuality(n_cat, 0, 1 << 16, 256 ** 3, is_thing, device='cuda')
+    pq.update(dev(pred), dev(tgt))
+    state = None
+    for b in range(B):
+        *state, _ = oracle.pq_compare_and_accumulate(pred[b], tgt[b], n_cat, 0, 1 << 16, 256 ** 3,
+                                                     state=state)
+    torch.cuda.synchronize()
+    got = [pq.iou_per_class, pq.tp_per_class, pq.fn_per_class, pq.fp_per_class]
+    for g, w in zip(got, state):
+        assert np.array_equal(g.cpu().numpy(), np.asarray(w, dtype=np.float64)), (seed, B, H, W)
+    miou = MeanIntersectionOverUnion(n_cat, device='cuda')
+    miou.update(dev(pred // 65536), dev(tgt // 65536))
+    cm = oracle.confmat_update(pred // 65536, tgt // 65536, n_cat)
+    assert np.array_equal(miou.confmat.cpu().numpy(), cm)
+
+
+@settings(max_examples=120, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), Hs=st.integers(1, 40), Ws=st.integers(1, 48),
+       Ho=st.integers(1, 70), Wo=st.integers(1, 90), C=st.integers(1, 6))
+def test_fuzz_resize_vs_oracle(oracle, seed, Hs, Ws, Ho, Wo, C):
+    """random crop / resize geometries (up, down, 1-pixel planes, ragged widths): nearest maps and
+    bilinear logits bit-exact, fused resized argmax == argmax of the resized logits"""
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    y0 = int(rng.integers(0, Hs)); x0 = int(rng.integers(0, Ws))
+    y1 = int(rng.integers(y0 + 1, Hs + 1)); x1 = int(rng.integers(x0 + 1, Ws + 1))
+    crop = (slice(y0, y1), slice(x0, x1))
+    size = (Ho, Wo)
+    ids = rng.integers(0, 1 << 26, (2, Hs, Ws)).astype(np.int64)
+    assert np.array_equal(ops.resize_nearest(dev(ids), size, crop).cpu().numpy(),
+                          oracle.resize_nearest(ids, size, crop))
+    u8 = rng.integers(0, 256, (2, Hs, Ws)).astype(np.uint8)
+    assert np.array_equal(ops.resize_nearest(dev(u8), size, crop).cpu().numpy(),
+                          oracle.resize_nearest(u8, size, crop))
+    x = (rng.integers(-8, 9, (2, C, Hs, Ws)) * 0.37).astype(np.float32)   # few levels: ties
+    want = oracle.resize_bilinear(x, size, crop)
+    assert np.array_equal(ops.resize_bilinear(dev(x), size, crop).cpu().numpy(), want)
+    idx, score = oracle.semantic_argmax(want)
+    r = ops.semantic_argmax_resized(dev(x), size, crop, want_u8=True)
+    assert np.array_equal(r['idx'].cpu().numpy(), idx)
+    np.testing.assert_allclose(r['score'].cpu().numpy(), score, rtol=1e-5, atol=1e-7)
+
+
+@settings(max_examples=80, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(3, 36), W=st.integers(3, 44),
+       NC=st.integers(2, 8), n_inst=st.integers(0, 12), sigma=st.integers(1, 5),
+       normalized=st.booleans())
+def test_fuzz_targets_vs_oracle(oracle, seed, B, H, W, NC, n_inst, sigma, normalized):
+    """random small label maps (rectangles with sparse uint16 ids, mixed classes): target
+    generators bit-exact vs the oracle"""
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    sem = rng.integers(0, NC, (B, H, W)).astype(np.uint8)
+    ins = np.zeros((B, H, W), np.int32)
+    for b in range(B):
+        for _ in range(n_inst):
+            ya, xa = rng.integers(0, H), rng.integers(0, W)
+            yb, xb = rng.integers(ya, H) + 1, rng.integers(xa, W) + 1
+            ins[b, ya:yb, xa:xb] = rng.integers(1, 65536)
+            if rng.random() < 0.6:
+                sem[b, ya:yb, xa:xb] = rng.integers(0, NC)
+    is_thing = rng.random(NC) < 0.5
+    is_thing[0] = False
+    stuff = np.zeros((NC,), np.uint8)
+    stuff[np.where(~is_thing)[0][1:]] = 1
+    r = ops.instance_targets(dev(sem), dev(ins), NC, dev(is_thing.astype(np.uint8)), dev(stuff),
+                             sigma, normalized)
+    torch.cuda.synchronize()
+    assert int(r['status'].item()) == 0
+    o = oracle.instance_targets(sem, ins, NC, is_thing, stuff, sigma, normalized)
+    assert np.array_equal(r['center'].cpu().numpy(), o['center'])
+    assert np.array_equal(r['offset'].cpu().numpy(), o['offset'])
+    assert np.array_equal(r['foreground'].cpu().numpy(), o['foreground'])
+    assert np.array_equal(r['center_mask'].cpu().numpy(), o['center_mask'])
+    ne, ns = r['n_encoded'].cpu().numpy(), r['n_skipped'].cpu().numpy()
+    for b in range(B):
+        assert r['encoded_ids'][b, :ne[b]].cpu().tolist() == o['encoded'][b]
+        assert r['skipped_ids'][b, :ns[b]].cpu().tolist() == o['skipped'][b]
+    p = ops.panoptic_targets(dev(sem), dev(ins), NC, dev(is_thing.astype(np.uint8)), 1 << 16, 0)
+    assert int(p['status'].item()) == 0
+    pan, dicts = oracle.naive_merge(sem, ins, 1 << 16, np.where(is_thing)[0], 0)
+    assert np.array_equal(p['panoptic'].cpu().numpy(), pan)
+    got = ids_from_arrays(p['n_ids'].cpu().numpy(), p['ids_pan'].cpu().numpy(), p['ids_ins'].cpu().numpy())
+    assert [list(d.items()) for d in got] == [list(d.items()) for d in dicts]
