@@ -197,3 +197,62 @@ def test_fuzz_targets_vs_oracle(oracle, seed, B, H, W, NC, n_inst, sigma, normal
     assert np.array_equal(p['panoptic'].cpu().numpy(), pan)
     got = ids_from_arrays(p['n_ids'].cpu().numpy(), p['ids_pan'].cpu().numpy(), p['ids_ins'].cpu().numpy())
     assert [list(d.items()) for d in got] == [list(d.items()) for d in dicts]
+
+
+@settings(max_examples=120, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(2, 30), W=st.integers(2, 41),
+       NC=st.integers(2, 9), n_rect=st.integers(0, 10), wide=st.booleans())
+def test_fuzz_standalone_merge_vs_oracle(oracle, seed, B, H, W, NC, n_rect, wide):
+    """deeplab_merge_batch kernels (uint8 ids and ranked uint16 ids) on random maps where the
+    thing mask, the instance map and the semantic map deliberately disagree"""
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    sem = rng.integers(0, NC, (B, H, W)).astype(np.int64)
+    ins = np.zeros((B, H, W), np.int64)
+    for b in range(B):
+        for _ in range(n_rect):
+            ya, xa = rng.integers(0, H), rng.integers(0, W)
+            yb, xb = rng.integers(ya, H) + 1, rng.integers(xa, W) + 1
+            ins[b, ya:yb, xa:xb] = rng.integers(1, 65536 if wide else 256)
+    thing_ids = [int(c) for c in range(1, NC) if rng.random() < 0.5]
+    lut = np.zeros((NC,), np.uint8)
+    lut[thing_ids] = 1
+    thing_seg = (lut[sem] > 0) ^ (rng.random((B, H, W)) < 0.1)          # disagree on ~10 % of px
+    want_pan, want_ids = oracle.deeplab_merge(sem, ins, thing_seg, 1 << 16, thing_ids, 0)
+    if wide:
+        r = ops.panoptic_merge_wide(dev(sem), dev(ins.astype(np.int32)), dev(thing_seg), dev(lut),
+                                    1 << 16, 0)
+        assert int(r['status'].item()) == 0
+    else:
+        r = ops.panoptic_merge(dev(sem), dev(ins.astype(np.uint8)), dev(thing_seg), dev(lut), 1 << 16, 0)
+    torch.cuda.synchronize()
+    assert np.array_equal(r['panoptic'].cpu().numpy(), want_pan), (seed, wide)
+    got = ids_from_arrays(r['n_ids'].cpu().numpy(), r['ids_pan'].cpu().numpy(), r['ids_ins'].cpu().numpy())
+    assert [list(d.items()) for d in got] == [list(d.items()) for d in want_ids]
+
+
+@settings(max_examples=60, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(2, 30), W=st.integers(2, 41),
+       n_rect=st.integers(0, 8), with_mask=st.booleans())
+def test_fuzz_orientation_vs_oracle(oracle, seed, B, H, W, n_rect, with_mask):
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    ori = rng.standard_normal((B, 2, H, W)).astype(np.float32)
+    inst = np.zeros((B, H, W), np.uint8)
+    for b in range(B):
+        for _ in range(n_rect):
+            ya, xa = rng.integers(0, H), rng.integers(0, W)
+            yb, xb = rng.integers(ya, H) + 1, rng.integers(xa, W) + 1
+            inst[b, ya:yb, xa:xb] = rng.integers(1, 256)
+    mask = (rng.random((B, H, W)) < 0.7) if with_mask else None
+    want = oracle.instance_orientation(ori, inst, mask)
+    r = ops.instance_orientation_sums(dev(ori), dev(inst), None if mask is None else dev(mask))
+    torch.cuda.synchronize()
+    sums, cnt = r['sums'].cpu().numpy(), r['count'].cpu().numpy()
+    for b in range(B):
+        assert sorted(np.nonzero(cnt[b])[0].tolist()) == sorted(want[b].keys())
+        for i, ang in want[b].items():
+            got = float(np.arctan2(np.float32(sums[b, i, 1]), np.float32(sums[b, i, 0])))
+            assert abs(got - ang) < 1e-4 or abs(abs(got - ang) - 2 * np.pi) < 1e-4
