@@ -37,7 +37,8 @@ def cases(draw):
     apply_fg = draw(st.booleans())
     dist_thr = draw(st.sampled_from([None, 0.0, 2.0, 7.5]))
     n_thing = draw(st.integers(0, C))
-    return dict(B=B, C=C, H=H, W=W, seed=seed, levels=levels, heat_levels=heat_levels, off_q=off_q,
+    dtype = draw(st.sampled_from(['float32', 'bfloat16', 'float16']))
+    return dict(dtype=dtype, B=B, C=C, H=H, W=W, seed=seed, levels=levels, heat_levels=heat_levels, off_q=off_q,
                 ksize=ksize, topk=topk, thr=thr, apply_fg=apply_fg, dist_thr=dist_thr, n_thing=n_thing)
 
 
@@ -61,8 +62,10 @@ def test_fuzz_pipeline_vs_oracle(oracle, p):
     from nicr_mt_scene_analysis_amd import ops
     logits, heat, offset, is_thing = make_inputs(p)
     B, C, H, W = logits.shape
+    # the logit levels are small integers: exactly representable in bf16 / f16
     r = ops.panoptic_pipeline(
-        dev(logits), dev(heat), dev(offset), dev(is_thing), threshold=p['thr'],
+        dev(logits).to(getattr(torch, p['dtype'])), dev(heat), dev(offset), dev(is_thing),
+        threshold=p['thr'],
         kernel_size=p['ksize'], top_k=p['topk'], apply_foreground_mask=p['apply_fg'],
         distance_threshold=p['dist_thr'], want_score=True, want_panoptic_semantic=True,
         max_centers=1024)
