@@ -99,6 +99,60 @@ __device__ __noinline__ bool column_degenerate(const void* logits, size_t col0, 
     return nan_or_pinf || !any_finite;
 }
 
+// Exact argmax + score of one column (rare: the group-wise fast path of the WITH_SCORE kernels
+// came out with a NaN denominator): the reference's softmax -> max incl. its degenerate columns.
+// returns (score, class index as int bits): by value, so that no scratch slot is needed
+template <int DTYPE>
+__device__ __noinline__ float2 column_exact(const void* logits, size_t col0, int P, int C)
+{
+    auto ld = [&](int c) -> float {
+        if (DTYPE == NMSA_F32) return ((const float*)logits)[col0 + (size_t)c * P];
+        const uint16_t h = ((const uint16_t*)logits)[col0 + (size_t)c * P];
+        return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
+    };
+    bool nan_or_pinf = false, any_finite = false;
+    float m = -INFINITY;
+    int am = 0;
+    for (int c = 0; c < C; ++c) {
+        const float v = ld(c);
+        if (v != v || v == INFINITY) nan_or_pinf = true;
+        if (fabsf(v) < INFINITY) any_finite = true;
+        if (v > m) { m = v; am = c; }
+    }
+    if (nan_or_pinf || !any_finite) return make_float2(__int_as_float(0x7fc00000), __int_as_float(0));
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) {
+        const float v = ld(c);
+        se += (v == -INFINITY) ? 0.f : __expf(v - m);
+    }
+    return make_float2(1.0f / se, __int_as_float(am));
+}
+
+// classes c0 .. c0+3 of the 4 pixels of a lane (WITH_SCORE: one rescale per group, see
+// argmax_state.hpp; otherwise the per-class step)
+template <bool WITH_SCORE>
+__device__ __forceinline__ void argmax_quad(ArgmaxState& st, const float4& a, const float4& b,
+                                            const float4& c, const float4& d, int c0)
+{
+    if (WITH_SCORE) {
+        const float p0[4] = {a.x, b.x, c.x, d.x}, p1[4] = {a.y, b.y, c.y, d.y};
+        const float p2[4] = {a.z, b.z, c.z, d.z}, p3[4] = {a.w, b.w, c.w, d.w};
+        argmax_group4_score(st, 0, p0, c0);
+        argmax_group4_score(st, 1, p1, c0);
+        argmax_group4_score(st, 2, p2, c0);
+        argmax_group4_score(st, 3, p3, c0);
+    } else {
+        const float4 q[4] = {a, b, c, d};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            argmax_step<false>(st, 0, q[u].x, c0 + u);
+            argmax_step<false>(st, 1, q[u].y, c0 + u);
+            argmax_step<false>(st, 2, q[u].z, c0 + u);
+            argmax_step<false>(st, 3, q[u].w, c0 + u);
+        }
+    }
+}
+
 // ---- exact nearest-center search for 4 pixels -----------------------------------
 __device__ __forceinline__ float sqdist(float cy, float cx, float ly, float lx)
 {
@@ -227,38 +281,45 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
         ArgmaxState st;
         argmax_init(st);
         int c = 0;
+        static_assert(UNROLL % 4 == 0, "class groups of 4");
         for (; c + UNROLL <= C; c += UNROLL) {
             float4 v[UNROLL];
 #pragma unroll
             for (int u = 0; u < UNROLL; ++u)
                 v[u] = load_px4<DTYPE, VEC, NT>(logits, img_logits + (size_t)(c + u) * P + p0, nvalid);
 #pragma unroll
-            for (int u = 0; u < UNROLL; ++u) {
-                argmax_step<WITH_SCORE>(st, 0, v[u].x, c + u);
-                argmax_step<WITH_SCORE>(st, 1, v[u].y, c + u);
-                argmax_step<WITH_SCORE>(st, 2, v[u].z, c + u);
-                argmax_step<WITH_SCORE>(st, 3, v[u].w, c + u);
-            }
+            for (int u = 0; u < UNROLL; u += 4)
+                argmax_quad<WITH_SCORE>(st, v[u], v[u + 1], v[u + 2], v[u + 3], c + u);
         }
-        for (; c < C; ++c) {
-            const float4 v = load_px4<DTYPE, VEC, NT>(logits, img_logits + (size_t)c * P + p0, nvalid);
-            argmax_step<WITH_SCORE>(st, 0, v.x, c);
-            argmax_step<WITH_SCORE>(st, 1, v.y, c);
-            argmax_step<WITH_SCORE>(st, 2, v.z, c);
-            argmax_step<WITH_SCORE>(st, 3, v.w, c);
+        for (; c < C; c += 4) {                       // tail: pad the last group with -inf
+            float4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                v[u] = (c + u < C)
+                    ? load_px4<DTYPE, VEC, NT>(logits, img_logits + (size_t)(c + u) * P + p0, nvalid)
+                    : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+            argmax_quad<WITH_SCORE>(st, v[0], v[1], v[2], v[3], c);
         }
         int cls[4];
         bool fg[4];
         bool any_fg = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            // softmax of a column with a NaN / +inf / all -inf is all-NaN and
-            // torch.max then returns index 0 (semantic.py:52-53)
-            bool degenerate = false;
-            if (st.nf[j] != st.nf[j] && j < nvalid)     // some non-finite logit: exact re-check
-                degenerate = column_degenerate<DTYPE>(logits, img_logits + p0 + j, P, C);
-            cls[j] = degenerate ? 0 : st.am[j];
-            if (WITH_SCORE) st.se[j] = degenerate ? __int_as_float(0x7fc00000) : (1.0f / st.se[j]);
+            // softmax of a column with a NaN / +inf / all -inf is all-NaN and torch.max then
+            // returns index 0 (semantic.py:52-53).  A non-finite logit shows as NaN in `nf`
+            // (argmax only) or in the softmax denominator (with score): exact re-check, rare.
+            cls[j] = st.am[j];
+            if (WITH_SCORE) {
+                float sc = 1.0f / st.se[j];
+                if (st.se[j] != st.se[j] && j < nvalid) {
+                    const float2 ex = column_exact<DTYPE>(logits, img_logits + p0 + j, P, C);
+                    sc = ex.x;
+                    cls[j] = __float_as_int(ex.y);
+                }
+                st.se[j] = sc;
+            } else if (st.nf[j] != st.nf[j] && j < nvalid) {
+                if (column_degenerate<DTYPE>(logits, img_logits + p0 + j, P, C)) cls[j] = 0;
+            }
             fg[j] = (j < nvalid) && (thing[cls[j]] != 0);               // panoptic.py:123-127
             any_fg = any_fg || fg[j];
         }
@@ -346,29 +407,34 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_argmax(
 #pragma unroll
         for (int u = 0; u < 8; ++u)
             v[u] = load_px4<DTYPE, VEC, true>(logits, img + (size_t)(c + u) * P + p0, nvalid);
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            argmax_step<WITH_SCORE>(st, 0, v[u].x, c + u);
-            argmax_step<WITH_SCORE>(st, 1, v[u].y, c + u);
-            argmax_step<WITH_SCORE>(st, 2, v[u].z, c + u);
-            argmax_step<WITH_SCORE>(st, 3, v[u].w, c + u);
-        }
+        argmax_quad<WITH_SCORE>(st, v[0], v[1], v[2], v[3], c);
+        argmax_quad<WITH_SCORE>(st, v[4], v[5], v[6], v[7], c + 4);
     }
-    for (; c < C; ++c) {
-        const float4 v = load_px4<DTYPE, VEC, true>(logits, img + (size_t)c * P + p0, nvalid);
-        argmax_step<WITH_SCORE>(st, 0, v.x, c);
-        argmax_step<WITH_SCORE>(st, 1, v.y, c);
-        argmax_step<WITH_SCORE>(st, 2, v.z, c);
-        argmax_step<WITH_SCORE>(st, 3, v.w, c);
+    for (; c < C; c += 4) {                           // tail: pad the last group with -inf
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            v[u] = (c + u < C) ? load_px4<DTYPE, VEC, true>(logits, img + (size_t)(c + u) * P + p0, nvalid)
+                               : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        argmax_quad<WITH_SCORE>(st, v[0], v[1], v[2], v[3], c);
     }
     for (int j = 0; j < nvalid; ++j) {
-        bool degenerate = false;
-        if (st.nf[j] != st.nf[j]) degenerate = column_degenerate<DTYPE>(logits, img + p0 + j, P, C);
-        const int cls = degenerate ? 0 : st.am[j];
+        int cls = st.am[j];
+        float sc = 0.f;
+        if (WITH_SCORE) {
+            sc = 1.0f / st.se[j];
+            if (st.se[j] != st.se[j]) {
+                const float2 ex = column_exact<DTYPE>(logits, img + p0 + j, P, C);
+                sc = ex.x;
+                cls = __float_as_int(ex.y);
+            }
+        } else if (st.nf[j] != st.nf[j]) {
+            if (column_degenerate<DTYPE>(logits, img + p0 + j, P, C)) cls = 0;
+        }
         const size_t o = (size_t)b * P + p0 + j;
         if (idx_u8) idx_u8[o] = (uint8_t)cls;
         if (idx_i64) idx_i64[o] = cls;
-        if (WITH_SCORE) score[o] = degenerate ? __int_as_float(0x7fc00000) : (1.0f / st.se[j]);
+        if (WITH_SCORE) score[o] = sc;
     }
 }
 
@@ -976,12 +1042,12 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     if (vec && !score && DTYPE != NMSA_F32 && unroll16 != 8) {
         if (unroll16 == 16) NMSA_LAUNCH_FUSED_V(16, true);
         else if (unroll16 == 20) NMSA_LAUNCH_FUSED_V(20, true);
-        else NMSA_LAUNCH_FUSED_V(10, true);
+        else NMSA_LAUNCH_FUSED_V(12, true);
     } else if (vec && !score && DTYPE == NMSA_F32 && (unroll != 8 || !nt)) {
         if (unroll == 4 && !nt) NMSA_LAUNCH_FUSED_V(4, false);
-        else if (unroll == 10 && !nt) NMSA_LAUNCH_FUSED_V(10, false);
+        else if (unroll == 12 && !nt) NMSA_LAUNCH_FUSED_V(12, false);
         else if (unroll == 4) NMSA_LAUNCH_FUSED_V(4, true);
-        else if (unroll == 10) NMSA_LAUNCH_FUSED_V(10, true);
+        else if (unroll == 12) NMSA_LAUNCH_FUSED_V(12, true);
         else NMSA_LAUNCH_FUSED_V(8, false);
     } else if (vec) { if (score) NMSA_LAUNCH_FUSED(true, true); else NMSA_LAUNCH_FUSED(true, false); }
     else { if (score) NMSA_LAUNCH_FUSED(false, true); else NMSA_LAUNCH_FUSED(false, false); }

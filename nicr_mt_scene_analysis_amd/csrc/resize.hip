@@ -389,10 +389,11 @@ __device__ __forceinline__ float lds_elem(const void* plane, int i)
 
 // Exact re-evaluation of one output column (rare: the fast path's denominator came out NaN):
 // softmax-then-max semantics of semantic.py:74-75 incl. the degenerate columns.
+// returns (score, class index as int bits) by value: no scratch slot
 template <int DTYPE>
-__device__ __noinline__ void resized_column_exact(
+__device__ __noinline__ float2 resized_column_exact(
     const void* logits, size_t o00, size_t o01, size_t o10, size_t o11, size_t plane_stride,
-    int C, float wx0, float wx1, float wy0, float wy1, int& cls, float& score)
+    int C, float wx0, float wx1, float wy0, float wy1)
 {
     bool nan_or_pinf = false, any_finite = false;
     float m = -INFINITY;
@@ -407,7 +408,7 @@ __device__ __noinline__ void resized_column_exact(
         if (fabsf(v) < INFINITY) any_finite = true;
         if (v > m) { m = v; am = c; }
     }
-    if (nan_or_pinf || !any_finite) { cls = 0; score = __int_as_float(0x7fc00000); return; }
+    if (nan_or_pinf || !any_finite) return make_float2(__int_as_float(0x7fc00000), __int_as_float(0));
     float se = 0.f;
     for (int c = 0; c < C; ++c) {
         const size_t pc = (size_t)c * plane_stride;
@@ -417,8 +418,7 @@ __device__ __noinline__ void resized_column_exact(
             wx0, wx1, wy0, wy1));
         se += (v == -INFINITY) ? 0.f : __expf(v - m);
     }
-    cls = am;
-    score = 1.0f / se;
+    return make_float2(1.0f / se, __int_as_float(am));
 }
 
 template <int DTYPE, int MODE, int K16>
@@ -560,8 +560,10 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
             const size_t img = (size_t)p_begin * plane_stride;
             const size_t q0 = img + (size_t)(g.y0 + ys0 + r0[j] / P) * g.Ws + g.x0;
             const size_t q1 = img + (size_t)(g.y0 + ys0 + r1[j] / P) * g.Ws + g.x0;
-            resized_column_exact<DTYPE>(src, q0 + ix0, q0 + ix1, q1 + ix0, q1 + ix1, plane_stride, C,
-                                        wx0, wx1, wy0[j], wy1[j], cls, sc);
+            const float2 ex = resized_column_exact<DTYPE>(src, q0 + ix0, q0 + ix1, q1 + ix0, q1 + ix1,
+                                                          plane_stride, C, wx0, wx1, wy0[j], wy1[j]);
+            sc = ex.x;
+            cls = __float_as_int(ex.y);
         }
         const size_t o = ((size_t)grp * g.Ho + yy[j]) * g.Wo + x;
         if (idx_u8) idx_u8[o] = (uint8_t)cls;
