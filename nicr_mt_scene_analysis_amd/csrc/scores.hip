@@ -38,7 +38,8 @@ __device__ __forceinline__ int64_t class_of(int64_t pan, int64_t mipc, int shift
     return shift >= 0 ? (pan >> shift) : (pan / mipc);
 }
 
-template <int DTYPE>
+// 4 consecutive pixels per thread; VEC = 4-pixel aligned images (wide loads / stores)
+template <int DTYPE, bool VEC>
 __global__ __launch_bounds__(SC_THREADS) void k_scores_semantic(
     const void* __restrict__ logits, const uint8_t* __restrict__ sem_idx,
     const float* __restrict__ sem_prob, const uint8_t* __restrict__ inst,
@@ -60,26 +61,55 @@ __global__ __launch_bounds__(SC_THREADS) void k_scores_semantic(
     const size_t img_logits = (size_t)b * C * P;
     const int begin = blockIdx.x * SC_PX_PER_BLOCK;
     const int end = min(begin + SC_PX_PER_BLOCK, P);
-    for (int p = begin + threadIdx.x; p < end; p += SC_THREADS) {
-        const int64_t pn = pan[img + p];
-        const int64_t k = class_of(pn, mipc, shift);          // 0 = void, else class + 1
-        float s = 0.f;
-        if (k > 0 && k <= C) {
-            const int c = (int)k - 1, am = sem_idx[img + p];
-            const float pm = sem_prob[img + p];
-            if (c == am) {
-                s = pm;
-            } else {
-                const float xc = ld_logit<DTYPE>(logits, img_logits + (size_t)c * P + p);
-                const float xm = ld_logit<DTYPE>(logits, img_logits + (size_t)am * P + p);
-                s = __expf(xc - xm) * pm;
+    for (int p0 = begin + threadIdx.x * 4; p0 < end; p0 += SC_THREADS * 4) {
+        const int nvalid = min(4, end - p0);
+        int64_t pn[4] = {0, 0, 0, 0};
+        int am[4] = {0, 0, 0, 0}, id[4] = {0, 0, 0, 0};
+        float pm[4] = {0.f, 0.f, 0.f, 0.f}, s[4];
+        if (VEC) {
+            const longlong2 a = *(const longlong2*)(pan + img + p0), c = *(const longlong2*)(pan + img + p0 + 2);
+            pn[0] = a.x; pn[1] = a.y; pn[2] = c.x; pn[3] = c.y;
+            const uchar4 m4 = *(const uchar4*)(sem_idx + img + p0), i4 = *(const uchar4*)(inst + img + p0);
+            am[0] = m4.x; am[1] = m4.y; am[2] = m4.z; am[3] = m4.w;
+            id[0] = i4.x; id[1] = i4.y; id[2] = i4.z; id[3] = i4.w;
+            const float4 f = *(const float4*)(sem_prob + img + p0);
+            pm[0] = f.x; pm[1] = f.y; pm[2] = f.z; pm[3] = f.w;
+        } else {
+            for (int j = 0; j < nvalid; ++j) {
+                pn[j] = pan[img + p0 + j]; am[j] = sem_idx[img + p0 + j];
+                id[j] = inst[img + p0 + j]; pm[j] = sem_prob[img + p0 + j];
             }
         }
-        out_sem_score[img + p] = s;
-        const int id = inst[img + p];
-        if (id > 0 && s_pan[id] == pn) {
-            atomicAdd(&s_sum[id], (double)s);
-            atomicAdd(&s_cnt[id], 1u);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int64_t k = class_of(pn[j], mipc, shift);     // 0 = void, else class + 1
+            s[j] = 0.f;
+            if (j < nvalid && k > 0 && k <= C) {
+                const int c = (int)k - 1;
+                if (c == am[j]) {
+                    s[j] = pm[j];
+                } else {
+                    const float xc = ld_logit<DTYPE>(logits, img_logits + (size_t)c * P + p0 + j);
+                    const float xm = ld_logit<DTYPE>(logits, img_logits + (size_t)am[j] * P + p0 + j);
+                    s[j] = __expf(xc - xm) * pm[j];
+                }
+            }
+        }
+        if (VEC) *(float4*)(out_sem_score + img + p0) = make_float4(s[0], s[1], s[2], s[3]);
+        else for (int j = 0; j < nvalid; ++j) out_sem_score[img + p0 + j] = s[j];
+        // per-instance sum / count of the painted pixels: one LDS atomic per lane when its 4
+        // pixels belong to the same painted instance
+        bool painted[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) painted[j] = j < nvalid && id[j] > 0 && s_pan[id[j]] == pn[j];
+        if (painted[0] && painted[1] && painted[2] && painted[3] && id[0] == id[1] && id[1] == id[2] &&
+            id[2] == id[3]) {
+            atomicAdd(&s_sum[id[0]], (double)s[0] + (double)s[1] + (double)s[2] + (double)s[3]);
+            atomicAdd(&s_cnt[id[0]], 4u);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (painted[j]) { atomicAdd(&s_sum[id[j]], (double)s[j]); atomicAdd(&s_cnt[id[j]], 1u); }
         }
     }
     __syncthreads();
@@ -91,6 +121,7 @@ __global__ __launch_bounds__(SC_THREADS) void k_scores_semantic(
     }
 }
 
+template <bool VEC>
 __global__ __launch_bounds__(SC_THREADS) void k_scores_paint(
     const float* __restrict__ sem_score, const uint8_t* __restrict__ inst,
     const int64_t* __restrict__ pan, const int64_t* __restrict__ pan_of_inst,
@@ -118,11 +149,35 @@ __global__ __launch_bounds__(SC_THREADS) void k_scores_paint(
     const size_t img = (size_t)b * P;
     const int begin = blockIdx.x * SC_PX_PER_BLOCK;
     const int end = min(begin + SC_PX_PER_BLOCK, P);
-    for (int p = begin + threadIdx.x; p < end; p += SC_THREADS) {
-        const int id = inst[img + p];
-        const bool painted = id > 0 && s_pan[id] == pan[img + p];
-        out_inst_score[img + p] = painted ? s_inst[id] : 0.f;
-        out_pan_score[img + p] = painted ? s_prod[id] : sem_score[img + p];
+    for (int p0 = begin + threadIdx.x * 4; p0 < end; p0 += SC_THREADS * 4) {
+        const int nvalid = min(4, end - p0);
+        int64_t pn[4] = {0, 0, 0, 0};
+        int id[4] = {0, 0, 0, 0};
+        float ss[4] = {0.f, 0.f, 0.f, 0.f}, oi[4], op[4];
+        if (VEC) {
+            const longlong2 a = *(const longlong2*)(pan + img + p0), c = *(const longlong2*)(pan + img + p0 + 2);
+            pn[0] = a.x; pn[1] = a.y; pn[2] = c.x; pn[3] = c.y;
+            const uchar4 i4 = *(const uchar4*)(inst + img + p0);
+            id[0] = i4.x; id[1] = i4.y; id[2] = i4.z; id[3] = i4.w;
+            const float4 f = *(const float4*)(sem_score + img + p0);
+            ss[0] = f.x; ss[1] = f.y; ss[2] = f.z; ss[3] = f.w;
+        } else {
+            for (int j = 0; j < nvalid; ++j) {
+                pn[j] = pan[img + p0 + j]; id[j] = inst[img + p0 + j]; ss[j] = sem_score[img + p0 + j];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool painted = id[j] > 0 && s_pan[id[j]] == pn[j];
+            oi[j] = painted ? s_inst[id[j]] : 0.f;
+            op[j] = painted ? s_prod[id[j]] : ss[j];
+        }
+        if (VEC) {
+            *(float4*)(out_inst_score + img + p0) = make_float4(oi[0], oi[1], oi[2], oi[3]);
+            *(float4*)(out_pan_score + img + p0) = make_float4(op[0], op[1], op[2], op[3]);
+        } else {
+            for (int j = 0; j < nvalid; ++j) { out_inst_score[img + p0 + j] = oi[j]; out_pan_score[img + p0 + j] = op[j]; }
+        }
     }
 }
 
@@ -140,12 +195,19 @@ int launch_scores(const void* logits, const uint8_t* sem_idx, const float* sem_p
     rc = check_hip(hipMemsetAsync(counts, 0, (size_t)B * 256 * sizeof(uint32_t), stream));
     if (rc) return rc;
     dim3 grid((P + SC_PX_PER_BLOCK - 1) / SC_PX_PER_BLOCK, B), block(SC_THREADS);
-    hipLaunchKernelGGL((k_scores_semantic<DTYPE>), grid, block, 0, stream, logits, sem_idx, sem_prob,
-                       inst, pan, pan_of_inst, C, P, mipc, shift, out_sem, sums, counts);
+    const bool vec = P % 4 == 0 && (uintptr_t)pan % 16 == 0 && (uintptr_t)sem_idx % 4 == 0 &&
+                     (uintptr_t)inst % 4 == 0 && (uintptr_t)sem_prob % 16 == 0 &&
+                     ((uintptr_t)out_sem | (uintptr_t)out_inst | (uintptr_t)out_pan) % 16 == 0;
+    if (vec) hipLaunchKernelGGL((k_scores_semantic<DTYPE, true>), grid, block, 0, stream, logits, sem_idx,
+                                sem_prob, inst, pan, pan_of_inst, C, P, mipc, shift, out_sem, sums, counts);
+    else hipLaunchKernelGGL((k_scores_semantic<DTYPE, false>), grid, block, 0, stream, logits, sem_idx,
+                            sem_prob, inst, pan, pan_of_inst, C, P, mipc, shift, out_sem, sums, counts);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_scores_paint, grid, block, 0, stream, out_sem, inst, pan, pan_of_inst,
-                       inst_score_tab, sums, counts, P, out_inst, out_pan, mean_sem);
+    if (vec) hipLaunchKernelGGL(k_scores_paint<true>, grid, block, 0, stream, out_sem, inst, pan, pan_of_inst,
+                                inst_score_tab, sums, counts, P, out_inst, out_pan, mean_sem);
+    else hipLaunchKernelGGL(k_scores_paint<false>, grid, block, 0, stream, out_sem, inst, pan, pan_of_inst,
+                            inst_score_tab, sums, counts, P, out_inst, out_pan, mean_sem);
     return check_launch();
 }
 
