@@ -78,22 +78,24 @@ class InstancePostprocessing(DensePostprocessingBase):
     # ------------------------------------------------------------- segmentation
     @staticmethod
     def _meta_from_tables(n_host, centers_yx, scores, area) -> List[Dict[int, dict]]:
-        k = centers_yx.shape[1]
-        packed = torch.cat([centers_yx.reshape(centers_yx.shape[0], -1).to(torch.float64),
-                            scores.to(torch.float64),
-                            area.to(torch.float64)], dim=1).cpu().tolist()
+        """ONE small device->host copy: only the first max(n) columns of the tables travel."""
+        B = centers_yx.shape[0]
+        nmax = max(1, min(max(n_host) if len(n_host) else 1, centers_yx.shape[1]))
+        ka = min(nmax, 255)
+        packed = torch.cat([centers_yx[:, :nmax].reshape(B, -1).to(torch.float64),
+                            scores[:, :nmax].to(torch.float64),
+                            area[:, 1:ka + 1].to(torch.float64)], dim=1).cpu().tolist()
         meta = []
         for b, n in enumerate(n_host):
             row = packed[b]
-            d = {}
-            for i in range(n):
-                # ids wrap at 256 (uint8, instance.py:236): bincount(minlength=n+1) has
-                # no entries beyond 255
-                a = int(row[3 * k + i + 1]) if i + 1 <= 255 else 0
-                d[i + 1] = {'center_yx': (int(row[2 * i]), int(row[2 * i + 1])),
-                            'area': a,
-                            'score': row[2 * k + i]}
-            meta.append(d)
+            n = min(n, nmax)
+            # ids wrap at 256 (uint8, instance.py:236): bincount(minlength=n+1) has no entries
+            # beyond 255
+            areas = row[3 * nmax:3 * nmax + min(n, ka)] + [0.0] * max(0, n - ka)
+            meta.append({
+                i + 1: {'center_yx': (int(y), int(x)), 'area': int(a), 'score': sc}
+                for i, (y, x, sc, a) in enumerate(zip(row[0:2 * n:2], row[1:2 * n:2],
+                                                      row[2 * nmax:2 * nmax + n], areas))})
         return meta
 
     def _get_instance_segmentation(

@@ -125,7 +125,8 @@ class PanopticPostprocessing(DensePostprocessingBase):
         pan_semantic = p['panoptic_semantic']
         r['panoptic_foreground_mask'] = p['foreground']
         r['panoptic_segmentation_deeplab'] = panoptic_seg
-        panoptic_ids = _ids_to_dicts(p['ids_pan'], p['ids_ins'], p['n_ids'])
+        # every id-dict entry is an instance: at most max(n_centers) (<= 255 ids) per image
+        panoptic_ids = _ids_to_dicts(p['ids_pan'], p['ids_ins'], p['n_ids'], limit=min(n_max, 255))
         r['panoptic_segmentation_deeplab_ids'] = panoptic_ids
         r['panoptic_segmentation_deeplab_semantic_idx'] = pan_semantic
         r['panoptic_segmentation_deeplab_instance_idx'] = instance_seg

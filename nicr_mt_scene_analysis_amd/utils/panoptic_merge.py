@@ -18,15 +18,18 @@ from .. import ops
 _MAX_INSTANCE_ID = 255
 
 
-def _ids_to_dicts(ids_pan: torch.Tensor, ids_ins: torch.Tensor,
-                  n_ids: torch.Tensor) -> List[Dict[int, int]]:
-    """ONE device->host copy of the small per-image id tables."""
-    packed = torch.cat([ids_pan, ids_ins, n_ids.to(torch.int64).unsqueeze(1)], dim=1).cpu()
-    k = ids_pan.shape[1]
+def _ids_to_dicts(ids_pan: torch.Tensor, ids_ins: torch.Tensor, n_ids: torch.Tensor,
+                  limit: Optional[int] = None) -> List[Dict[int, int]]:
+    """ONE device->host copy of the small per-image id tables.  `limit`: a known upper bound of
+    n_ids (e.g. the largest number of instances of an image), so that only that many columns
+    travel."""
+    k = ids_pan.shape[1] if limit is None else max(1, min(int(limit), ids_pan.shape[1]))
+    packed = torch.cat([ids_pan[:, :k], ids_ins[:, :k], n_ids.to(torch.int64).unsqueeze(1)],
+                       dim=1).cpu()
     out = []
     for row in packed.tolist():
-        n = row[2 * k]
-        out.append({row[i]: row[k + i] for i in range(n)})    # insertion order = ascending id
+        n = min(row[2 * k], k)
+        out.append(dict(zip(row[:n], row[k:k + n])))           # insertion order = ascending id
     return out
 
 

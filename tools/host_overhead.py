@@ -36,3 +36,27 @@ m.wait()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f'with metrics  : host enqueue {1e6*(t1-t0)/N:7.1f} us/step, total {1e6*(t2-t0)/N:7.1f} us/step')
+
+# ---- the reference-shaped API: PanopticPostprocessing.postprocess (one host sync per call for
+#      the center counts, Python dicts for ids / instance meta) --------------------------------
+from nicr_mt_scene_analysis_amd.data.preprocessing import APPLIED_PREPROCESSING_KEY   # noqa: E402
+from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class  # noqa: E402
+
+is_thing = tuple(bool(x) for x in inp['semantic_classes_is_thing'].cpu().tolist())
+post = get_postprocessing_class('panoptic')(
+    semantic_postprocessing=get_postprocessing_class('semantic')(),
+    instance_postprocessing=get_postprocessing_class('instance')(),
+    semantic_classes_is_thing=is_thing, semantic_class_has_orientation=is_thing)
+batch = {'rgb_fullres': torch.zeros((32, 3, 480, 640)),
+         APPLIED_PREPROCESSING_KEY: [[{'type': 'Resize', 'valid_region_slice_y': slice(0, 480),
+                                       'valid_region_slice_x': slice(0, 640)}]] * 32}
+data = ((a[0], (a[1], a[2])), (None, None))
+for _ in range(5):
+    post.postprocess(data, batch, is_training=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(50):
+    rr = post.postprocess(data, batch, is_training=False)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 50
+print(f'postprocess() : {1e6*dt:7.1f} us/call  ({32*480*640/dt/1e6:8.1f} Mpix/s, dicts + meta included)')
