@@ -1,21 +1,16 @@
-"""`LossBase` (reference loss/base.py:12-33): one (loss, n_elements) pair per scale."""
-import abc
-from typing import Sequence, Tuple
-
+"""Multi-scale loss container (interface of reference loss/base.py:12-33): a loss module is
+called with the list of predictions (main output first, then the side outputs) and the list
+of matching targets and answers with one `(loss_sum, n_elements)` pair per scale."""
 import torch
 
 
-class LossBase(abc.ABC, torch.nn.Module):
-    def __init__(self) -> None:
-        super().__init__()
+class LossBase(torch.nn.Module):
+    def _compute_loss(self, input_, target):
+        """one scale -> (loss, number of loss elements)"""
+        raise NotImplementedError(f'{type(self).__name__} must define _compute_loss')
 
-    @abc.abstractmethod
-    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor):
-        """-> (loss, number of loss elements)"""
-
-    def forward(
-        self,
-        input_tensors: Sequence[torch.Tensor],
-        target_tensors: Sequence[torch.Tensor]
-    ) -> Tuple[Tuple[torch.Tensor, int], ...]:
-        return tuple(self._compute_loss(i, t) for i, t in zip(input_tensors, target_tensors))
+    def forward(self, input_tensors, target_tensors):
+        pairs = []
+        for prediction, target in zip(input_tensors, target_tensors):
+            pairs.append(self._compute_loss(prediction, target))
+        return tuple(pairs)

@@ -24,9 +24,9 @@ class VonMisesLossBiternion(LossBase):
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor):
         if input_.ndim != 2 or target.ndim != 2:
             raise ValueError(
-                "VonMisesLossBiternion does only support 2d inputs with shape (n, 2), you can "
-                "transpose your input to channels last and reshape to shape (b*h*w, c=2), "
-                "e.g., (b, c, h, w) -> (b, h, w, c) -> (b*h*w, c) with c = 2.")
+                f"expected biternion rows of shape (n, 2), got {tuple(input_.shape)} / "
+                f"{tuple(target.shape)}; permute (b, 2, h, w) to (b, h, w, 2) and flatten to "
+                "(b*h*w, 2) first, or call masked_sum() with the planar tensors")
         n = input_.shape[0]
         if self._reduction == 'none' or not input_.is_cuda or n == 0:
             cos = (input_ * target).sum(dim=1, keepdim=True)

@@ -25,36 +25,47 @@ def _abs_angle_error_f32(pred_angle: float, target_angle: float) -> float:
     return float(abs_angle_error_rad(torch.tensor(pred_angle), torch.tensor(target_angle)))
 
 
-class MeanAbsoluteAngularError(Metric):
-    def __init__(self, **kwargs) -> None:
-        super().__init__(**kwargs)
+class _AngularErrorStates:
+    """the two accumulators both metrics share: sum of |angle error| (rad) and its count"""
+
+    def _add_angular_states(self) -> None:
         self.add_state('sum_angular_error', torch.tensor(0, dtype=torch.float64),
                        dist_reduce_fx='sum')
-        self.add_state('n_elements', torch.tensor(0, dtype=torch.int64),
-                       dist_reduce_fx='sum')
+        self.add_state('n_elements', torch.tensor(0, dtype=torch.int64), dist_reduce_fx='sum')
 
-    def update(self, orientation_preds: List[OrientationDict],
-               orientation_target: List[OrientationDict]) -> None:
+    def _accumulate(self, pairs) -> None:
+        """pairs: iterable of (predicted angle, target angle) in rad"""
         total, n = 0.0, 0
-        for preds, targets in zip(orientation_preds, orientation_target):
-            for key, pred_angle in preds.items():
-                total += _abs_angle_error_f32(float(pred_angle), float(targets[key]))
-                n += 1
+        for pred_angle, target_angle in pairs:
+            total += _abs_angle_error_f32(float(pred_angle), float(target_angle))
+            n += 1
         self.sum_angular_error += total
         self.n_elements += n
 
+    def _mean_rad(self) -> torch.Tensor:
+        return self.sum_angular_error / self.n_elements
+
+
+class MeanAbsoluteAngularError(_AngularErrorStates, Metric):
+    def __init__(self, **kwargs) -> None:
+        super().__init__(**kwargs)
+        self._add_angular_states()
+
+    def update(self, orientation_preds: List[OrientationDict],
+               orientation_target: List[OrientationDict]) -> None:
+        self._accumulate((angle, targets[key])
+                         for preds, targets in zip(orientation_preds, orientation_target)
+                         for key, angle in preds.items())
+
     def compute(self) -> Tuple[torch.Tensor, torch.Tensor]:
-        rad = self.sum_angular_error / self.n_elements
+        rad = self._mean_rad()
         return rad, torch.rad2deg(rad)
 
 
-class PanopticQualityWithOrientationMAE(PanopticQuality):
+class PanopticQualityWithOrientationMAE(_AngularErrorStates, PanopticQuality):
     def __init__(self, *args, **kwargs) -> None:
         super().__init__(*args, **kwargs)
-        self.add_state('sum_angular_error', torch.tensor(0, dtype=torch.float64),
-                       dist_reduce_fx='sum')
-        self.add_state('n_elements', torch.tensor(0, dtype=torch.int64),
-                       dist_reduce_fx='sum')
+        self._add_angular_states()
 
     def update(self,
                panoptic_preds: torch.Tensor,
@@ -83,29 +94,25 @@ class PanopticQualityWithOrientationMAE(PanopticQuality):
     def update_mae(self, orientation_preds: OrientationDict, panoptic_preds_id_dicts: Dict,
                    orientation_target: OrientationDict, panoptic_target_id_dicts: Dict,
                    matching: List[Tuple[int, int]]) -> None:
-        total, n = 0.0, 0
+        """matching: (target panoptic id, predicted panoptic id) of the true positives; a pair
+        counts when both ids map to instances that carry an orientation (mae.py:129-162)"""
+        def angle_of(pan_id, id_dict, angles):
+            instance = id_dict.get(pan_id)
+            return None if instance is None else angles.get(instance)
+
+        pairs = []
         for target_id, pred_id in matching:
             if target_id == 0:                                  # stuff / void / background
                 continue
-            if target_id not in panoptic_target_id_dicts:
-                continue
-            target_instance = panoptic_target_id_dicts[target_id]
-            if target_instance not in orientation_target:
-                continue
-            if pred_id not in panoptic_preds_id_dicts:
-                continue
-            pred_instance = panoptic_preds_id_dicts[pred_id]
-            if pred_instance not in orientation_preds:
-                continue
-            total += _abs_angle_error_f32(float(orientation_preds[pred_instance]),
-                                          float(orientation_target[target_instance]))
-            n += 1
-        self.sum_angular_error += total
-        self.n_elements += n
+            target_angle = angle_of(target_id, panoptic_target_id_dicts, orientation_target)
+            pred_angle = angle_of(pred_id, panoptic_preds_id_dicts, orientation_preds)
+            if target_angle is not None and pred_angle is not None:
+                pairs.append((pred_angle, target_angle))
+        self._accumulate(pairs)
 
     def compute(self, suffix: str = '') -> Dict[str, torch.Tensor]:
         r = super().compute(suffix=suffix)
-        rad = self.sum_angular_error / self.n_elements
+        rad = self._mean_rad()
         r[f'mae{suffix}_rad'] = rad
         r[f'mae{suffix}_deg'] = torch.rad2deg(rad)
         return r

@@ -1,30 +1,18 @@
-"""`PostprocessingBase` — the interface decoders call
-(reference model/postprocessing/base.py:13-41)."""
-import abc
-
-from ...types import BatchType
-from ...types import DecoderRawOutputType
-from ...types import PostprocessingOutputType
+"""Entry point the decoders call on their raw outputs (interface of reference
+model/postprocessing/base.py:13-41): `postprocess(data, batch, is_training)` routes to the
+training or the inference variant; a subclass that only defines the training variant uses it
+for inference too."""
 
 
-class PostprocessingBase(abc.ABC):
-    def postprocess(
-        self,
-        data: DecoderRawOutputType,
-        batch: BatchType,
-        is_training: bool = True
-    ) -> PostprocessingOutputType:
-        fn = self._postprocess_training if is_training else self._postprocess_inference
-        return fn(data, batch)
+class PostprocessingBase:
+    def postprocess(self, data, batch, is_training=True):
+        """data: (output, side_outputs) of a decoder; batch: the collated input batch."""
+        if is_training:
+            return self._postprocess_training(data, batch)
+        return self._postprocess_inference(data, batch)
 
-    @abc.abstractmethod
-    def _postprocess_training(
-        self, data: DecoderRawOutputType, batch: BatchType
-    ) -> PostprocessingOutputType:
-        ...
+    def _postprocess_training(self, data, batch):
+        raise NotImplementedError(f'{type(self).__name__} must define _postprocess_training')
 
-    def _postprocess_inference(
-        self, data: DecoderRawOutputType, batch: BatchType
-    ) -> PostprocessingOutputType:
-        # default: inference == training
+    def _postprocess_inference(self, data, batch):
         return self._postprocess_training(data, batch)

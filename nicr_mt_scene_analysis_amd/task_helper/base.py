@@ -1,133 +1,131 @@
-"""`TaskHelperBase` and the step decorators (reference task_helper/base.py:17-210).
+"""Common machinery of the task helpers (interface of reference task_helper/base.py:17-210).
 
-Same interface (initialize / training_step / validation_step / validation_epoch_end,
-collect_* helpers, `accumulate_losses`, `mark_as_total`).  Element counts may be device
-scalars here (the HIP losses return them without a host sync); `accumulate_losses` then
-stays on the device as well.
+A task helper owns the losses and metrics of one task: `initialize(device)`, then per batch
+`training_step` / `validation_step` -> (loss dict, log dict) and `validation_epoch_end` ->
+(artifacts, examples, logs).  The `collect_*` helpers pair the main output and the side
+outputs of a decoder with the targets of the matching resolution.
+
+Element counts may be DEVICE scalars here (the HIP losses return them without a host sync);
+`accumulate_losses` then stays on the device as well.
 """
-import abc
 import functools
 import time
 import warnings
-from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import torch
 
 from ..data.preprocessing.multiscale_supervision import get_downscale
-from ..types import BatchType
 
 TOTAL_LOSS_SUFFIX = '_total_loss'
 
 
-def get_total_loss_key(key: str) -> str:
-    return f'{key}{TOTAL_LOSS_SUFFIX}'
+def get_total_loss_key(key):
+    return key + TOTAL_LOSS_SUFFIX
 
 
-def append_detached_losses_to_logs(disabled: bool = False):
-    def decorator(f):
-        @functools.wraps(f)
-        def wrapper(*args, **kwargs):
-            losses, logs = f(*args, **kwargs)
-            if not disabled:
-                logs.update({k: v.detach().clone() for k, v in losses.items()})
-            return losses, logs
-        return wrapper
-    return decorator
+def _around_step(after):
+    """decorator factory: run the step, then `after(result, seconds)` may amend the result"""
+    def decorate(step):
+        @functools.wraps(step)
+        def run(*args, **kwargs):
+            started = time.perf_counter()
+            result = step(*args, **kwargs)
+            after(result, time.perf_counter() - started)
+            return result
+        return run
+    return decorate
 
 
-def append_profile_to_logs(key: str, disabled: bool = False):
-    def decorator(f):
-        @functools.wraps(f)
-        def wrapper(*args, **kwargs):
-            if disabled:
-                return f(*args, **kwargs)
-            t0 = time.perf_counter()
-            results = f(*args, **kwargs)
-            assert isinstance(results[-1], dict)       # last element: dict of logs
-            results[-1][key] = time.perf_counter() - t0
-            return results
-        return wrapper
-    return decorator
+def append_detached_losses_to_logs(disabled=False):
+    """(losses, logs) steps: copy every loss, detached, into the logs"""
+    def after(result, _seconds):
+        losses, logs = result
+        if not disabled:
+            for name, value in losses.items():
+                logs[name] = value.detach().clone()
+    return _around_step(after)
 
 
-class TaskHelperBase(abc.ABC, torch.nn.Module):
-    def __init__(self) -> None:
-        super().__init__()
+def append_profile_to_logs(key, disabled=False):
+    """store the wall time of the step under `key` in the trailing log dict of its result"""
+    def after(result, seconds):
+        if disabled:
+            return
+        logs = result[-1]
+        assert isinstance(logs, dict)
+        logs[key] = seconds
+    return _around_step(after)
 
-    def initialize(self, device: torch.device):
-        pass
 
-    def collect_predictions_and_targets_for_loss(
-        self, batch: BatchType, batch_key: str, predictions_post: BatchType,
-        predictions_post_key: str, side_outputs_key: Optional[str] = None
-    ) -> Tuple[List[torch.Tensor], List[torch.Tensor], List[str]]:
-        inputs, keys, downscales = self.collect_predictions_for_loss(
-            predictions_post, predictions_post_key, side_outputs_key)
-        targets = self.collect_targets_for_loss(batch, batch_key, downscales)
-        return inputs, targets, keys
+def _last_dim(output):
+    """width of a decoder output (instance decoders hand over a tuple of tensors)"""
+    if isinstance(output, tuple):
+        output = output[0]
+    if not isinstance(output, torch.Tensor):
+        raise Exception("Error while determining downscale")
+    return output.shape[-1]
 
-    def collect_predictions_for_loss(
-        self, predictions_post: BatchType, predictions_post_key: str,
-        side_outputs_key: Optional[str] = None
-    ) -> Tuple[List[Any], List[str], List[int]]:
-        def width(output):
-            if isinstance(output, torch.Tensor):
-                return output.shape[-1]
-            if isinstance(output, tuple):                  # instance: tuple of tensors
-                return output[0].shape[-1]
-            raise Exception("Error while determining downscale")
 
-        tensors = [predictions_post[predictions_post_key]]
-        keys = ['main']
-        downscales: List[int] = []
-        if side_outputs_key is not None:
-            main_width = width(predictions_post[predictions_post_key])
-            for side in predictions_post[side_outputs_key] or ():
-                if side is None:                           # no side outputs / eval mode
-                    continue
-                tensors.append(side)
-                downscales.append(main_width // width(side))
-                keys.append(f'down_{downscales[-1]}')
+class TaskHelperBase(torch.nn.Module):
+    def initialize(self, device):
+        """create losses / metrics on `device`"""
+
+    # ---- pairing predictions and targets over the supervision scales ---------------------
+    def collect_predictions_for_loss(self, predictions_post, predictions_post_key,
+                                     side_outputs_key=None):
+        """-> (tensors, keys, downscales): the main output as 'main', every side output that is
+        not None as 'down_<factor>' (factor = main width // side width)"""
+        main = predictions_post[predictions_post_key]
+        tensors, keys, downscales = [main], ['main'], []
+        sides = predictions_post[side_outputs_key] if side_outputs_key is not None else None
+        for side in sides or ():
+            if side is None:                # evaluation mode / decoder without side outputs
+                continue
+            factor = _last_dim(main) // _last_dim(side)
+            tensors.append(side)
+            keys.append(f'down_{factor}')
+            downscales.append(factor)
         return tensors, keys, downscales
 
-    def collect_targets_for_loss(
-        self, batch: BatchType, batch_key: str, downscales: Optional[List[int]] = None
-    ) -> List[torch.Tensor]:
+    def collect_targets_for_loss(self, batch, batch_key, downscales=None):
+        """targets of the main resolution and of every downscale present in the batch"""
         targets = [batch[batch_key]]
-        for d in downscales or ():
-            sub = get_downscale(batch, d)
-            if sub is None:                                # multiscale disabled
-                continue
-            targets.append(sub[batch_key])
+        for factor in downscales or ():
+            scaled = get_downscale(batch, factor)
+            if scaled is not None:          # None: multiscale supervision disabled
+                targets.append(scaled[batch_key])
         return targets
 
-    def accumulate_losses(self, losses: Sequence[torch.Tensor], n_elements: Sequence) -> torch.Tensor:
-        """sum(losses) / sum(n_elements) over main + side outputs (base.py:161-182)."""
-        total_loss = torch.sum(torch.stack(list(losses)))
-        total_n = sum(n_elements)
-        if isinstance(total_n, torch.Tensor):
-            # device count: no host sync; n == 0 returns the (zero) loss sum like the reference
-            safe = total_n.clamp(min=1).to(total_loss.dtype)
-            return torch.where(total_n == 0, total_loss, total_loss / safe)
-        if total_n == 0:
+    def collect_predictions_and_targets_for_loss(self, batch, batch_key, predictions_post,
+                                                 predictions_post_key, side_outputs_key=None):
+        tensors, keys, downscales = self.collect_predictions_for_loss(
+            predictions_post, predictions_post_key, side_outputs_key)
+        return tensors, self.collect_targets_for_loss(batch, batch_key, downscales), keys
+
+    # ---- reductions --------------------------------------------------------------------------
+    def accumulate_losses(self, losses, n_elements):
+        """sum(losses) / sum(n_elements) over the main and the side outputs (base.py:161-182);
+        an empty selection returns the (zero) loss sum instead of dividing by zero."""
+        loss_sum = torch.stack(list(losses)).sum()
+        count = sum(n_elements)
+        if isinstance(count, torch.Tensor):                 # device count: no host sync
+            return torch.where(count == 0, loss_sum,
+                               loss_sum / count.clamp(min=1).to(loss_sum.dtype))
+        if count == 0:
             warnings.warn("Total number of loss elements is 0. Returning 0 as  "
                           "loss to avoid division by zero.")
-            return total_loss
-        return total_loss / total_n
+            return loss_sum
+        return loss_sum / count
 
-    def mark_as_total(self, key: str) -> str:
+    def mark_as_total(self, key):
         return get_total_loss_key(key)
 
-    @abc.abstractmethod
-    def training_step(self, batch: BatchType, batch_idx: int, predictions_post: BatchType
-                      ) -> Tuple[Dict[str, torch.Tensor], Dict[str, Any]]:
-        ...
+    # ---- to be provided by the task ------------------------------------------------------------
+    def training_step(self, batch, batch_idx, predictions_post):
+        raise NotImplementedError
 
-    @abc.abstractmethod
-    def validation_step(self, batch: BatchType, batch_idx: int, predictions_post: BatchType
-                        ) -> Tuple[Dict[str, torch.Tensor], Dict[str, Any]]:
-        ...
+    def validation_step(self, batch, batch_idx, predictions_post):
+        raise NotImplementedError
 
-    @abc.abstractmethod
     def validation_epoch_end(self):
-        ...
+        raise NotImplementedError

@@ -1,81 +1,79 @@
-"""`SemanticTaskHelper` (reference task_helper/semantic.py:22-165): weighted CE over the main
-and side outputs, masked mIoU on full resolution.  Visualisation examples are out of scope
-(`_examples` stays empty)."""
-from typing import Any, Dict, Optional, Sequence, Tuple, Union
+"""Semantic segmentation task (interface of reference task_helper/semantic.py:22-165).
 
-import numpy as np
+Training: (weighted, label-smoothed) cross entropy over the main output and the side outputs,
+normalised by the total number of non-void pixels.  Validation additionally feeds the
+full-resolution argmax into the mIoU confusion matrix with void pixels masked out — on the GPU
+next to the predictions (the reference keeps that metric on the CPU).  Visualisation examples
+are out of scope: the example dict stays empty.
+"""
 import torch
 
 from ..data.preprocessing.resize import get_fullres
 from ..data.preprocessing.resize import get_fullres_key
 from ..loss import CrossEntropyLossSemantic
 from ..metric import MeanIntersectionOverUnion
-from ..types import BatchType
 from .base import TaskHelperBase
 from .base import append_detached_losses_to_logs
 from .base import append_profile_to_logs
 
+_TASK = 'semantic'
+
 
 class SemanticTaskHelper(TaskHelperBase):
-    def __init__(
-        self,
-        n_classes: int,
-        class_weights: Optional[np.ndarray] = None,
-        label_smoothing: float = 0.0,
-        disable_multiscale_supervision: bool = False,
-        examples_cmap: Union[Sequence[Tuple[int, int, int]], np.ndarray, None] = None
-    ) -> None:
+    def __init__(self, n_classes, class_weights=None, label_smoothing=0.0,
+                 disable_multiscale_supervision=False, examples_cmap=None):
         super().__init__()
         self._n_classes = n_classes
         self._class_weights = class_weights
         self._label_smoothing = label_smoothing
         self._disable_multiscale_supervision = disable_multiscale_supervision
-        self._examples: Dict[str, Any] = {}
         self._examples_cmap = examples_cmap
+        self._examples = {}
 
-    def initialize(self, device: torch.device):
-        if self._class_weights is not None:
-            self._class_weights = torch.as_tensor(self._class_weights, dtype=torch.float,
-                                                  device=device)
-        self._loss = CrossEntropyLossSemantic(weights=self._class_weights,
+    def initialize(self, device):
+        weights = self._class_weights
+        if weights is not None:
+            weights = torch.as_tensor(weights, dtype=torch.float, device=device)
+            self._class_weights = weights
+        self._loss = CrossEntropyLossSemantic(weights=weights,
                                               label_smoothing=self._label_smoothing)
-        # the reference keeps this metric on the CPU "because it is faster"; here the
-        # confusion matrix lives on the GPU next to the predictions
         self._metric_iou = MeanIntersectionOverUnion(n_classes=self._n_classes, device=device)
         self._metric_iou.reset()
 
-    def _compute_losses(self, batch, batch_idx, predictions_post) -> Dict[str, torch.Tensor]:
-        no_multiscale = self._disable_multiscale_supervision
-        preds, targets, keys = self.collect_predictions_and_targets_for_loss(
-            batch=batch, batch_key='semantic', predictions_post=predictions_post,
-            predictions_post_key='semantic_output',
-            side_outputs_key=None if no_multiscale else 'semantic_side_outputs')
-        outs = self._loss(input_tensors=preds, target_tensors=targets)
-        loss_dict = {f'semantic_loss_{key}': loss / n for key, (loss, n) in zip(keys, outs)}
-        loss_dict[self.mark_as_total('semantic')] = self.accumulate_losses(
-            losses=[loss for loss, _ in outs], n_elements=[n for _, n in outs])
-        return loss_dict
+    # ---- losses ------------------------------------------------------------------------------
+    def _compute_losses(self, batch, batch_idx, predictions_post):
+        side_key = None if self._disable_multiscale_supervision else f'{_TASK}_side_outputs'
+        predictions, targets, scale_names = self.collect_predictions_and_targets_for_loss(
+            batch=batch, batch_key=_TASK, predictions_post=predictions_post,
+            predictions_post_key=f'{_TASK}_output', side_outputs_key=side_key)
+        per_scale = self._loss(input_tensors=predictions, target_tensors=targets)
+        sums = [loss_sum for loss_sum, _ in per_scale]
+        counts = [count for _, count in per_scale]
+        losses = {f'{_TASK}_loss_{name}': s / n for name, s, n in zip(scale_names, sums, counts)}
+        losses[self.mark_as_total(_TASK)] = self.accumulate_losses(losses=sums, n_elements=counts)
+        return losses
 
-    @append_profile_to_logs('semantic_step_time')
+    @append_profile_to_logs(f'{_TASK}_step_time')
     @append_detached_losses_to_logs()
     def training_step(self, batch, batch_idx, predictions_post):
         return self._compute_losses(batch, batch_idx, predictions_post), {}
 
-    @append_profile_to_logs('semantic_step_time')
+    # ---- validation --------------------------------------------------------------------------
+    @append_profile_to_logs(f'{_TASK}_step_time')
     @append_detached_losses_to_logs()
     def validation_step(self, batch, batch_idx, predictions_post):
-        loss_dict = self._compute_losses(batch, batch_idx, predictions_post)
-        # preds[target != 0] vs target[target != 0] - 1 (semantic.py:124-128), fused
-        target = get_fullres(batch, 'semantic')
-        preds = predictions_post[get_fullres_key('semantic_segmentation_idx')]
-        self._metric_iou.update_masked_void(preds, target)
-        return loss_dict, {}
+        losses = self._compute_losses(batch, batch_idx, predictions_post)
+        # mIoU on preds[target != 0] vs target[target != 0] - 1 (semantic.py:124-128): the void
+        # masking happens inside the confusion-matrix kernel
+        self._metric_iou.update_masked_void(
+            predictions_post[get_fullres_key(f'{_TASK}_segmentation_idx')],
+            get_fullres(batch, _TASK))
+        return losses, {}
 
-    @append_profile_to_logs('semantic_epoch_end_time')
+    @append_profile_to_logs(f'{_TASK}_epoch_end_time')
     def validation_epoch_end(self):
         miou, ious = self._metric_iou.compute(return_ious=True)
-        logs = {'semantic_miou': miou}
-        artifacts = {'semantic_cm': self._metric_iou.confmat.clone(),
-                     'semantic_ious_per_class': ious.clone()}
+        artifacts = {f'{_TASK}_cm': self._metric_iou.confmat.clone(),
+                     f'{_TASK}_ious_per_class': ious.clone()}
         self._metric_iou.reset()
-        return artifacts, self._examples, logs
+        return artifacts, self._examples, {f'{_TASK}_miou': miou}

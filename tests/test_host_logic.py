@@ -187,7 +187,7 @@ def test_loss_host_paths_and_errors():
         assert n == 2 * 5 * 7 and float(l) == pytest.approx(float(f(x - y).mean(1).sum()), rel=1e-6)
     with pytest.raises(AssertionError):
         MSELoss('avg')
-    with pytest.raises(ValueError, match='2d inputs'):
+    with pytest.raises(ValueError, match='shape \(n, 2\)'):
         VonMisesLossBiternion()([x], [y])
     with pytest.raises(AssertionError):
         VonMisesLossBiternion(reduction='mean')
