@@ -48,6 +48,9 @@ def parse_args():
     ap.add_argument('--no-side-stream', action='store_true',
                     help='enqueue the metric kernels on the main stream (no overlap)')
     ap.add_argument('--cpu-sample-images', type=int, default=32)
+    ap.add_argument('--metric-sync', choices=('step', 'end'), default='step',
+                    help='N>1: all-reduce the metric accumulators every step (default) or once '
+                         'after the last step, inside the timed region (what torchmetrics does)')
     ap.add_argument('--streams', type=int, default=2,
                     help='batches in flight: consecutive steps alternate over this many HIP streams')
     return ap.parse_args()
@@ -130,7 +133,8 @@ def main():
         try:
             from nicr_mt_scene_analysis_amd.metric import bench_support
             metrics = bench_support.MetricAccumulators(C + 1, dev, inp, rank, world_size=world,
-                                                       side_stream=not args.no_side_stream)
+                                                       side_stream=not args.no_side_stream,
+                                                       sync_every_step=args.metric_sync == 'step')
         except ImportError:
             metrics = None
 
@@ -157,6 +161,8 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = step(i, True)
+    if metrics is not None:
+        metrics.finalize(dist)                 # --metric-sync end: the one all-reduce, timed
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -223,7 +229,8 @@ def main():
                    'batch_per_gpu': B, 'global_batch': B * world, 'classes': C,
                    'height': H, 'width': W, 'centers_per_image': args.centers,
                    'batches_in_flight': len(streams),
-                   'parallelism': f'dp{world} (images sharded, accumulators all-reduced)'},
+                   'parallelism': f'dp{world} (images sharded, accumulators all-reduced '
+                                  f'every {"step" if args.metric_sync == "step" else "epoch"})'},
         'roofline': roofline,
     }
 

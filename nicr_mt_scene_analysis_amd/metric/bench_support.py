@@ -22,9 +22,13 @@ from .pq import PanopticQuality
 class MetricAccumulators:
     def __init__(self, n_classes_with_void: int, device, inputs, rank: int = 0,
                  max_instances_per_category: int = 1 << 16, world_size: int = 1,
-                 side_stream: bool = True) -> None:
+                 side_stream: bool = True, sync_every_step: bool = True) -> None:
+        """sync_every_step=False: ranks accumulate locally and `finalize()` sums the totals
+        over the ranks ONCE — the torchmetrics behaviour of the reference (`dist_reduce_fx`
+        is applied by `compute()`, metric/miou.py:21-25)."""
         self.max_inst = max_instances_per_category
-        self.world_size = world_size
+        self.reduce_world = world_size
+        self.world_size = world_size if sync_every_step else 1      # per-step behaviour
         n = n_classes_with_void
         is_thing = [False] + [bool(x) for x in inputs['semantic_classes_is_thing'].cpu().tolist()]
         self.miou = MeanIntersectionOverUnion(n, ignore_first_class=True, device=device)
@@ -37,6 +41,7 @@ class MetricAccumulators:
         n_conf = self._step_flat[0].numel()
         self._packed = torch.zeros((n_conf + self._step_flat[1].numel(),), dtype=torch.float64,
                                    device=device) if world_size > 1 else None
+        self._finalized = False
         self._n_conf = n_conf
         self.stream = torch.cuda.Stream(device=device) if side_stream else None
         self._ready = torch.cuda.Event()
@@ -76,6 +81,22 @@ class MetricAccumulators:
                     self._all_reduce(dist, self._packed)
                 self._total_flat[0] += self._packed[:n].to(torch.int64)
                 self._total_flat[1] += self._packed[n:]
+
+    def finalize(self, dist=None) -> None:
+        """end of the epoch: with local accumulation, sum the totals over the ranks (one
+        all-reduce); a no-op when every step was already reduced or there is one rank"""
+        if self.world_size > 1 or self.reduce_world == 1 or self._finalized or dist is None:
+            return
+        cur = torch.cuda.current_stream(self._packed.device)
+        stream = self.stream if self.stream is not None else cur
+        with torch.cuda.stream(stream):
+            n = self._n_conf
+            self._packed[:n].copy_(self._total_flat[0])               # < 2^53: exact in f64
+            self._packed[n:].copy_(self._total_flat[1])
+            self._all_reduce(dist, self._packed)
+            self._total_flat[0].copy_(self._packed[:n].to(torch.int64))
+            self._total_flat[1].copy_(self._packed[n:])
+        self._finalized = True
 
     @staticmethod
     def _all_reduce(dist, buf: torch.Tensor) -> None:
