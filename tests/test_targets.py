@@ -155,3 +155,37 @@ def test_reference_property_checks():
     fg = r['instance_foreground'].cpu().numpy()
     assert np.array_equal(fg, np.isin(sem, thing_classes) & (ins > 0))
     assert float(r['instance_center'].max()) == 1.0 and float(r['instance_center'].min()) >= 0.0
+
+
+def test_naive_and_deeplab_merge_agree_on_gt_style_maps():
+    """the invariant of the reference's tests/test_merge.py:27-102 on the HIP path: on ground-truth
+    style maps (every instance lies inside ONE thing class, stuff pixels carry id 0) the naive merge
+    (target generation) and the deeplab merge (evaluation side) paint the same panoptic map."""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.utils.panoptic_merge import deeplab_merge_batch
+    m = syn.make_label_maps(2, 21, 120, 160, 40, seed=12, mixed_fraction=0.0, max_radius=14)
+    is_thing = m['semantic_classes_is_thing']
+    sem = m['semantic'].copy()
+    ins = m['instance'].copy()
+    ins[~is_thing[sem]] = 0                         # stuff: no instance
+    # pixels of a thing class without an instance would stay void in both merges; make every
+    # instance single-class (mixed_fraction = 0 paints the class in) and drop overpainted rims
+    for b in range(sem.shape[0]):
+        for iid in np.unique(ins[b]):
+            if iid == 0:
+                continue
+            mask = ins[b] == iid
+            cls = np.bincount(sem[b][mask]).argmax()
+            sem[b][mask] = cls
+    thing_ids = np.where(is_thing)[0]
+    naive = ops.panoptic_targets(dev(sem), dev(ins), len(is_thing), dev(is_thing.astype(np.uint8)),
+                                 1 << 16, 0)
+    pan_d, ids_d = deeplab_merge_batch(dev(sem.astype(np.int64)), dev(ins), dev(ins > 0), 1 << 16,
+                                       thing_ids, 0, n_classes=len(is_thing))
+    torch.cuda.synchronize()
+    got_n, got_d = naive['panoptic'].cpu().numpy(), pan_d.cpu().numpy()
+    has_inst_or_stuff = (ins > 0) | ~is_thing[sem]
+    assert np.array_equal(got_n[has_inst_or_stuff], got_d[has_inst_or_stuff])
+    ids_n = ids_from_arrays(naive['n_ids'].cpu().numpy(), naive['ids_pan'].cpu().numpy(),
+                            naive['ids_ins'].cpu().numpy())
+    assert [sorted(d.items()) for d in ids_n] == [sorted(d.items()) for d in ids_d]
