@@ -369,6 +369,27 @@ int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int
                    int workspace_is_clean, nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * a11 + a12 in ONE pass over the prediction (PanopticTaskHelper.validation_step,
+ *     task_helper/panoptic.py:104-126, updates both metrics from the same panoptic map):
+ *     PQ exactly as nmsa_pq_update, plus confmat[target_semantic, pred // pred_div] += 1
+ *     exactly as nmsa_confmat_update(mode 0) — the i64 prediction map is read once.
+ *   target_semantic u8 [B,H,W]; confmat i64 [n,n] with n = confmat_classes <= 64;
+ *   confmat_status: the status word of the mIoU metric (label outside [0, n) -> bit 8);
+ *   confmat_workspace: nmsa_pq_confmat_workspace_bytes(B,H,W,n) bytes (0 = not supported).
+ * ------------------------------------------------------------------------- */
+size_t nmsa_pq_confmat_workspace_bytes(int B, int H, int W, int n_classes);
+int nmsa_pq_update_with_confmat(
+    const int64_t* pred, const int64_t* target, const uint8_t* target_semantic,
+    int B, int H, int W,
+    int num_categories, int64_t ignored_label, int64_t max_instances_per_category, int64_t offset,
+    int64_t void_segment_id,
+    double* iou_per_class, double* tp_per_class, double* fn_per_class, double* fp_per_class,
+    int64_t* matches, int match_capacity, int32_t* n_matches,
+    int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
+    int confmat_classes, int64_t pred_div, int64_t* confmat, int32_t* confmat_status,
+    void* confmat_workspace, size_t confmat_workspace_bytes, nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * a6-a10  per-pixel multi-task losses (forward + backward)
  * Common conventions: predictions f32|bf16|f16 (code in `dtype`), targets f32,
  * labels / masks u8, planar NCHW.  Forward returns device scalars

@@ -274,16 +274,47 @@ __device__ __forceinline__ longlong2 ld_i64x2_stream(const int64_t* p)
     return make_longlong2(v.x, v.y);
 }
 
+// WITH_CM: the same pass over the prediction also feeds the mIoU confusion matrix of
+// task_helper/panoptic.py:123-126 (confmat[target_sem, pred // pred_div]++): the i64 prediction
+// map is read ONCE for both metrics.  Per-block LDS histogram -> slab, summed by
+// k_confmat_reduce exactly like the stand-alone k_confmat.
+template <bool WITH_CM>
 __global__ __launch_bounds__(256) void k_pq_count(
     const int64_t* __restrict__ pred, const int64_t* __restrict__ target,
     int P, int64_t offset, int px_per_block,
-    unsigned char* __restrict__ ws, int* __restrict__ status)
+    unsigned char* __restrict__ ws, int* __restrict__ status,
+    const uint8_t* __restrict__ target_sem, int cm_n, int64_t cm_div, int cm_shift,
+    uint32_t* __restrict__ cm_slab, int* __restrict__ cm_status)
 {
     __shared__ int64_t lkI[PQ_LI];
     __shared__ uint32_t lcI[PQ_LI];
+    extern __shared__ uint32_t cm_hist_pq[];
     const int b = blockIdx.y;
+    const int cm_bins = WITH_CM ? cm_n * cm_n : 0;
     for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) { lkI[i] = KEY_EMPTY; lcI[i] = 0; }
+    if (WITH_CM) for (int i = threadIdx.x; i < cm_bins; i += blockDim.x) cm_hist_pq[i] = 0;
     __syncthreads();
+    const uint8_t* ts = WITH_CM ? target_sem + (size_t)b * P : nullptr;
+    bool cm_bad = false;
+    auto cm_key = [&](int64_t t, int64_t p, bool valid) -> int {
+        if (!valid) return -1;
+        if (p < 0) { cm_bad = true; return -1; }            // bincount rejects negatives
+        const int64_t pc = cm_shift >= 0 ? (p >> cm_shift) : (p / cm_div);
+        if (t >= cm_n || pc >= cm_n) { cm_bad = true; return -1; }
+        return (int)(t * cm_n + pc);                        // miou.py:50
+    };
+    auto cm_runs = [&](int key, uint32_t weight) {
+        const int prev = __shfl_up(key, 1);
+        const bool head = key >= 0 && (lane_id() == 0 || prev != key);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long gaps = __ballot(key < 0);
+        if (head) {
+            const int l = lane_id();
+            const unsigned long long stop = (heads | gaps) & ~((2ull << l) - 1ull);
+            const int nxt = stop ? (__ffsll((long long)stop) - 1) : 64;
+            atomicAdd(&cm_hist_pq[key], weight * (uint32_t)(nxt - l));
+        }
+    };
     int64_t* gk = pq_keys(ws, b);
     uint32_t* gc = pq_cnts(ws, b);
     const int64_t* pr = pred + (size_t)b * P;
@@ -324,11 +355,13 @@ __global__ __launch_bounds__(256) void k_pq_count(
 
     // the image plane is consumed as 16-B (2 px) loads when the rows allow it
     const bool vec = ((P & 1) == 0) && ((start & 1) == 0) &&
-                     ((((uintptr_t)pr | (uintptr_t)tg) & 15) == 0);
+                     ((((uintptr_t)pr | (uintptr_t)tg) & 15) == 0) &&
+                     (!WITH_CM || (((uintptr_t)ts) & 1) == 0);
     if (vec) {
         const int tile = blockDim.x * 2 * PQ_UNROLL;            // px per block iteration
         for (int base = start; base < end; base += tile) {
             longlong2 tv[PQ_UNROLL], pv[PQ_UNROLL];
+            uint32_t sv[PQ_UNROLL];
             bool ok[PQ_UNROLL];
 #pragma unroll
             for (int u = 0; u < PQ_UNROLL; ++u) {
@@ -336,6 +369,16 @@ __global__ __launch_bounds__(256) void k_pq_count(
                 ok[u] = i < end;                                // end is even on this path
                 tv[u] = ok[u] ? ld_i64x2_stream(tg + i) : make_longlong2(0, 0);
                 pv[u] = ok[u] ? ld_i64x2_stream(pr + i) : make_longlong2(0, 0);
+                sv[u] = (WITH_CM && ok[u]) ? (uint32_t)*(const uint16_t*)(ts + i) : 0u;
+            }
+            if (WITH_CM) {
+#pragma unroll
+                for (int u = 0; u < PQ_UNROLL; ++u) {
+                    const int k0 = cm_key(sv[u] & 0xFFu, pv[u].x, ok[u]);
+                    const int k1 = cm_key(sv[u] >> 8, pv[u].y, ok[u]);
+                    if (__all(k0 == k1)) cm_runs(k0, 2u);
+                    else { cm_runs(k0, 1u); cm_runs(k1, 1u); }
+                }
             }
 #pragma unroll
             for (int u = 0; u < PQ_UNROLL; ++u) {
@@ -355,9 +398,15 @@ __global__ __launch_bounds__(256) void k_pq_count(
             const int i = start + k * blockDim.x + threadIdx.x;
             const bool valid = i < end;
             wave_runs(valid, valid ? tg[i] : 0, valid ? pr[i] : 0, 1u);
+            if (WITH_CM) cm_runs(cm_key(valid ? ts[i] : 0, valid ? pr[i] : 0, valid), 1u);
         }
     }
     __syncthreads();
+    if (WITH_CM) {
+        uint32_t* mine = cm_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * cm_bins;
+        for (int i = threadIdx.x; i < cm_bins; i += blockDim.x) mine[i] = cm_hist_pq[i];
+        if (cm_bad) atomicOr(cm_status, ST_VALUE_RANGE);
+    }
     // flush the block-private table
     for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x)
         if (lkI[i] != KEY_EMPTY && !table_add(gk, gc, PQ_I_CAP - 1, lkI[i], lcI[i], PQ_I_CAP))
@@ -656,17 +705,25 @@ extern "C" size_t nmsa_pq_workspace_bytes(int B, int num_categories)
     return (size_t)B * pq_image_bytes() + (size_t)B * 4 * num_categories * sizeof(double);
 }
 
-extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int W,
-                              int num_categories, int64_t ignored_label,
-                              int64_t max_instances_per_category, int64_t offset,
-                              int64_t void_segment_id,
-                              double* iou_per_class, double* tp_per_class,
-                              double* fn_per_class, double* fp_per_class,
-                              int64_t* matches, int match_capacity, int32_t* n_matches,
-                              int32_t* status, void* workspace, size_t workspace_bytes,
-                              int workspace_is_clean, nmsa_stream_t stream_)
+namespace {
+
+constexpr int PQ_CM_MAX_CLASSES = 64;        // fused confusion matrix: n*n u32 in LDS next to the PQ table
+
+int pq_px_per_block()
 {
-    hipStream_t stream = (hipStream_t)stream_;
+    static const int px_per_block_env = getenv("NMSA_PQ_PXB") ? atoi(getenv("NMSA_PQ_PXB")) : 0;
+    return px_per_block_env > 0 ? (px_per_block_env & ~1) : 8192;     // tuning knob
+}
+
+int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int W,
+                   int num_categories, int64_t ignored_label,
+                   int64_t max_instances_per_category, int64_t offset, int64_t void_segment_id,
+                   double* iou_per_class, double* tp_per_class, double* fn_per_class,
+                   double* fp_per_class, int64_t* matches, int match_capacity, int32_t* n_matches,
+                   int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
+                   const uint8_t* target_sem, int cm_n, int64_t cm_div, int64_t* confmat,
+                   int32_t* cm_status, void* cm_workspace, hipStream_t stream)
+{
     if (!pred || !target || !iou_per_class || !tp_per_class || !fn_per_class || !fp_per_class ||
         !status || !workspace)
         return NMSA_ERR_ARG;
@@ -684,12 +741,28 @@ extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B,
         hipLaunchKernelGGL(k_pq_init, dim3(2, B), dim3(256), 0, stream, ws);
         if ((rc = check_launch())) return rc;
     }
-    static const int px_per_block_env = getenv("NMSA_PQ_PXB") ? atoi(getenv("NMSA_PQ_PXB")) : 0;
-    const int px_per_block = px_per_block_env > 0 ? (px_per_block_env & ~1) : 8192;     // tuning knob (profiles/r01_tune_notes.md)
-    hipLaunchKernelGGL(k_pq_count, dim3((P + px_per_block - 1) / px_per_block, B), dim3(256), 0, stream,
-                       pred, target, P, offset, px_per_block, ws, status);
+    const int px_per_block = pq_px_per_block();
+    const dim3 grid((P + px_per_block - 1) / px_per_block, B);
+    if (target_sem) {
+        int shift = -1;
+        if ((cm_div & (cm_div - 1)) == 0) shift = __builtin_ctzll((unsigned long long)cm_div);
+        hipLaunchKernelGGL(k_pq_count<true>, grid, dim3(256), (size_t)cm_n * cm_n * sizeof(uint32_t),
+                           stream, pred, target, P, offset, px_per_block, ws, status, target_sem, cm_n,
+                           cm_div, shift, (uint32_t*)cm_workspace, cm_status);
+    } else {
+        hipLaunchKernelGGL(k_pq_count<false>, grid, dim3(256), 0, stream, pred, target, P, offset,
+                           px_per_block, ws, status, (const uint8_t*)nullptr, 0, (int64_t)1, -1,
+                           (uint32_t*)nullptr, (int*)nullptr);
+    }
     rc = check_launch();
     if (rc) return rc;
+    if (target_sem) {
+        const int nbins = cm_n * cm_n;
+        hipLaunchKernelGGL(k_confmat_reduce, dim3((nbins + 255) / 256, CM_REDUCE_GROUPS), dim3(256), 0,
+                           stream, (const uint32_t*)cm_workspace, (int)(grid.x * grid.y), nbins,
+                           (unsigned long long*)confmat);
+        if ((rc = check_launch())) return rc;
+    }
     hipLaunchKernelGGL(k_pq_match, dim3(B), dim3(PQ_MATCH_THREADS), 0, stream, ws, num_categories,
                        ignored_label, max_instances_per_category, offset, void_segment_id,
                        img_state, matches, match_capacity, n_matches, status);
@@ -699,4 +772,55 @@ extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B,
                        img_state, B, num_categories, iou_per_class, tp_per_class, fn_per_class,
                        fp_per_class);
     return check_launch();
+}
+
+}  // namespace
+
+extern "C" int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int W,
+                              int num_categories, int64_t ignored_label,
+                              int64_t max_instances_per_category, int64_t offset,
+                              int64_t void_segment_id,
+                              double* iou_per_class, double* tp_per_class,
+                              double* fn_per_class, double* fp_per_class,
+                              int64_t* matches, int match_capacity, int32_t* n_matches,
+                              int32_t* status, void* workspace, size_t workspace_bytes,
+                              int workspace_is_clean, nmsa_stream_t stream_)
+{
+    return pq_update_impl(pred, target, B, H, W, num_categories, ignored_label,
+                          max_instances_per_category, offset, void_segment_id, iou_per_class,
+                          tp_per_class, fn_per_class, fp_per_class, matches, match_capacity, n_matches,
+                          status, workspace, workspace_bytes, workspace_is_clean,
+                          nullptr, 0, 1, nullptr, nullptr, nullptr, (hipStream_t)stream_);
+}
+
+extern "C" size_t nmsa_pq_confmat_workspace_bytes(int B, int H, int W, int n_classes)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || n_classes <= 0 || n_classes > PQ_CM_MAX_CLASSES) return 0;
+    const int px_per_block = pq_px_per_block();
+    const size_t blocks = (size_t)(((int64_t)H * W + px_per_block - 1) / px_per_block) * B;
+    return blocks * (size_t)n_classes * n_classes * sizeof(uint32_t);
+}
+
+extern "C" int nmsa_pq_update_with_confmat(
+    const int64_t* pred, const int64_t* target, const uint8_t* target_semantic,
+    int B, int H, int W,
+    int num_categories, int64_t ignored_label, int64_t max_instances_per_category, int64_t offset,
+    int64_t void_segment_id,
+    double* iou_per_class, double* tp_per_class, double* fn_per_class, double* fp_per_class,
+    int64_t* matches, int match_capacity, int32_t* n_matches,
+    int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
+    int confmat_classes, int64_t pred_div, int64_t* confmat, int32_t* confmat_status,
+    void* confmat_workspace, size_t confmat_workspace_bytes, nmsa_stream_t stream_)
+{
+    if (!target_semantic || !confmat || !confmat_status || !confmat_workspace) return NMSA_ERR_ARG;
+    if (confmat_classes <= 0 || confmat_classes > PQ_CM_MAX_CLASSES || pred_div <= 0) return NMSA_ERR_ARG;
+    const size_t need = nmsa_pq_confmat_workspace_bytes(B, H, W, confmat_classes);
+    if (need == 0) return NMSA_ERR_ARG;
+    if (confmat_workspace_bytes < need) return NMSA_ERR_WORKSPACE;
+    return pq_update_impl(pred, target, B, H, W, num_categories, ignored_label,
+                          max_instances_per_category, offset, void_segment_id, iou_per_class,
+                          tp_per_class, fn_per_class, fp_per_class, matches, match_capacity, n_matches,
+                          status, workspace, workspace_bytes, workspace_is_clean,
+                          target_semantic, confmat_classes, pred_div, confmat, confmat_status,
+                          confmat_workspace, (hipStream_t)stream_);
 }

@@ -27,6 +27,7 @@ class MetricAccumulators:
         over the ranks ONCE — the torchmetrics behaviour of the reference (`dist_reduce_fx`
         is applied by `compute()`, metric/miou.py:21-25)."""
         self.max_inst = max_instances_per_category
+        self.fused_metrics = not __import__('os').environ.get('NMSA_BENCH_SEPARATE_METRICS')
         self.reduce_world = world_size
         self.world_size = world_size if sync_every_step else 1      # per-step behaviour
         n = n_classes_with_void
@@ -70,9 +71,14 @@ class MetricAccumulators:
                 self.miou.zero_()
                 self.pq.zero_()
             # miou.update(pan // max_inst, semantic target)   (task_helper/panoptic.py:123-126)
-            self.miou.update_from_panoptic(panoptic_pred, self.target_semantic, self.max_inst)
             # pq.update(pan, panoptic target)                  (task_helper/panoptic.py:111-118)
-            self.pq.update(panoptic_pred, self.target_panoptic)
+            # -> one pass over the prediction for both accumulators
+            if self.fused_metrics:
+                self.pq.update_with_miou(panoptic_pred, self.target_panoptic, self.miou,
+                                         self.target_semantic, self.max_inst)
+            else:
+                self.miou.update_from_panoptic(panoptic_pred, self.target_semantic, self.max_inst)
+                self.pq.update(panoptic_pred, self.target_panoptic)
             if self.world_size > 1:
                 n = self._n_conf
                 self._packed[:n].copy_(self._step_flat[0])            # i64 -> f64, exact

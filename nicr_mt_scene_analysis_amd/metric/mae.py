@@ -73,11 +73,23 @@ class PanopticQualityWithOrientationMAE(_AngularErrorStates, PanopticQuality):
                panoptic_preds_id_dicts: Optional[List[Dict]],
                panoptic_target: torch.Tensor,
                orientation_target: Optional[List[OrientationDict]],
-               panoptic_target_id_dicts: Optional[List[Dict]]) -> None:
+               panoptic_target_id_dicts: Optional[List[Dict]],
+               miou=None, semantic_target: Optional[torch.Tensor] = None,
+               pred_div: int = 1) -> None:
+        """`miou` / `semantic_target` / `pred_div` (extension): also do
+        `miou.update(panoptic_preds // pred_div, semantic_target)` — in the same pass over the
+        prediction when the fused kernel applies (see PanopticQuality.update_with_miou)."""
         assert panoptic_preds.ndim == 3
         assert len(panoptic_target) == len(panoptic_preds)
         with_mae = orientation_preds is not None and orientation_target is not None
-        res = self._device_update(panoptic_preds, panoptic_target, want_matches=with_mae)
+        fuse = {}
+        if miou is not None:
+            if self._can_fuse(panoptic_preds, miou, semantic_target):
+                miou._require_gpu()
+                fuse = dict(miou=miou, target_semantic=semantic_target, pred_div=pred_div)
+            else:
+                miou.update_from_panoptic(panoptic_preds, semantic_target, pred_div)
+        res = self._device_update(panoptic_preds, panoptic_target, want_matches=with_mae, **fuse)
         if not with_mae:
             return
         matches, n_matches = res

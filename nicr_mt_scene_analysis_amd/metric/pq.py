@@ -69,8 +69,9 @@ class PanopticQuality(Metric):
             self._status = torch.zeros((1,), dtype=torch.int32, device=self.device)
 
     # ------------------------------------------------------------------ update
-    def _device_update(self, preds: torch.Tensor, targets: torch.Tensor,
-                       want_matches: bool) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+    def _device_update(self, preds: torch.Tensor, targets: torch.Tensor, want_matches: bool,
+                       miou=None, target_semantic: Optional[torch.Tensor] = None,
+                       pred_div: int = 1) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
         if self.device.type != 'cuda':
             raise L.NmsaError('PanopticQuality.update needs the MI355X '
                               '(states live on the GPU; no CPU fallback)')
@@ -94,16 +95,45 @@ class PanopticQuality(Metric):
         if want_matches:
             matches = torch.empty((B, self._match_capacity, 2), dtype=torch.int64, device=dev)
             n_matches = torch.empty((B,), dtype=torch.int32, device=dev)
-        L.check(lib.nmsa_pq_update(
-            L.ptr(p), L.ptr(t), B, H, W, self.num_categories, int(self.ignored_label),
-            int(self.max_instances_per_category), int(self.offset), int(self.void_segment_id),
-            L.ptr(self.iou_per_class), L.ptr(self.tp_per_class), L.ptr(self.fn_per_class),
-            L.ptr(self.fp_per_class), L.ptr(matches), self._match_capacity, L.ptr(n_matches),
-            L.ptr(self._status), L.ptr(ws), ws_bytes, int(clean), L.stream_ptr(dev)),
-            'nmsa_pq_update')
+        common = (B, H, W, self.num_categories, int(self.ignored_label),
+                  int(self.max_instances_per_category), int(self.offset), int(self.void_segment_id),
+                  L.ptr(self.iou_per_class), L.ptr(self.tp_per_class), L.ptr(self.fn_per_class),
+                  L.ptr(self.fp_per_class), L.ptr(matches), self._match_capacity, L.ptr(n_matches),
+                  L.ptr(self._status), L.ptr(ws), ws_bytes, int(clean))
+        if miou is None:
+            L.check(lib.nmsa_pq_update(L.ptr(p), L.ptr(t), *common, L.stream_ptr(dev)),
+                    'nmsa_pq_update')
+        else:
+            ts = target_semantic.to(dev).contiguous()
+            n_cm = miou._n_classes
+            cm_bytes = lib.nmsa_pq_confmat_workspace_bytes(B, H, W, n_cm)
+            cm_ws = torch.empty((cm_bytes,), dtype=torch.uint8, device=dev)
+            L.check(lib.nmsa_pq_update_with_confmat(
+                L.ptr(p), L.ptr(t), L.ptr(ts), *common, n_cm, int(pred_div), L.ptr(miou.confmat),
+                L.ptr(miou._status), L.ptr(cm_ws), cm_bytes, L.stream_ptr(dev)),
+                'nmsa_pq_update_with_confmat')
         if want_matches:
             return matches, n_matches
         return None
+
+    def _can_fuse(self, preds: torch.Tensor, miou, target_semantic: torch.Tensor) -> bool:
+        return (target_semantic.dtype == torch.uint8 and miou._n_classes <= 64
+                and miou.device == self.device and preds.ndim == 3
+                and target_semantic.shape == preds.shape)
+
+    def update_with_miou(self, preds: torch.Tensor, targets: torch.Tensor, miou,
+                         target_semantic: torch.Tensor, pred_div: int) -> None:
+        """`self.update(preds, targets)` and `miou.update(preds // pred_div, target_semantic)`
+        (the two metric updates of task_helper/panoptic.py:104-126) with ONE pass over the
+        prediction.  Falls back to the two separate kernels when the fused form does not apply
+        (semantic target not uint8, more than 64 classes, metrics on different devices)."""
+        if not self._can_fuse(preds, miou, target_semantic):
+            miou.update_from_panoptic(preds, target_semantic, pred_div)
+            self.update(preds, targets)
+            return
+        miou._require_gpu()
+        self._device_update(preds, targets, want_matches=False, miou=miou,
+                            target_semantic=target_semantic, pred_div=pred_div)
 
     def update(self, preds: torch.Tensor, targets: torch.Tensor) -> None:
         self._device_update(preds, targets, want_matches=False)

@@ -65,11 +65,11 @@ class PanopticTaskHelper(TaskHelperBase):
             panoptic_preds_id_dicts=predictions_post['panoptic_segmentation_deeplab_ids'],
             panoptic_target=panoptic_targets,
             orientation_target=orientations_targets,
-            panoptic_target_id_dicts=batch.get('panoptic_ids_to_instance_dict'))
-        # merging may change classes: mIoU of panoptic // max_instances (panoptic.py:120-126),
-        # the division is folded into the confusion-matrix kernel
-        self._metric_iou.update_from_panoptic(panoptic_preds, get_fullres(batch, 'semantic'),
-                                              self._max_instances_per_category)
+            panoptic_target_id_dicts=batch.get('panoptic_ids_to_instance_dict'),
+            # merging may change classes: mIoU of panoptic // max_instances (panoptic.py:120-126)
+            # rides on the PQ pass over the prediction (one read of the i64 map for both metrics)
+            miou=self._metric_iou, semantic_target=get_fullres(batch, 'semantic'),
+            pred_div=self._max_instances_per_category)
         return {}, {}
 
     @append_profile_to_logs('panoptic_epoch_end_time')

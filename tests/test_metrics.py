@@ -374,3 +374,39 @@ def test_bench_accumulators_packed_reduce_path():
     assert a.total_confmat.sum() > 0
     assert torch.equal(a.total_confmat, b.total_confmat)
     assert torch.equal(a.total_pq, b.total_pq)
+
+
+@gpu
+@pytest.mark.parametrize('shape', [(3, 48, 64), (2, 37, 41), (1, 480, 640)])
+def test_fused_pq_confmat_equals_separate_updates(shape):
+    """nmsa_pq_update_with_confmat (one pass over the prediction) == nmsa_pq_update +
+    nmsa_confmat_update, bit for bit, incl. odd sizes (scalar path) and repeated updates"""
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
+    B, H, W = shape
+    n = 9
+    g = torch.Generator(device='cuda').manual_seed(B * 1000 + W)
+    is_thing = [False, False, True, True, False, True, True, False, True]
+
+    def blocky(hi):
+        c = torch.randint(0, hi, (B, (H + 7) // 8, (W + 7) // 8), device='cuda', generator=g)
+        return c.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :H, :W].contiguous()
+    pred = blocky(n) * 65536 + blocky(3)
+    tgt = blocky(n) * 65536 + blocky(3)
+    tsem = blocky(n).to(torch.uint8)
+    pq_a, pq_b = (PanopticQuality(n, 0, 1 << 16, 256 ** 3, is_thing, device='cuda') for _ in range(2))
+    mi_a, mi_b = (MeanIntersectionOverUnion(n, device='cuda') for _ in range(2))
+    for _ in range(2):
+        pq_a.update(pred, tgt)
+        mi_a.update_from_panoptic(pred, tsem, 65536)
+        pq_b.update_with_miou(pred, tgt, mi_b, tsem, 65536)
+    torch.cuda.synchronize()
+    assert mi_a.confmat.sum() == 2 * B * H * W
+    assert torch.equal(mi_a.confmat, mi_b.confmat)
+    for name in ('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class'):
+        assert torch.equal(getattr(pq_a, name), getattr(pq_b, name)), name
+    # a label outside the matrix is reported through the mIoU status word
+    bad = tsem.clone()
+    bad[0, 0, 0] = 200
+    pq_b.update_with_miou(pred, tgt, mi_b, bad, 65536)
+    with pytest.raises(ValueError):
+        mi_b.compute()
