@@ -128,6 +128,15 @@ def test_fuzz_metrics_vs_oracle(oracle, seed, B, H, W, n_cat, n_seg):
     miou.update(dev(pred // 65536), dev(tgt // 65536))
     cm = oracle.confmat_update(pred // 65536, tgt // 65536, n_cat)
     assert np.array_equal(miou.confmat.cpu().numpy(), cm)
+    # the fused form (one pass over the prediction for both metrics)
+    tsem = rng.integers(0, n_cat, (B, H, W)).astype(np.uint8)
+    pq2 = PanopticQuality(n_cat, 0, 1 << 16, 256 ** 3, is_thing, device='cuda')
+    miou2 = MeanIntersectionOverUnion(n_cat, device='cuda')
+    pq2.update_with_miou(dev(pred), dev(tgt), miou2, dev(tsem), 65536)
+    torch.cuda.synchronize()
+    for g2, w in zip([pq2.iou_per_class, pq2.tp_per_class, pq2.fn_per_class, pq2.fp_per_class], state):
+        assert np.array_equal(g2.cpu().numpy(), np.asarray(w, dtype=np.float64)), (seed, 'fused')
+    assert np.array_equal(miou2.confmat.cpu().numpy(), oracle.confmat_update(pred // 65536, tsem, n_cat))
 
 
 @settings(max_examples=120, deadline=None, derandomize=True,
