@@ -324,10 +324,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
     int st = 0;
 
     // called by MANY lanes at once (one per run of equal pixels)
-    auto add = [&](int64_t t, int64_t p, uint32_t cnt) {
-        if (t < 0 || p < 0 || p >= offset) st |= ST_MISSING_KEY;      // ids would not decode
-        // intersection id with torch's int64 wrap-around arithmetic (pq.py:104)
-        const int64_t iid = (int64_t)((uint64_t)t * (uint64_t)offset + (uint64_t)p);
+    auto add = [&](int64_t iid, uint32_t cnt) {
         if (iid == KEY_EMPTY) { st |= ST_SENTINEL_KEY; return; }
         // fast path: key already in its home slot -> one LDS read, one LDS atomic
         const uint32_t sI = hash_id(iid) & (PQ_LI - 1);
@@ -335,21 +332,26 @@ __global__ __launch_bounds__(256) void k_pq_count(
         if (!table_add(lkI, lcI, PQ_LI - 1, iid, cnt, 32) &&
             !table_add(gk, gc, PQ_I_CAP - 1, iid, cnt, PQ_I_CAP)) st |= ST_TABLE_OVERFLOW;
     };
+    // intersection id with torch's int64 wrap-around arithmetic (pq.py:104); ids that would
+    // not decode uniquely (pq.py:83-109 then fails or mixes segments) raise ST_MISSING_KEY
+    auto iid_of = [&](int64_t t, int64_t p, bool valid) -> int64_t {
+        if (valid && (t < 0 || p < 0 || p >= offset)) st |= ST_MISSING_KEY;
+        return (int64_t)((uint64_t)t * (uint64_t)offset + (uint64_t)p);
+    };
     // One (target, pred) pair per lane, lanes = consecutive pixels.  Neighbouring pixels
-    // mostly share the pair, so the wave is cut into RUNS of equal lanes: every run head
-    // inserts its run length — all heads in parallel, no leader-serial loop.
-    auto wave_runs = [&](bool valid, int64_t t, int64_t p, uint32_t weight) {
-        const int64_t pt = __shfl_up(t, 1);
-        const int64_t pp = __shfl_up(p, 1);
+    // mostly share the pair, so the wave is cut into RUNS of equal intersection ids: every run
+    // head inserts its run length — all heads in parallel, no leader-serial loop.
+    auto wave_runs = [&](bool valid, int64_t iid, uint32_t weight) {
+        const int64_t prev = __shfl_up(iid, 1);
         const bool pvalid = __shfl_up((int)valid, 1) != 0;
-        const bool head = valid && (lane_id() == 0 || !pvalid || pt != t || pp != p);
+        const bool head = valid && (lane_id() == 0 || !pvalid || prev != iid);
         const unsigned long long heads = __ballot(head);
         const unsigned long long vmask = __ballot(valid);
         if (head) {
             const int l = lane_id();
             const unsigned long long stop = (heads | ~vmask) & ~((2ull << l) - 1ull);
             const int nxt = stop ? (__ffsll((long long)stop) - 1) : 64;
-            add(t, p, weight * (uint32_t)(nxt - l));
+            add(iid, weight * (uint32_t)(nxt - l));
         }
     };
 
@@ -382,12 +384,13 @@ __global__ __launch_bounds__(256) void k_pq_count(
             }
 #pragma unroll
             for (int u = 0; u < PQ_UNROLL; ++u) {
-                const bool same2 = tv[u].x == tv[u].y && pv[u].x == pv[u].y;
-                if (__all(same2 || !ok[u])) {
-                    wave_runs(ok[u], tv[u].x, pv[u].x, 2u);     // both px of every lane agree
+                const int64_t i0 = iid_of(tv[u].x, pv[u].x, ok[u]);
+                const int64_t i1 = iid_of(tv[u].y, pv[u].y, ok[u]);
+                if (__all(i0 == i1 || !ok[u])) {
+                    wave_runs(ok[u], i0, 2u);                   // both px of every lane agree
                 } else {
-                    wave_runs(ok[u], tv[u].x, pv[u].x, 1u);
-                    wave_runs(ok[u], tv[u].y, pv[u].y, 1u);
+                    wave_runs(ok[u], i0, 1u);
+                    wave_runs(ok[u], i1, 1u);
                 }
             }
         }
@@ -397,7 +400,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
         for (int k = 0; k < trips; ++k) {
             const int i = start + k * blockDim.x + threadIdx.x;
             const bool valid = i < end;
-            wave_runs(valid, valid ? tg[i] : 0, valid ? pr[i] : 0, 1u);
+            wave_runs(valid, iid_of(valid ? tg[i] : 0, valid ? pr[i] : 0, valid), 1u);
             if (WITH_CM) cm_runs(cm_key(valid ? ts[i] : 0, valid ? pr[i] : 0, valid), 1u);
         }
     }
