@@ -262,6 +262,17 @@ int nmsa_panoptic_scores(const void* logits, int logits_dtype,
 int nmsa_instance_orientation(const float* orientation, const uint8_t* inst,
                               const uint8_t* mask, int B, int H, int W,
                               double* sums, int32_t* count, nmsa_stream_t stream);
+/* the same for ground-truth instance maps (ids 0..65535 in any integer dtype, at most
+ * max_instances <= 4096 distinct masked ids per image; instance.py:432-438 passes
+ * batch['instance']): ids i32 [B,cap] ascending, n_ids i32 [B], sums f64 [B,cap,2],
+ * count i32 [B,cap] by position in `ids` (cap = max_instances rounded up to 1024);
+ * status bits: 1 too many ids, 32 id out of range;
+ * workspace: nmsa_targets_workspace_bytes(B, 1, max_instances) */
+int nmsa_instance_orientation_wide(const float* orientation, const void* instance, int ins_dtype,
+                                   const uint8_t* mask, int B, int H, int W, int max_instances,
+                                   int32_t* ids, int32_t* n_ids, double* sums, int32_t* count,
+                                   int32_t* status, void* workspace, size_t workspace_bytes,
+                                   nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * f4  ground-truth target generation on the device (per batch instead of per sample in the

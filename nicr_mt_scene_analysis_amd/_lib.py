@@ -81,6 +81,8 @@ _SIGNATURES = {
     'nmsa_panoptic_targets': (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_dve_targets': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    'nmsa_instance_orientation_wide': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
+                                            _vp, _vp, _sz, _vp]),
     'nmsa_instance_orientation': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     'nmsa_confmat_workspace_bytes': (_sz, [_i]),
     'nmsa_confmat_update': (_i, [_vp, _i, _i64, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -713,6 +713,117 @@ __global__ __launch_bounds__(256) void k_clear_stuff(
     }
 }
 
+// ---- orientation sums for sparse (ground-truth) instance ids ------------------------------------
+// InstancePostprocessing._get_instance_orientation (model/postprocessing/instance.py:271-319)
+// with dataset instance maps (uint16 ids): ids are ranked like above, the biternion sums are
+// taken per dense slot (fp64, LDS-privatised per workgroup).
+__global__ __launch_bounds__(256) void k_ow_presence(
+    const void* __restrict__ ins, int ins_dtype, const uint8_t* __restrict__ mask, int P, int cap,
+    unsigned char* __restrict__ ws, int* __restrict__ status)
+{
+    __shared__ int s_ids[TG_H1];
+    const int b = blockIdx.y;
+    TgView v = tg_view(ws, b, cap, 1);
+    if (threadIdx.x < TG_H1) s_ids[threadIdx.x] = -1;
+    __syncthreads();
+    bool bad = false;
+    const int stride = gridDim.x * blockDim.x;
+    const int trips = (P + stride - 1) / stride;
+    for (int k = 0; k < trips; ++k) {
+        const int p = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        int key = -1;
+        if (p < P) {
+            const size_t o = (size_t)b * P + p;
+            const int64_t i = mw_load(ins, ins_dtype, o);
+            if (i < 0 || i > MW_MAX_ID) bad = true;
+            else if (i > 0 && (!mask || mask[o])) key = (int)i;
+        }
+        int rl, rlast;
+        if (wave_run_head(key, rl, rlast) && lds_hash_slot(s_ids, TG_H1, key) < 0)
+            atomicOr(&v.bitmap[key >> 5], 1u << (key & 31));
+    }
+    __syncthreads();
+    if (threadIdx.x < TG_H1 && s_ids[threadIdx.x] >= 0) {
+        const int id = s_ids[threadIdx.x];
+        atomicOr(&v.bitmap[id >> 5], 1u << (id & 31));
+    }
+    if (bad) atomicOr(status, TG_ST_ID_RANGE);
+}
+
+__global__ __launch_bounds__(256) void k_ow_sums(
+    const float* __restrict__ orientation, const void* __restrict__ ins, int ins_dtype,
+    const uint8_t* __restrict__ mask, int P, int cap, unsigned char* __restrict__ ws,
+    double* __restrict__ sums, int32_t* __restrict__ count)
+{
+    __shared__ int s_key[TG_H1];
+    __shared__ double s_sum[TG_H1 * 2];
+    __shared__ int s_cnt[TG_H1];
+    const int b = blockIdx.y;
+    TgView v = tg_view(ws, b, cap, 1);
+    if (threadIdx.x < TG_H1) {
+        s_key[threadIdx.x] = -1; s_cnt[threadIdx.x] = 0;
+        s_sum[2 * threadIdx.x] = 0.0; s_sum[2 * threadIdx.x + 1] = 0.0;
+    }
+    __syncthreads();
+    const float* o0 = orientation + (size_t)b * 2 * P;
+    const float* o1 = o0 + P;
+    double* gs = sums + (size_t)b * cap * 2;
+    int32_t* gc = count + (size_t)b * cap;
+    const int stride = gridDim.x * blockDim.x;
+    const int trips = (P + stride - 1) / stride;
+    for (int k = 0; k < trips; ++k) {
+        const int p = (k * gridDim.x + blockIdx.x) * blockDim.x + threadIdx.x;
+        int d = -1;
+        double v0 = 0.0, v1 = 0.0;
+        if (p < P) {
+            const size_t o = (size_t)b * P + p;
+            const int64_t i = mw_load(ins, ins_dtype, o);
+            if (i > 0 && i <= MW_MAX_ID && (!mask || mask[o])) {
+                const int dd = id_rank_dense(v.bitmap, v.prefix, (int)i);
+                if (dd < cap) { d = dd; v0 = (double)o0[p]; v1 = (double)o1[p]; }
+            }
+        }
+        // one distinct instance at a time (1-3 per wave): the wave sums its lanes in fp64
+        unsigned long long todo = __ballot(d >= 0);
+        while (todo) {
+            const int leader = __ffsll((long long)todo) - 1;
+            const int kd = __shfl(d, leader);
+            const bool mine = (d == kd);
+            const unsigned long long same = __ballot(mine) & todo;
+            const double a0 = wave_reduce_sum(mine ? v0 : 0.0);
+            const double a1 = wave_reduce_sum(mine ? v1 : 0.0);
+            if (lane_id() == 0) {
+                const int slot = lds_hash_slot(s_key, TG_H1, kd);
+                const int n = (int)__popcll(same);
+                if (slot >= 0) {
+                    atomicAdd(&s_sum[2 * slot], a0); atomicAdd(&s_sum[2 * slot + 1], a1);
+                    atomicAdd(&s_cnt[slot], n);
+                } else {
+                    atomicAdd(&gs[2 * kd], a0); atomicAdd(&gs[2 * kd + 1], a1); atomicAdd(&gc[kd], n);
+                }
+            }
+            todo &= ~same;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TG_H1 && s_key[threadIdx.x] >= 0) {
+        const int kd = s_key[threadIdx.x];
+        atomicAdd(&gs[2 * kd], s_sum[2 * threadIdx.x]);
+        atomicAdd(&gs[2 * kd + 1], s_sum[2 * threadIdx.x + 1]);
+        atomicAdd(&gc[kd], s_cnt[threadIdx.x]);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_ow_export(unsigned char* __restrict__ ws, int cap,
+                                                   int32_t* __restrict__ ids, int32_t* __restrict__ n_ids)
+{
+    const int b = blockIdx.x;
+    TgView v = tg_view(ws, b, cap, 1);
+    const int n = v.counters[0];
+    for (int i = threadIdx.x; i < n; i += blockDim.x) ids[(size_t)b * cap + i] = v.id_of_dense[i];
+    if (threadIdx.x == 0) n_ids[b] = n;
+}
+
 int tg_cap(int max_instances) { return ((max_instances + 1023) / 1024) * 1024; }
 
 // the vectorised label loaders apply to the on-wire dtypes with 4-pixel aligned images
@@ -899,5 +1010,40 @@ extern "C" int nmsa_instance_clear_stuff(const void* semantic, int sem_dtype, vo
         case NMSA_I32: hipLaunchKernelGGL(k_clear_stuff<int32_t>, grid, block, 0, stream, semantic, sem_dtype, (int32_t*)instance, is_stuff_class, n_classes, (size_t)n_px); break;
         default: hipLaunchKernelGGL(k_clear_stuff<int64_t>, grid, block, 0, stream, semantic, sem_dtype, (int64_t*)instance, is_stuff_class, n_classes, (size_t)n_px); break;
     }
+    return check_launch();
+}
+
+extern "C" int nmsa_instance_orientation_wide(const float* orientation, const void* instance,
+                                              int ins_dtype, const uint8_t* mask,
+                                              int B, int H, int W, int max_instances,
+                                              int32_t* ids, int32_t* n_ids, double* sums, int32_t* count,
+                                              int32_t* status, void* workspace, size_t workspace_bytes,
+                                              nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!orientation || !instance || !ids || !n_ids || !sums || !count || !status || !workspace)
+        return NMSA_ERR_ARG;
+    if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || (int64_t)H * W > ((int64_t)1 << 30)) return NMSA_ERR_ARG;
+    if (max_instances <= 0 || max_instances > 4096 || tg_bad_dtype(ins_dtype)) return NMSA_ERR_ARG;
+    const int cap = tg_cap(max_instances);
+    const size_t need = nmsa_targets_workspace_bytes(B, 1, max_instances);
+    if (workspace_bytes < need) return NMSA_ERR_WORKSPACE;
+    if ((uintptr_t)workspace % 8) return NMSA_ERR_ARG;
+    unsigned char* ws = (unsigned char*)workspace;
+    const int P = H * W;
+    int rc = check_hip(hipMemsetAsync(ws, 0, need, stream));
+    if (rc) return rc;
+    if ((rc = check_hip(hipMemsetAsync(sums, 0, (size_t)B * cap * 2 * sizeof(double), stream)))) return rc;
+    if ((rc = check_hip(hipMemsetAsync(count, 0, (size_t)B * cap * sizeof(int32_t), stream)))) return rc;
+    int gx = (P + 4095) / 4096;
+    hipLaunchKernelGGL(k_ow_presence, dim3(gx, B), dim3(256), 0, stream, instance, ins_dtype, mask, P, cap,
+                       ws, status);
+    if ((rc = check_launch())) return rc;
+    hipLaunchKernelGGL(k_tg_rank, dim3(B), dim3(1024), 0, stream, ws, cap, 1, status);
+    if ((rc = check_launch())) return rc;
+    hipLaunchKernelGGL(k_ow_sums, dim3(gx, B), dim3(256), 0, stream, orientation, instance, ins_dtype,
+                       mask, P, cap, ws, sums, count);
+    if ((rc = check_launch())) return rc;
+    hipLaunchKernelGGL(k_ow_export, dim3(B), dim3(256), 0, stream, ws, cap, ids, n_ids);
     return check_launch();
 }

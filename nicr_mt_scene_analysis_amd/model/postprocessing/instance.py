@@ -124,10 +124,10 @@ class InstancePostprocessing(DensePostprocessingBase):
         seg = instance_segmentation
         if seg.ndim == 4:
             seg = seg[:, 0]
+        if seg.dtype == torch.bool:
+            seg = seg.view(torch.uint8)
         if seg.dtype != torch.uint8:
-            if int(seg.max()) > 255:
-                raise NotImplementedError('instance ids > 255 are not supported on the HIP path')
-            seg = seg.to(torch.uint8)
+            return self._get_instance_orientation_wide(orientation, seg, foreground_mask)
         r = ops.instance_orientation_sums(orientation, seg.contiguous(), foreground_mask)
         sums = r['sums'].to(torch.float32)
         # angle = atan2(sum(sin), sum(cos))  (utils/_orientation.py:39-42)
@@ -136,6 +136,34 @@ class InstancePostprocessing(DensePostprocessingBase):
         out = []
         for row in packed:
             out.append({i: row[i] for i in range(1, 256) if row[256 + i] > 0})
+        return out
+
+    def _get_instance_orientation_wide(self, orientation, seg, foreground_mask):
+        """ground-truth instance maps (uint16 ids stored as int32 / int64, instance.py:432-438):
+        ids are ranked on the device, the dict is keyed by the original ids"""
+        max_instances = 1024
+        while True:
+            r = ops.instance_orientation_sums_wide(orientation, seg.contiguous(), foreground_mask,
+                                                   max_instances)
+            head = torch.cat([r['status'], r['n_ids']]).cpu().tolist()
+            if head[0] & 1 and max_instances < 4096:
+                max_instances = 4096
+                continue
+            break
+        if head[0] & 32:
+            raise NotImplementedError('instance ids outside [0, 65535] are not supported '
+                                      '(dataset instance maps are uint16)')
+        if head[0] & 1:
+            raise NotImplementedError('more than 4096 distinct instance ids in one image')
+        nmax = max(1, max(head[1:]))
+        sums = r['sums'][:, :nmax].to(torch.float32)
+        angle = torch.atan2(sums[..., 1], sums[..., 0])
+        packed = torch.cat([r['ids'][:, :nmax].to(torch.float64), angle.to(torch.float64),
+                            r['count'][:, :nmax].to(torch.float64)], dim=1).cpu().tolist()
+        out = []
+        for b, row in enumerate(packed):
+            n = head[1 + b]
+            out.append({int(row[i]): row[nmax + i] for i in range(n) if row[2 * nmax + i] > 0})
         return out
 
     # ---------------------------------------------------------------- interface
@@ -200,6 +228,9 @@ class InstancePostprocessing(DensePostprocessingBase):
         if self.debug:
             fg_all = torch.ones_like(center_heatmap[:, 0], dtype=torch.bool)
             seg, _ = self._segment_with_foreground(center_heatmap, center_offset, fg_all)
+            # the reference builds this mask with ones_like(center_heatmap): its debug result
+            # keeps the channel axis, [B,1,H,W]
+            seg = seg.unsqueeze(1)
             r['instance_segmentation_all_foreground'] = seg
             r[get_fullres_key('instance_segmentation_all_foreground')] = _fullres(seg)
 

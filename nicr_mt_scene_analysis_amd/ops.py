@@ -579,3 +579,31 @@ def instance_orientation_sums(
         L.ptr(o), L.ptr(ins), L.ptr(_u8(mask)), B, H, W, L.ptr(sums), L.ptr(count),
         L.stream_ptr(dev)), 'nmsa_instance_orientation')
     return {'sums': sums, 'count': count}
+
+
+def instance_orientation_sums_wide(
+    orientation: torch.Tensor,
+    instance: torch.Tensor,
+    mask: Optional[torch.Tensor] = None,
+    max_instances: int = 1024,
+) -> Dict[str, torch.Tensor]:
+    """`instance_orientation_sums` for ground-truth instance maps (ids 0..65535, any integer
+    dtype): sums / counts by position in the ascending `ids` list."""
+    o = L.require_device_tensor(orientation, 'orientation')
+    if o.dtype != torch.float32:
+        o = o.float()
+    ins = L.require_device_tensor(instance, 'instance')
+    B, two, H, W = o.shape
+    dev = o.device
+    cap = ((int(max_instances) + 1023) // 1024) * 1024
+    ids = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    n_ids = torch.empty((B,), dtype=torch.int32, device=dev)
+    sums = torch.empty((B, cap, 2), dtype=torch.float64, device=dev)
+    count = torch.empty((B, cap), dtype=torch.int32, device=dev)
+    status = torch.zeros((1,), dtype=torch.int32, device=dev)
+    ws, ws_bytes = _targets_workspace(B, 1, int(max_instances), dev)
+    L.check(L.lib().nmsa_instance_orientation_wide(
+        L.ptr(o), L.ptr(ins), L.int_dtype_code(ins), L.ptr(_u8(mask)), B, H, W, int(max_instances),
+        L.ptr(ids), L.ptr(n_ids), L.ptr(sums), L.ptr(count), L.ptr(status), L.ptr(ws), ws_bytes,
+        L.stream_ptr(dev)), 'nmsa_instance_orientation_wide')
+    return {'ids': ids, 'n_ids': n_ids, 'sums': sums, 'count': count, 'status': status}

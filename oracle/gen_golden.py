@@ -802,6 +802,56 @@ def gen_targets(ref):
     save('target_cases', **out)
 
 
+def gen_instance_post(ref):
+    """InstancePostprocessing.postprocess (instance.py:337-468) with every ground-truth key:
+    GT foreground, debug all-foreground, a real crop + upscale, and the four orientation dicts —
+    incl. GT instance ids beyond 255 (dataset maps are uint16)."""
+    print('instance postprocessing with GT keys (reference InstancePostprocessing.postprocess)')
+    H, W = 96, 128
+    inp = syn.make_panoptic_inputs(2, n_classes=6, height=H, width=W, n_centers=6, seed=23,
+                                   with_orientation=True)
+    rng = np.random.default_rng(29)
+    fg = np.repeat(np.repeat(rng.random((2, H // 8, W // 8)) < 0.6, 8, 1), 8, 2)
+    gt_ids = rng.choice(np.arange(1, 60000), size=12, replace=False)
+    gt_inst = np.repeat(np.repeat(gt_ids[rng.integers(0, 12, (2, H // 16, W // 16))], 16, 1), 16, 2)
+    gt_inst = np.where(rng.random((2, H, W)) < 0.15, 0, gt_inst).astype(np.int32)
+    ori_fg = rng.random((2, H, W)) < 0.7
+    crop, size = (slice(4, 92), slice(0, 128)), (150, 200)
+    post = ref.post_instance.InstancePostprocessing(debug=True)
+    batch = {
+        'rgb_fullres': torch.zeros((2, 3) + size),
+        ref.APPLIED_PREPROCESSING_KEY: [[{
+            'type': 'Resize', 'valid_region_slice_y': crop[0], 'valid_region_slice_x': crop[1],
+        }]] * 2,
+        'instance_foreground': torch.from_numpy(fg),
+        'instance': torch.from_numpy(gt_inst),
+        'orientation_foreground': torch.from_numpy(ori_fg),
+    }
+    data = ((torch.from_numpy(inp['instance_center']), torch.from_numpy(inp['instance_offset']),
+             torch.from_numpy(inp['instance_orientation'])), None)
+    r = post.postprocess(data, batch, is_training=False)
+    out = dict(in_center=inp['instance_center'], in_offset=inp['instance_offset'],
+               in_orientation=inp['instance_orientation'], in_fg=fg, in_gt_instance=gt_inst,
+               in_orientation_fg=ori_fg,
+               crop=np.array([4, 92, 0, 128], np.int32), size=np.array(size, np.int32))
+    for k in ('instance_segmentation_gt_foreground', 'instance_segmentation_all_foreground'):
+        out[k] = r[k].numpy()
+        out[k + '_fullres'] = r[k + '_fullres'].numpy()
+    n, cyx, area, score = meta_to_arrays(r['instance_segmentation_gt_meta'])
+    out.update(meta_n=n, meta_center_yx=cyx, meta_area=area, meta_score=score)
+    for k in ('orientations_gt_instance_gt_orientation_foreground',
+              'orientations_instance_segmentation_gt_orientation_foreground',
+              'orientations_gt_instance', 'orientations_instance_segmentation'):
+        keys = np.full((2, 64), -1, np.int64)
+        vals = np.full((2, 64), np.nan, np.float32)
+        for b, d in enumerate(r[k]):
+            for i, (kk, vv) in enumerate(sorted(d.items())):
+                keys[b, i], vals[b, i] = kk, vv
+        out[k + '__ids'] = keys
+        out[k + '__angles'] = vals
+    save('instance_post_cases', **out)
+
+
 def main():
     ref = load_reference()
     only = set(sys.argv[1:])
@@ -830,6 +880,8 @@ def main():
         gen_fullres(ref)
     if want('scores'):
         gen_scores(ref)
+    if want('instance_post'):
+        gen_instance_post(ref)
     if want('targets'):
         gen_targets(ref)
 

@@ -319,3 +319,45 @@ def test_panoptic_scores_vs_oracle(oracle):
         for b, d in enumerate(ids):
             for ins_id in d.values():
                 assert abs(got_mean[b, ins_id] - mean[b, ins_id]) <= 1e-5 * abs(mean[b, ins_id])
+
+
+def test_instance_postprocess_gt_keys_vs_golden():
+    """InstancePostprocessing.postprocess with every GT key of the reference (GT foreground, debug
+    all-foreground, real crop + upscale, four orientation dicts incl. uint16-range GT instance ids)
+    against the reference's own output (oracle/gen_golden.py::gen_instance_post)."""
+    from nicr_mt_scene_analysis_amd.data.preprocessing import APPLIED_PREPROCESSING_KEY
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    g = load('instance_post_cases')
+    c = [int(v) for v in g['crop']]
+    size = tuple(int(v) for v in g['size'])
+    post = get_postprocessing_class('instance')(debug=True)
+    batch = {
+        'rgb_fullres': torch.zeros((2, 3) + size),
+        APPLIED_PREPROCESSING_KEY: [[{'type': 'Resize', 'valid_region_slice_y': slice(c[0], c[1]),
+                                      'valid_region_slice_x': slice(c[2], c[3])}]] * 2,
+        'instance_foreground': dev(g['in_fg']),
+        'instance': dev(g['in_gt_instance']),
+        'orientation_foreground': dev(g['in_orientation_fg']),
+    }
+    data = ((dev(g['in_center']), dev(g['in_offset']), dev(g['in_orientation'])), None)
+    r = post.postprocess(data, batch, is_training=False)
+    for k in ('instance_segmentation_gt_foreground', 'instance_segmentation_all_foreground'):
+        assert r[k].dtype == torch.uint8
+        assert np.array_equal(r[k].cpu().numpy(), g[k]), k
+        assert np.array_equal(r[k + '_fullres'].cpu().numpy(), g[k + '_fullres']), k
+    want_meta = meta_from_arrays(g['meta_n'], g['meta_center_yx'], g['meta_area'], g['meta_score'])
+    for a, b in zip(r['instance_segmentation_gt_meta'], want_meta):
+        assert a.keys() == b.keys()
+        for i in a:
+            assert a[i]['center_yx'] == b[i]['center_yx'] and a[i]['area'] == b[i]['area']
+            assert a[i]['score'] == b[i]['score']
+    for k in ('orientations_gt_instance_gt_orientation_foreground',
+              'orientations_instance_segmentation_gt_orientation_foreground',
+              'orientations_gt_instance', 'orientations_instance_segmentation'):
+        for b in range(2):
+            ids = [int(v) for v in g[k + '__ids'][b] if v >= 0]
+            assert sorted(r[k][b].keys()) == ids, k
+            for i, kk in enumerate(ids):
+                want = float(g[k + '__angles'][b, i])
+                got = r[k][b][kk]
+                assert abs(got - want) < 1e-4 or abs(abs(got - want) - 2 * np.pi) < 1e-4, (k, kk)

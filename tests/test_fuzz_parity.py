@@ -268,3 +268,35 @@ def test_fuzz_orientation_vs_oracle(oracle, seed, B, H, W, n_rect, with_mask):
         for i, ang in want[b].items():
             got = float(np.arctan2(np.float32(sums[b, i, 1]), np.float32(sums[b, i, 0])))
             assert abs(got - ang) < 1e-4 or abs(abs(got - ang) - 2 * np.pi) < 1e-4
+
+
+@settings(max_examples=60, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(2, 30), W=st.integers(2, 41),
+       n_rect=st.integers(0, 8), with_mask=st.booleans())
+def test_fuzz_orientation_wide_ids(oracle, seed, B, H, W, n_rect, with_mask):
+    """_get_instance_orientation with ground-truth instance maps (sparse uint16 ids in int32):
+    same angles as the uint8 oracle run on the rank-compressed ids, keyed by the original ids"""
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    rng = np.random.default_rng(seed)
+    ori = rng.standard_normal((B, 2, H, W)).astype(np.float32)
+    inst = np.zeros((B, H, W), np.int32)
+    for b in range(B):
+        for _ in range(n_rect):
+            ya, xa = rng.integers(0, H), rng.integers(0, W)
+            yb, xb = rng.integers(ya, H) + 1, rng.integers(xa, W) + 1
+            inst[b, ya:yb, xa:xb] = rng.integers(1, 65536)
+    mask = (rng.random((B, H, W)) < 0.7) if with_mask else None
+    post = get_postprocessing_class('instance')()
+    got = post._get_instance_orientation(dev(ori), dev(inst), None if mask is None else dev(mask))
+    for b in range(B):
+        ids = np.unique(inst[b])
+        small = np.searchsorted(ids, inst[b]).astype(np.uint8)            # ranks (0 stays 0: ids[0] == 0 or absent)
+        if ids[0] != 0:
+            small = (small + 1).astype(np.uint8)
+            ids = np.concatenate([[0], ids])
+        want = oracle.instance_orientation(ori[b:b + 1], small[None], None if mask is None else mask[b:b + 1])[0]
+        assert sorted(got[b].keys()) == sorted(int(ids[k]) for k in want), (seed, b)
+        for k, ang in want.items():
+            g = got[b][int(ids[k])]
+            assert abs(g - ang) < 1e-4 or abs(abs(g - ang) - 2 * np.pi) < 1e-4
