@@ -22,12 +22,15 @@ class CosineEmbeddingLoss(LossBase):
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor,
                       target_similarity: Optional[torch.Tensor] = None):
-        if target_similarity is not None and not bool((target_similarity == 1).all()):
-            raise NotImplementedError('only similar pairs (label +1) are on the hot path')
         n, d = input_.shape
-        if self._reduction != 'sum' or not input_.is_cuda or n == 0:
-            loss = torch.nn.functional.cosine_embedding_loss(
-                input_, target, torch.ones(n, device=input_.device), reduction='none')
+        # the HIP kernel covers what the task helper uses: similar pairs (label +1), 'sum';
+        # explicit labels (dissimilar pairs) and the other reductions are ATen's op on the
+        # tensors' own device
+        labelled = target_similarity is not None
+        if labelled or self._reduction != 'sum' or not input_.is_cuda or n == 0:
+            labels = target_similarity if labelled else torch.ones(n, device=input_.device)
+            loss = torch.nn.functional.cosine_embedding_loss(input_, target, labels,
+                                                             reduction='none')
             if self._reduction == 'sum':
                 return loss.sum(), loss.numel()
             if self._reduction == 'mean':

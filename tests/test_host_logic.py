@@ -194,8 +194,10 @@ def test_loss_host_paths_and_errors():
     rows, tg = torch.rand((9, 2)), torch.rand((9, 2))
     (l, n), = VonMisesLossBiternion()([rows], [tg])
     assert n == 9 and float(l) == pytest.approx(float((1 - torch.exp((rows * tg).sum(1) - 1)).sum()))
-    with pytest.raises(NotImplementedError):
-        CosineEmbeddingLoss()._compute_loss(rows, tg, target_similarity=-torch.ones(9))
+    # explicit similarity labels (dissimilar pairs) follow torch's CosineEmbeddingLoss (cos_emb.py:29-43)
+    l, n = CosineEmbeddingLoss()._compute_loss(rows, tg, target_similarity=-torch.ones(9))
+    want = torch.nn.functional.cosine_embedding_loss(rows, tg, -torch.ones(9), reduction='none')
+    assert n == 9 and float(l) == pytest.approx(float(want.sum()))
 
 
 def test_task_helper_base_logic():
