@@ -191,3 +191,32 @@ class PanopticQuality(Metric):
                 for k in ('pq', 'sq', 'rq', 'num_categories'):
                     results[f'{name}_{k}'] = torch.tensor(0)
         return results
+
+
+def compare_and_accumulate(
+    pred: torch.Tensor,
+    target: torch.Tensor,
+    num_categories: int,
+    ignored_label: int,
+    max_instances_per_category,
+    offset: int,
+    void_segment_id: int
+) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, set]:
+    """The reference's per-image function (metric/pq.py:60-179) with its signature and return
+    value — (iou, tp, fn, fp per class as float64 [num_categories], set of matched
+    (target segment id, predicted segment id)) — computed by the HIP kernels for one
+    [H,W] pair.  `PanopticQuality.update` batches the same kernels over all images."""
+    if pred.ndim != 2 or target.shape != pred.shape:
+        raise ValueError('compare_and_accumulate expects one [H,W] prediction / target pair')
+    dev = pred.device if pred.is_cuda else torch.device('cuda', torch.cuda.current_device())
+    one = PanopticQuality(num_categories, ignored_label, int(max_instances_per_category), offset,
+                          [False] * num_categories, device=dev)
+    one.void_segment_id = int(void_segment_id)
+    matches, n_matches = one._device_update(pred.unsqueeze(0), target.unsqueeze(0), want_matches=True)
+    n = int(n_matches.cpu()[0])
+    one._check_status()
+    if n > one._match_capacity:
+        raise ValueError('more matched segments than the match table holds')
+    matched = {(int(t), int(p)) for t, p in matches[0, :n].cpu().tolist()}
+    return (one.iou_per_class.clone(), one.tp_per_class.clone(), one.fn_per_class.clone(),
+            one.fp_per_class.clone(), matched)

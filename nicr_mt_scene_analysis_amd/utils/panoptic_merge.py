@@ -6,8 +6,9 @@ the hot path (`deeplab_merge_batch` :18-40, `deeplab_merge_semantic_and_instance
 :172-225).  The arithmetic runs in the HIP kernels k_merge_votes / k_assign /
 k_merge_paint (csrc/panoptic.hip) through `nmsa_panoptic_merge`.
 
-The numpy twins of the reference (`*_np`, used only by the CPU dataloader's
-PanopticTargetGenerator) are GT-side and out of scope (SURVEY.md §8 a5').
+The numpy twins of the reference (`*_np`, used by the CPU dataloader's
+PanopticTargetGenerator) keep their signatures at the end of this module and run on the same
+HIP kernels (upload, merge, download).
 """
 from typing import Dict, List, Optional, Sequence, Tuple
 
@@ -106,3 +107,59 @@ def deeplab_merge_semantic_and_instance(
                                      semantic_thing_seg.unsqueeze(0),
                                      max_instances_per_category, thing_ids, void_label)
     return pan[0], dicts[0]
+
+
+# ---- numpy entry points (reference utils/panoptic_merge.py:43-169) -------------------------------
+# The reference's dataloader-side twins take and return numpy arrays (semantic uint8 / uint16,
+# instance uint16 -> panoptic uint32 + id dict).  Same signatures here; the arrays are uploaded,
+# merged by the HIP kernels and downloaded again — for batches use the tensor forms
+# (`PanopticTargetGenerator`, `deeplab_merge_batch`), which stay on the device.
+def _np_inputs(sem_seg, ins_seg, void_label):
+    import numpy as np
+    assert sem_seg.dtype in (np.uint8, np.uint16)
+    assert ins_seg.dtype == np.uint16
+    assert void_label >= 0
+    if not torch.cuda.is_available():
+        raise ops.L.NmsaError('the panoptic merge needs the MI355X HIP path (no CPU fallback)')
+    dev = torch.device('cuda', torch.cuda.current_device())
+    sem = torch.from_numpy(sem_seg.astype(np.int32)).to(dev).unsqueeze(0)
+    ins = torch.from_numpy(ins_seg.astype(np.int32)).to(dev).unsqueeze(0)
+    return np, dev, sem, ins
+
+
+def naive_merge_semantic_and_instance_np(sem_seg, ins_seg, max_instances_per_category: int,
+                                         thing_ids: Sequence[int], void_label: int):
+    """reference utils/panoptic_merge.py:43-107 (every (instance, class) pair is a segment)."""
+    np, dev, sem, ins = _np_inputs(sem_seg, ins_seg, void_label)
+    n_classes = int(sem_seg.max()) + 1 if sem_seg.size else 1
+    lut = torch.zeros((n_classes,), dtype=torch.uint8)
+    for t in thing_ids:
+        if 0 <= int(t) < n_classes:
+            lut[int(t)] = 1
+    max_instances, max_segments = 1024, 2048
+    while True:
+        r = ops.panoptic_targets(sem, ins, n_classes, lut.to(dev), int(max_instances_per_category),
+                                 int(void_label), max_instances, max_segments)
+        st = int(r['status'].item())
+        if st & 1 and max_instances < 4096:
+            max_instances = 4096
+            continue
+        if st & 128 and max_segments < (1 << 16):
+            max_segments *= 4
+            continue
+        break
+    if st:
+        raise NotImplementedError(f'naive merge: unsupported input (status {st})')
+    dicts = _ids_to_dicts(r['ids_pan'], r['ids_ins'], r['n_ids'])
+    return r['panoptic'][0].cpu().numpy().astype(np.uint32), dicts[0]
+
+
+def deeplab_merge_semantic_and_instance_np(sem_seg, ins_seg, semantic_thing_seg,
+                                           max_instances_per_category: int,
+                                           thing_ids: Sequence[int], void_label: int):
+    """reference utils/panoptic_merge.py:108-169 (majority vote per instance)."""
+    np, dev, sem, ins = _np_inputs(sem_seg, ins_seg, void_label)
+    thing = torch.from_numpy(np.ascontiguousarray(semantic_thing_seg > 0)).to(dev).unsqueeze(0)
+    pan, dicts = deeplab_merge_batch(sem, ins, thing, max_instances_per_category, thing_ids,
+                                     void_label)
+    return pan[0].cpu().numpy().astype(np.uint32), dicts[0]

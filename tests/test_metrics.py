@@ -410,3 +410,18 @@ def test_fused_pq_confmat_equals_separate_updates(shape):
     pq_b.update_with_miou(pred, tgt, mi_b, bad, 65536)
     with pytest.raises(ValueError):
         mi_b.compute()
+
+
+@gpu
+def test_compare_and_accumulate_function(oracle):
+    """module-level compare_and_accumulate (reference pq.py:60-179 signature) on the HIP path"""
+    from nicr_mt_scene_analysis_amd.metric.pq import compare_and_accumulate
+    rng = np.random.default_rng(5)
+    blocks = rng.integers(0, 6, (2, 6, 8))
+    pred = np.repeat(np.repeat(blocks[0] * 65536 + rng.integers(0, 3, (6, 8)), 8, 0), 8, 1).astype(np.int64)
+    tgt = np.repeat(np.repeat(blocks[1] * 65536 + rng.integers(0, 3, (6, 8)), 8, 0), 8, 1).astype(np.int64)
+    iou, tp, fn, fp, matched = compare_and_accumulate(T(pred), T(tgt), 6, 0, 1 << 16, 256 ** 3, 0)
+    w_iou, w_tp, w_fn, w_fp, w_m = oracle.pq_compare_and_accumulate(pred, tgt, 6, 0, 1 << 16, 256 ** 3)
+    assert np.array_equal(iou.cpu().numpy(), w_iou) and np.array_equal(tp.cpu().numpy(), w_tp)
+    assert np.array_equal(fn.cpu().numpy(), w_fn) and np.array_equal(fp.cpu().numpy(), w_fp)
+    assert matched == set(w_m)

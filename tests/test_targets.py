@@ -189,3 +189,23 @@ def test_naive_and_deeplab_merge_agree_on_gt_style_maps():
     ids_n = ids_from_arrays(naive['n_ids'].cpu().numpy(), naive['ids_pan'].cpu().numpy(),
                             naive['ids_ins'].cpu().numpy())
     assert [sorted(d.items()) for d in ids_n] == [sorted(d.items()) for d in ids_d]
+
+
+def test_numpy_merge_entry_points(oracle):
+    """the reference's numpy twins (utils/panoptic_merge.py:43-169): same signatures, dtypes
+    and dict order, computed by the HIP kernels"""
+    from nicr_mt_scene_analysis_amd.utils.panoptic_merge import (
+        deeplab_merge_semantic_and_instance_np, naive_merge_semantic_and_instance_np)
+    m = syn.make_label_maps(1, 9, 60, 80, 11, seed=21)
+    sem = m['semantic'][0].astype(np.uint8)
+    ins = m['instance'][0].astype(np.uint16)
+    thing_ids = np.where(m['semantic_classes_is_thing'])[0]
+    pan, ids = naive_merge_semantic_and_instance_np(sem, ins, 1 << 16, thing_ids, 0)
+    w_pan, w_ids = oracle.naive_merge(sem[None], ins[None], 1 << 16, thing_ids, 0)
+    assert pan.dtype == np.uint32 and np.array_equal(pan, w_pan[0])
+    assert list(ids.items()) == list(w_ids[0].items())
+    thing_seg = m['semantic_classes_is_thing'][sem]
+    pan, ids = deeplab_merge_semantic_and_instance_np(sem, ins, thing_seg, 1 << 16, thing_ids, 0)
+    w_pan, w_ids = oracle.deeplab_merge(sem[None], ins[None], thing_seg[None], 1 << 16, thing_ids, 0)
+    assert pan.dtype == np.uint32 and np.array_equal(pan, w_pan[0])
+    assert list(ids.items()) == list(w_ids[0].items())
