@@ -300,3 +300,72 @@ def test_fuzz_orientation_wide_ids(oracle, seed, B, H, W, n_rect, with_mask):
         for k, ang in want.items():
             g = got[b][int(ids[k])]
             assert abs(g - ang) < 1e-4 or abs(abs(g - ang) - 2 * np.pi) < 1e-4
+
+
+@settings(max_examples=60, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), C=st.integers(1, 11), H=st.integers(1, 19),
+       W=st.integers(1, 23), weighted=st.booleans(), ls=st.sampled_from([0.0, 0.1, 0.5]),
+       dtype=st.sampled_from(['float32', 'bfloat16']))
+def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype):
+    """every loss kernel (sum, count, gradient) on random odd shapes against the C oracle"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    rng = np.random.default_rng(seed)
+    tdt = getattr(torch, dtype)
+    tol = dict(rtol=2e-5, atol=2e-6) if dtype == 'float32' else dict(rtol=2e-2, atol=2e-2)
+
+    def leaf(a):
+        return torch.from_numpy(a).to(tdt).cuda().requires_grad_(True)
+
+    def as_f32(t):                      # the values the kernel actually saw
+        return t.detach().float().cpu().numpy()
+
+    # ---- cross entropy (a6) ----
+    x = leaf((rng.standard_normal((B, C, H, W)) * 3).astype(np.float32))
+    t = rng.integers(0, C + 1, (B, H, W)).astype(np.uint8)              # 0 = void
+    w = (rng.random(C) + 0.5).astype(np.float32) if weighted else None
+    loss, n, wsum = F_.cross_entropy_sum(x, dev(t), None if w is None else dev(w), ls)
+    loss.backward()
+    s_ref, n_ref, w_ref, g_ref = oracle.loss_ce(as_f32(x), t, w, ls, want_grad=True)
+    assert int(n) == n_ref
+    np.testing.assert_allclose(float(loss.detach()), s_ref, rtol=1e-5 if dtype == 'float32' else 2e-3, atol=1e-5)
+    np.testing.assert_allclose(float(wsum), w_ref, rtol=1e-6, atol=1e-6)
+    np.testing.assert_allclose(x.grad.float().cpu().numpy(), g_ref, **tol)
+
+    # ---- masked MSE / L1 (a7) ----
+    for kind, Cn in (('mse', 1), ('l1', 2)):
+        shape = (B, H, W) if Cn == 1 else (B, Cn, H, W)
+        p = leaf(rng.standard_normal(shape).astype(np.float32))
+        y = rng.standard_normal(shape).astype(np.float32)
+        m = rng.random((B, H, W)) < 0.6
+        loss, n = F_.masked_elementwise_sum(p, dev(y), dev(m), kind)
+        loss.backward()
+        s_ref, n_ref, g_ref = oracle.loss_masked_elementwise(as_f32(p), y, m, kind, want_grad=True)
+        assert int(n) == n_ref
+        np.testing.assert_allclose(float(loss.detach()), s_ref, rtol=1e-5 if dtype == 'float32' else 2e-3, atol=1e-5)
+        np.testing.assert_allclose(p.grad.float().cpu().numpy(), g_ref, **tol)
+
+    # ---- von Mises (a8) ----
+    def unit(a):
+        return a / np.linalg.norm(a, axis=1, keepdims=True)
+    p = leaf(unit(rng.standard_normal((B, 2, H, W))).astype(np.float32))
+    y = unit(rng.standard_normal((B, 2, H, W))).astype(np.float32)
+    m = rng.random((B, H, W)) < 0.5
+    loss, n = F_.vonmises_sum(p, dev(y), dev(m), 1.0)
+    loss.backward()
+    s_ref, n_ref, g_ref = oracle.loss_vonmises(as_f32(p), y, m, 1.0, want_grad=True)
+    assert int(n) == n_ref
+    np.testing.assert_allclose(float(loss.detach()), s_ref, rtol=1e-5 if dtype == 'float32' else 2e-3, atol=1e-5)
+    np.testing.assert_allclose(p.grad.float().cpu().numpy(), g_ref, **tol)
+
+    # ---- cosine embedding with LUT (a9) ----
+    D, L = int(rng.integers(1, 9)), int(rng.integers(1, 6))
+    p = leaf(rng.standard_normal((B, D, H, W)).astype(np.float32))
+    idx = rng.integers(0, L + 1, (B, H, W)).astype(np.int32)          # 0 = no target
+    lut = unit(rng.standard_normal((B * L, D))).reshape(B, L, D).astype(np.float32)
+    loss, n = F_.cosine_embedding_lut_sum(p, dev(idx), dev(lut))
+    loss.backward()
+    s_ref, n_ref, g_ref = oracle.loss_cosine_embedding(as_f32(p), idx, lut, want_grad=True)
+    assert int(n) == n_ref
+    np.testing.assert_allclose(float(loss.detach()), s_ref, rtol=1e-5 if dtype == 'float32' else 2e-3, atol=1e-5)
+    np.testing.assert_allclose(p.grad.float().cpu().numpy(), g_ref, **tol)
