@@ -37,8 +37,10 @@ class MetricAccumulators:
         # flat state buffers (same packing as Metric._pack); totals only when all-reducing
         self._step_flat = [next(iter(self.miou._pack().values())),
                            next(iter(self.pq._pack().values()))]
+        # per-step reduction keeps separate running totals; local accumulation adds straight
+        # into the metric states and `finalize()` reduces those in place
         self._total_flat = [torch.zeros_like(f) for f in self._step_flat] \
-            if world_size > 1 else self._step_flat
+            if self.world_size > 1 else self._step_flat
         n_conf = self._step_flat[0].numel()
         self._packed = torch.zeros((n_conf + self._step_flat[1].numel(),), dtype=torch.float64,
                                    device=device) if world_size > 1 else None

@@ -425,3 +425,46 @@ def test_compare_and_accumulate_function(oracle):
     assert np.array_equal(iou.cpu().numpy(), w_iou) and np.array_equal(tp.cpu().numpy(), w_tp)
     assert np.array_equal(fn.cpu().numpy(), w_fn) and np.array_equal(fp.cpu().numpy(), w_fp)
     assert matched == set(w_m)
+
+
+@gpu
+def test_bench_accumulators_local_accumulation_then_one_reduce():
+    """bench.py's default at N > 1: local accumulation, ONE all-reduce in finalize().  A stand-in
+    for torch.distributed that doubles the buffer plays two identical ranks."""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.metric.bench_support import MetricAccumulators
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+
+    class TwoIdenticalRanks:
+        calls = 0
+
+        class ReduceOp:
+            SUM = 'sum'
+
+        @staticmethod
+        def get_backend():
+            return 'nccl'
+
+        @classmethod
+        def all_reduce(cls, buf, op=None):
+            cls.calls += 1
+            buf.mul_(2)
+
+    inp = syn.make_panoptic_inputs_torch(2, 8, 96, 128, n_centers=6, seed=3, device='cuda')
+    a = MetricAccumulators(9, torch.device('cuda'), inp, world_size=1, side_stream=False)
+    b = MetricAccumulators(9, torch.device('cuda'), inp, world_size=2, side_stream=True,
+                           sync_every_step=False)
+    pan = ops.panoptic_pipeline(inp['semantic_logits'], inp['instance_center'],
+                                inp['instance_offset'], inp['semantic_classes_is_thing'])['panoptic']
+    for _ in range(3):
+        a.update_and_reduce(pan)
+        b.update_and_reduce(pan, dist=TwoIdenticalRanks)
+    assert TwoIdenticalRanks.calls == 0                 # nothing per step
+    b.finalize(TwoIdenticalRanks)
+    b.finalize(TwoIdenticalRanks)                       # idempotent
+    b.wait()
+    torch.cuda.synchronize()
+    assert TwoIdenticalRanks.calls == 1
+    assert a.total_confmat.sum() > 0
+    assert torch.equal(2 * a.total_confmat, b.total_confmat)
+    assert torch.equal(2 * a.total_pq, b.total_pq)
