@@ -155,6 +155,8 @@ def main():
 
     for i in range(args.warmup):
         r = step(i, False)
+    if metrics is not None:
+        metrics.warm_collective(dist)
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()

@@ -90,6 +90,16 @@ class MetricAccumulators:
                 self._total_flat[0] += self._packed[:n].to(torch.int64)
                 self._total_flat[1] += self._packed[n:]
 
+    def warm_collective(self, dist=None) -> None:
+        """untimed: run the packed all-reduce once on scratch data so that communicator set-up
+        and the first-use costs of the collective do not land in the timed region"""
+        if dist is None or self._packed is None:
+            return
+        cur = torch.cuda.current_stream(self._packed.device)
+        stream = self.stream if self.stream is not None else cur
+        with torch.cuda.stream(stream):
+            self._all_reduce(dist, torch.zeros_like(self._packed))
+
     def finalize(self, dist=None) -> None:
         """end of the epoch: with local accumulation, sum the totals over the ranks (one
         all-reduce); a no-op when every step was already reduced or there is one rank"""
