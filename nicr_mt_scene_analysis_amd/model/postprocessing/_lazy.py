@@ -10,6 +10,13 @@ first time it is read.
 from typing import Any, Callable, Dict
 
 
+class _Derived:
+    __slots__ = ('fn',)
+
+    def __init__(self, fn):
+        self.fn = fn
+
+
 class LazyDict(dict):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
@@ -19,10 +26,18 @@ class LazyDict(dict):
         self._thunks[key] = thunk
         super().__setitem__(key, None)        # reserve the slot / ordering
 
+    def set_derived(self, key: str, fn: Callable[['LazyDict'], Any]) -> None:
+        """lazy entry computed from OTHER entries: `fn` receives the dict it is read from
+        (a thunk that captured the dict itself would form a reference cycle and keep every
+        tensor of the result alive until the cycle collector runs)"""
+        self._thunks[key] = _Derived(fn)
+        super().__setitem__(key, None)
+
     def _force(self, key):
         thunk = self._thunks.pop(key, None)
         if thunk is not None:
-            super().__setitem__(key, thunk())
+            value = thunk.fn(self) if isinstance(thunk, _Derived) else thunk()
+            super().__setitem__(key, value)
 
     def __getitem__(self, key):
         self._force(key)
@@ -61,7 +76,8 @@ class LazyDict(dict):
         if isinstance(other, LazyDict):
             for k in other.keys():
                 if k in other._thunks:
-                    self.set_lazy(k, other._thunks[k])
+                    self._thunks[k] = other._thunks[k]
+                    dict.__setitem__(self, k, None)
                 else:
                     self[k] = dict.__getitem__(other, k)
         else:

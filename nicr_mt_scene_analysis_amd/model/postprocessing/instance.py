@@ -11,6 +11,7 @@ are built from); the dense maps never leave the GPU.
 """
 from typing import Dict, List, Optional, Tuple, Union
 
+import numpy as np
 import torch
 
 from ... import ops
@@ -77,26 +78,33 @@ class InstancePostprocessing(DensePostprocessingBase):
 
     # ------------------------------------------------------------- segmentation
     @staticmethod
-    def _meta_from_tables(n_host, centers_yx, scores, area) -> List[Dict[int, dict]]:
-        """ONE small device->host copy: only the first max(n) columns of the tables travel."""
-        B = centers_yx.shape[0]
-        nmax = max(1, min(max(n_host) if len(n_host) else 1, centers_yx.shape[1]))
+    def _meta_from_host(n_host, centers_yx, scores, area) -> List[Dict[int, dict]]:
+        """host (numpy) tables -> the reference's per-image meta dicts (instance.py:255-266)"""
+        K = scores.shape[1]
+        nmax = max(1, min(max(n_host) if len(n_host) else 1, K))
         ka = min(nmax, 255)
-        packed = torch.cat([centers_yx[:, :nmax].reshape(B, -1).to(torch.float64),
-                            scores[:, :nmax].to(torch.float64),
-                            area[:, 1:ka + 1].to(torch.float64)], dim=1).cpu().tolist()
+        yx = centers_yx[:, :nmax].astype(np.int64).tolist()
+        sc = scores[:, :nmax].astype(np.float64).tolist()
+        ar = area[:, 1:ka + 1].astype(np.int64).tolist()
         meta = []
         for b, n in enumerate(n_host):
-            row = packed[b]
             n = min(n, nmax)
             # ids wrap at 256 (uint8, instance.py:236): bincount(minlength=n+1) has no entries
             # beyond 255
-            areas = row[3 * nmax:3 * nmax + min(n, ka)] + [0.0] * max(0, n - ka)
+            areas = ar[b][:min(n, ka)] + [0] * max(0, n - ka)
             meta.append({
-                i + 1: {'center_yx': (int(y), int(x)), 'area': int(a), 'score': sc}
-                for i, (y, x, sc, a) in enumerate(zip(row[0:2 * n:2], row[1:2 * n:2],
-                                                      row[2 * nmax:2 * nmax + n], areas))})
+                i + 1: {'center_yx': (y, x), 'area': a, 'score': s_}
+                for i, ((y, x), s_, a) in enumerate(zip(yx[b][:n], sc[b][:n], areas))})
         return meta
+
+    @staticmethod
+    def _meta_from_tables(n_host, centers_yx, scores, area) -> List[Dict[int, dict]]:
+        """ONE small device->host copy of the (center, score, area) tables"""
+        B, K = scores.shape
+        flat = torch.cat([centers_yx.reshape(B, 2 * K).to(torch.float64),
+                          scores.to(torch.float64), area.to(torch.float64)], dim=1).cpu().numpy()
+        return InstancePostprocessing._meta_from_host(
+            n_host, flat[:, :2 * K].reshape(B, K, 2), flat[:, 2 * K:3 * K], flat[:, 3 * K:])
 
     def _get_instance_segmentation(
         self,

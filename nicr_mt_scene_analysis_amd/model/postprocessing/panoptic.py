@@ -21,7 +21,6 @@ from ...data.preprocessing.resize import get_valid_region_slices_and_fullres_sha
 from ...types import BatchType
 from ...types import DecoderRawOutputType
 from ...types import PostprocessingOutputType
-from ...utils.panoptic_merge import _ids_to_dicts
 from ._lazy import LazyDict
 from .dense_base import DensePostprocessingBase
 from .instance import InstancePostprocessing
@@ -53,6 +52,7 @@ class PanopticPostprocessing(DensePostprocessingBase):
         self._normalized_offset = normalized_offset
         self._compute_scores = compute_scores
         self._max_instances_per_category = 1 << 16
+        self._host_columns = 32          # table columns fetched per image (grows on demand)
         self._device_luts: Dict[torch.device, Tuple[torch.Tensor, torch.Tensor]] = {}
 
     @property
@@ -89,7 +89,8 @@ class PanopticPostprocessing(DensePostprocessingBase):
         dev = s_output.device
         thing_lut, ori_lut = self._luts(dev)
 
-        # ---- the hot path: 4 launches, no host sync ---------------------------------
+        # ---- the hot path: 5 launches; ONE device->host copy (= the one sync) of the small
+        #      per-image tables, cut to the number of columns recent batches needed -----------
         while True:
             p = ops.panoptic_pipeline(
                 s_output, center_heatmap, center_offset, thing_lut,
@@ -102,11 +103,16 @@ class PanopticPostprocessing(DensePostprocessingBase):
                 max_instances_per_category=self._max_instances_per_category,
                 void_label=0, max_centers=post._max_centers,
                 want_score=True, want_foreground=True, want_panoptic_semantic=True)
-            n_host = p['n_centers'].cpu()          # the one sync of this step
-            n_max = int(n_host.max()) if n_host.numel() else 0
-            if n_max <= post._max_centers:
-                break
-            post._max_centers = 1 << (n_max - 1).bit_length()
+            host = self._fetch_tables(p, self._host_columns)
+            n_host = host['n_centers']
+            n_max = max(n_host) if n_host else 0
+            if n_max > post._max_centers:              # center table overflow: re-run, larger
+                post._max_centers = 1 << (n_max - 1).bit_length()
+                continue
+            if n_max > host['columns']:                # rare: more instances than columns fetched
+                self._host_columns = 1 << (n_max - 1).bit_length()
+                host = self._fetch_tables(p, self._host_columns)
+            break
 
         # ---- semantic entries (semantic.py:46-80) -------------------------------------
         r = LazyDict(semantic_output=s_output, semantic_side_outputs=s_side_outputs)
@@ -125,17 +131,17 @@ class PanopticPostprocessing(DensePostprocessingBase):
         pan_semantic = p['panoptic_semantic']
         r['panoptic_foreground_mask'] = p['foreground']
         r['panoptic_segmentation_deeplab'] = panoptic_seg
-        # every id-dict entry is an instance: at most max(n_centers) (<= 255 ids) per image
-        panoptic_ids = _ids_to_dicts(p['ids_pan'], p['ids_ins'], p['n_ids'], limit=min(n_max, 255))
-        r['panoptic_segmentation_deeplab_ids'] = panoptic_ids
+        # id dicts / instance meta: Python objects built from the host tables when first read
+        r.set_lazy('panoptic_segmentation_deeplab_ids', lambda: self._id_dicts_from_host(host))
         r['panoptic_segmentation_deeplab_semantic_idx'] = pan_semantic
         r['panoptic_segmentation_deeplab_instance_idx'] = instance_seg
-        meta = InstancePostprocessing._meta_from_tables(
-            n_host.tolist(), p['centers_yx'], p['center_scores'], p['area'])
-        r['panoptic_segmentation_deeplab_instance_meta'] = meta
+        r.set_lazy('panoptic_segmentation_deeplab_instance_meta',
+                   lambda: InstancePostprocessing._meta_from_host(
+                       n_host, host['centers_yx'], host['scores'], host['area']))
 
         if self._compute_scores:
-            self._add_scores(r, p, panoptic_ids, meta)
+            self._add_scores(r, p, r['panoptic_segmentation_deeplab_ids'],
+                             r['panoptic_segmentation_deeplab_instance_meta'])
 
         # ---- full resolution (panoptic.py:242-291) --------------------------------------
         crop, shape = get_valid_region_slices_and_fullres_shape(batch, 'instance')
@@ -159,10 +165,38 @@ class PanopticPostprocessing(DensePostprocessingBase):
             fg_orientation = ori_lut[pan_semantic].to(torch.bool)
             ori = post._get_instance_orientation(orientation, instance_seg, fg_orientation)
             r['orientations_panoptic_segmentation_deeplab_instance'] = ori
-            for b, m in enumerate(meta):
+            for b, m in enumerate(r['panoptic_segmentation_deeplab_instance_meta']):
                 for id_ in m:
                     m[id_]['orientation'] = ori[b].get(id_, float('nan'))
         return r
+
+    @staticmethod
+    def _fetch_tables(p, columns: int) -> dict:
+        """n_centers, centers, scores, areas, n_ids and the id tables of one pipeline run in ONE
+        device->host copy (float64 holds every entry exactly: ids < 2^53, f32 scores)"""
+        B, K = p['center_scores'].shape
+        kc = max(1, min(int(columns), K))
+        ki = min(kc, p['ids_pan'].shape[1])
+        ka = min(kc + 1, p['area'].shape[1])
+        parts = [p['n_centers'].view(B, 1), p['n_ids'].view(B, 1),
+                 p['centers_yx'][:, :kc].reshape(B, 2 * kc), p['center_scores'][:, :kc],
+                 p['area'][:, :ka], p['ids_pan'][:, :ki], p['ids_ins'][:, :ki]]
+        flat = torch.cat([t.to(torch.float64) for t in parts], dim=1).cpu().numpy()
+        edges = np.cumsum([0, 1, 1, 2 * kc, kc, ka, ki, ki])
+        cols = [flat[:, a:b] for a, b in zip(edges[:-1], edges[1:])]
+        return {'columns': kc,
+                'n_centers': cols[0][:, 0].astype(np.int64).tolist(),
+                'n_ids': cols[1][:, 0].astype(np.int64).tolist(),
+                'centers_yx': cols[2].reshape(B, kc, 2), 'scores': cols[3], 'area': cols[4],
+                'ids_pan': cols[5], 'ids_ins': cols[6]}
+
+    @staticmethod
+    def _id_dicts_from_host(host) -> List[dict]:
+        """{panoptic id: instance id} per image, insertion order = ascending instance id
+        (panoptic_merge.py:195-213)"""
+        pan = host['ids_pan'].astype(np.int64).tolist()
+        ins = host['ids_ins'].astype(np.int64).tolist()
+        return [dict(zip(pr[:n], ir[:n])) for pr, ir, n in zip(pan, ins, host['n_ids'])]
 
     # f3 (SURVEY §8f): score maps of panoptic.py:171-239 — two HIP kernels
     # (`nmsa_panoptic_scores`), no softmax tensor, no per-instance loops over images.

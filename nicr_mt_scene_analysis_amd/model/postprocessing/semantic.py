@@ -46,7 +46,7 @@ class SemanticPostprocessing(DensePostprocessingBase):
             'semantic_segmentation_idx'))
         if tuple(cropped.shape[-2:]) != tuple(shape):
             r.set_lazy(k_out, lambda: ops.resize_bilinear(output, shape, crop))
-            r.set_lazy(k_sm, lambda: ops.semantic_softmax(r[k_out]))
+            r.set_derived(k_sm, lambda d: ops.semantic_softmax(d[k_out]))
             am = ops.semantic_argmax_resized(output, shape, crop,
                                              want_u8=False, want_i64=True, want_score=True)
             r[k_score] = am['score']
@@ -59,7 +59,7 @@ class SemanticPostprocessing(DensePostprocessingBase):
             for k in ('semantic_softmax_scores', 'semantic_segmentation_score',
                       'semantic_segmentation_idx'):
                 if r.is_pending(k):
-                    r.set_lazy(get_fullres_key(k), (lambda kk: (lambda: r[kk]))(k))
+                    r.set_derived(get_fullres_key(k), (lambda kk: (lambda d: d[kk]))(k))
                 else:
                     r[get_fullres_key(k)] = r[k]
         else:

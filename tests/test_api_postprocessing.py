@@ -261,6 +261,35 @@ def test_many_centers_regrow_table():
         assert meta[0][i]['area'] == want[0][i]['area']
 
 
+
+def test_panoptic_postprocess_more_instances_than_fetched_columns(oracle):
+    """the host tables travel cut to `_host_columns` columns; an image with more instances
+    makes the postprocessing fetch again with wider tables (dicts complete, in order)."""
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+    inp = syn.make_panoptic_inputs(2, 12, 96, 128, n_centers=48, seed=5, sigma=3.0)
+    is_thing = inp['semantic_classes_is_thing']
+    post = build_panoptic(is_thing)
+    assert post._host_columns == 32
+    i_out = (dev(inp['instance_center']), dev(inp['instance_offset']))
+    r = post.postprocess(((dev(inp['semantic_logits']), i_out), (None, None)),
+                         make_batch(2, 96, 128), is_training=False)
+    H, W = 96, 128
+    idx, _ = oracle.semantic_argmax(inp['semantic_logits'])
+    fg = np.asarray(is_thing, dtype=bool)[idx]
+    cyx, n, _, _ = oracle.center_nms_topk(inp['instance_center'], max_centers=256)
+    inst, _ = oracle.group_offsets(inp['instance_offset'], fg, cyx, n, scale_y=H, scale_x=W)
+    pan, ids = oracle.deeplab_merge(idx + 1, inst, fg, 1 << 16, np.where(is_thing)[0] + 1, 0)
+    assert max(n) > 32
+    assert post._host_columns >= max(n)
+    assert (r['panoptic_segmentation_deeplab'].cpu().numpy() == pan).all()
+    for b, d in enumerate(r['panoptic_segmentation_deeplab_ids']):
+        assert list(d.items()) == list(ids[b].items())
+    for b, m in enumerate(r['panoptic_segmentation_deeplab_instance_meta']):
+        assert len(m) == n[b]
+        for i, e in m.items():
+            assert e['center_yx'] == tuple(int(v) for v in cyx[b][i - 1])
+            assert e['area'] == int((inst[b] == i).sum())
+
 def test_compute_scores_vs_golden():
     """f3: score maps + meta of the reference's compute_scores branch (panoptic.py:171-239),
     produced by `nmsa_panoptic_scores`, against the reference's own output."""

@@ -54,9 +54,35 @@ data = ((a[0], (a[1], a[2])), (None, None))
 for _ in range(5):
     post.postprocess(data, batch, is_training=False)
 torch.cuda.synchronize()
-t0 = time.perf_counter()
-for _ in range(50):
+per_call = []
+for _ in range(100):
+    t0 = time.perf_counter()
     rr = post.postprocess(data, batch, is_training=False)
+    per_call.append(time.perf_counter() - t0)
 torch.cuda.synchronize()
-dt = (time.perf_counter() - t0) / 50
-print(f'postprocess() : {1e6*dt:7.1f} us/call  ({32*480*640/dt/1e6:8.1f} Mpix/s, dicts + meta included)')
+per_call.sort()
+dt = per_call[len(per_call) // 2]
+print(f'postprocess() : median {1e6*dt:7.1f} us/call (min {1e6*per_call[0]:.1f}, max {1e6*per_call[-1]:.1f}; '
+      f'{32*480*640/dt/1e6:8.1f} Mpix/s; id dicts / meta lazy)')
+per_call = []
+for _ in range(100):
+    t0 = time.perf_counter()
+    rr = post.postprocess(data, batch, is_training=False)
+    ids, meta = rr['panoptic_segmentation_deeplab_ids'], rr['panoptic_segmentation_deeplab_instance_meta']
+    per_call.append(time.perf_counter() - t0)
+torch.cuda.synchronize()
+per_call.sort()
+dt = per_call[len(per_call) // 2]
+print(f'  + dicts/meta: median {1e6*dt:7.1f} us/call (min {1e6*per_call[0]:.1f}, max {1e6*per_call[-1]:.1f}; '
+      f'{32*480*640/dt/1e6:8.1f} Mpix/s)')
+
+if '--profile' in sys.argv:
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(50):
+        rr = post.postprocess(data, batch, is_training=False)
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats('cumulative').print_stats(45)
