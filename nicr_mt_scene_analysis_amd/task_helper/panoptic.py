@@ -53,16 +53,19 @@ class PanopticTaskHelper(TaskHelperBase):
             orientations_results = \
                 predictions_post['orientations_panoptic_segmentation_deeplab_instance']
             orientations_targets = batch['orientations_present']
+            # only the orientation matching walks the id dicts (lazy entry: built when read)
+            pred_id_dicts = predictions_post['panoptic_segmentation_deeplab_ids']
         else:
             orientations_results = None
             orientations_targets = None
+            pred_id_dicts = None
 
         panoptic_targets = get_fullres(batch, 'panoptic')
         panoptic_preds = predictions_post[get_fullres_key('panoptic_segmentation_deeplab')]
         self._mae_pq_deeplab.update(
             panoptic_preds=panoptic_preds,
             orientation_preds=orientations_results,
-            panoptic_preds_id_dicts=predictions_post['panoptic_segmentation_deeplab_ids'],
+            panoptic_preds_id_dicts=pred_id_dicts,
             panoptic_target=panoptic_targets,
             orientation_target=orientations_targets,
             panoptic_target_id_dicts=batch.get('panoptic_ids_to_instance_dict'),
