@@ -175,6 +175,54 @@ __device__ __forceinline__ float sqrt_tie_upper(float d)
     return u;
 }
 
+// all-lanes minimum (fminf: a NaN operand is ignored)
+__device__ __forceinline__ float wave_all_min(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fminf(v, __shfl_xor(v, o));
+    return v;
+}
+
+// Candidate centers of one wave (n <= 64): bit i set = center i can be the nearest center of
+// some active pixel of this wave.  The wave's locations lie in a bounding box; lane i bounds
+// the squared distance from center i to any point of the box from below (lo) and above (hi).
+// With U = min_i hi_i every pixel has a center within sqrt(U), so a center with lo > U is
+// farther from EVERY pixel than that pixel's nearest center — by the relative margin 1e-5,
+// far outside the sqrt-rounding tie band (2^-22) that the exact search resolves.  A non-finite
+// location switches the culling off for the wave (NaN / inf distances select index 0).
+__device__ __forceinline__ uint64_t wave_candidate_centers(const float2* __restrict__ cen, int n,
+                                                           const float ly[4], const float lx[4],
+                                                           const bool act[4])
+{
+    float lo_y = INFINITY, lo_x = INFINITY, nhi_y = INFINITY, nhi_x = INFINITY;   // nhi = -max
+    bool finite = true;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        if (act[j]) {
+            finite = finite && (fabsf(ly[j]) < INFINITY) && (fabsf(lx[j]) < INFINITY);
+            lo_y = fminf(lo_y, ly[j]);  nhi_y = fminf(nhi_y, -ly[j]);
+            lo_x = fminf(lo_x, lx[j]);  nhi_x = fminf(nhi_x, -lx[j]);
+        }
+    }
+    const uint64_t all = (n >= 64) ? ~0ull : ((1ull << n) - 1ull);
+    if (__any(!finite)) return all;
+    lo_y = wave_all_min(lo_y);  nhi_y = wave_all_min(nhi_y);
+    lo_x = wave_all_min(lo_x);  nhi_x = wave_all_min(nhi_x);
+    if (!(lo_y < INFINITY)) return 0ull;                 // no active pixel in this wave
+    const float hi_y = -nhi_y, hi_x = -nhi_x;
+    const int lane = lane_id();
+    const float2 c = cen[min(lane, n - 1)];
+    const float a0 = c.x - lo_y, a1 = hi_y - c.x;         // >= 0 inside the box
+    const float b0 = c.y - lo_x, b1 = hi_x - c.y;
+    const float near_y = fmaxf(0.f, fmaxf(-a0, -a1)), near_x = fmaxf(0.f, fmaxf(-b0, -b1));
+    const float far_y = fmaxf(fabsf(a0), fabsf(a1)), far_x = fmaxf(fabsf(b0), fabsf(b1));
+    const float lo = near_y * near_y + near_x * near_x;
+    const float hi = (lane < n) ? far_y * far_y + far_x * far_x : INFINITY;
+    const float U = wave_all_min(hi);
+    return __ballot(lane < n && lo <= U * 1.00001f) & all;
+}
+
+template <bool CULL = true>
 __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
                                        const float ly[4], const float lx[4],
                                        const bool act[4], int use_thr, float thr,
@@ -185,16 +233,29 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
     // moment of the last update)
     float smin[4], prev[4];
     int imin[4];
+    // ascending index order over the wave's candidates keeps the first-index rule
+    const bool cull = CULL && n <= 64;
+    uint64_t m = cull ? wave_candidate_centers(cen, n, ly, lx, act) : 0ull;
+    int first = 0;
+    if (cull) {
+        if (m == 0ull) {                                  // wave without an active pixel
+#pragma unroll
+            for (int j = 0; j < 4; ++j) id[j] = 0u;
+            return;
+        }
+        first = __ffsll((unsigned long long)m) - 1;
+        m &= m - 1;
+    }
     {
-        const float2 c0 = cen[0];
+        const float2 c0 = cen[first];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             smin[j] = sqdist(c0.x, c0.y, ly[j], lx[j]);
             prev[j] = INFINITY;
-            imin[j] = 0;
+            imin[j] = first;
         }
     }
-    for (int i = 1; i < n; ++i) {
+    auto visit = [&](const int i) {
         const float2 c = cen[i];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -204,6 +265,15 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
             imin[j] = upd ? i : imin[j];
             smin[j] = upd ? s : smin[j];
         }
+    };
+    if (cull) {
+        while (m) {
+            const int i = __ffsll((unsigned long long)m) - 1;
+            m &= m - 1;
+            visit(i);
+        }
+    } else {
+        for (int i = 1; i < n; ++i) visit(i);
     }
     // The reference compares d = sqrt_rn(s) and takes the LOWEST index among equal d.
     // imin is already that index unless an earlier center has s in (smin, U], U = largest
@@ -334,7 +404,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
             thing[threadIdx.x] = ((int)threadIdx.x < C) ? (uint8_t)my_thing : (uint8_t)0;
             __syncthreads();
         }
-        if (!active) return;
+        // threads beyond the image (tail chunk) stay in the wave: nvalid == 0 keeps them out of
+        // every pixel decision, and the wave-level steps below need all lanes
         int cls[4];
         bool fg[4];
         bool any_fg = false;
@@ -361,8 +432,8 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
 
         // ---- a3: offset grouping ------------------------------------------------------
         uint32_t id[4] = {0u, 0u, 0u, 0u};
-        if (any_fg && n > 0) {
-            if (!EARLY_OFFSETS) {
+        if (__any(any_fg) && n > 0) {           // wave-uniform: group4 culls centers per wave
+            if (!EARLY_OFFSETS && any_fg) {
                 oy = load_px4<NMSA_F32, VEC, NT>(offy, (size_t)p0, nvalid);
                 ox = load_px4<NMSA_F32, VEC, NT>(offx, (size_t)p0, nvalid);
             }
@@ -382,7 +453,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
         }
 
         // ---- stores --------------------------------------------------------------------
-        if (VEC) {
+        if (VEC && active) {
             *(uchar4*)(sem_u8 + (size_t)b * P + p0) =
                 make_uchar4((uint8_t)cls[0], (uint8_t)cls[1], (uint8_t)cls[2], (uint8_t)cls[3]);
             *(uchar4*)(inst + (size_t)b * P + p0) =
@@ -631,10 +702,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
     const int chunk_start = blockIdx.x * iters * PX_PER_ITER;
     for (int it = 0; it < iters; ++it) {
         const int p0 = chunk_start + it * PX_PER_ITER + threadIdx.x * PX_PER_THREAD;
-        if (p0 >= P) break;
-        const int nvalid = min(4, P - p0);
+        const bool active = p0 < P;             // tail threads stay for the wave-level steps
+        const int nvalid = active ? min(4, P - p0) : 0;
         bool fg[4] = {false, false, false, false};
-        if (VEC) {
+        if (VEC && active) {
             const uchar4 f = *(const uchar4*)(fgmask + (size_t)b * P + p0);
             fg[0] = f.x != 0; fg[1] = f.y != 0; fg[2] = f.z != 0; fg[3] = f.w != 0;
         } else {
@@ -642,9 +713,12 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
         }
         const bool any_fg = fg[0] || fg[1] || fg[2] || fg[3];
         uint32_t id[4] = {0u, 0u, 0u, 0u};
-        if (any_fg && n > 0) {
-            const float4 oy = load_px4<NMSA_F32, VEC, true>(offy, (size_t)p0, nvalid);
-            const float4 ox = load_px4<NMSA_F32, VEC, true>(offx, (size_t)p0, nvalid);
+        if (__any(any_fg) && n > 0) {           // wave-uniform: group4 culls centers per wave
+            float4 oy = make_float4(0.f, 0.f, 0.f, 0.f), ox = oy;
+            if (any_fg) {
+                oy = load_px4<NMSA_F32, VEC, true>(offy, (size_t)p0, nvalid);
+                ox = load_px4<NMSA_F32, VEC, true>(offx, (size_t)p0, nvalid);
+            }
             const float oyv[4] = {oy.x, oy.y, oy.z, oy.w};
             const float oxv[4] = {ox.x, ox.y, ox.z, ox.w};
             float ly[4], lx[4];
@@ -657,7 +731,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
             }
             group4(cen, n, ly, lx, fg, use_thr, thr, id);
         }
-        if (VEC) {
+        if (VEC && active) {
             *(uchar4*)(inst + (size_t)b * P + p0) =
                 make_uchar4((uint8_t)id[0], (uint8_t)id[1], (uint8_t)id[2], (uint8_t)id[3]);
         } else {

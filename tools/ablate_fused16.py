@@ -14,7 +14,8 @@ from microbench import timeit                                     # noqa: E402
 
 B, C, H, W = 32, 40, 480, 640
 dev = torch.device('cuda')
-inp = syn.make_panoptic_inputs_torch(B, C, H, W, device=dev, seed=1)
+NCEN = int(os.environ.get('ABLATE_CENTERS', '24'))
+inp = syn.make_panoptic_inputs_torch(B, C, H, W, device=dev, seed=1, n_centers=NCEN)
 cen = ops.center_nms_topk(inp['instance_center'])
 thing = inp['semantic_classes_is_thing'].view(torch.uint8)
 off = inp['instance_offset']
@@ -52,7 +53,7 @@ for dt in (torch.float32, torch.bfloat16, torch.float16):
             rows = [('argmax u8', lambda: argmax(lb, False), eb * C + 1),
                     ('argmax u8+score', lambda: argmax(lb, True), eb * C + 5),
                     ('fused, 0 centers', lambda: fused(n0, lb), eb * C + 9),
-                    ('fused, 24 centers', lambda: fused(cen['n_centers'], lb), eb * C + 9)]
+                    (f'fused, {NCEN} centers', lambda: fused(cen['n_centers'], lb), eb * C + 9)]
             for name, fn, bpp in rows:
                 us = timeit(fn)
                 print(f'{str(dt):16s} {tag} {name:20s} {us:8.1f} us  {px * bpp / us / 1e6:6.2f} TB/s ({bpp} B/px)')
