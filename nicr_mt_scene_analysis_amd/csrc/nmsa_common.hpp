@@ -52,6 +52,23 @@ __device__ __forceinline__ void wave_aggregate_add(int key, AddFn add)
     }
 }
 
+// Lanes hold consecutive pixel groups, so equal keys come in RUNS: every run head learns its
+// run's length and last lane from two ballots — all heads then act in parallel (one atomic per
+// run), with no leader-serial loop over the distinct keys.  key < 0 = gap.  Wave-uniform call.
+__device__ __forceinline__ bool wave_run_head(int key, int& len, int& last)
+{
+    const int prev = __shfl_up(key, 1);
+    const int l = lane_id();
+    const bool head = key >= 0 && (l == 0 || prev != key);
+    const unsigned long long heads = __ballot(head);
+    const unsigned long long gaps = __ballot(key < 0);
+    const unsigned long long stop = (heads | gaps) & ~((2ull << l) - 1ull);
+    const int nxt = stop ? (__ffsll((long long)stop) - 1) : 64;
+    len = nxt - l;
+    last = nxt - 1;
+    return head;
+}
+
 // Slot of `key` in a small LDS hash set / table `keys[n]` (n a power of two, empty = -1): linear
 // probing, 4 tries, -1 when full there (callers then fall back to a global atomic).  Used to
 // privatise per-workgroup accumulators whose keys (instance ids, (instance, class) pairs) are

@@ -34,6 +34,7 @@
 namespace nmsa {
 
 constexpr int FUSED_THREADS = 256;
+constexpr int FUSED_VOTE_SLOTS = 256;
 constexpr int PX_PER_THREAD = 4;
 constexpr int PX_PER_ITER = FUSED_THREADS * PX_PER_THREAD;   // 1024
 
@@ -307,7 +308,7 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
 
 // =================================================================================
 // fused: argmax + fg + grouping + class votes
-// dynamic LDS: float2 centers[max_centers] | u32 hist[lds_rows * NC] | u8 thing[256]
+// dynamic LDS: float2 centers[max_centers] | i32 vote_key[FUSED_VOTE_SLOTS] | u32 vote_cnt[..] | u8 thing[256]
 // =================================================================================
 template <int DTYPE, bool VEC, bool WITH_SCORE, int UNROLL = 8, bool NT = true,
           bool EARLY_OFFSETS = false>
@@ -322,9 +323,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float2* cen = (float2*)smem;
-    uint32_t* hist = (uint32_t*)(cen + max_centers);
+    // (instance, class) vote counters of this workgroup: a 1024-pixel chunk meets a handful of
+    // (id, class) pairs, so a small LDS hash table (one slot per thread: cleared and flushed with
+    // one LDS access each) replaces a dense [ids, classes] histogram
+    int* vote_key = (int*)(cen + max_centers);
+    uint32_t* vote_cnt = (uint32_t*)(vote_key + FUSED_VOTE_SLOTS);
     const int NC = C + 1;
-    uint8_t* thing = (uint8_t*)(hist + lds_rows * NC);
+    uint8_t* thing = (uint8_t*)(vote_cnt + FUSED_VOTE_SLOTS);
 
     const int b = blockIdx.y;
     const int P = H * W;
@@ -336,7 +341,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
     // tables are only needed AFTER the class loop, so they are filled — and the workgroup
     // barrier sits — behind the first chunk's argmax.
     static_assert(FUSED_THREADS == 256, "one LUT entry per thread");
-    for (int i = threadIdx.x; i < lds_rows * NC; i += FUSED_THREADS) hist[i] = 0;
+    static_assert(FUSED_VOTE_SLOTS == FUSED_THREADS, "one vote slot per thread");
+    vote_key[threadIdx.x] = -1;
+    vote_cnt[threadIdx.x] = 0;
 
     const size_t img_logits = (size_t)b * C * P;
     const float* offy = offset + (size_t)b * 2 * P;
@@ -473,16 +480,30 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
             }
         }
 
-        // ---- a5 (votes): hist[id][class+1] += 1, wave-aggregated ----------------------------
+        // ---- a5 (votes): votes[id][class+1] += 1 --------------------------------------------
+        // Lanes whose 4 pixels agree (all but the few on a segment boundary) form RUNS of equal
+        // keys across the wave: every run head adds 4 x its run length with one LDS atomic, all
+        // heads in parallel (two ballots, no loop over the distinct keys).  Boundary lanes add
+        // their pixels one by one.
         const bool wave_has_inst = __any((id[0] | id[1] | id[2] | id[3]) != 0u);
         if (wave_has_inst) {
+            int key[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int key = (id[j] != 0u) ? (int)(id[j] * NC + cls[j] + 1) : -1;
-                wave_aggregate_add(key, [&](int k, uint32_t cnt) {
-                    if (k < lds_rows * NC) atomicAdd(&hist[k], cnt);
-                    else atomicAdd(&votes_b[k], cnt);
-                });
+            for (int j = 0; j < 4; ++j)
+                key[j] = (id[j] != 0u) ? (int)(id[j] * NC + cls[j] + 1) : -1;
+            auto add = [&](int k, uint32_t cnt) {
+                const int slot = lds_hash_slot(vote_key, FUSED_VOTE_SLOTS, k);
+                if (slot >= 0) atomicAdd(&vote_cnt[slot], cnt);
+                else atomicAdd(&votes_b[k], cnt);            // table full around that slot
+            };
+            const bool uniform = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
+            int run_len, run_last;
+            if (wave_run_head(uniform ? key[0] : -1, run_len, run_last))
+                add(key[0], 4u * (uint32_t)run_len);
+            if (!uniform) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (key[j] >= 0) add(key[j], 1u);
             }
         }
     };
@@ -490,9 +511,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
     for (int it = 1; it < iters; ++it) chunk(it, std::false_type{});
 
     __syncthreads();
-    for (int i = threadIdx.x; i < lds_rows * NC; i += FUSED_THREADS) {
-        const uint32_t v = hist[i];
-        if (v) atomicAdd(&votes_b[i], v);
+    {
+        const int k = vote_key[threadIdx.x];
+        if (k >= 0) atomicAdd(&votes_b[k], vote_cnt[threadIdx.x]);
     }
 }
 
@@ -738,11 +759,19 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
             for (int j = 0; j < nvalid; ++j) inst[(size_t)b * P + p0 + j] = (uint8_t)id[j];
         }
         if (area && n > 0 && __any(any_fg)) {
+            // bincount over the foreground pixels, id 0 included (instance.py:253): runs of lanes
+            // whose 4 pixels agree add 4 x run length at the run head, boundary lanes per pixel
+            int key[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                // bincount over the foreground pixels, id 0 included (instance.py:253)
-                const int key = fg[j] ? (int)id[j] : -1;
-                wave_aggregate_add(key, [&](int k, uint32_t cnt) { atomicAdd(&ahist[k], cnt); });
+            for (int j = 0; j < 4; ++j) key[j] = fg[j] ? (int)id[j] : -1;
+            const bool uniform = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
+            int run_len, run_last;
+            if (wave_run_head(uniform ? key[0] : -1, run_len, run_last))
+                atomicAdd(&ahist[key[0]], 4u * (uint32_t)run_len);
+            if (!uniform) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (key[j] >= 0) atomicAdd(&ahist[key[j]], 1u);
             }
         }
     }
@@ -1143,14 +1172,9 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     const int P = H * W;
     const int iters = fused_iters(P);
     const int chunks = (P + iters * PX_PER_ITER - 1) / (iters * PX_PER_ITER);
-    const int NC = C + 1;
-    // LDS-privatised vote rows: the ids the caller expects (top_k + 1), capped at
-    // ~40 KB; votes for ids beyond (ties at the k-th value) go to global atomics
-    int lds_rows = (40 * 1024) / (NC * 4);
-    if (lds_rows > 256) lds_rows = 256;
-    if (vote_rows_hint > 0 && vote_rows_hint < lds_rows) lds_rows = vote_rows_hint;
-    if (lds_rows < 1) lds_rows = 1;
-    const size_t lds = (size_t)max_centers * sizeof(float2) + (size_t)lds_rows * NC * 4 + 256;
+    (void)vote_rows_hint;       // the LDS vote table is a fixed-size hash now: no sizing hint needed
+    const int lds_rows = 0;
+    const size_t lds = (size_t)max_centers * sizeof(float2) + (size_t)FUSED_VOTE_SLOTS * 8 + 256;
     if (lds > 64 * 1024) return NMSA_ERR_ARG;
     const bool vec = (P % 4 == 0) &&
                      (((uintptr_t)logits | (uintptr_t)offset | (uintptr_t)sem_u8 |

@@ -127,23 +127,6 @@ __device__ __forceinline__ void wave_aggregate_add_w(int key, uint32_t weight, A
 
 constexpr int TG_PX_PER_BLOCK = 256 * 4;
 
-// Lanes hold consecutive pixel groups, so equal keys come in RUNS: every run head learns its
-// run's length and last lane from two ballots — all heads then act in parallel (one atomic per
-// run), with no leader-serial loop over the distinct keys.  key < 0 = gap.  Wave-uniform call.
-__device__ __forceinline__ bool wave_run_head(int key, int& len, int& last)
-{
-    const int prev = __shfl_up(key, 1);
-    const int l = lane_id();
-    const bool head = key >= 0 && (l == 0 || prev != key);
-    const unsigned long long heads = __ballot(head);
-    const unsigned long long gaps = __ballot(key < 0);
-    const unsigned long long stop = (heads | gaps) & ~((2ull << l) - 1ull);
-    const int nxt = stop ? (__ffsll((long long)stop) - 1) : 64;
-    len = nxt - l;
-    last = nxt - 1;
-    return head;
-}
-
 // A 1024-pixel workgroup meets only a handful of instances, but a big instance is met by
 // hundreds of workgroups: accumulate in small LDS hash tables (linear probing, 4 tries, global
 // atomic as the fallback) and flush each used slot with ONE global atomic per workgroup.
