@@ -123,8 +123,8 @@ int nmsa_semantic_softmax(const void* logits, int logits_dtype,
  *   votes      u32 [B,256,C+1]; votes[b,id,c] = #px of instance id whose (class+1) == c.
  *              Zeroed by this call unless votes_are_zero != 0 (the caller keeps a
  *              persistent table that nmsa_panoptic_assign(clear_votes=1) left clean)
- *   vote_rows_hint  expected #instance ids + 1 (e.g. top_k_instances + 1): rows
- *              privatised in LDS; larger ids still count (global atomics). 0 = auto
+ *   vote_rows_hint  kept for ABI stability, ignored: the per-workgroup vote counters are a
+ *              fixed-size LDS hash table keyed by (instance id, class); 0 is fine
  * nmsa_panoptic_assign: per instance: class = mode (smallest on ties), running
  * per-class counter in ascending id order -> panoptic id (panoptic_merge.py:
  * 192-210).
