@@ -190,6 +190,112 @@ __global__ __launch_bounds__(1024) void k_nms_strip(
     }
 }
 
+// 3x3 fast path (the reference's default kernel size, W % 32 == 0): no LDS, no barrier.  A wave
+// owns a 256-pixel-wide column band and NR_ROWS rows; lane = 4 consecutive pixels (one 16-B
+// load per row, 1 KiB per wave and row), all NR_ROWS + 2 row loads are issued before the first
+// use.  Horizontal neighbours come from the adjacent lanes (two lane shifts per row; the band's
+// outer columns from one extra 4-B load by lanes 0 / 63), vertical neighbours are the other
+// rows' registers.  Eight lanes OR their 4 survivor bits into one 32-bit candidate word.
+constexpr int NR_ROWS = 8;
+
+__global__ __launch_bounds__(256) void k_nms_rows3(
+    const float* __restrict__ center, uint32_t* __restrict__ cand_bits,
+    int H, int W, int words_per_image, float thr)
+{
+    const int b = blockIdx.y;
+    const int lane = lane_id();
+    const int bands = (W + 255) >> 8;
+    const int wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int seg = wave / bands, band = wave - seg * bands;
+    const int y0 = seg * NR_ROWS;
+    if (y0 >= H) return;                                   // whole wave
+    const int xb = band << 8;
+    const int x0 = xb + 4 * lane;
+    const bool in_x = x0 < W;                              // W % 4 == 0: all 4 pixels or none
+    const float* img = center + (size_t)b * H * W;
+    // band edge columns: lane 0 fetches the pixel left of the band, lane 63 the one right of it
+    const int xe = (lane == 0) ? xb - 1 : xb + 256;
+    const bool edge_lane = (lane == 0 || lane == 63) && xe >= 0 && xe < W;
+
+    float4 row[NR_ROWS + 2];
+    float edge[NR_ROWS + 2];
+#pragma unroll
+    for (int r = 0; r < NR_ROWS + 2; ++r) {
+        const int gy = min(max(y0 - 1 + r, 0), H - 1);     // rows outside the image: any value
+        row[r] = in_x ? *(const float4*)(img + (size_t)gy * W + x0) : make_float4(-1.f, -1.f, -1.f, -1.f);
+        edge[r] = edge_lane ? img[(size_t)gy * W + xe] : -1.f;
+    }
+    // thresholded row with its two horizontal neighbours: e[0] = left of pixel 0 ... e[5] = right of pixel 3
+    auto extend = [&](int r, float e[6]) {
+        const float4 v = row[r];
+        e[1] = threshold_m1(v.x, thr); e[2] = threshold_m1(v.y, thr);
+        e[3] = threshold_m1(v.z, thr); e[4] = threshold_m1(v.w, thr);
+        const float ev = threshold_m1(edge[r], thr);
+        const float l = __shfl_up(e[4], 1), rr = __shfl_down(e[1], 1);
+        e[0] = (lane == 0) ? ev : l;
+        e[5] = (lane == 63) ? ev : rr;
+    };
+    uint32_t* bits = cand_bits + (size_t)b * words_per_image;
+    // hm[j] = max of the three horizontal neighbours around pixel j (NaN ignored): the pooled
+    // maximum is max3 of three rows' hm, so almost every pixel is rejected by ONE compare
+    // (h < pooled, or the thresholded background h == -1); the exact first-maximum rule runs
+    // only in waves that hold a potential peak.
+    auto hmax3 = [](const float e[6], float hm[4]) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) hm[j] = fmaxf(fmaxf(e[j], e[j + 1]), e[j + 2]);
+    };
+    float top[6], mid[6], bot[6], htop[4], hmid[4], hbot[4];
+    extend(0, mid);
+    hmax3(mid, hmid);
+    extend(1, bot);
+    hmax3(bot, hbot);
+#pragma unroll
+    for (int r = 1; r <= NR_ROWS; ++r) {
+        const int y = y0 + r - 1;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { top[k] = mid[k]; mid[k] = bot[k]; }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { htop[k] = hmid[k]; hmid[k] = hbot[k]; }
+        extend(r + 1, bot);                                // wave-uniform: all lanes shift
+        hmax3(bot, hbot);
+        if (y >= H) break;                                 // wave-uniform
+        const bool border_y = y < 1 || y >= H - 1;
+        bool maybe[4];
+        bool any_maybe = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float h = mid[j + 1];
+            const float pooled = fmaxf(fmaxf(htop[j], hmid[j]), hbot[j]);
+            // NaN h: never a candidate (h >= 0 fails); NaN neighbours are caught by the exact rule
+            maybe[j] = in_x && h >= 0.0f && (border_y || h == pooled || x0 + j < 1 || x0 + j >= W - 1);
+            any_maybe = any_maybe || maybe[j];
+        }
+        uint32_t nib = 0;
+        if (__any(any_maybe)) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int x = x0 + j;
+                const float h = mid[j + 1];
+                bool survive;
+                if (border_y || x < 1 || x >= W - 1) {
+                    survive = (y * W + x == 0) && (h == 0.0f);     // zero-padded pool output
+                } else {
+                    // first maximum in row-major window order, no NaN in the window
+                    survive = (top[j] < h) && (top[j + 1] < h) && (top[j + 2] < h) && (mid[j] < h) &&
+                              (mid[j + 2] <= h) && (bot[j] <= h) && (bot[j + 1] <= h) &&
+                              (bot[j + 2] <= h) && (h == h);
+                }
+                if (maybe[j] && survive) nib |= 1u << j;
+            }
+        }
+        uint32_t word = nib << (4 * (lane & 7));
+        word |= __shfl_xor(word, 1);
+        word |= __shfl_xor(word, 2);
+        word |= __shfl_xor(word, 4);
+        if ((lane & 7) == 0 && in_x) bits[(y * W + x0) >> 5] = word;
+    }
+}
+
 // ---- block-wide helpers (1024 threads = 16 waves) ---------------------------
 __device__ __forceinline__ int wave_inclusive_scan(int v)
 {
@@ -384,7 +490,12 @@ extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
     int R = rows_env > 0 ? rows_env : 4;
     while (R > 1 && (size_t)(R + 2 * pad) * (W + 2 * pad) * sizeof(float) > 48 * 1024) R >>= 1;
     const size_t strip_lds = (size_t)(R + 2 * pad) * (W + 2 * pad) * sizeof(float);
-    if ((W % 32) == 0 && pad <= NMS_PAD_MAX && strip_lds <= 64 * 1024) {
+    static const int rows3_env = getenv("NMSA_NMS_ROWS3") ? atoi(getenv("NMSA_NMS_ROWS3")) : 1;
+    if (pad == 1 && (W % 32) == 0 && rows3_env) {
+        const int waves = ((W + 255) / 256) * ((H + NR_ROWS - 1) / NR_ROWS);
+        hipLaunchKernelGGL(k_nms_rows3, dim3((waves + 3) / 4, B), dim3(256), 0, stream, center, bits,
+                           H, W, words, threshold);
+    } else if ((W % 32) == 0 && pad <= NMS_PAD_MAX && strip_lds <= 64 * 1024) {
         dim3 grid((H + R - 1) / R, B);
         // one thread per column when the row fits a workgroup (every wave fully used)
         static const int thr_env = getenv("NMSA_NMS_THREADS") ? atoi(getenv("NMSA_NMS_THREADS")) : 0;
