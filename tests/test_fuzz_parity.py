@@ -94,6 +94,34 @@ def test_fuzz_pipeline_vs_oracle(oracle, p):
     assert [list(d.items()) for d in got] == [list(d.items()) for d in ids], p
 
 
+@settings(max_examples=120, deadline=None, derandomize=True,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 2), H=st.integers(1, 21),
+       W=st.sampled_from([32, 64, 96, 256, 288, 320, 544]), ksize=st.sampled_from([3, 3, 3, 5, 9]),
+       levels=st.sampled_from([2, 3, 7, 64]), thr=st.sampled_from([-0.5, 0.0, 0.1, 0.6]),
+       topk=st.integers(1, 40), n_nan=st.integers(0, 3))
+def test_fuzz_center_nms_word_aligned_widths(oracle, seed, B, H, W, ksize, levels, thr, topk, n_nan):
+    """W % 32 == 0 takes the band kernels (3x3: k_nms_rows3, else k_nms_strip): plateaus, peaks
+    on band / image borders, NaNs, a negative threshold (the zero-padded-pool rule for pixel 0)"""
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    heat = (rng.integers(0, levels, (B, 1, H, W)) / max(levels - 1, 1)).astype(np.float32)
+    heat[:, :, :, ::max(W // 7, 1)] = rng.choice([0.0, 0.5, 1.0])       # columns incl. band edges
+    if rng.random() < 0.3:
+        heat[:, 0, 0, 0] = 0.0
+    for _ in range(n_nan):
+        heat[rng.integers(B), 0, rng.integers(H), rng.integers(W)] = np.nan
+    cyx, n, scores, mask = oracle.center_nms_topk(heat, threshold=thr, ksize=ksize, topk=topk,
+                                                  max_centers=4096)
+    r = ops.center_nms_topk(dev(heat), threshold=thr, kernel_size=ksize, top_k=topk,
+                            max_centers=4096, want_mask=True)
+    assert (r['n_centers'].cpu().numpy() == n).all()
+    assert (r['center_mask'].cpu().numpy() == mask).all()
+    got = r['centers_yx'].cpu().numpy()
+    for b in range(B):
+        assert (got[b, :n[b]] == cyx[b, :n[b]]).all()
+
+
 @settings(max_examples=150, deadline=None, derandomize=True,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(4, 30), W=st.integers(4, 37),
