@@ -380,6 +380,18 @@ int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int
                    int workspace_is_clean, nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
+ * Host hand-over of the per-image tables of one pipeline run (the Python objects of
+ *     panoptic.py:118-167 — id dicts, instance meta — are built on the host): packs
+ *     [n_centers, n_ids, centers_yx[kc][2], scores[kc], area[min(kc+1,256)],
+ *      ids_pan[min(kc,256)], ids_ins[min(kc,256)]], kc = min(columns, max_centers), into one
+ *     f64 row per image (exact: ids < 2^53, f32 scores) -> ONE device->host copy per batch.
+ * ------------------------------------------------------------------------- */
+int nmsa_pack_tables(const int32_t* n_centers, const int32_t* n_ids,
+                     const int32_t* centers_yx, const float* scores,
+                     const int32_t* area, const int64_t* ids_pan, const int64_t* ids_ins,
+                     int B, int max_centers, int columns, double* out, nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * a11 + a12 in ONE pass over the prediction (PanopticTaskHelper.validation_step,
  *     task_helper/panoptic.py:104-126, updates both metrics from the same panoptic map):
  *     PQ exactly as nmsa_pq_update, plus confmat[target_semantic, pred // pred_div] += 1

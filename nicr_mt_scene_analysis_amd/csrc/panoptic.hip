@@ -1465,3 +1465,53 @@ extern "C" int nmsa_instance_orientation(const float* orientation, const uint8_t
                             inst, mask, P, sums, count);
     return check_launch();
 }
+
+// ---------------------------------------------------------------------------------
+// host hand-over of the small per-image tables: ONE launch packs the first `columns` entries
+// of every table into one f64 row per image (every value is exact in f64: ids < 2^53, f32
+// scores), so that the host needs a single device->host copy per batch.
+// row = [n_centers, n_ids, centers_yx[columns][2], scores[columns], area[columns + 1],
+//        ids_pan[columns], ids_ins[columns]]
+// ---------------------------------------------------------------------------------
+namespace nmsa {
+__global__ __launch_bounds__(256) void k_pack_tables(
+    const int32_t* __restrict__ n_centers, const int32_t* __restrict__ n_ids,
+    const int32_t* __restrict__ centers_yx, const float* __restrict__ scores,
+    const int32_t* __restrict__ area, const int64_t* __restrict__ ids_pan,
+    const int64_t* __restrict__ ids_ins, int max_centers, int kc, int ka, int ki,
+    double* __restrict__ out)
+{
+    const int b = blockIdx.x;
+    const int row = 2 + 3 * kc + ka + 2 * ki;
+    double* o = out + (size_t)b * row;
+    for (int i = threadIdx.x; i < row; i += blockDim.x) {
+        int k = i;
+        double v;
+        if (k == 0) v = n_centers[b];
+        else if (k == 1) v = n_ids[b];
+        else if ((k -= 2) < 2 * kc) v = centers_yx[(size_t)b * max_centers * 2 + k];
+        else if ((k -= 2 * kc) < kc) v = scores[(size_t)b * max_centers + k];
+        else if ((k -= kc) < ka) v = area[(size_t)b * 256 + k];
+        else if ((k -= ka) < ki) v = (double)ids_pan[(size_t)b * 256 + k];
+        else v = (double)ids_ins[(size_t)b * 256 + (k - ki)];
+        o[i] = v;
+    }
+}
+}  // namespace nmsa
+
+extern "C" int nmsa_pack_tables(const int32_t* n_centers, const int32_t* n_ids,
+                                const int32_t* centers_yx, const float* scores,
+                                const int32_t* area, const int64_t* ids_pan, const int64_t* ids_ins,
+                                int B, int max_centers, int columns, double* out,
+                                nmsa_stream_t stream_)
+{
+    if (!n_centers || !n_ids || !centers_yx || !scores || !area || !ids_pan || !ids_ins || !out)
+        return NMSA_ERR_ARG;
+    if (B <= 0 || max_centers <= 0 || columns <= 0) return NMSA_ERR_ARG;
+    const int kc = columns < max_centers ? columns : max_centers;
+    const int ka = kc + 1 < 256 ? kc + 1 : 256;
+    const int ki = kc < 256 ? kc : 256;
+    hipLaunchKernelGGL(nmsa::k_pack_tables, dim3(B), dim3(256), 0, (hipStream_t)stream_, n_centers, n_ids,
+                       centers_yx, scores, area, ids_pan, ids_ins, max_centers, kc, ka, ki, out);
+    return nmsa::check_launch();
+}

@@ -102,7 +102,8 @@ class PanopticPostprocessing(DensePostprocessingBase):
                 distance_threshold=post._offset_distance_threshold,
                 max_instances_per_category=self._max_instances_per_category,
                 void_label=0, max_centers=post._max_centers,
-                want_score=True, want_foreground=True, want_panoptic_semantic=True)
+                want_score=self._compute_scores, want_foreground=True,
+                want_panoptic_semantic=False)
             host = self._fetch_tables(p, self._host_columns)
             n_host = host['n_centers']
             n_max = max(n_host) if n_host else 0
@@ -118,7 +119,12 @@ class PanopticPostprocessing(DensePostprocessingBase):
         r = LazyDict(semantic_output=s_output, semantic_side_outputs=s_side_outputs)
         sem_u8 = p['semantic_idx_u8']
         r.set_lazy('semantic_softmax_scores', lambda: ops.semantic_softmax(s_output))
-        r['semantic_segmentation_score'] = p['semantic_score']
+        if self._compute_scores:                  # the score maps need it: fused pass computes it
+            r['semantic_segmentation_score'] = p['semantic_score']
+        else:                                     # otherwise only when somebody reads it
+            r.set_lazy('semantic_segmentation_score',
+                       lambda: ops.semantic_argmax(s_output, want_u8=False, want_i64=False,
+                                                   want_score=True)['score'])
         r.set_lazy('semantic_segmentation_idx', lambda: sem_u8.long())
         self._semantic_postprocessing._fullres_entries(r, s_output, batch)
 
@@ -128,12 +134,15 @@ class PanopticPostprocessing(DensePostprocessingBase):
         # ---- panoptic entries (panoptic.py:118-167) ---------------------------------------
         panoptic_seg = p['panoptic']
         instance_seg = p['instance']
-        pan_semantic = p['panoptic_semantic']
         r['panoptic_foreground_mask'] = p['foreground']
         r['panoptic_segmentation_deeplab'] = panoptic_seg
         # id dicts / instance meta: Python objects built from the host tables when first read
         r.set_lazy('panoptic_segmentation_deeplab_ids', lambda: self._id_dicts_from_host(host))
-        r['panoptic_segmentation_deeplab_semantic_idx'] = pan_semantic
+        # panoptic // max_instances (panoptic.py:160): 8 B/px more to write — built when read
+        max_inst = self._max_instances_per_category
+        r.set_derived('panoptic_segmentation_deeplab_semantic_idx',
+                      lambda d: torch.div(d['panoptic_segmentation_deeplab'], max_inst,
+                                          rounding_mode='floor'))
         r['panoptic_segmentation_deeplab_instance_idx'] = instance_seg
         r.set_lazy('panoptic_segmentation_deeplab_instance_meta',
                    lambda: InstancePostprocessing._meta_from_host(
@@ -158,11 +167,14 @@ class PanopticPostprocessing(DensePostprocessingBase):
                      'panoptic_segmentation_deeplab_instance_score',
                      'panoptic_segmentation_deeplab_panoptic_score']
         for k in keys:
-            r[get_fullres_key(k)] = _fullres(r[k])
+            if r.is_pending(k):
+                r.set_derived(get_fullres_key(k), (lambda kk: (lambda d: _fullres(d[kk])))(k))
+            else:
+                r[get_fullres_key(k)] = _fullres(r[k])
 
         # ---- orientation (panoptic.py:294-314) ---------------------------------------------
         if with_orientation:
-            fg_orientation = ori_lut[pan_semantic].to(torch.bool)
+            fg_orientation = ori_lut[r['panoptic_segmentation_deeplab_semantic_idx']].to(torch.bool)
             ori = post._get_instance_orientation(orientation, instance_seg, fg_orientation)
             r['orientations_panoptic_segmentation_deeplab_instance'] = ori
             for b, m in enumerate(r['panoptic_segmentation_deeplab_instance_meta']):
@@ -178,10 +190,14 @@ class PanopticPostprocessing(DensePostprocessingBase):
         kc = max(1, min(int(columns), K))
         ki = min(kc, p['ids_pan'].shape[1])
         ka = min(kc + 1, p['area'].shape[1])
-        parts = [p['n_centers'].view(B, 1), p['n_ids'].view(B, 1),
-                 p['centers_yx'][:, :kc].reshape(B, 2 * kc), p['center_scores'][:, :kc],
-                 p['area'][:, :ka], p['ids_pan'][:, :ki], p['ids_ins'][:, :ki]]
-        flat = torch.cat([t.to(torch.float64) for t in parts], dim=1).cpu().numpy()
+        flat_dev = torch.empty((B, 2 + 3 * kc + ka + 2 * ki), dtype=torch.float64,
+                               device=p['center_scores'].device)
+        L = ops.L
+        L.check(L.lib().nmsa_pack_tables(
+            L.ptr(p['n_centers']), L.ptr(p['n_ids']), L.ptr(p['centers_yx']),
+            L.ptr(p['center_scores']), L.ptr(p['area']), L.ptr(p['ids_pan']), L.ptr(p['ids_ins']),
+            B, K, kc, L.ptr(flat_dev), L.stream_ptr(flat_dev.device)), 'nmsa_pack_tables')
+        flat = flat_dev.cpu().numpy()
         edges = np.cumsum([0, 1, 1, 2 * kc, kc, ka, ki, ki])
         cols = [flat[:, a:b] for a, b in zip(edges[:-1], edges[1:])]
         return {'columns': kc,

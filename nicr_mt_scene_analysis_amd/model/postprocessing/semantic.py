@@ -29,10 +29,14 @@ class SemanticPostprocessing(DensePostprocessingBase):
 
     @staticmethod
     def _argmax_entries(r: LazyDict, logits: torch.Tensor, suffix: str = '') -> None:
-        """idx / score now, softmax lazily (semantic.py:52-59 / :71-80)."""
-        am = ops.semantic_argmax(logits, want_u8=False, want_i64=True, want_score=True)
+        """idx now; the softmax tensor and the score of the winning class when they are read
+        (semantic.py:52-59 / :71-80): the argmax alone needs no exponentials, and validation
+        loops only consume the class map."""
+        am = ops.semantic_argmax(logits, want_u8=False, want_i64=True, want_score=False)
         r.set_lazy('semantic_softmax_scores' + suffix, lambda: ops.semantic_softmax(logits))
-        r['semantic_segmentation_score' + suffix] = am['score']
+        r.set_lazy('semantic_segmentation_score' + suffix,
+                   lambda: ops.semantic_argmax(logits, want_u8=False, want_i64=False,
+                                               want_score=True)['score'])
         r['semantic_segmentation_idx' + suffix] = am['idx']
 
     def _fullres_entries(self, r: LazyDict, output: torch.Tensor, batch: BatchType) -> None:
@@ -48,8 +52,9 @@ class SemanticPostprocessing(DensePostprocessingBase):
             r.set_lazy(k_out, lambda: ops.resize_bilinear(output, shape, crop))
             r.set_derived(k_sm, lambda d: ops.semantic_softmax(d[k_out]))
             am = ops.semantic_argmax_resized(output, shape, crop,
-                                             want_u8=False, want_i64=True, want_score=True)
-            r[k_score] = am['score']
+                                             want_u8=False, want_i64=True, want_score=False)
+            r.set_lazy(k_score, lambda: ops.semantic_argmax_resized(
+                output, shape, crop, want_u8=False, want_i64=False, want_score=True)['score'])
             r[k_idx] = am['idx']
             return
         r[k_out] = cropped
