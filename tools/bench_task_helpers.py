@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Training-step cost through the reference-shaped task helpers, cfg3 shapes:
+B=64, 40 classes, 640x480, bf16 predictions, main output + two side outputs (1/2, 1/4).
+Reports wall time per `training_step` + `backward` and the host-enqueue share.
+  python tools/bench_task_helpers.py [--profile]"""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper, SemanticTaskHelper   # noqa: E402
+from nicr_mt_scene_analysis_amd.task_helper.base import get_total_loss_key               # noqa: E402
+
+B, C, H, W = 64, 40, 480, 640
+dev = torch.device('cuda')
+g = torch.Generator(device=dev).manual_seed(0)
+
+
+def rnd(*shape, dtype=torch.float32):
+    return torch.randn(shape, device=dev, generator=g).to(dtype)
+
+
+def down(t, s):
+    return t[..., ::s, ::s].contiguous()
+
+
+batch = {
+    'semantic': torch.randint(0, C + 1, (B, H, W), device=dev, generator=g).to(torch.uint8),
+    'instance_center': torch.rand((B, H, W), device=dev, generator=g),
+    'instance_center_mask': torch.rand((B, H, W), device=dev, generator=g) < 0.7,
+    'instance_offset': rnd(B, 2, H, W) * 0.1,
+    'instance_foreground': torch.rand((B, H, W), device=dev, generator=g) < 0.5,
+    'orientation': torch.nn.functional.normalize(rnd(B, 2, H, W), dim=1),
+    'orientation_foreground': torch.rand((B, H, W), device=dev, generator=g) < 0.3,
+}
+for s in (2, 4):
+    batch[f'_down_{s}'] = {k: down(v, s) for k, v in batch.items() if isinstance(v, torch.Tensor)}
+dt = torch.bfloat16
+sem_main = rnd(B, C, H, W, dtype=dt).requires_grad_(True)
+sem_side = tuple(rnd(B, C, H // s, W // s, dtype=dt).requires_grad_(True) for s in (2, 4))
+
+
+def inst(s):
+    return tuple(t.requires_grad_(True) for t in (
+        rnd(B, 1, H // s, W // s, dtype=dt), rnd(B, 2, H // s, W // s, dtype=dt),
+        torch.nn.functional.normalize(rnd(B, 2, H // s, W // s), dim=1).to(dt)))
+
+
+preds = {'semantic_output': sem_main, 'semantic_side_outputs': sem_side,
+         'instance_output': inst(1), 'instance_side_outputs': (inst(2), inst(4))}
+is_thing = tuple(c >= C // 2 for c in range(C))
+sem = SemanticTaskHelper(n_classes=C, class_weights=torch.rand(C) + 0.5)
+ins = InstanceTaskHelper(semantic_n_classes=C + 1, semantic_classes_is_thing=(False,) + is_thing)
+sem.initialize(dev)
+ins.initialize(dev)
+
+
+leaves = [sem_main, *sem_side, *preds['instance_output'],
+          *(t for side in preds['instance_side_outputs'] for t in side)]
+
+
+def step():
+    for t in leaves:                            # optimizer.zero_grad(set_to_none=True)
+        t.grad = None
+    ls, _ = sem.training_step(batch, 0, preds)
+    li, _ = ins.training_step(batch, 0, preds)
+    total = ls[get_total_loss_key('semantic')] + sum(v for k, v in li.items() if k.endswith('_total_loss'))
+    total.backward()
+    return total
+
+
+for _ in range(5):
+    step()
+torch.cuda.synchronize()
+N = 30
+t0 = time.perf_counter()
+for _ in range(N):
+    step()
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+px = B * H * W
+print(f'training_step (semantic + instance, 3 scales) + backward: {1e3*(t2-t0)/N:.3f} ms/step '
+      f'(host enqueue {1e3*(t1-t0)/N:.3f} ms), {px/((t2-t0)/N)/1e6:.0f} Mpix/s')
+if '--profile' in sys.argv:
+    import cProfile
+    import pstats
+    pr = cProfile.Profile()
+    pr.enable()
+    for _ in range(20):
+        step()
+    torch.cuda.synchronize()
+    pr.disable()
+    pstats.Stats(pr).sort_stats('tottime').print_stats(25)
