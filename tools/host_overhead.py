@@ -47,7 +47,8 @@ post = get_postprocessing_class('panoptic')(
     semantic_postprocessing=get_postprocessing_class('semantic')(),
     instance_postprocessing=get_postprocessing_class('instance')(),
     semantic_classes_is_thing=is_thing, semantic_class_has_orientation=is_thing)
-batch = {'rgb_fullres': torch.zeros((32, 3, 480, 640)),
+FH, FW = (int(v) for v in os.environ.get('FULLRES', '480x640').split('x'))   # dataset resolution
+batch = {'rgb_fullres': torch.zeros((32, 3, FH, FW)),
          APPLIED_PREPROCESSING_KEY: [[{'type': 'Resize', 'valid_region_slice_y': slice(0, 480),
                                        'valid_region_slice_x': slice(0, 640)}]] * 32}
 data = ((a[0], (a[1], a[2])), (None, None))
@@ -58,6 +59,8 @@ per_call = []
 for _ in range(100):
     t0 = time.perf_counter()
     rr = post.postprocess(data, batch, is_training=False)
+    if (FH, FW) != (480, 640):                  # what a validation step reads
+        _ = rr['semantic_segmentation_idx_fullres'], rr['panoptic_segmentation_deeplab_fullres']
     per_call.append(time.perf_counter() - t0)
 torch.cuda.synchronize()
 per_call.sort()
