@@ -193,8 +193,9 @@ def pq_compare_and_accumulate(pred, target, num_categories, ignored_label,
     target = _c(target, np.int64).reshape(-1)
     if void_segment_id is None:
         void_segment_id = ignored_label * max_instances_per_category
-    if state is None:
-        state = [np.zeros((num_categories,), np.float64) for _ in range(4)]
+    # the per-image function starts from zeros (pq.py:76-79); `PanopticQuality.update` then adds
+    # the image's vectors to the states (pq.py:291-296) — same rounding order here
+    img = [np.zeros((num_categories,), np.float64) for _ in range(4)]
     matches = np.zeros((match_cap, 2), np.int64)
     nm = C.c_int32(0)
     _chk(lib().orc_pq_compare_and_accumulate(
@@ -202,10 +203,16 @@ def pq_compare_and_accumulate(pred, target, num_categories, ignored_label,
         num_categories, C.c_int64(ignored_label),
         C.c_int64(max_instances_per_category), C.c_int64(offset),
         C.c_int64(void_segment_id),
-        _p(state[0], C.c_double), _p(state[1], C.c_double),
-        _p(state[2], C.c_double), _p(state[3], C.c_double),
+        _p(img[0], C.c_double), _p(img[1], C.c_double),
+        _p(img[2], C.c_double), _p(img[3], C.c_double),
         match_cap, _p(matches, C.c_int64), C.byref(nm)), 'pq')
     m = [(int(a), int(b)) for a, b in matches[:nm.value]]
+    if state is None:
+        state = img
+    else:
+        state = list(state)
+        for i in range(4):
+            state[i] = state[i] + img[i]
     return state[0], state[1], state[2], state[3], m
 
 

@@ -5,6 +5,8 @@ plateaus in the heat-map, equidistant centers, equal top-k values) are common, o
 top-k, every heat-map kernel size, optional foreground masking and distance threshold.
 The oracle itself is pinned to the reference by tests/test_oracle_vs_golden.py.
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -14,7 +16,17 @@ from _golden import ids_from_arrays
 pytestmark = pytest.mark.gpu
 
 hypothesis = pytest.importorskip('hypothesis')
-from hypothesis import given, settings, strategies as st, HealthCheck   # noqa: E402
+from hypothesis import example, given, settings, strategies as st, HealthCheck   # noqa: E402
+
+
+# NMSA_FUZZ_SCALE=k: k times the examples, drawn at random (bug hunting on the GPU box); the
+# default run is derandomized so that the suite is reproducible
+_SCALE = int(os.environ.get('NMSA_FUZZ_SCALE', '1'))
+_DERANDOMIZE = _SCALE == 1
+
+
+def _n(examples):
+    return examples * _SCALE
 
 
 def dev(a):
@@ -55,7 +67,7 @@ def make_inputs(p):
     return logits, heat, offset, is_thing
 
 
-@settings(max_examples=300, deadline=None, derandomize=True,
+@settings(max_examples=_n(300), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(p=cases())
 def test_fuzz_pipeline_vs_oracle(oracle, p):
@@ -94,7 +106,7 @@ def test_fuzz_pipeline_vs_oracle(oracle, p):
     assert [list(d.items()) for d in got] == [list(d.items()) for d in ids], p
 
 
-@settings(max_examples=120, deadline=None, derandomize=True,
+@settings(max_examples=_n(120), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 2), H=st.integers(1, 21),
        W=st.sampled_from([32, 64, 96, 256, 288, 320, 544]), ksize=st.sampled_from([3, 3, 3, 5, 9]),
@@ -111,6 +123,13 @@ def test_fuzz_center_nms_word_aligned_widths(oracle, seed, B, H, W, ksize, level
         heat[:, 0, 0, 0] = 0.0
     for _ in range(n_nan):
         heat[rng.integers(B), 0, rng.integers(H), rng.integers(W)] = np.nan
+    if topk > H * W:                    # torch.topk raises (instance.py:130): so do both sides
+        with pytest.raises(Exception):
+            oracle.center_nms_topk(heat, threshold=thr, ksize=ksize, topk=topk, max_centers=4096)
+        with pytest.raises(Exception):
+            ops.center_nms_topk(dev(heat), threshold=thr, kernel_size=ksize, top_k=topk,
+                                max_centers=4096, want_mask=True)
+        return
     cyx, n, scores, mask = oracle.center_nms_topk(heat, threshold=thr, ksize=ksize, topk=topk,
                                                   max_centers=4096)
     r = ops.center_nms_topk(dev(heat), threshold=thr, kernel_size=ksize, top_k=topk,
@@ -122,10 +141,11 @@ def test_fuzz_center_nms_word_aligned_widths(oracle, seed, B, H, W, ksize, level
         assert (got[b, :n[b]] == cyx[b, :n[b]]).all()
 
 
-@settings(max_examples=150, deadline=None, derandomize=True,
+@settings(max_examples=_n(150), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(4, 30), W=st.integers(4, 37),
        n_cat=st.integers(2, 7), n_seg=st.integers(1, 9))
+@example(seed=7, B=3, H=4, W=31, n_cat=2, n_seg=7)     # IoU sums: per image first, then the states
 def test_fuzz_metrics_vs_oracle(oracle, seed, B, H, W, n_cat, n_seg):
     """random blocky panoptic maps: PQ states and confusion matrix bit-exact vs the oracle"""
     from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
@@ -167,7 +187,7 @@ def test_fuzz_metrics_vs_oracle(oracle, seed, B, H, W, n_cat, n_seg):
     assert np.array_equal(miou2.confmat.cpu().numpy(), oracle.confmat_update(pred // 65536, tsem, n_cat))
 
 
-@settings(max_examples=120, deadline=None, derandomize=True,
+@settings(max_examples=_n(120), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), Hs=st.integers(1, 40), Ws=st.integers(1, 48),
        Ho=st.integers(1, 70), Wo=st.integers(1, 90), C=st.integers(1, 6))
@@ -195,7 +215,7 @@ def test_fuzz_resize_vs_oracle(oracle, seed, Hs, Ws, Ho, Wo, C):
     np.testing.assert_allclose(r['score'].cpu().numpy(), score, rtol=1e-5, atol=1e-7)
 
 
-@settings(max_examples=80, deadline=None, derandomize=True,
+@settings(max_examples=_n(80), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(3, 36), W=st.integers(3, 44),
        NC=st.integers(2, 8), n_inst=st.integers(0, 12), sigma=st.integers(1, 5),
@@ -239,7 +259,7 @@ def test_fuzz_targets_vs_oracle(oracle, seed, B, H, W, NC, n_inst, sigma, normal
     assert [list(d.items()) for d in got] == [list(d.items()) for d in dicts]
 
 
-@settings(max_examples=120, deadline=None, derandomize=True,
+@settings(max_examples=_n(120), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(2, 30), W=st.integers(2, 41),
        NC=st.integers(2, 9), n_rect=st.integers(0, 10), wide=st.booleans())
@@ -272,7 +292,7 @@ def test_fuzz_standalone_merge_vs_oracle(oracle, seed, B, H, W, NC, n_rect, wide
     assert [list(d.items()) for d in got] == [list(d.items()) for d in want_ids]
 
 
-@settings(max_examples=60, deadline=None, derandomize=True,
+@settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(2, 30), W=st.integers(2, 41),
        n_rect=st.integers(0, 8), with_mask=st.booleans())
@@ -298,7 +318,7 @@ def test_fuzz_orientation_vs_oracle(oracle, seed, B, H, W, n_rect, with_mask):
             assert abs(got - ang) < 1e-4 or abs(abs(got - ang) - 2 * np.pi) < 1e-4
 
 
-@settings(max_examples=60, deadline=None, derandomize=True,
+@settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(2, 30), W=st.integers(2, 41),
        n_rect=st.integers(0, 8), with_mask=st.booleans())
@@ -330,7 +350,7 @@ def test_fuzz_orientation_wide_ids(oracle, seed, B, H, W, n_rect, with_mask):
             assert abs(g - ang) < 1e-4 or abs(abs(g - ang) - 2 * np.pi) < 1e-4
 
 
-@settings(max_examples=60, deadline=None, derandomize=True,
+@settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), C=st.integers(1, 11), H=st.integers(1, 19),
        W=st.integers(1, 23), weighted=st.booleans(), ls=st.sampled_from([0.0, 0.1, 0.5]),
@@ -357,7 +377,11 @@ def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype):
     loss.backward()
     s_ref, n_ref, w_ref, g_ref = oracle.loss_ce(as_f32(x), t, w, ls, want_grad=True)
     assert int(n) == n_ref
-    np.testing.assert_allclose(float(loss.detach()), s_ref, rtol=1e-5 if dtype == 'float32' else 2e-3, atol=1e-5)
+    # lse - x[target] cancels: each pixel carries ~1e-7 * |x| of absolute error (all of the loss
+    # when there is a single class and the exact result is 0)
+    cancel = 3e-7 * float(np.abs(as_f32(x)).max(axis=1).sum())
+    np.testing.assert_allclose(float(loss.detach()), s_ref, rtol=1e-5 if dtype == 'float32' else 2e-3,
+                               atol=1e-5 + cancel)
     np.testing.assert_allclose(float(wsum), w_ref, rtol=1e-6, atol=1e-6)
     np.testing.assert_allclose(x.grad.float().cpu().numpy(), g_ref, **tol)
 
