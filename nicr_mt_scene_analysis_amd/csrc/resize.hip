@@ -100,12 +100,23 @@ __device__ __forceinline__ uint16_t f32_to_bf16_bits(float v)
     return (uint16_t)(u >> 16);
 }
 
+// f32 -> f16 bits, rounding the f32 VALUE (round-to-nearest-even).  The reference rounds an
+// interpolated value to f32 first and to f16 afterwards; without the opaque copy the compiler
+// folds the producing fma and the conversion into v_fma_mixlo_f16, which rounds once and lands
+// on the other side of double-rounding ties.
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float v)
+{
+    float r = v;
+    asm volatile("" : "+v"(r));
+    return __builtin_bit_cast(uint16_t, (_Float16)r);
+}
+
 template <int DTYPE>
 __device__ __forceinline__ float round_to_storage(float v)
 {
     if (DTYPE == NMSA_F32) return v;
     if (DTYPE == NMSA_BF16) return bf16_to_f32(f32_to_bf16_bits(v));
-    return (float)(_Float16)v;
+    return f16_to_f32(f32_to_f16_bits(v));
 }
 
 // XCD-aware tile order: consecutive workgroup ids go round-robin over the 8 XCDs (each
@@ -186,7 +197,7 @@ __device__ __forceinline__ void store_px4(void* dst, size_t o, const float v[4],
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             hbits[j] = (DTYPE == NMSA_BF16) ? f32_to_bf16_bits(v[j])
-                                            : __builtin_bit_cast(uint16_t, (_Float16)v[j]);
+                                            : f32_to_f16_bits(v[j]);
         if (VEC) {
             typedef unsigned short u16x4_t __attribute__((ext_vector_type(4)));
             u16x4_t ov;
@@ -533,7 +544,7 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
                         const size_t o = ((size_t)(p_begin + c0 + cc) * g.Ho + yy[j]) * g.Wo + x;
                         if (DTYPE == NMSA_F32) __builtin_nontemporal_store(v[cc], (float*)dst + o);
                         else if (DTYPE == NMSA_BF16) ((uint16_t*)dst)[o] = f32_to_bf16_bits(v[cc]);
-                        else ((uint16_t*)dst)[o] = __builtin_bit_cast(uint16_t, (_Float16)v[cc]);
+                        else ((uint16_t*)dst)[o] = f32_to_f16_bits(v[cc]);
                     }
                 }
             } else if (MODE == LT_MODE_ARGMAX_SCORE) {

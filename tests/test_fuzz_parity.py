@@ -236,6 +236,48 @@ def test_fuzz_resize_vs_oracle(oracle, seed, Hs, Ws, Ho, Wo, C):
     np.testing.assert_allclose(r['score'].cpu().numpy(), score, rtol=1e-5, atol=1e-7)
 
 
+@settings(max_examples=_n(40), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), Hs=st.integers(20, 90), Ws=st.integers(70, 200),
+       fy=st.floats(1.0, 2.6), fx=st.floats(1.0, 2.6), C=st.integers(1, 13),
+       dtype=st.sampled_from(['float32', 'bfloat16', 'float16']), cropped=st.booleans())
+def test_fuzz_upscaling_tiles_vs_oracle(oracle, seed, Hs, Ws, fy, fx, C, dtype, cropped):
+    """upscaling geometries wide enough for the LDS-staged tile kernels (64 x 16 output tiles,
+    windows shifted at the right border, one or two staging slots): resized logits bit-exact,
+    fused argmax / score == argmax of the resized logits, for all three logit dtypes"""
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    y0 = x0 = 0
+    y1, x1 = Hs, Ws
+    if cropped:
+        y0 = int(rng.integers(0, Hs // 3)); x0 = int(rng.integers(0, Ws // 4))
+        y1 = int(rng.integers(2 * Hs // 3, Hs + 1)); x1 = int(rng.integers(3 * Ws // 4, Ws + 1))
+    crop = (slice(y0, y1), slice(x0, x1))
+    size = (max(1, int(round((y1 - y0) * fy))), max(1, int(round((x1 - x0) * fx))))
+    tdt = getattr(torch, dtype)
+    # few levels -> exact ties between classes; all levels exact in bf16 / f16
+    x = (rng.integers(-8, 9, (2, C, Hs, Ws)) * 0.375).astype(np.float32)
+    if rng.random() < 0.2:
+        x[0, rng.integers(C), rng.integers(Hs), rng.integers(Ws)] = np.nan
+    xd = dev(x).to(tdt)
+    seen = xd.float().cpu().numpy()
+    want = oracle.resize_bilinear(seen, size, crop)
+    got = ops.resize_bilinear(xd, size, crop)
+    if dtype == 'float32':
+        assert np.array_equal(got.cpu().numpy(), want, equal_nan=True)
+        want_lo = want
+    else:           # the reference's interpolate returns the storage dtype: round like it
+        want_lo = torch.from_numpy(want).to(tdt).float().numpy()
+        assert np.array_equal(got.float().cpu().numpy(), want_lo, equal_nan=True)
+    idx, score = oracle.semantic_argmax(want_lo)
+    r = ops.semantic_argmax_resized(xd, size, crop, want_u8=True)
+    assert np.array_equal(r['idx'].cpu().numpy(), idx)
+    assert np.array_equal(r['idx_u8'].cpu().numpy(), idx.astype(np.uint8))
+    np.testing.assert_allclose(r['score'].cpu().numpy(), score, rtol=1e-5, atol=1e-7, equal_nan=True)
+    only = ops.semantic_argmax_resized(xd, size, crop, want_u8=False, want_i64=True, want_score=False)
+    assert np.array_equal(only['idx'].cpu().numpy(), idx)
+
+
 @settings(max_examples=_n(80), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(3, 36), W=st.integers(3, 44),
