@@ -25,6 +25,9 @@ _SCALE = int(os.environ.get('NMSA_FUZZ_SCALE', '1'))
 _DERANDOMIZE = _SCALE == 1
 
 
+_EFFECTIVE = {}
+
+
 def _n(examples):
     return examples * _SCALE
 
@@ -490,3 +493,71 @@ def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype):
     # d cos / d x divides by |x|^2: short vectors amplify the fp32 rounding of the norm
     cos_tol = dict(rtol=1e-3, atol=1e-5) if dtype == 'float32' else tol
     np.testing.assert_allclose(p.grad.float().cpu().numpy(), g_ref, **cos_tol)
+
+
+@settings(max_examples=_n(40), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
+                                 HealthCheck.data_too_large])
+@given(p=cases(medium=True))
+def test_fuzz_compute_scores_vs_oracle(oracle, p):
+    """f3: score maps / per-instance mean semantic score of random pipelines vs the oracle"""
+    from nicr_mt_scene_analysis_amd import ops
+    logits, heat, offset, is_thing = make_inputs(p)
+    logits = logits + np.random.default_rng(p['seed']).random(logits.shape).astype(np.float32)
+    B, C, H, W = logits.shape
+    x = dev(logits).to(getattr(torch, p['dtype']))
+    r = ops.panoptic_pipeline(x, dev(heat), dev(offset), dev(is_thing), threshold=p['thr'],
+                              kernel_size=p['ksize'], top_k=p['topk'],
+                              apply_foreground_mask=p['apply_fg'], distance_threshold=p['dist_thr'],
+                              want_score=True, want_panoptic_semantic=True, max_centers=256)
+    if int(r['n_centers'].max()) > 255:
+        return                                           # more tied centers than the 256-row table
+    _EFFECTIVE['scores'] = _EFFECTIVE.get('scores', 0) + 1
+    tab = torch.zeros((B, 256), dtype=torch.float32, device='cuda')
+    tab[:, 1:] = r['center_scores'][:, :255]
+    sc = ops.panoptic_scores(x, r['semantic_idx_u8'], r['semantic_score'], r['instance'],
+                             r['panoptic'], r['pan_of_inst'], tab, 1 << 16)
+    torch.cuda.synchronize()
+    ids = ids_from_arrays(r['n_ids'].cpu().numpy(), r['ids_pan'].cpu().numpy(), r['ids_ins'].cpu().numpy())
+    sem, ins, pns, mean = oracle.panoptic_scores(
+        x.float().cpu().numpy(), r['panoptic_semantic'].cpu().numpy(), r['panoptic'].cpu().numpy(),
+        ids, tab.cpu().numpy())
+    np.testing.assert_allclose(sc['semantic_score'].cpu().numpy(), sem, rtol=2e-5, atol=1e-7)
+    assert np.array_equal(sc['instance_score'].cpu().numpy(), ins)
+    np.testing.assert_allclose(sc['panoptic_score'].cpu().numpy(), pns, rtol=2e-5, atol=1e-7)
+    got_mean = sc['mean_semantic_score'].cpu().numpy()
+    for b, d in enumerate(ids):
+        for ins_id in d.values():
+            assert abs(got_mean[b, ins_id] - mean[b, ins_id]) <= 2e-5 * abs(mean[b, ins_id]) + 1e-9
+
+
+@settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(1, 70), W=st.integers(1, 90),
+       n_keys=st.integers(0, 64), n_ids=st.integers(1, 80))
+def test_fuzz_dve_indices_vs_oracle(oracle, seed, B, H, W, n_keys, n_ids):
+    """f4: panoptic map -> 1-based index of its id in the image's key list (0 = not listed):
+    random blocky maps, keys in random order, ids missing from the list, empty lists"""
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    pool = rng.integers(0, 200 * 65536, n_ids).astype(np.int64)
+    cells = pool[rng.integers(0, n_ids, (B, (H + 4) // 5, (W + 6) // 7))]
+    pan = np.repeat(np.repeat(cells, 5, 1), 7, 2)[:, :H, :W].copy()
+    K = max(n_keys, 1)
+    keys = np.zeros((B, K), np.int64)
+    nk = np.zeros((B,), np.int32)
+    lists = []
+    for b in range(B):
+        n = int(rng.integers(0, n_keys + 1))
+        chosen = rng.permutation(np.unique(np.concatenate([pool, rng.integers(0, 1 << 24, 8)])))[:n]
+        keys[b, :len(chosen)] = chosen
+        nk[b] = len(chosen)
+        lists.append([int(v) for v in chosen])
+    got = ops.dve_targets(dev(pan), dev(keys), dev(nk))['indices']
+    assert np.array_equal(got.cpu().numpy(), oracle.dve_indices(pan, lists))
+
+
+def test_fuzz_effective_cases():
+    """runs last: the fuzz tests that may skip a draw must still have exercised the kernels"""
+    if 'scores' in _EFFECTIVE:
+        assert _EFFECTIVE['scores'] >= 10, _EFFECTIVE
