@@ -19,8 +19,9 @@
 //             i1 = min(i0 + 1, in - 1);  w1 = clamp(s - i0, 0, 1);  w0 = 1 - w1
 //             t0 = fmaf(a, wx0, b*wx1); t1 = fmaf(c, wx0, d*wx1);  (width first)
 //             out = fmaf(t0, wy0, t1*wy1)
-//   (upsample_generic_Nd_kernel_impl — what ATen runs for every output of >= 4096 px;
-//   for tiny outputs ATen switches to a 4-weight form that differs by <= 1 ulp.)
+//   (upsample_generic_Nd_kernel_impl — what ATen runs unless Ho + Wo <= 128, where it
+//   dispatches to its channels-last kernel: a 4-weight form whose rounding depends on the
+//   host's SIMD width)
 // Integer maps take the reference's float32 round trip (dense_base.py:38-40), which is
 // the identity below 2^24 and reproduced above it.
 #include <stdlib.h>
