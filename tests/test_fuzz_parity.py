@@ -557,6 +557,80 @@ def test_fuzz_dve_indices_vs_oracle(oracle, seed, B, H, W, n_keys, n_ids):
     assert np.array_equal(got.cpu().numpy(), oracle.dve_indices(pan, lists))
 
 
+
+@settings(max_examples=_n(40), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
+                                 HealthCheck.data_too_large])
+@given(p=cases(medium=True), fy=st.floats(0.8, 1.8), fx=st.floats(0.8, 1.8), cropped=st.booleans(),
+       compute_scores=st.booleans())
+def test_fuzz_postprocess_api_vs_ops(p, fy, fx, cropped, compute_scores):
+    """the reference-shaped `PanopticPostprocessing.postprocess` (lazy entries, packed table
+    hand-over, crop + full-resolution twins) against the bare ops — themselves checked against
+    the oracle above — on random geometries"""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.data.preprocessing import APPLIED_PREPROCESSING_KEY
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    logits, heat, offset, is_thing = make_inputs(p)
+    B, C, H, W = logits.shape
+    rng = np.random.default_rng(p['seed'] + 1)
+    y0 = x0 = 0
+    y1, x1 = H, W
+    if cropped:
+        y1, x1 = int(rng.integers(H // 2, H + 1)), int(rng.integers(W // 2, W + 1))
+        y0, x0 = int(rng.integers(0, y1 // 3 + 1)), int(rng.integers(0, x1 // 3 + 1))
+    FH, FW = max(2, int(round((y1 - y0) * fy))), max(2, int(round((x1 - x0) * fx)))
+    crop = (slice(y0, y1), slice(x0, x1))
+    kw = dict(heatmap_threshold=p['thr'], heatmap_nms_kernel_size=p['ksize'],
+              heatmap_apply_foreground_mask=p['apply_fg'], top_k_instances=p['topk'],
+              offset_distance_threshold=p['dist_thr'])
+    post = get_postprocessing_class('panoptic')(
+        semantic_postprocessing=get_postprocessing_class('semantic')(),
+        instance_postprocessing=get_postprocessing_class('instance')(**kw),
+        semantic_classes_is_thing=tuple(bool(v) for v in is_thing),
+        semantic_class_has_orientation=tuple(bool(v) for v in is_thing),
+        compute_scores=compute_scores)
+    batch = {'rgb_fullres': torch.zeros((B, 3, FH, FW)),
+             APPLIED_PREPROCESSING_KEY: [[{'type': 'Resize', 'valid_region_slice_y': crop[0],
+                                           'valid_region_slice_x': crop[1]}]] * B}
+    x = dev(logits).to(getattr(torch, p['dtype']))
+    d_heat, d_off, d_thing = dev(heat), dev(offset), dev(is_thing)
+    r = post.postprocess(((x, (d_heat, d_off)), (None, None)), batch, is_training=False)
+    o = ops.panoptic_pipeline(x, d_heat, d_off, d_thing, threshold=p['thr'], kernel_size=p['ksize'],
+                              top_k=p['topk'], apply_foreground_mask=p['apply_fg'],
+                              distance_threshold=p['dist_thr'], want_score=True,
+                              want_panoptic_semantic=True, max_centers=post._instance_postprocessing._max_centers)
+    eq = torch.equal
+    assert eq(r['panoptic_segmentation_deeplab'], o['panoptic'])
+    assert eq(r['panoptic_segmentation_deeplab_instance_idx'], o['instance'])
+    assert eq(r['panoptic_segmentation_deeplab_semantic_idx'], o['panoptic_semantic'])
+    assert eq(r['panoptic_foreground_mask'], o['foreground'])
+    assert eq(r['semantic_segmentation_idx'], o['semantic_idx_u8'].long())
+    assert eq(r['semantic_segmentation_score'], o['semantic_score'])
+    size = (FH, FW)
+    for key, src in (('panoptic_segmentation_deeplab', o['panoptic']),
+                     ('panoptic_segmentation_deeplab_instance_idx', o['instance']),
+                     ('panoptic_segmentation_deeplab_semantic_idx', o['panoptic_semantic'])):
+        assert eq(r[key + '_fullres'], ops.resize_nearest(src, size, crop)), key
+    am = ops.semantic_argmax_resized(x, size, crop, want_u8=False, want_i64=True, want_score=True)
+    assert eq(r['semantic_segmentation_idx_fullres'], am['idx'])
+    assert eq(r['semantic_segmentation_score_fullres'], am['score'])
+    n = o['n_centers'].cpu().tolist()
+    ids = ids_from_arrays(o['n_ids'].cpu().numpy(), o['ids_pan'].cpu().numpy(), o['ids_ins'].cpu().numpy())
+    assert [list(d.items()) for d in r['panoptic_segmentation_deeplab_ids']] == [list(d.items()) for d in ids]
+    cyx, sc, area = (o[k].cpu().numpy() for k in ('centers_yx', 'center_scores', 'area'))
+    meta = r['panoptic_segmentation_deeplab_instance_meta']
+    for b in range(B):
+        assert list(meta[b].keys()) == list(range(1, n[b] + 1))
+        for i, m in meta[b].items():
+            assert m['center_yx'] == (int(cyx[b, i - 1, 0]), int(cyx[b, i - 1, 1]))
+            assert m['score'] == float(sc[b, i - 1])
+            assert m['area'] == (int(area[b, i]) if i <= 255 else 0)
+    if compute_scores:
+        for k in ('semantic', 'instance', 'panoptic'):
+            key = f'panoptic_segmentation_deeplab_{k}_score'
+            assert eq(r[key + '_fullres'], ops.resize_nearest(r[key], size, crop)), key
+
+
 def test_fuzz_effective_cases():
     """runs last: the fuzz tests that may skip a draw must still have exercised the kernels"""
     if 'scores' in _EFFECTIVE:
