@@ -613,7 +613,9 @@ def test_fuzz_postprocess_api_vs_ops(p, fy, fx, cropped, compute_scores):
         assert eq(r[key + '_fullres'], ops.resize_nearest(src, size, crop)), key
     am = ops.semantic_argmax_resized(x, size, crop, want_u8=False, want_i64=True, want_score=True)
     assert eq(r['semantic_segmentation_idx_fullres'], am['idx'])
-    assert eq(r['semantic_segmentation_score_fullres'], am['score'])
+    # identity geometry shares the network-resolution score (another kernel): tolerance, not bits
+    torch.testing.assert_close(r['semantic_segmentation_score_fullres'], am['score'], rtol=1e-5,
+                               atol=1e-7, equal_nan=True)
     n = o['n_centers'].cpu().tolist()
     ids = ids_from_arrays(o['n_ids'].cpu().numpy(), o['ids_pan'].cpu().numpy(), o['ids_ins'].cpu().numpy())
     assert [list(d.items()) for d in r['panoptic_segmentation_deeplab_ids']] == [list(d.items()) for d in ids]
