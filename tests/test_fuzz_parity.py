@@ -633,7 +633,44 @@ def test_fuzz_postprocess_api_vs_ops(p, fy, fx, cropped, compute_scores):
             assert eq(r[key + '_fullres'], ops.resize_nearest(r[key], size, crop)), key
 
 
+
+@settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
+                                 HealthCheck.data_too_large])
+@given(p=cases(medium=True), p_fg=st.floats(0.0, 1.0), blocky=st.booleans())
+def test_fuzz_standalone_grouping_vs_oracle(oracle, p, p_fg, blocky):
+    """a3 with a GIVEN foreground mask (`nmsa_group_offsets`, the GT-foreground branch of
+    InstancePostprocessing): instance ids and per-id areas vs the oracle"""
+    from nicr_mt_scene_analysis_amd import ops
+    _, heat, offset, _ = make_inputs(p)
+    B, _, H, W = heat.shape
+    rng = np.random.default_rng(p['seed'] + 7)
+    if blocky:
+        cells = rng.random((B, (H + 7) // 8, (W + 15) // 16)) < p_fg
+        fg = np.repeat(np.repeat(cells, 8, 1), 16, 2)[:, :H, :W].copy()
+    else:
+        fg = rng.random((B, H, W)) < p_fg
+    try:
+        cyx, n, _, _ = oracle.center_nms_topk(heat, threshold=p['thr'], ksize=p['ksize'],
+                                              topk=p['topk'], max_centers=256)
+    except oracle.OracleError:
+        return
+    if n.max() > 255:
+        return
+    inst, area = oracle.group_offsets(offset, fg, cyx, n, scale_y=H, scale_x=W, dist_thr=p['dist_thr'])
+    cen = ops.center_nms_topk(dev(heat), threshold=p['thr'], kernel_size=p['ksize'], top_k=p['topk'],
+                              max_centers=256)
+    r = ops.group_offsets(dev(offset), dev(fg), cen['centers_yx'], cen['n_centers'], float(H), float(W),
+                          p['dist_thr'])
+    assert np.array_equal(r['instance'].cpu().numpy(), inst)
+    got_area = r['area'].cpu().numpy()
+    for b in range(B):
+        assert np.array_equal(got_area[b, :n[b] + 1], np.asarray(area[b][:n[b] + 1])), (b, n[b])
+    _EFFECTIVE['grouping'] = _EFFECTIVE.get('grouping', 0) + 1
+
+
 def test_fuzz_effective_cases():
     """runs last: the fuzz tests that may skip a draw must still have exercised the kernels"""
-    if 'scores' in _EFFECTIVE:
-        assert _EFFECTIVE['scores'] >= 10, _EFFECTIVE
+    for name in ('scores', 'grouping'):
+        if name in _EFFECTIVE:
+            assert _EFFECTIVE[name] >= 10, _EFFECTIVE
