@@ -696,7 +696,10 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_softmax_reg(
 // standalone a3: grouping with a given foreground mask (+ per-id area)
 // dynamic LDS: float2 centers[max_centers] | u32 area_hist[256]
 // =================================================================================
-template <bool VEC>
+// TILED (needs VEC): a workgroup covers a 64 x 16 pixel tile instead of 1024 consecutive pixels,
+// a wave 64 x 4 — compact in the image, so the wave's locations cluster around 1-3 centers and
+// the candidate culling of group4 leaves just those (a 256-pixel row segment spans ~10 of 24).
+template <bool VEC, bool TILED = false>
 __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
     const float* __restrict__ offset, const uint8_t* __restrict__ fgmask,
     const int32_t* __restrict__ centers_yx, const int32_t* __restrict__ n_centers,
@@ -721,9 +724,21 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
     const float* offy = offset + (size_t)b * 2 * P;
     const float* offx = offy + P;
     const int chunk_start = blockIdx.x * iters * PX_PER_ITER;
+    const int tiles_x = (W + 63) >> 6;
     for (int it = 0; it < iters; ++it) {
-        const int p0 = chunk_start + it * PX_PER_ITER + threadIdx.x * PX_PER_THREAD;
-        const bool active = p0 < P;             // tail threads stay for the wave-level steps
+        int p0;
+        bool active;                            // tail threads stay for the wave-level steps
+        if (TILED) {
+            const int tile = blockIdx.x * iters + it;
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const int row = ty * 16 + (int)(threadIdx.x >> 4);        // 16 lanes per tile row
+            const int col = tx * 64 + (int)(threadIdx.x & 15) * 4;
+            active = row < H && col < W;                               // W % 4 == 0: 4 pixels or none
+            p0 = active ? row * W + col : 0;
+        } else {
+            p0 = chunk_start + it * PX_PER_ITER + threadIdx.x * PX_PER_THREAD;
+            active = p0 < P;
+        }
         const int nvalid = active ? min(4, P - p0) : 0;
         bool fg[4] = {false, false, false, false};
         if (VEC && active) {
@@ -1278,7 +1293,13 @@ extern "C" int nmsa_group_offsets(const float* offset, const uint8_t* fg,
     const bool vec = (P % 4 == 0) &&
                      (((uintptr_t)offset | (uintptr_t)fg | (uintptr_t)inst) % 16 == 0);
     dim3 grid(chunks, B), block(FUSED_THREADS);
-    if (vec)
+    static const int tiled_env = getenv("NMSA_GROUP_TILED") ? atoi(getenv("NMSA_GROUP_TILED")) : 1;
+    if (vec && W % 4 == 0 && tiled_env) {
+        const int tiles = ((W + 63) / 64) * ((H + 15) / 16);
+        hipLaunchKernelGGL((k_group_offsets<true, true>), dim3((tiles + iters - 1) / iters, B), block, lds,
+                           stream, offset, fg, centers_yx, n_centers, H, W, max_centers, iters,
+                           scale_y, scale_x, use_dist_thr, dist_thr, inst, area);
+    } else if (vec)
         hipLaunchKernelGGL(k_group_offsets<true>, grid, block, lds, stream, offset, fg, centers_yx,
                            n_centers, H, W, max_centers, iters, scale_y, scale_x, use_dist_thr,
                            dist_thr, inst, area);
