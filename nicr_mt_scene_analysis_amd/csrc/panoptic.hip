@@ -311,7 +311,7 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
 // dynamic LDS: float2 centers[max_centers] | i32 vote_key[FUSED_VOTE_SLOTS] | u32 vote_cnt[..] | u8 thing[256]
 // =================================================================================
 template <int DTYPE, bool VEC, bool WITH_SCORE, int UNROLL = 8, bool NT = true,
-          bool EARLY_OFFSETS = false>
+          bool EARLY_OFFSETS = false, bool TILED = false>
 __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
     const void* __restrict__ logits, const float* __restrict__ offset,
     const int32_t* __restrict__ centers_yx, const int32_t* __restrict__ n_centers,
@@ -354,8 +354,20 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
     // one chunk of 1024 pixels; the first one (FIRST) also fills the LDS tables
     auto chunk = [&](const int it, auto first_tag) {
         constexpr bool FIRST = decltype(first_tag)::value;
-        const int p0 = chunk_start + it * PX_PER_ITER + threadIdx.x * PX_PER_THREAD;
-        const bool active = p0 < P;             // whole thread out of range in the tail chunk
+        int p0;
+        bool active;                            // whole thread out of range in the tail chunk
+        if (TILED) {                            // 64 x 16 pixel tile per workgroup, 64 x 4 per wave
+            const int tiles_x = (W + 63) >> 6;
+            const int tile = blockIdx.x * iters + it;
+            const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
+            const int row = ty * 16 + (int)(threadIdx.x >> 4);
+            const int col = tx * 64 + (int)(threadIdx.x & 15) * 4;
+            active = row < H && col < W;        // W % 4 == 0: all 4 pixels or none
+            p0 = active ? row * W + col : 0;
+        } else {
+            p0 = chunk_start + it * PX_PER_ITER + threadIdx.x * PX_PER_THREAD;
+            active = p0 < P;
+        }
         const int nvalid = active ? min(4, P - p0) : 0;
 
         // offsets of this thread's pixels.  Default: requested after the argmax and only by
@@ -1199,37 +1211,18 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     hipLaunchKernelGGL((k_panoptic_fused<DTYPE, V, S>), grid, block, lds, stream, logits,    \
                        offset, centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, \
                        sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows)
-    // tuning variants of the headline instantiation (f32, vector path, no score)
-    static const int unroll = env_int("NMSA_FUSED_UNROLL", 8);
-    static const int nt = env_int("NMSA_FUSED_NT", 1);
-#define NMSA_LAUNCH_FUSED_V(U, N)                                                              \
-    hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, U, N>), grid, block, lds, stream, \
-                       logits, offset, centers_yx, n_centers, is_thing, C, H, W, max_centers,  \
-                       iters, sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows)
-    static const int unroll16 = env_int("NMSA_FUSED_UNROLL16", 8);     // 16-bit logits
-    static const int early = env_int("NMSA_FUSED_EARLY", -1);          // offsets before the classes?
-    if (vec && !score && early > 0) {
-        if (early) hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, true>), grid, block,
-                                      lds, stream, logits, offset, centers_yx, n_centers, is_thing, C, H,
-                                      W, max_centers, iters, sy, sx, use_thr, thr, sem_u8, inst, fg_out,
-                                      score, votes, lds_rows);
-        else hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false>), grid, block,
-                                lds, stream, logits, offset, centers_yx, n_centers, is_thing, C, H,
-                                W, max_centers, iters, sy, sx, use_thr, thr, sem_u8, inst, fg_out,
-                                score, votes, lds_rows);
-    } else if (vec && !score && DTYPE != NMSA_F32 && unroll16 != 8) {
-        if (unroll16 == 16) NMSA_LAUNCH_FUSED_V(16, true);
-        else if (unroll16 == 20) NMSA_LAUNCH_FUSED_V(20, true);
-        else NMSA_LAUNCH_FUSED_V(12, true);
-    } else if (vec && !score && DTYPE == NMSA_F32 && (unroll != 8 || !nt)) {
-        if (unroll == 4 && !nt) NMSA_LAUNCH_FUSED_V(4, false);
-        else if (unroll == 12 && !nt) NMSA_LAUNCH_FUSED_V(12, false);
-        else if (unroll == 4) NMSA_LAUNCH_FUSED_V(4, true);
-        else if (unroll == 12) NMSA_LAUNCH_FUSED_V(12, true);
-        else NMSA_LAUNCH_FUSED_V(8, false);
+    // 64 x 16 pixel tiles per workgroup (compact waves -> effective center culling) pay for
+    // 16-bit logits (153 vs 183 us with 64 centers, 153 vs 155 with 24); for f32 the four 256-B
+    // row pieces per wave load cost more than the hidden search saves (287 vs 278 us)
+    static const int tiled = env_int("NMSA_FUSED_TILED", 1);           // 0: never, 1: 16-bit, 2: all
+    if (vec && !score && W % 4 == 0 && (tiled == 2 || (tiled == 1 && DTYPE != NMSA_F32))) {
+        const int tiles = ((W + 63) / 64) * ((H + 15) / 16);
+        hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true>),
+                           dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
+                           centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
+                           use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
     } else if (vec) { if (score) NMSA_LAUNCH_FUSED(true, true); else NMSA_LAUNCH_FUSED(true, false); }
     else { if (score) NMSA_LAUNCH_FUSED(false, true); else NMSA_LAUNCH_FUSED(false, false); }
-#undef NMSA_LAUNCH_FUSED_V
 #undef NMSA_LAUNCH_FUSED
     return check_launch();
 }
