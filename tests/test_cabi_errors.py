@@ -1,0 +1,124 @@
+"""The C ABI never throws and never launches on bad arguments: every entry point answers a
+negative NMSA_ERR_* code (include/nmsa.h) for null pointers, impossible shapes, unknown dtype
+codes and short workspaces — the Python wrappers turn those into the reference's exception
+types.  Runs on the GPU box (valid calls in between prove that the process stays healthy)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ERR_ARG, ERR_WORKSPACE = -1, -3
+
+
+@pytest.fixture(scope='module')
+def env():
+    from nicr_mt_scene_analysis_amd import _lib as L
+    dev = torch.device('cuda')
+    B, C, H, W = 2, 5, 16, 32
+    t = {
+        'logits': torch.randn((B, C, H, W), device=dev),
+        'center': torch.rand((B, H, W), device=dev),
+        'offset': torch.zeros((B, 2, H, W), device=dev),
+        'fg': torch.ones((B, H, W), dtype=torch.uint8, device=dev),
+        'u8': torch.zeros((B, H, W), dtype=torch.uint8, device=dev),
+        'u8b': torch.zeros((B, H, W), dtype=torch.uint8, device=dev),
+        'i64': torch.zeros((B, H, W), dtype=torch.int64, device=dev),
+        'i64b': torch.zeros((B, H, W), dtype=torch.int64, device=dev),
+        'cyx': torch.zeros((B, 256, 2), dtype=torch.int32, device=dev),
+        'n': torch.zeros((B,), dtype=torch.int32, device=dev),
+        'scores': torch.zeros((B, 256), dtype=torch.float32, device=dev),
+        'thing': torch.ones((C,), dtype=torch.uint8, device=dev),
+        'votes': torch.zeros((B, 256, C + 1), dtype=torch.int32, device=dev),
+        'f64': torch.zeros((4, 8), dtype=torch.float64, device=dev),
+        'status': torch.zeros((1,), dtype=torch.int32, device=dev),
+        'ws': torch.zeros((1 << 20,), dtype=torch.uint8, device=dev),
+    }
+    return L, L.lib(), dev, (B, C, H, W), t
+
+
+def test_strerror_names_every_code(env):
+    L, lib, *_ = env
+    for code in (0, -1, -2, -3, -4):
+        assert lib.nmsa_strerror(code).decode()
+    assert lib.nmsa_version() > 0
+
+
+def test_bad_arguments_return_codes(env):
+    L, lib, dev, (B, C, H, W), t = env
+    p, st = L.ptr, L.stream_ptr(dev)
+    ws_nms = lib.nmsa_center_nms_workspace_bytes(B, H, W)
+
+    def nms(center=t['center'], ksize=3, topk=4, h=H, w=W, ws_bytes=ws_nms, max_centers=256):
+        return lib.nmsa_center_nms_topk(p(center), None, B, h, w, 0.1, ksize, topk, 0, max_centers,
+                                        p(t['cyx']), p(t['n']), p(t['scores']), None, p(t['ws']),
+                                        ws_bytes, st)
+    assert nms() == 0
+    assert nms(center=None) == ERR_ARG
+    assert nms(ksize=4) == ERR_ARG                       # instance.py:37: odd kernel sizes only
+    assert nms(topk=0) == ERR_ARG
+    assert nms(topk=H * W + 1) == ERR_ARG                # torch.topk would raise
+    assert nms(h=0) == ERR_ARG
+    assert nms(ws_bytes=8) == ERR_WORKSPACE
+
+    def argmax(logits=t['logits'], dtype=0, c=C):
+        return lib.nmsa_semantic_argmax(p(logits), dtype, B, c, H, W, p(t['u8']), None, None, st)
+    assert argmax() == 0
+    assert argmax(logits=None) == ERR_ARG
+    assert argmax(dtype=7) == ERR_ARG
+    assert argmax(c=0) == ERR_ARG
+    assert argmax(c=300) == ERR_ARG                      # u8 class map: at most 256 classes
+
+    def fused(max_centers=256, logits=t['logits']):
+        return lib.nmsa_panoptic_fused(p(logits), 0, p(t['offset']), p(t['cyx']), p(t['n']),
+                                       p(t['thing']), B, C, H, W, max_centers, float(H), float(W), 0,
+                                       0.0, p(t['u8']), p(t['u8b']), None, None, p(t['votes']), 0, 0, st)
+    assert fused() == 0
+    assert fused(logits=None) == ERR_ARG
+    assert fused(max_centers=1 << 16) == ERR_ARG         # center table would not fit the LDS
+
+    def nearest(h=H, w=W, ho=8, wo=8, elem=3):
+        return lib.nmsa_resize_nearest(p(t['i64']), elem, B, H, W, 0, 0, h, w, ho, wo, p(t['i64b']), st)
+    assert nearest() == 0
+    assert nearest(h=H + 1) == ERR_ARG                   # crop outside the plane
+    assert nearest(ho=0) == ERR_ARG
+    assert nearest(elem=42) == ERR_ARG
+
+    cm = torch.zeros((C, C), dtype=torch.int64, device=dev)
+    ws_cm = lib.nmsa_confmat_workspace_bytes(C)
+    cm_ws = torch.zeros((ws_cm,), dtype=torch.uint8, device=dev)
+
+    def confmat(n_classes=C, ws_bytes=ws_cm, preds=t['u8']):
+        return lib.nmsa_confmat_update(p(preds), 0, 1, p(t['u8b']), 0, B * H * W, n_classes, 0,
+                                       p(cm), p(t['status']), p(cm_ws), ws_bytes, st)
+    assert confmat() == 0
+    assert confmat(preds=None) == ERR_ARG
+    assert confmat(n_classes=0) == ERR_ARG
+    assert confmat(ws_bytes=8) == ERR_WORKSPACE
+
+    ws_pq = lib.nmsa_pq_workspace_bytes(B, C)
+    pq_ws = torch.zeros((ws_pq,), dtype=torch.uint8, device=dev)
+
+    def pq(num_categories=C, ws_bytes=ws_pq, offset=256 ** 3):
+        f = t['f64']
+        return lib.nmsa_pq_update(p(t['i64']), p(t['i64b']), B, H, W, num_categories, 0, 1 << 16, offset,
+                                  0, p(f[0]), p(f[1]), p(f[2]), p(f[3]), None, 0, None, p(t['status']),
+                                  p(pq_ws), ws_bytes, 0, st)
+    assert pq() == 0
+    assert pq(num_categories=0) == ERR_ARG
+    assert pq(offset=0) == ERR_ARG
+    assert pq(ws_bytes=16) == ERR_WORKSPACE
+    torch.cuda.synchronize()                             # nothing faulted on the way
+
+
+def test_wrappers_raise_the_reference_exception_types(env):
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    L, lib, dev, (B, C, H, W), t = env
+    with pytest.raises(L.NmsaError):                     # CPU tensors: no silent CPU fallback
+        ops.semantic_argmax(t['logits'].cpu())
+    with pytest.raises(L.NmsaError):
+        ops.center_nms_topk(t['center'], top_k=H * W + 1)
+    with pytest.raises(AssertionError):
+        get_postprocessing_class('instance')(heatmap_nms_kernel_size=2)
+    with pytest.raises(ValueError):
+        get_postprocessing_class('nope')
