@@ -1105,9 +1105,8 @@ __global__ __launch_bounds__(256) void k_orientation_sums(
     __syncthreads();
     const float* o0 = orientation + (size_t)b * 2 * P;
     const float* o1 = o0 + P;
-    // 4 consecutive pixels per lane.  A lane whose pixels belong to one instance contributes its
-    // partial sums to ONE wave round: per distinct id (1-3 per wave) the wave sums its lanes in
-    // fp64 and lane 0 adds to the LDS table; boundary lanes add their pixels on their own.
+    // 4 consecutive pixels per lane.  A lane whose pixels belong to one instance adds its fp64
+    // partial sums with one LDS atomic per component; boundary lanes add their pixels one by one.
     for (int p0 = (blockIdx.x * 256 + threadIdx.x) * 4; p0 - (int)threadIdx.x * 4 < P;
          p0 += gridDim.x * MG_PX_PER_BLOCK) {
         int id[4] = {0, 0, 0, 0};
@@ -1132,21 +1131,14 @@ __global__ __launch_bounds__(256) void k_orientation_sums(
         const int lid = same4 ? id[0] : 0;
         const double l0 = (double)a[0] + (double)a[1] + (double)a[2] + (double)a[3];
         const double l1 = (double)c[0] + (double)c[1] + (double)c[2] + (double)c[3];
-        unsigned long long todo = __ballot(lid != 0);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int kid = __shfl(lid, leader);
-            const bool mine = (lid == kid);
-            const unsigned long long same = __ballot(mine) & todo;
-            const double r0 = wave_reduce_sum(mine ? l0 : 0.0);
-            const double r1 = wave_reduce_sum(mine ? l1 : 0.0);
-            if (lane_id() == 0) {
-                atomicAdd(&s_sum[kid * 2 + 0], r0);
-                atomicAdd(&s_sum[kid * 2 + 1], r1);
-                atomicAdd(&s_cnt[kid], 4 * (int)__popcll(same));
-            }
-            todo &= ~same;
+        if (lid) {      // LDS fp64 atomics: same-address lanes serialise in the LDS unit (~1 / clk),
+                        // cheaper than fp64 wave reductions through ds_bpermute per distinct id
+            atomicAdd(&s_sum[lid * 2 + 0], l0);
+            atomicAdd(&s_sum[lid * 2 + 1], l1);
         }
+        // counts: runs of equal ids add 4 x run length at the run head
+        int run_len, run_last;
+        if (wave_run_head(lid ? lid : -1, run_len, run_last)) atomicAdd(&s_cnt[lid], 4 * run_len);
         if (!same4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
