@@ -1039,10 +1039,11 @@ __global__ __launch_bounds__(256) void k_merge_votes(
                 if (j < nvalid && i4[j] > 0 && i4[j] < 256 && t4[j] && s4[j] >= 0 && s4[j] < NC)
                     key[j] = (int)(i4[j] * NC + s4[j]);
         }
-        // lanes whose 4 pixels agree share one aggregated round of weight 4; boundary lanes add
-        // their own pixels
+        // lanes whose 4 pixels agree form runs across the wave: the run head adds 4 x run length
+        // (two ballots, no loop over the distinct keys); boundary lanes add their own pixels
         const bool same4 = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
-        wave_aggregate_add(same4 ? key[0] : -1, [&](int kk, uint32_t cnt) { add(kk, 4u * cnt); });
+        int run_len, run_last;
+        if (wave_run_head(same4 ? key[0] : -1, run_len, run_last)) add(key[0], 4u * (uint32_t)run_len);
         if (!same4) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) if (key[j] >= 0) add(key[j], 1u);

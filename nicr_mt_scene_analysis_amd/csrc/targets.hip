@@ -766,26 +766,28 @@ __global__ __launch_bounds__(256) void k_ow_sums(
                 if (dd < cap) { d = dd; v0 = (double)o0[p]; v1 = (double)o1[p]; }
             }
         }
-        // one distinct instance at a time (1-3 per wave): the wave sums its lanes in fp64
-        unsigned long long todo = __ballot(d >= 0);
-        while (todo) {
-            const int leader = __ffsll((long long)todo) - 1;
-            const int kd = __shfl(d, leader);
-            const bool mine = (d == kd);
-            const unsigned long long same = __ballot(mine) & todo;
-            const double a0 = wave_reduce_sum(mine ? v0 : 0.0);
-            const double a1 = wave_reduce_sum(mine ? v1 : 0.0);
-            if (lane_id() == 0) {
-                const int slot = lds_hash_slot(s_key, TG_H1, kd);
-                const int n = (int)__popcll(same);
-                if (slot >= 0) {
-                    atomicAdd(&s_sum[2 * slot], a0); atomicAdd(&s_sum[2 * slot + 1], a1);
-                    atomicAdd(&s_cnt[slot], n);
-                } else {
-                    atomicAdd(&gs[2 * kd], a0); atomicAdd(&gs[2 * kd + 1], a1); atomicAdd(&gc[kd], n);
-                }
+        // equal ids come in runs of lanes: the run head resolves the LDS slot once and passes it
+        // down its run; every lane then adds its fp64 values with LDS atomics (same-address lanes
+        // serialise in the LDS unit — cheaper than fp64 wave reductions per distinct id)
+        int run_len, run_last;
+        const bool head = wave_run_head(d, run_len, run_last);
+        int slot = -1;
+        if (head) slot = lds_hash_slot(s_key, TG_H1, d);
+        // lane l belongs to the run whose head is the last head at or before l
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long upto = heads & ((2ull << lane_id()) - 1ull);
+        const int my_head = upto ? 63 - __clzll((long long)upto) : 0;
+        slot = __shfl(slot, my_head);
+        if (d >= 0) {
+            if (slot >= 0) {
+                atomicAdd(&s_sum[2 * slot], v0); atomicAdd(&s_sum[2 * slot + 1], v1);
+            } else {
+                atomicAdd(&gs[2 * d], v0); atomicAdd(&gs[2 * d + 1], v1);
             }
-            todo &= ~same;
+            if (head) {
+                if (slot >= 0) atomicAdd(&s_cnt[slot], run_len);
+                else atomicAdd(&gc[d], run_len);
+            }
         }
     }
     __syncthreads();
