@@ -65,9 +65,9 @@ __global__ __launch_bounds__(256) void k_mw_presence(
                 else key = (int)i;
             }
         }
-        wave_aggregate_add(key, [&](int id, uint32_t) {
-            if (lds_hash_slot(s_ids, 64, id) < 0) atomicOr(&v.bitmap[id >> 5], 1u << (id & 31));
-        });
+        int run_len, run_last;              // one insert per run of equal ids, all heads in parallel
+        if (wave_run_head(key, run_len, run_last) && lds_hash_slot(s_ids, 64, key) < 0)
+            atomicOr(&v.bitmap[key >> 5], 1u << (key & 31));
     }
     __syncthreads();
     if (threadIdx.x < 64 && s_ids[threadIdx.x] >= 0) {
@@ -134,11 +134,12 @@ __global__ __launch_bounds__(256) void k_mw_votes(
                 if (d < cap) key = d * NC + (int)s;
             }
         }
-        wave_aggregate_add(key, [&](int kk, uint32_t cnt) {
-            const int slot = lds_hash_slot(s_key, 256, kk);
-            if (slot >= 0) atomicAdd(&s_cnt[slot], cnt);
-            else atomicAdd(&v.votes[kk], cnt);
-        });
+        int run_len, run_last;              // the head of a run of equal keys adds the run length
+        if (wave_run_head(key, run_len, run_last)) {
+            const int slot = lds_hash_slot(s_key, 256, key);
+            if (slot >= 0) atomicAdd(&s_cnt[slot], (uint32_t)run_len);
+            else atomicAdd(&v.votes[key], (uint32_t)run_len);
+        }
     }
     __syncthreads();
     if (s_key[threadIdx.x] >= 0 && s_cnt[threadIdx.x])
