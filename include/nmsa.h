@@ -434,6 +434,9 @@ int nmsa_pq_update_with_confmat(
  *     with the masking of task_helper/instance.py:129-139,154-167:
  *     sum_px mean_c f(pred*mask - target), n = sum(mask); mask u8 [B,H,W] or NULL;
  *     kind 0 = MSE, 1 = L1; C = 1 for [B,H,W] inputs
+ *     kind 2 = center focal loss — EXTENSION, not in the reference: CenterNet's penalty-reduced
+ *     focal loss (alpha 2, beta 4, pred clamped to [1e-4, 1-1e-4]) over the masked pixels;
+ *     n_mask then counts the positive (target == 1) masked pixels
  * nmsa_loss_vonmises_* VonMisesLossBiternion  loss/vonmises.py:27-51 over the px
  *     where mask != 0 (gather of task_helper/instance.py:186-216), pred/target [B,2,H,W]
  * nmsa_loss_cos_emb_*  CosineEmbeddingLoss  loss/cos_emb.py:21-56 with the LUT gather of

@@ -394,7 +394,27 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
 // a7: masked MSE / L1 with channel mean (C = 1: center, C = 2: offset)
 //   loss = sum_px mean_c f(pred*mask - target);  n = sum(mask)
 // =================================================================================
-template <int DTYPE, int KIND /* 0 mse, 1 l1 */>
+// KIND 2 — center focal loss (EXTENSION: the reference has only MSE / L1 for the center heat-map;
+// the penalty-reduced focal loss of CenterNet, alpha = 2, beta = 4, on p = clamp(pred, 1e-4,
+// 1 - 1e-4)):  -(1-p)^2 log p where target == 1,  -(1-target)^4 p^2 log(1-p) elsewhere; masked-out
+// pixels contribute nothing and the count is the number of positive (target == 1) masked pixels.
+__device__ __forceinline__ float focal_value(float x, float y)
+{
+    const float p = fminf(fmaxf(x, 1e-4f), 1.0f - 1e-4f);
+    if (y == 1.0f) return -(1.0f - p) * (1.0f - p) * __logf(p);
+    const float w = (1.0f - y) * (1.0f - y);
+    return -w * w * p * p * __logf(1.0f - p);
+}
+__device__ __forceinline__ float focal_grad(float x, float y)
+{
+    if (!(x > 1e-4f && x < 1.0f - 1e-4f)) return 0.f;     // clamped: no gradient
+    const float q = 1.0f - x;
+    if (y == 1.0f) return 2.0f * q * __logf(x) - q * q / x;
+    const float w = (1.0f - y) * (1.0f - y);
+    return -w * w * (2.0f * x * __logf(q) - x * x / q);
+}
+
+template <int DTYPE, int KIND /* 0 mse, 1 l1, 2 center focal */>
 __global__ __launch_bounds__(LOSS_THREADS) void k_elem_fwd(
     const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
     int C, int P, int vec, LossPartial* __restrict__ partials)
@@ -415,12 +435,16 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_fwd(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 if (j >= nvalid) continue;
+                if (KIND == 2) {
+                    if (mk[j]) { part += focal_value(xv[j], yv[j]); cnt += (yv[j] == 1.0f); }
+                    continue;
+                }
                 const float d = (mk[j] ? xv[j] : 0.f) - yv[j];       // pred*mask - target
                 part += (KIND == 0) ? d * d : fabsf(d);
             }
         }
         acc += part * invC;
-        for (int j = 0; j < 4; ++j) cnt += (j < nvalid) && mk[j];
+        if (KIND != 2) for (int j = 0; j < 4; ++j) cnt += (j < nvalid) && mk[j];
     }
     block_partial(acc, 0.0, cnt, partials);
 }
@@ -445,7 +469,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_bwd(
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float d = (mk[j] ? xv[j] : 0.f) - yv[j];
-                const float dd = (KIND == 0) ? 2.0f * d : (float)((d > 0.f) - (d < 0.f));
+                const float dd = (KIND == 2) ? focal_grad(xv[j], yv[j])
+                               : (KIND == 0) ? 2.0f * d : (float)((d > 0.f) - (d < 0.f));
                 o[j] = mk[j] ? g * dd : 0.f;                          // through the mask multiply
             }
             st4<DTYPE>(grad, off, nvalid, vec, o);
@@ -812,7 +837,7 @@ extern "C" int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* ta
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !target || !loss_sum || !n_mask || !workspace) return NMSA_ERR_ARG;
-    if (bad_shape(B, H, W) || C <= 0 || (kind != 0 && kind != 1)) return NMSA_ERR_ARG;
+    if (bad_shape(B, H, W) || C <= 0 || kind < 0 || kind > 2) return NMSA_ERR_ARG;
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
     const int vec = (P % 4 == 0) && ((((uintptr_t)pred | (uintptr_t)target | (uintptr_t)mask) & 15) == 0);
@@ -821,7 +846,9 @@ extern "C" int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* ta
 #define CALL(DT)                                                                                     \
     if (kind == 0) hipLaunchKernelGGL((k_elem_fwd<DT, 0>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, \
                                       pred, target, mask, C, P, vec, partials);                      \
-    else hipLaunchKernelGGL((k_elem_fwd<DT, 1>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, pred,    \
+    else if (kind == 1) hipLaunchKernelGGL((k_elem_fwd<DT, 1>), dim3(gx, B), dim3(LOSS_THREADS), 0,   \
+                                           stream, pred, target, mask, C, P, vec, partials);         \
+    else hipLaunchKernelGGL((k_elem_fwd<DT, 2>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, pred,    \
                             target, mask, C, P, vec, partials)
     NMSA_DISPATCH_DTYPE(dtype, CALL)
 #undef CALL
@@ -836,7 +863,7 @@ extern "C" int nmsa_loss_masked_bwd(const void* pred, int dtype, const float* ta
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !target || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
-    if (bad_shape(B, H, W) || C <= 0 || (kind != 0 && kind != 1)) return NMSA_ERR_ARG;
+    if (bad_shape(B, H, W) || C <= 0 || kind < 0 || kind > 2) return NMSA_ERR_ARG;
     const int P = H * W;
     const int vec = (P % 4 == 0) &&
                     ((((uintptr_t)pred | (uintptr_t)target | (uintptr_t)mask | (uintptr_t)grad_pred) & 15) == 0);
@@ -844,7 +871,10 @@ extern "C" int nmsa_loss_masked_bwd(const void* pred, int dtype, const float* ta
 #define CALL(DT)                                                                                     \
     if (kind == 0) hipLaunchKernelGGL((k_elem_bwd<DT, 0>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, \
                                       pred, target, mask, C, P, vec, grad_scale, grad_pred);         \
-    else hipLaunchKernelGGL((k_elem_bwd<DT, 1>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, pred,    \
+    else if (kind == 1) hipLaunchKernelGGL((k_elem_bwd<DT, 1>), dim3(gx, B), dim3(LOSS_THREADS), 0,   \
+                                           stream, pred, target, mask, C, P, vec, grad_scale,        \
+                                           grad_pred);                                               \
+    else hipLaunchKernelGGL((k_elem_bwd<DT, 2>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, pred,    \
                             target, mask, C, P, vec, grad_scale, grad_pred)
     NMSA_DISPATCH_DTYPE(dtype, CALL)
 #undef CALL

@@ -2,6 +2,7 @@
 from .base import LossBase
 from .ce import CrossEntropyLossSemantic
 from .cos_emb import CosineEmbeddingLoss
+from .focal import CenterFocalLoss
 from .l1 import L1Loss
 from .mse import MSELoss
 from .vonmises import VonMisesLossBiternion

@@ -205,7 +205,7 @@ def cross_entropy_sum(logits, target, weights=None, label_smoothing=0.0
 
 
 def masked_elementwise_sum(pred, target, mask, kind: str) -> Tuple[torch.Tensor, torch.Tensor]:
-    return MaskedElementwiseFunction.apply(pred, target, mask, 0 if kind == 'mse' else 1)
+    return MaskedElementwiseFunction.apply(pred, target, mask, {'mse': 0, 'l1': 1, 'focal': 2}[kind])
 
 
 def vonmises_sum(pred, target, mask, kappa: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:

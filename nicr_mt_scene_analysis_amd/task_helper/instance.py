@@ -10,6 +10,7 @@ import torch
 
 from ..data.preprocessing.resize import get_fullres
 from ..data.preprocessing.resize import get_fullres_key
+from ..loss import CenterFocalLoss
 from ..loss import L1Loss
 from ..loss import MSELoss
 from ..loss import VonMisesLossBiternion
@@ -21,7 +22,7 @@ from .base import TaskHelperBase
 from .base import append_detached_losses_to_logs
 from .base import append_profile_to_logs
 
-KNOWN_INSTANCE_CENTER_LOSS_FUNCTIONS = ('mse', 'l1')
+KNOWN_INSTANCE_CENTER_LOSS_FUNCTIONS = ('mse', 'l1', 'focal')    # 'focal': extension, loss/focal.py
 
 
 class InstanceTaskHelper(TaskHelperBase):
@@ -44,8 +45,8 @@ class InstanceTaskHelper(TaskHelperBase):
 
     def initialize(self, device: torch.device):
         assert self._loss_name_instance_center in KNOWN_INSTANCE_CENTER_LOSS_FUNCTIONS
-        self._loss_center = MSELoss(reduction='sum') \
-            if self._loss_name_instance_center == 'mse' else L1Loss(reduction='sum')
+        self._loss_center = {'mse': MSELoss, 'l1': L1Loss, 'focal': CenterFocalLoss}[
+            self._loss_name_instance_center](reduction='sum')
         self._loss_offset = L1Loss(reduction='sum')
         self._loss_orientation = VonMisesLossBiternion()
         self._mae_pq_deeplab = PanopticQualityWithOrientationMAE(

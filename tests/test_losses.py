@@ -205,3 +205,51 @@ def test_bf16_predictions_and_grads():
     ref = ((p.double() * m.unsqueeze(1)) - y.double()).abs().mean(dim=1).sum()
     np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL)
     assert int(n) == int(m.sum())
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_center_focal_loss_extension_vs_torch(dtype):
+    """`CenterFocalLoss` is an extension (the reference has MSE / L1 only): parity unpinned, checked
+    against a plain PyTorch fp32 implementation of the documented formula, values and gradient"""
+    from nicr_mt_scene_analysis_amd.loss import CenterFocalLoss
+    g = torch.Generator(device='cuda').manual_seed(3)
+    B, H, W = 3, 37, 53
+    pred = torch.rand((B, H, W), device='cuda', generator=g)
+    pred[0, 0, :4] = torch.tensor([0.0, 1.0, 1e-6, 1 - 1e-6], device='cuda')      # clamped ends
+    target = torch.rand((B, H, W), device='cuda', generator=g) ** 4
+    target[torch.rand((B, H, W), device='cuda', generator=g) < 0.02] = 1.0
+    mask = torch.rand((B, H, W), device='cuda', generator=g) < 0.7
+    x = pred.to(dtype).requires_grad_(True)
+    loss, n = CenterFocalLoss().masked_sum(x, target, mask)
+    loss.backward()
+
+    xr = x.detach().float().requires_grad_(True)
+    p = xr.clamp(1e-4, 1 - 1e-4)
+    pos = target == 1
+    val = torch.where(pos, -(1 - p) ** 2 * torch.log(p), -(1 - target) ** 4 * p ** 2 * torch.log(1 - p))
+    ref = (val * mask).sum()
+    ref.backward()
+    assert int(n) == max(int((pos & mask).sum()), 1)
+    torch.testing.assert_close(loss.detach(), ref.detach(), rtol=2e-5, atol=1e-5)
+    tol = dict(rtol=1e-4, atol=1e-5) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(x.grad.float(), xr.grad, **tol)
+
+
+def test_instance_task_helper_accepts_focal_center_loss():
+    from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper
+    h = InstanceTaskHelper(semantic_n_classes=5, semantic_classes_is_thing=(False, True, True, False, True),
+                           loss_name_instance_center='focal', disable_multiscale_supervision=True)
+    h.initialize(torch.device('cuda'))
+    B, H, W = 2, 16, 24
+    g = torch.Generator(device='cuda').manual_seed(1)
+    center = torch.rand((B, 1, H, W), device='cuda', generator=g, requires_grad=True)
+    offset = torch.zeros((B, 2, H, W), device='cuda', requires_grad=True)
+    tgt = torch.rand((B, H, W), device='cuda', generator=g)
+    tgt[:, 4, 4] = 1.0
+    batch = {'instance_center': tgt, 'instance_center_mask': torch.ones((B, H, W), dtype=torch.bool, device='cuda'),
+             'instance_offset': torch.zeros((B, 2, H, W), device='cuda'),
+             'instance_foreground': torch.ones((B, H, W), dtype=torch.bool, device='cuda')}
+    losses, _ = h.training_step(batch, 0, {'instance_output': (center, offset), 'instance_side_outputs': (None,)})
+    total = losses['instance_center_total_loss']
+    total.backward()
+    assert torch.isfinite(total) and float(total) > 0 and center.grad.abs().sum() > 0
