@@ -1390,18 +1390,14 @@ extern "C" int nmsa_panoptic_paint(const uint8_t* sem_u8, const uint8_t* inst,
     const int P = H * W;
     const bool vec = (P % 8 == 0) &&
                      (((uintptr_t)sem_u8 | (uintptr_t)inst | (uintptr_t)pan | (uintptr_t)pan_sem) % 16 == 0);
-    static const int paint_iters = env_int("NMSA_PAINT_ITERS", 1);      // tuning knob
-    const int iters = paint_iters > 0 ? paint_iters : 1;
+    const int iters = 1;
     dim3 grid((P + 2048 * iters - 1) / (2048 * iters), B), block(256);
-    // variant 2 (whole-line stores) measured 16.8 us vs 27.4 us for variant 1 at B=32 640x480
-    static const int paint_variant = env_int("NMSA_PAINT_VARIANT", 2);
-    if (vec && paint_variant == 2) {
+    // whole-line stores (k_paint2) measured 16.8 us vs 27.4 us for 4 px per lane at B=32 640x480
+    if (vec) {
         const int steps = 4 * iters;                       // 512 px per step and block
         hipLaunchKernelGGL(k_paint2, grid, block, 0, stream, sem_u8, inst, pan_of_inst, is_thing,
                            C, P, steps, max_instances_per_category, void_label, pan, pan_sem);
-    } else if (vec)
-        hipLaunchKernelGGL(k_paint<true>, grid, block, 0, stream, sem_u8, inst, pan_of_inst, is_thing,
-                           C, P, iters, max_instances_per_category, void_label, pan, pan_sem);
+    }
     else
         hipLaunchKernelGGL(k_paint<false>, grid, block, 0, stream, sem_u8, inst, pan_of_inst, is_thing,
                            C, P, iters, max_instances_per_category, void_label, pan, pan_sem);
