@@ -196,6 +196,11 @@ def test_fuzz_metrics_vs_oracle(oracle, seed, B, H, W, n_cat, n_seg):
     got = [pq.iou_per_class, pq.tp_per_class, pq.fn_per_class, pq.fp_per_class]
     for g, w in zip(got, state):
         assert np.array_equal(g.cpu().numpy(), np.asarray(w, dtype=np.float64)), (seed, B, H, W)
+    # the matched (target id, prediction id) pairs the orientation MAE walks (mae.py:129-162)
+    from nicr_mt_scene_analysis_amd.metric.pq import compare_and_accumulate
+    *_, want_matches = oracle.pq_compare_and_accumulate(pred[0], tgt[0], n_cat, 0, 1 << 16, 256 ** 3)
+    *_, got_matches = compare_and_accumulate(dev(pred[0]), dev(tgt[0]), n_cat, 0, 1 << 16, 256 ** 3, 0)
+    assert got_matches == set(want_matches)
     miou = MeanIntersectionOverUnion(n_cat, device='cuda')
     miou.update(dev(pred // 65536), dev(tgt // 65536))
     cm = oracle.confmat_update(pred // 65536, tgt // 65536, n_cat)
