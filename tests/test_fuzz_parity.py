@@ -58,7 +58,8 @@ def cases(draw, medium=False):
     dist_thr = draw(st.sampled_from([None, 0.0, 2.0, 7.5]))
     n_thing = draw(st.integers(0, C))
     dtype = draw(st.sampled_from(['float32', 'bfloat16', 'float16']))
-    return dict(dtype=dtype, B=B, C=C, H=H, W=W, seed=seed, levels=levels, heat_levels=heat_levels, off_q=off_q,
+    specials = draw(st.sampled_from([False, False, False, True]))
+    return dict(specials=specials, dtype=dtype, B=B, C=C, H=H, W=W, seed=seed, levels=levels, heat_levels=heat_levels, off_q=off_q,
                 ksize=ksize, topk=topk, thr=thr, apply_fg=apply_fg, dist_thr=dist_thr, n_thing=n_thing)
 
 
@@ -72,6 +73,12 @@ def make_inputs(p):
     offset = np.stack([off_px[:, 0] / H, off_px[:, 1] / W], 1).astype(np.float32)
     is_thing = np.zeros((C,), bool)
     is_thing[rng.permutation(C)[:p['n_thing']]] = True
+    if p.get('specials'):       # non-finite logits: softmax-then-max semantics (index 0, NaN score)
+        for _ in range(int(rng.integers(1, 6))):
+            logits[rng.integers(B), rng.integers(C), rng.integers(H), rng.integers(W)] = \
+                rng.choice([np.nan, np.inf, -np.inf])
+        if rng.random() < 0.3:  # a column of nothing but -inf
+            logits[rng.integers(B), :, rng.integers(H), rng.integers(W)] = -np.inf
     return logits, heat, offset, is_thing
 
 
@@ -114,7 +121,7 @@ def check_pipeline(oracle, p, max_centers=1024):
     torch.cuda.synchronize()
     r = {k: (v.cpu().numpy() if isinstance(v, torch.Tensor) else v) for k, v in r.items()}
     assert (r['semantic_idx_u8'] == idx).all(), p
-    np.testing.assert_allclose(r['semantic_score'], score, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(r['semantic_score'], score, rtol=1e-5, atol=1e-7, equal_nan=True)
     assert (r['foreground'] == fg).all(), p
     assert (r['n_centers'] == n).all(), p
     for b in range(B):
@@ -527,13 +534,14 @@ def test_fuzz_compute_scores_vs_oracle(oracle, p):
     sem, ins, pns, mean = oracle.panoptic_scores(
         x.float().cpu().numpy(), r['panoptic_semantic'].cpu().numpy(), r['panoptic'].cpu().numpy(),
         ids, tab.cpu().numpy())
-    np.testing.assert_allclose(sc['semantic_score'].cpu().numpy(), sem, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(sc['semantic_score'].cpu().numpy(), sem, rtol=2e-5, atol=1e-7, equal_nan=True)
     assert np.array_equal(sc['instance_score'].cpu().numpy(), ins)
-    np.testing.assert_allclose(sc['panoptic_score'].cpu().numpy(), pns, rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(sc['panoptic_score'].cpu().numpy(), pns, rtol=2e-5, atol=1e-7, equal_nan=True)
     got_mean = sc['mean_semantic_score'].cpu().numpy()
     for b, d in enumerate(ids):
         for ins_id in d.values():
-            assert abs(got_mean[b, ins_id] - mean[b, ins_id]) <= 2e-5 * abs(mean[b, ins_id]) + 1e-9
+            g_, w_ = got_mean[b, ins_id], mean[b, ins_id]
+            assert (np.isnan(g_) and np.isnan(w_)) or abs(g_ - w_) <= 2e-5 * abs(w_) + 1e-9
 
 
 @settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
@@ -604,7 +612,10 @@ def test_fuzz_postprocess_api_vs_ops(p, fy, fx, cropped, compute_scores):
                               top_k=p['topk'], apply_foreground_mask=p['apply_fg'],
                               distance_threshold=p['dist_thr'], want_score=True,
                               want_panoptic_semantic=True, max_centers=post._instance_postprocessing._max_centers)
-    eq = torch.equal
+    def eq(a, b):                       # exact, NaN == NaN (non-finite logits give NaN scores)
+        if a.is_floating_point():
+            return a.shape == b.shape and bool(torch.allclose(a, b, rtol=0, atol=0, equal_nan=True))
+        return torch.equal(a, b)
     assert eq(r['panoptic_segmentation_deeplab'], o['panoptic'])
     assert eq(r['panoptic_segmentation_deeplab_instance_idx'], o['instance'])
     assert eq(r['panoptic_segmentation_deeplab_semantic_idx'], o['panoptic_semantic'])
@@ -616,7 +627,11 @@ def test_fuzz_postprocess_api_vs_ops(p, fy, fx, cropped, compute_scores):
                      ('panoptic_segmentation_deeplab_instance_idx', o['instance']),
                      ('panoptic_segmentation_deeplab_semantic_idx', o['panoptic_semantic'])):
         assert eq(r[key + '_fullres'], ops.resize_nearest(src, size, crop)), key
-    am = ops.semantic_argmax_resized(x, size, crop, want_u8=False, want_i64=True, want_score=True)
+    if size == (y1 - y0, x1 - x0):      # dense_base.py:27-30: same size -> no interpolation at all
+        am = ops.semantic_argmax(x[..., crop[0], crop[1]].contiguous(), want_u8=False, want_i64=True,
+                                 want_score=True)
+    else:
+        am = ops.semantic_argmax_resized(x, size, crop, want_u8=False, want_i64=True, want_score=True)
     assert eq(r['semantic_segmentation_idx_fullres'], am['idx'])
     # identity geometry shares the network-resolution score (another kernel): tolerance, not bits
     torch.testing.assert_close(r['semantic_segmentation_score_fullres'], am['score'], rtol=1e-5,
