@@ -665,6 +665,11 @@ def test_fuzz_standalone_grouping_vs_oracle(oracle, p, p_fg, blocky):
     _, heat, offset, _ = make_inputs(p)
     B, _, H, W = heat.shape
     rng = np.random.default_rng(p['seed'] + 7)
+    if p.get('specials'):               # non-finite offsets: NaN / inf distances pick index 0
+        offset = offset.copy()
+        for _ in range(int(rng.integers(1, 8))):
+            offset[rng.integers(B), rng.integers(2), rng.integers(H), rng.integers(W)] = \
+                rng.choice([np.nan, np.inf, -np.inf, 1e30])
     if blocky:
         cells = rng.random((B, (H + 7) // 8, (W + 15) // 16)) < p_fg
         fg = np.repeat(np.repeat(cells, 8, 1), 16, 2)[:, :H, :W].copy()
