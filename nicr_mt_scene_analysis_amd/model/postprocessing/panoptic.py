@@ -27,6 +27,20 @@ from .instance import InstancePostprocessing
 from .semantic import SemanticPostprocessing
 
 
+class _HostTables:
+    """the per-image tables of one pipeline run on the host, fetched (or awaited) on first use"""
+
+    def __init__(self, fetch) -> None:
+        self._fetch = fetch
+        self._host = None
+
+    def get(self) -> dict:
+        if self._host is None:
+            self._host = self._fetch()
+            self._fetch = None
+        return self._host
+
+
 class PanopticPostprocessing(DensePostprocessingBase):
     def __init__(
         self,
@@ -36,6 +50,7 @@ class PanopticPostprocessing(DensePostprocessingBase):
         semantic_class_has_orientation: Tuple[bool],
         normalized_offset: bool = True,
         compute_scores: bool = False,
+        defer_host_sync: bool = False,
         **kwargs
     ) -> None:
         super().__init__()
@@ -51,6 +66,13 @@ class PanopticPostprocessing(DensePostprocessingBase):
 
         self._normalized_offset = normalized_offset
         self._compute_scores = compute_scores
+        # extension: True = `postprocess` never waits for the GPU.  The small per-image tables
+        # travel with an asynchronous copy and the Python objects built from them (id dicts,
+        # instance meta, orientation dicts) wait for it when first read.  The one thing the
+        # eager mode does with those tables up front — re-running with a larger center table
+        # when more than `_max_centers` tied centers survive — then surfaces as a RuntimeError
+        # at that first read instead.
+        self._defer_host_sync = defer_host_sync
         self._max_instances_per_category = 1 << 16
         self._host_columns = 32          # table columns fetched per image (grows on demand)
         self._device_luts: Dict[torch.device, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -91,8 +113,8 @@ class PanopticPostprocessing(DensePostprocessingBase):
 
         # ---- the hot path: 5 launches; ONE device->host copy (= the one sync) of the small
         #      per-image tables, cut to the number of columns recent batches needed -----------
-        while True:
-            p = ops.panoptic_pipeline(
+        def run():
+            return ops.panoptic_pipeline(
                 s_output, center_heatmap, center_offset, thing_lut,
                 threshold=post._heatmap_threshold,
                 kernel_size=post._heatmap_nms_kernel_size,
@@ -104,16 +126,22 @@ class PanopticPostprocessing(DensePostprocessingBase):
                 void_label=0, max_centers=post._max_centers,
                 want_score=self._compute_scores, want_foreground=True,
                 want_panoptic_semantic=False)
-            host = self._fetch_tables(p, self._host_columns)
-            n_host = host['n_centers']
-            n_max = max(n_host) if n_host else 0
-            if n_max > post._max_centers:              # center table overflow: re-run, larger
-                post._max_centers = 1 << (n_max - 1).bit_length()
-                continue
-            if n_max > host['columns']:                # rare: more instances than columns fetched
-                self._host_columns = 1 << (n_max - 1).bit_length()
+        if self._defer_host_sync:
+            p = run()
+            tables = _HostTables(self._fetch_tables_async(p, post))
+        else:
+            while True:
+                p = run()
                 host = self._fetch_tables(p, self._host_columns)
-            break
+                n_max = max(host['n_centers'], default=0)
+                if n_max > post._max_centers:          # center table overflow: re-run, larger
+                    post._max_centers = 1 << (n_max - 1).bit_length()
+                    continue
+                if n_max > host['columns']:            # rare: more instances than columns fetched
+                    self._host_columns = 1 << (n_max - 1).bit_length()
+                    host = self._fetch_tables(p, self._host_columns)
+                break
+            tables = _HostTables(lambda: host)
 
         # ---- semantic entries (semantic.py:46-80) -------------------------------------
         r = LazyDict(semantic_output=s_output, semantic_side_outputs=s_side_outputs)
@@ -137,16 +165,31 @@ class PanopticPostprocessing(DensePostprocessingBase):
         r['panoptic_foreground_mask'] = p['foreground']
         r['panoptic_segmentation_deeplab'] = panoptic_seg
         # id dicts / instance meta: Python objects built from the host tables when first read
-        r.set_lazy('panoptic_segmentation_deeplab_ids', lambda: self._id_dicts_from_host(host))
+        r.set_lazy('panoptic_segmentation_deeplab_ids',
+                   lambda: self._id_dicts_from_host(tables.get()))
         # panoptic // max_instances (panoptic.py:160): 8 B/px more to write — built when read
         max_inst = self._max_instances_per_category
         r.set_derived('panoptic_segmentation_deeplab_semantic_idx',
                       lambda d: torch.div(d['panoptic_segmentation_deeplab'], max_inst,
                                           rounding_mode='floor'))
         r['panoptic_segmentation_deeplab_instance_idx'] = instance_seg
-        r.set_lazy('panoptic_segmentation_deeplab_instance_meta',
-                   lambda: InstancePostprocessing._meta_from_host(
-                       n_host, host['centers_yx'], host['scores'], host['area']))
+        ori_key = 'orientations_panoptic_segmentation_deeplab_instance'
+
+        def _meta(d):
+            h = tables.get()
+            meta = InstancePostprocessing._meta_from_host(h['n_centers'], h['centers_yx'],
+                                                          h['scores'], h['area'])
+            if with_orientation:                  # panoptic.py:306-314
+                for m, o in zip(meta, d[ori_key]):
+                    for id_ in m:
+                        m[id_]['orientation'] = o.get(id_, float('nan'))
+            return meta
+        r.set_derived('panoptic_segmentation_deeplab_instance_meta', _meta)
+        if with_orientation:                      # panoptic.py:294-304, built when read
+            def _orientation(d):
+                fg = ori_lut[d['panoptic_segmentation_deeplab_semantic_idx']].to(torch.bool)
+                return post._get_instance_orientation(orientation, instance_seg, fg)
+            r.set_derived(ori_key, _orientation)
 
         if self._compute_scores:
             self._add_scores(r, p, r['panoptic_segmentation_deeplab_ids'],
@@ -172,14 +215,6 @@ class PanopticPostprocessing(DensePostprocessingBase):
             else:
                 r[get_fullres_key(k)] = _fullres(r[k])
 
-        # ---- orientation (panoptic.py:294-314) ---------------------------------------------
-        if with_orientation:
-            fg_orientation = ori_lut[r['panoptic_segmentation_deeplab_semantic_idx']].to(torch.bool)
-            ori = post._get_instance_orientation(orientation, instance_seg, fg_orientation)
-            r['orientations_panoptic_segmentation_deeplab_instance'] = ori
-            for b, m in enumerate(r['panoptic_segmentation_deeplab_instance_meta']):
-                for id_ in m:
-                    m[id_]['orientation'] = ori[b].get(id_, float('nan'))
         return r
 
     @staticmethod
@@ -197,7 +232,46 @@ class PanopticPostprocessing(DensePostprocessingBase):
             L.ptr(p['n_centers']), L.ptr(p['n_ids']), L.ptr(p['centers_yx']),
             L.ptr(p['center_scores']), L.ptr(p['area']), L.ptr(p['ids_pan']), L.ptr(p['ids_ins']),
             B, K, kc, L.ptr(flat_dev), L.stream_ptr(flat_dev.device)), 'nmsa_pack_tables')
-        flat = flat_dev.cpu().numpy()
+        return PanopticPostprocessing._split_tables(flat_dev.cpu().numpy(), B, kc, ka, ki)
+
+    def _fetch_tables_async(self, p, post):
+        """`defer_host_sync`: pack + asynchronous copy into pinned host memory now; the returned
+        function waits for the copy (first read of a host-built entry) and parses it"""
+        B, K = p['center_scores'].shape
+        kc = max(1, min(int(self._host_columns), K))
+        ki = min(kc, p['ids_pan'].shape[1])
+        ka = min(kc + 1, p['area'].shape[1])
+        dev = p['center_scores'].device
+        flat_dev = torch.empty((B, 2 + 3 * kc + ka + 2 * ki), dtype=torch.float64, device=dev)
+        L = ops.L
+        L.check(L.lib().nmsa_pack_tables(
+            L.ptr(p['n_centers']), L.ptr(p['n_ids']), L.ptr(p['centers_yx']),
+            L.ptr(p['center_scores']), L.ptr(p['area']), L.ptr(p['ids_pan']), L.ptr(p['ids_ins']),
+            B, K, kc, L.ptr(flat_dev), L.stream_ptr(dev)), 'nmsa_pack_tables')
+        flat_host = torch.empty(flat_dev.shape, dtype=torch.float64, pin_memory=True)
+        flat_host.copy_(flat_dev, non_blocking=True)
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        max_centers = post._max_centers
+
+        def finish():
+            done.synchronize()
+            host = self._split_tables(flat_host.numpy(), B, kc, ka, ki)
+            n_max = max(host['n_centers'], default=0)
+            if n_max > max_centers:
+                post._max_centers = 1 << (n_max - 1).bit_length()
+                raise RuntimeError(
+                    f'{n_max} centers survived the top-k ties but the center table held '
+                    f'{max_centers}: this result is truncated (defer_host_sync=True cannot re-run '
+                    'it); the table has been enlarged for the following calls')
+            if n_max > kc:                        # rare: more instances than columns fetched
+                self._host_columns = 1 << (n_max - 1).bit_length()
+                host = self._fetch_tables(p, self._host_columns)
+            return host
+        return finish
+
+    @staticmethod
+    def _split_tables(flat, B, kc, ka, ki) -> dict:
         edges = np.cumsum([0, 1, 1, 2 * kc, kc, ka, ki, ki])
         cols = [flat[:, a:b] for a, b in zip(edges[:-1], edges[1:])]
         return {'columns': kc,

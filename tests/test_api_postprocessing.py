@@ -290,6 +290,71 @@ def test_panoptic_postprocess_more_instances_than_fetched_columns(oracle):
             assert e['center_yx'] == tuple(int(v) for v in cyx[b][i - 1])
             assert e['area'] == int((inst[b] == i).sum())
 
+
+@pytest.mark.parametrize('name', ['panoptic_small', 'panoptic_edges_thr'])
+def test_deferred_host_sync_equals_eager(name):
+    """`defer_host_sync=True`: postprocess never waits for the GPU (asynchronous table copy, host
+    objects built on first read) — same entries as the eager mode"""
+    g = load(name)
+    kw = jload(g['kwargs']) if 'kwargs' in g else None
+    with_ori = 'in_instance_orientation' in g
+    logits, center, offset = (dev(g['in_semantic_logits']), dev(g['in_instance_center']),
+                              dev(g['in_instance_offset']))
+    B, _, H, W = logits.shape
+    i_out = (center, offset) + ((dev(g['in_instance_orientation']),) if with_ori else ())
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    results = []
+    for defer in (False, True):
+        post = get_postprocessing_class('panoptic')(
+            semantic_postprocessing=get_postprocessing_class('semantic')(),
+            instance_postprocessing=get_postprocessing_class('instance')(**(kw or {})),
+            semantic_classes_is_thing=tuple(bool(x) for x in g['in_semantic_classes_is_thing']),
+            semantic_class_has_orientation=tuple(bool(x) for x in g['in_semantic_classes_is_thing']),
+            defer_host_sync=defer)
+        results.append(post.postprocess(((logits, i_out), (None, None)), make_batch(B, H, W),
+                                        is_training=False))
+    eager, deferred = results
+    assert list(eager.keys()) == list(deferred.keys())
+    assert torch.equal(eager['panoptic_segmentation_deeplab'], deferred['panoptic_segmentation_deeplab'])
+    assert [list(d.items()) for d in eager['panoptic_segmentation_deeplab_ids']] == \
+        [list(d.items()) for d in deferred['panoptic_segmentation_deeplab_ids']]
+    assert eager['panoptic_segmentation_deeplab_instance_meta'] == \
+        deferred['panoptic_segmentation_deeplab_instance_meta'] or with_ori     # NaN != NaN below
+    if with_ori:
+        k = 'orientations_panoptic_segmentation_deeplab_instance'
+        assert eager[k] == deferred[k]
+        for a, b in zip(eager['panoptic_segmentation_deeplab_instance_meta'],
+                        deferred['panoptic_segmentation_deeplab_instance_meta']):
+            assert a.keys() == b.keys()
+            for i in a:
+                assert {kk: v for kk, v in a[i].items() if v == v} == \
+                    {kk: v for kk, v in b[i].items() if v == v}
+
+
+def test_deferred_host_sync_reports_center_table_overflow():
+    """more tied centers than the table holds: the eager mode re-runs with a larger table, the
+    deferred mode cannot — it raises when the host tables are first read and enlarges the table
+    for the following calls"""
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    g = load('grouping_adversarial')
+    heat = dev(g['wrap_300_centers__heat'])
+    B, _, H, W = heat.shape
+    logits = torch.zeros((B, 3, H, W), device='cuda')
+    logits[:, 1] = 1.0
+    offset = torch.zeros((B, 2, H, W), device='cuda')
+    post = get_postprocessing_class('panoptic')(
+        semantic_postprocessing=get_postprocessing_class('semantic')(),
+        instance_postprocessing=get_postprocessing_class('instance')(top_k_instances=254),
+        semantic_classes_is_thing=(False, True, True),
+        semantic_class_has_orientation=(False, True, True), defer_host_sync=True)
+    r = post.postprocess(((logits, (heat, offset)), (None, None)), make_batch(B, H, W), is_training=False)
+    with pytest.raises(RuntimeError):
+        r['panoptic_segmentation_deeplab_ids']
+    assert post._instance_postprocessing._max_centers >= 300
+    r = post.postprocess(((logits, (heat, offset)), (None, None)), make_batch(B, H, W), is_training=False)
+    assert len(r['panoptic_segmentation_deeplab_instance_meta'][0]) == 300
+
+
 def test_compute_scores_vs_golden():
     """f3: score maps + meta of the reference's compute_scores branch (panoptic.py:171-239),
     produced by `nmsa_panoptic_scores`, against the reference's own output."""

@@ -79,6 +79,24 @@ dt = per_call[len(per_call) // 2]
 print(f'  + dicts/meta: median {1e6*dt:7.1f} us/call (min {1e6*per_call[0]:.1f}, max {1e6*per_call[-1]:.1f}; '
       f'{32*480*640/dt/1e6:8.1f} Mpix/s)')
 
+# ---- defer_host_sync=True: no wait inside postprocess(); consecutive calls pipeline -------------
+post_d = get_postprocessing_class('panoptic')(
+    semantic_postprocessing=get_postprocessing_class('semantic')(),
+    instance_postprocessing=get_postprocessing_class('instance')(),
+    semantic_classes_is_thing=is_thing, semantic_class_has_orientation=is_thing,
+    defer_host_sync=True)
+for _ in range(5):
+    post_d.postprocess(data, batch, is_training=False)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(100):
+    rr = post_d.postprocess(data, batch, is_training=False)
+t1 = time.perf_counter()
+torch.cuda.synchronize()
+t2 = time.perf_counter()
+print(f'postprocess(defer_host_sync=True): host {1e6*(t1-t0)/100:7.1f} us/call, '
+      f'pipelined total {1e6*(t2-t0)/100:7.1f} us/call ({32*480*640/((t2-t0)/100)/1e6:8.1f} Mpix/s)')
+
 if '--profile' in sys.argv:
     import cProfile
     import pstats
