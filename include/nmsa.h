@@ -385,6 +385,8 @@ int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int
  *     [n_centers, n_ids, centers_yx[kc][2], scores[kc], area[min(kc+1,256)],
  *      ids_pan[min(kc,256)], ids_ins[min(kc,256)]], kc = min(columns, max_centers), into one
  *     f64 row per image (exact: ids < 2^53, f32 scores) -> ONE device->host copy per batch.
+ *     n_ids / ids_pan / ids_ins may be NULL together (instance-only postprocessing): the row
+ *     then ends after the areas and its second entry is 0.
  * ------------------------------------------------------------------------- */
 int nmsa_pack_tables(const int32_t* n_centers, const int32_t* n_ids,
                      const int32_t* centers_yx, const float* scores,

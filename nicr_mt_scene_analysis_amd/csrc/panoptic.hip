@@ -1491,7 +1491,7 @@ __global__ __launch_bounds__(256) void k_pack_tables(
         int k = i;
         double v;
         if (k == 0) v = n_centers[b];
-        else if (k == 1) v = n_ids[b];
+        else if (k == 1) v = n_ids ? n_ids[b] : 0;
         else if ((k -= 2) < 2 * kc) v = centers_yx[(size_t)b * max_centers * 2 + k];
         else if ((k -= 2 * kc) < kc) v = scores[(size_t)b * max_centers + k];
         else if ((k -= kc) < ka) v = area[(size_t)b * 256 + k];
@@ -1508,12 +1508,12 @@ extern "C" int nmsa_pack_tables(const int32_t* n_centers, const int32_t* n_ids,
                                 int B, int max_centers, int columns, double* out,
                                 nmsa_stream_t stream_)
 {
-    if (!n_centers || !n_ids || !centers_yx || !scores || !area || !ids_pan || !ids_ins || !out)
-        return NMSA_ERR_ARG;
+    if (!n_centers || !centers_yx || !scores || !area || !out) return NMSA_ERR_ARG;
+    const bool with_ids = n_ids && ids_pan && ids_ins;      // NULL id tables: no id columns
     if (B <= 0 || max_centers <= 0 || columns <= 0) return NMSA_ERR_ARG;
     const int kc = columns < max_centers ? columns : max_centers;
     const int ka = kc + 1 < 256 ? kc + 1 : 256;
-    const int ki = kc < 256 ? kc : 256;
+    const int ki = with_ids ? (kc < 256 ? kc : 256) : 0;
     hipLaunchKernelGGL(nmsa::k_pack_tables, dim3(B), dim3(256), 0, (hipStream_t)stream_, n_centers, n_ids,
                        centers_yx, scores, area, ids_pan, ids_ins, max_centers, kc, ka, ki, out);
     return nmsa::check_launch();

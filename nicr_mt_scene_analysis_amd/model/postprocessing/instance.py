@@ -97,14 +97,38 @@ class InstancePostprocessing(DensePostprocessingBase):
                 for i, ((y, x), s_, a) in enumerate(zip(yx[b][:n], sc[b][:n], areas))})
         return meta
 
-    @staticmethod
-    def _meta_from_tables(n_host, centers_yx, scores, area) -> List[Dict[int, dict]]:
-        """ONE small device->host copy of the (center, score, area) tables"""
-        B, K = scores.shape
-        flat = torch.cat([centers_yx.reshape(B, 2 * K).to(torch.float64),
-                          scores.to(torch.float64), area.to(torch.float64)], dim=1).cpu().numpy()
-        return InstancePostprocessing._meta_from_host(
-            n_host, flat[:, :2 * K].reshape(B, K, 2), flat[:, 2 * K:3 * K], flat[:, 3 * K:])
+    def _segment(self, center_heatmap, center_offset, foreground_mask, scale_y, scale_x):
+        """centers + grouping + meta with ONE device->host copy (= one sync) per call: the center
+        list, scores and areas travel packed by `nmsa_pack_tables`; more tied centers than the
+        device table holds -> larger table, run again"""
+        while True:
+            cen = ops.center_nms_topk(
+                center_heatmap, foreground_mask,
+                threshold=self._heatmap_threshold,
+                kernel_size=self._heatmap_nms_kernel_size,
+                top_k=self._top_k_instances,
+                apply_foreground_mask=self._heatmap_apply_foreground_mask,
+                max_centers=self._max_centers)
+            grp = ops.group_offsets(center_offset, foreground_mask, cen['centers_yx'],
+                                    cen['n_centers'], scale_y, scale_x,
+                                    self._offset_distance_threshold)
+            B, K = cen['scores'].shape
+            ka = min(K + 1, 256)
+            flat_dev = torch.empty((B, 2 + 3 * K + ka), dtype=torch.float64, device=cen['scores'].device)
+            L = ops.L
+            L.check(L.lib().nmsa_pack_tables(
+                L.ptr(cen['n_centers']), None, L.ptr(cen['centers_yx']), L.ptr(cen['scores']),
+                L.ptr(grp['area']), None, None, B, K, K, L.ptr(flat_dev),
+                L.stream_ptr(flat_dev.device)), 'nmsa_pack_tables')
+            flat = flat_dev.cpu().numpy()
+            n_host = flat[:, 0].astype(np.int64).tolist()
+            n_max = max(n_host, default=0)
+            if n_max > self._max_centers:
+                self._max_centers = 1 << (n_max - 1).bit_length()
+                continue
+            meta = self._meta_from_host(n_host, flat[:, 2:2 + 2 * K].reshape(B, K, 2),
+                                        flat[:, 2 + 2 * K:2 + 3 * K], flat[:, 2 + 3 * K:])
+            return grp['instance'], meta
 
     def _get_instance_segmentation(
         self,
@@ -114,13 +138,7 @@ class InstancePostprocessing(DensePostprocessingBase):
     ) -> Tuple[torch.Tensor, List[Dict[int, dict]]]:
         """`center_offset` is expected de-normalised (pixels), as in the reference
         where the caller multiplies by (H, W) first (instance.py:361-365)."""
-        cen = self._run_center_kernel(center_heatmap, foreground_mask)
-        grp = ops.group_offsets(center_offset, foreground_mask, cen['centers_yx'],
-                                cen['n_centers'], 1.0, 1.0,
-                                self._offset_distance_threshold)
-        meta = self._meta_from_tables(cen['n_host'], cen['centers_yx'], cen['scores'],
-                                      grp['area'])
-        return grp['instance'], meta
+        return self._segment(center_heatmap, center_offset, foreground_mask, 1.0, 1.0)
 
     # -------------------------------------------------------------- orientation
     def _get_instance_orientation(
@@ -191,12 +209,7 @@ class InstancePostprocessing(DensePostprocessingBase):
         """grouping on the raw (normalised) offsets: the x H / x W of
         instance.py:361-365 happens inside the kernel (same fp32 rounding)."""
         sy, sx = self._denormalized_offset_scales(center_offset)
-        cen = self._run_center_kernel(center_heatmap, foreground_mask)
-        grp = ops.group_offsets(center_offset, foreground_mask, cen['centers_yx'],
-                                cen['n_centers'], sy, sx, self._offset_distance_threshold)
-        meta = self._meta_from_tables(cen['n_host'], cen['centers_yx'], cen['scores'],
-                                      grp['area'])
-        return grp['instance'], meta
+        return self._segment(center_heatmap, center_offset, foreground_mask, sy, sx)
 
     def _postprocess_inference(
         self, data: DecoderRawOutputType, batch: BatchType
