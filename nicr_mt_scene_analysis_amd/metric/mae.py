@@ -93,11 +93,15 @@ class PanopticQualityWithOrientationMAE(_AngularErrorStates, PanopticQuality):
         if not with_mae:
             return
         matches, n_matches = res
-        n_host = n_matches.cpu().tolist()               # the one sync of this update
-        self._check_status()
+        # match counts and the status word in one copy (the sync of this update)
+        head = torch.cat([n_matches, self._status]).cpu().tolist()
+        n_host, status = head[:-1], head[-1]
+        if status:
+            self._check_status()
         if max(n_host, default=0) > self._match_capacity:
             raise ValueError('more matched segments per image than the match table holds')
-        m_host = matches.cpu().tolist()
+        # only the filled rows travel (the table holds 1024 pairs per image)
+        m_host = matches[:, :max(max(n_host, default=0), 1)].cpu().tolist()
         for b, n in enumerate(n_host):
             self.update_mae(orientation_preds[b], panoptic_preds_id_dicts[b],
                             orientation_target[b], panoptic_target_id_dicts[b],
