@@ -73,6 +73,8 @@ class PanopticPostprocessing(DensePostprocessingBase):
         # when more than `_max_centers` tied centers survive — then surfaces as a RuntimeError
         # at that first read instead.
         self._defer_host_sync = defer_host_sync
+        self._pinned_ring: Dict[tuple, list] = {}
+        self._pinned_next: Dict[tuple, int] = {}
         self._max_instances_per_category = 1 << 16
         self._host_columns = 32          # table columns fetched per image (grows on demand)
         self._device_luts: Dict[torch.device, Tuple[torch.Tensor, torch.Tensor]] = {}
@@ -248,15 +250,29 @@ class PanopticPostprocessing(DensePostprocessingBase):
             L.ptr(p['n_centers']), L.ptr(p['n_ids']), L.ptr(p['centers_yx']),
             L.ptr(p['center_scores']), L.ptr(p['area']), L.ptr(p['ids_pan']), L.ptr(p['ids_ins']),
             B, K, kc, L.ptr(flat_dev), L.stream_ptr(dev)), 'nmsa_pack_tables')
-        flat_host = torch.empty(flat_dev.shape, dtype=torch.float64, pin_memory=True)
+        # pinned staging buffers come from a small ring owned by this object: allocating pinned
+        # memory per call is slow, and the caching host allocator cannot recycle a block while the
+        # host runs ahead of the GPU.  A slot that is reused while its previous result has not
+        # been read yet first hands that result a private copy.
+        slot = self._pinned_slot(tuple(flat_dev.shape))
+        flat_host = slot['buffer']
         flat_host.copy_(flat_dev, non_blocking=True)
-        done = torch.cuda.Event()
+        done = slot['event']
         done.record(torch.cuda.current_stream(dev))
         max_centers = post._max_centers
+        state = {'flat': None}
+
+        def detach():                           # called when the slot is about to be reused
+            if state['flat'] is None:
+                done.synchronize()
+                state['flat'] = flat_host.numpy().copy()
+        slot['detach'] = detach
 
         def finish():
-            done.synchronize()
-            host = self._split_tables(flat_host.numpy(), B, kc, ka, ki)
+            detach()
+            if slot.get('detach') is detach:
+                slot['detach'] = None
+            host = self._split_tables(state['flat'], B, kc, ka, ki)
             n_max = max(host['n_centers'], default=0)
             if n_max > max_centers:
                 post._max_centers = 1 << (n_max - 1).bit_length()
@@ -269,6 +285,23 @@ class PanopticPostprocessing(DensePostprocessingBase):
                 host = self._fetch_tables(p, self._host_columns)
             return host
         return finish
+
+    def _pinned_slot(self, shape, ring: int = 8) -> dict:
+        slots = self._pinned_ring.setdefault(shape, [])
+        if len(slots) < ring:
+            slots.append({'buffer': torch.empty(shape, dtype=torch.float64, pin_memory=True),
+                          'event': torch.cuda.Event(), 'detach': None})
+            self._pinned_next[shape] = 0
+            return slots[-1]
+        i = self._pinned_next[shape]
+        self._pinned_next[shape] = (i + 1) % ring
+        slot = slots[i]
+        if slot['detach'] is not None:          # an unread result still points at this buffer
+            slot['detach']()
+            slot['detach'] = None
+        else:
+            slot['event'].synchronize()         # the previous copy into this buffer has landed
+        return slot
 
     @staticmethod
     def _split_tables(flat, B, kc, ka, ki) -> dict:
