@@ -30,6 +30,17 @@ batch = {'rgb_fullres': torch.zeros((B, 3, FH, FW)),
          APPLIED_PREPROCESSING_KEY: [[{'type': 'Resize', 'valid_region_slice_y': slice(0, H),
                                        'valid_region_slice_x': slice(0, W)}]] * B}
 data = ((inp['semantic_logits'], (inp['instance_center'], inp['instance_offset'])), (None, None))
+# ground-truth panoptic map like bench.py's: the prediction shifted by 3 px with a void
+# band — spatially coherent segments, not per-pixel noise
+_post = get_postprocessing_class('panoptic')(
+    semantic_postprocessing=get_postprocessing_class('semantic')(),
+    instance_postprocessing=get_postprocessing_class('instance')(),
+    semantic_classes_is_thing=is_thing, semantic_class_has_orientation=is_thing)
+_pan = _post.postprocess(data, batch, is_training=False)['panoptic_segmentation_deeplab_fullres']
+_tgt = torch.roll(_pan, shifts=(3, 3), dims=(1, 2)).contiguous()
+_tgt[:, :3] = 0
+batch['panoptic_fullres'] = _tgt
+del _post, _pan
 for defer in (False, True):
     post = get_postprocessing_class('panoptic')(
         semantic_postprocessing=get_postprocessing_class('semantic')(),
