@@ -21,6 +21,10 @@ class LazyDict(dict):
     def __init__(self, *args, **kwargs):
         super().__init__(*args, **kwargs)
         self._thunks: Dict[str, Callable[[], Any]] = {}
+        # compact twins of entries for in-package consumers (e.g. the uint8 class map behind the
+        # int64 'semantic_segmentation_idx'): NOT keys of the dict, so the key set stays the
+        # reference's
+        self.aux: Dict[str, Any] = {}
 
     def set_lazy(self, key: str, thunk: Callable[[], Any]) -> None:
         self._thunks[key] = thunk
@@ -74,6 +78,7 @@ class LazyDict(dict):
     def merge(self, other: dict) -> 'LazyDict':
         """update() that keeps the other dict's pending thunks pending."""
         if isinstance(other, LazyDict):
+            self.aux.update(other.aux)
             for k in other.keys():
                 if k in other._thunks:
                     self._thunks[k] = other._thunks[k]

@@ -156,6 +156,7 @@ class PanopticPostprocessing(DensePostprocessingBase):
                        lambda: ops.semantic_argmax(s_output, want_u8=False, want_i64=False,
                                                    want_score=True)['score'])
         r.set_lazy('semantic_segmentation_idx', lambda: sem_u8.long())
+        r.aux['semantic_segmentation_idx'] = sem_u8
         self._semantic_postprocessing._fullres_entries(r, s_output, batch)
 
         # ---- instance entries (instance.py:337-468): GT-foreground variants etc. ------

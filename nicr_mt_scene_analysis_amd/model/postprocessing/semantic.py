@@ -32,12 +32,18 @@ class SemanticPostprocessing(DensePostprocessingBase):
         """idx now; the softmax tensor and the score of the winning class when they are read
         (semantic.py:52-59 / :71-80): the argmax alone needs no exponentials, and validation
         loops only consume the class map."""
-        am = ops.semantic_argmax(logits, want_u8=False, want_i64=True, want_score=False)
+        narrow = logits.shape[1] <= 256
+        am = ops.semantic_argmax(logits, want_u8=narrow, want_i64=not narrow, want_score=False)
         r.set_lazy('semantic_softmax_scores' + suffix, lambda: ops.semantic_softmax(logits))
         r.set_lazy('semantic_segmentation_score' + suffix,
                    lambda: ops.semantic_argmax(logits, want_u8=False, want_i64=False,
                                                want_score=True)['score'])
-        r['semantic_segmentation_idx' + suffix] = am['idx']
+        if narrow:      # uint8 class map for the metrics, the reference's int64 map when read
+            idx_u8 = am['idx_u8']
+            r.aux['semantic_segmentation_idx' + suffix] = idx_u8
+            r.set_lazy('semantic_segmentation_idx' + suffix, lambda: idx_u8.long())
+        else:
+            r['semantic_segmentation_idx' + suffix] = am['idx']
 
     def _fullres_entries(self, r: LazyDict, output: torch.Tensor, batch: BatchType) -> None:
         """semantic.py:61-80.  With a real resize, idx / score come from ONE fused pass over the
@@ -51,11 +57,17 @@ class SemanticPostprocessing(DensePostprocessingBase):
         if tuple(cropped.shape[-2:]) != tuple(shape):
             r.set_lazy(k_out, lambda: ops.resize_bilinear(output, shape, crop))
             r.set_derived(k_sm, lambda d: ops.semantic_softmax(d[k_out]))
-            am = ops.semantic_argmax_resized(output, shape, crop,
-                                             want_u8=False, want_i64=True, want_score=False)
+            narrow = output.shape[1] <= 256
+            am = ops.semantic_argmax_resized(output, shape, crop, want_u8=narrow,
+                                             want_i64=not narrow, want_score=False)
             r.set_lazy(k_score, lambda: ops.semantic_argmax_resized(
                 output, shape, crop, want_u8=False, want_i64=False, want_score=True)['score'])
-            r[k_idx] = am['idx']
+            if narrow:
+                idx_u8 = am['idx_u8']
+                r.aux[k_idx] = idx_u8
+                r.set_lazy(k_idx, lambda: idx_u8.long())
+            else:
+                r[k_idx] = am['idx']
             return
         r[k_out] = cropped
         if cropped.shape == output.shape:
@@ -67,6 +79,8 @@ class SemanticPostprocessing(DensePostprocessingBase):
                     r.set_derived(get_fullres_key(k), (lambda kk: (lambda d: d[kk]))(k))
                 else:
                     r[get_fullres_key(k)] = r[k]
+                if k in r.aux:
+                    r.aux[get_fullres_key(k)] = r.aux[k]
         else:
             self._argmax_entries(r, cropped.contiguous(), suffix='_fullres')
 

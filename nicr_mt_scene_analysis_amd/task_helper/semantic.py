@@ -65,9 +65,10 @@ class SemanticTaskHelper(TaskHelperBase):
         losses = self._compute_losses(batch, batch_idx, predictions_post)
         # mIoU on preds[target != 0] vs target[target != 0] - 1 (semantic.py:124-128): the void
         # masking happens inside the confusion-matrix kernel
-        self._metric_iou.update_masked_void(
-            predictions_post[get_fullres_key(f'{_TASK}_segmentation_idx')],
-            get_fullres(batch, _TASK))
+        key = get_fullres_key(f'{_TASK}_segmentation_idx')
+        aux = getattr(predictions_post, 'aux', {})      # uint8 twin of the int64 class map
+        self._metric_iou.update_masked_void(aux[key] if key in aux else predictions_post[key],
+                                            get_fullres(batch, _TASK))
         return losses, {}
 
     @append_profile_to_logs(f'{_TASK}_epoch_end_time')
