@@ -17,7 +17,8 @@ from ..loss import VonMisesLossBiternion
 from ..metric.mae import MeanAbsoluteAngularError
 from ..metric.mae import PanopticQualityWithOrientationMAE
 from ..types import BatchType
-from ..utils.panoptic_merge import deeplab_merge_batch
+from ..utils.panoptic_merge import _ids_to_dicts
+from ..utils.panoptic_merge import _merge_on_device
 from .base import TaskHelperBase
 from .base import append_detached_losses_to_logs
 from .base import append_profile_to_logs
@@ -131,10 +132,14 @@ class InstanceTaskHelper(TaskHelperBase):
         instance_foreground = instance_batch != 0
         panoptic_targets = get_fullres(batch, 'panoptic').to(dev)
         panoptic_targets_id_dicts = batch['panoptic_ids_to_instance_dict']
-        panoptic_preds, panoptic_id_dicts = deeplab_merge_batch(
-            semantic_batch, instance_result, instance_foreground,
-            self._max_instances_per_category, self._thing_ids, 0,
-            n_classes=self._semantic_n_classes)
+        # same kernels as deeplab_merge_batch; the {panoptic id: instance id} dicts (one
+        # device->host copy) are only built when the orientation matching walks them
+        merged = _merge_on_device(semantic_batch, instance_result, instance_foreground,
+                                  self._max_instances_per_category, self._thing_ids, 0,
+                                  n_classes=self._semantic_n_classes)
+        panoptic_preds = merged['panoptic']
+        panoptic_id_dicts = _ids_to_dicts(merged['ids_pan'], merged['ids_ins'], merged['n_ids']) \
+            if self._with_orientation else None
         self._mae_pq_deeplab.update(panoptic_preds, orientations_results, panoptic_id_dicts,
                                     panoptic_targets, orientations_targets,
                                     panoptic_targets_id_dicts)

@@ -34,6 +34,44 @@ def _ids_to_dicts(ids_pan: torch.Tensor, ids_ins: torch.Tensor, n_ids: torch.Ten
     return out
 
 
+_THING_LUTS: Dict[tuple, torch.Tensor] = {}
+
+
+def _merge_on_device(sem, ins, fg, max_instances_per_category, thing_ids, void_label,
+                     n_classes=None) -> Dict[str, torch.Tensor]:
+    """the kernels behind `deeplab_merge_batch` on device tensors, no host objects: the result
+    dict holds 'panoptic' and the id tables (`_ids_to_dicts` turns those into the reference's
+    dicts).  In-package callers that do not need the dicts stop here — no device->host copy."""
+    dev = sem.device
+    if n_classes is None:
+        n_classes = int(sem.max()) + 1
+    n_classes = max(int(n_classes), 1)
+    thing_list = tuple(int(t) for t in thing_ids)
+    key = (dev, n_classes, thing_list)
+    lut = _THING_LUTS.get(key)
+    if lut is None:                             # uploaded once per (device, classes, thing ids)
+        lut = torch.zeros((n_classes,), dtype=torch.uint8)
+        for t in thing_list:
+            if 0 <= t < n_classes:
+                lut[t] = 1
+        lut = _THING_LUTS[key] = lut.to(dev)
+    if ins.dtype in (torch.uint8, torch.bool):
+        # prediction path: uint8 ids (reference instance.py:236), direct-indexed kernels
+        return ops.panoptic_merge(sem, ins, fg, lut, int(max_instances_per_category),
+                                  int(void_label))
+    # ground-truth maps: ids 0..65535, ranked per image on the device
+    for max_segments in (1024, 4096):
+        r = ops.panoptic_merge_wide(sem, ins, fg, lut, int(max_instances_per_category),
+                                    int(void_label), max_segments=max_segments)
+        st = int(r['status'].item())
+        if st & 32:
+            raise NotImplementedError('instance ids outside [0, 65535] are not supported '
+                                      '(dataset instance maps are uint16)')
+        if not (st & 1):
+            return r
+    raise NotImplementedError('more than 4096 distinct instance ids in one image')
+
+
 def deeplab_merge_batch(
     semantic_batch: torch.Tensor,
     instance_batch: torch.Tensor,
@@ -61,32 +99,7 @@ def deeplab_merge_batch(
     if sem.ndim != 3 or ins.shape != sem.shape or fg.shape != sem.shape:
         raise ValueError('expected three tensors of shape (B, H, W)')
 
-    if n_classes is None:
-        n_classes = int(sem.max()) + 1
-    thing_list = [int(t) for t in thing_ids]
-    n_classes = max(n_classes, 1)
-    lut = torch.zeros((n_classes,), dtype=torch.uint8)
-    for t in thing_list:
-        if 0 <= t < n_classes:
-            lut[t] = 1
-    lut = lut.to(dev)
-    if ins.dtype in (torch.uint8, torch.bool):
-        # prediction path: uint8 ids (reference instance.py:236), direct-indexed kernels
-        r = ops.panoptic_merge(sem, ins, fg, lut, int(max_instances_per_category),
-                               int(void_label))
-    else:
-        # ground-truth maps: ids 0..65535, ranked per image on the device
-        for max_segments in (1024, 4096):
-            r = ops.panoptic_merge_wide(sem, ins, fg, lut, int(max_instances_per_category),
-                                        int(void_label), max_segments=max_segments)
-            st = int(r['status'].item())
-            if st & 32:
-                raise NotImplementedError('instance ids outside [0, 65535] are not supported '
-                                          '(dataset instance maps are uint16)')
-            if not (st & 1):
-                break
-        else:
-            raise NotImplementedError('more than 4096 distinct instance ids in one image')
+    r = _merge_on_device(sem, ins, fg, max_instances_per_category, thing_ids, void_label, n_classes)
     dicts = _ids_to_dicts(r['ids_pan'], r['ids_ins'], r['n_ids'])
     pan = r['panoptic']
     if in_device.type != 'cuda':
