@@ -34,6 +34,106 @@ def test_lazy_dict_semantics():
     assert {**d}['c'] == 3                               # plain-dict unpacking works
 
 
+# keys of the inference output dict the reference checks for a panoptic + orientation model
+# (reference tests/test_decoders+postprocessing.py:208-258)
+REFERENCE_OUTPUT_KEYS = (
+    'semantic_output', 'semantic_side_outputs', 'semantic_softmax_scores',
+    'semantic_segmentation_score', 'semantic_segmentation_idx', 'semantic_output_fullres',
+    'semantic_softmax_scores_fullres', 'semantic_segmentation_score_fullres',
+    'semantic_segmentation_idx_fullres', 'instance_output', 'instance_side_outputs',
+    'instance_centers', 'instance_offsets', 'instance_segmentation_gt_foreground',
+    'instance_segmentation_gt_meta', 'instance_segmentation_gt_foreground_fullres',
+    'panoptic_foreground_mask', 'panoptic_segmentation_deeplab',
+    'panoptic_segmentation_deeplab_fullres', 'panoptic_segmentation_deeplab_ids',
+    'panoptic_segmentation_deeplab_semantic_idx',
+    'panoptic_segmentation_deeplab_semantic_idx_fullres',
+    'panoptic_segmentation_deeplab_semantic_score',
+    'panoptic_segmentation_deeplab_semantic_score_fullres',
+    'panoptic_segmentation_deeplab_instance_idx',
+    'panoptic_segmentation_deeplab_instance_idx_fullres',
+    'panoptic_segmentation_deeplab_instance_meta',
+    'panoptic_segmentation_deeplab_instance_score',
+    'panoptic_segmentation_deeplab_instance_score_fullres',
+    'panoptic_segmentation_deeplab_panoptic_score',
+    'panoptic_segmentation_deeplab_panoptic_score_fullres',
+    'orientations_panoptic_segmentation_deeplab_instance',
+    'orientations_gt_instance_gt_orientation_foreground',
+    'orientations_instance_segmentation_gt_orientation_foreground')
+
+
+def _all_pending_result():
+    """a LazyDict with EVERY reference key pending (set_lazy / set_derived alternating)"""
+    from nicr_mt_scene_analysis_amd.model.postprocessing._lazy import LazyDict
+    r = LazyDict()
+    for i, k in enumerate(REFERENCE_OUTPUT_KEYS):
+        if i % 2:
+            r.set_derived(k, (lambda kk: (lambda d: ('value', kk)))(k))
+        else:
+            r.set_lazy(k, (lambda kk: (lambda: ('value', kk)))(k))
+    return r
+
+
+def _assert_plain_and_complete(d, kind=dict):
+    assert type(d) is kind, type(d)
+    assert list(d.keys()) == list(REFERENCE_OUTPUT_KEYS)
+    for k in REFERENCE_OUTPUT_KEYS:
+        assert d[k] == ('value', k), (k, d[k])
+
+
+def test_lazy_dict_is_a_drop_in_dict_under_merge_idioms():
+    """the reference merges the per-task result dicts with {**a, **b}
+    (model/postprocessing/panoptic.py:75,94); no idiom may see a placeholder"""
+    import copy
+    import pickle
+    from nicr_mt_scene_analysis_amd.model.postprocessing._lazy import LazyDict
+
+    _assert_plain_and_complete({**_all_pending_result()})
+    _assert_plain_and_complete(dict(_all_pending_result()))
+    x = {}
+    x.update(_all_pending_result())
+    _assert_plain_and_complete(x)
+    _assert_plain_and_complete({**{}, **_all_pending_result()})
+    _assert_plain_and_complete(dict(_all_pending_result(), **{}))
+    _assert_plain_and_complete({} | _all_pending_result(), LazyDict)
+    _assert_plain_and_complete(_all_pending_result() | {}, LazyDict)
+    _assert_plain_and_complete((lambda **kw: kw)(**_all_pending_result()))
+    _assert_plain_and_complete(pickle.loads(pickle.dumps(_all_pending_result())))
+    _assert_plain_and_complete(copy.deepcopy(_all_pending_result()))
+    _assert_plain_and_complete({k: v for k, v in _all_pending_result().items()})
+    assert list(_all_pending_result().values()) == [('value', k) for k in REFERENCE_OUTPUT_KEYS]
+    assert sorted(_all_pending_result()) == sorted(REFERENCE_OUTPUT_KEYS)       # iteration
+    r = _all_pending_result()
+    assert r == {k: ('value', k) for k in REFERENCE_OUTPUT_KEYS}
+    assert not (_all_pending_result() != {k: ('value', k) for k in REFERENCE_OUTPUT_KEYS})
+    assert 'None' not in repr(_all_pending_result())
+
+    # shallow copies stay lazy and independent
+    r = _all_pending_result()
+    for c in (copy.copy(r), r.copy()):
+        assert isinstance(c, LazyDict) and c.is_pending('semantic_softmax_scores')
+        _assert_plain_and_complete(dict(c))
+    assert r.is_pending('semantic_softmax_scores')
+
+    # writes win over pending thunks
+    k0, k1, k2, k3 = REFERENCE_OUTPUT_KEYS[:4]
+    r = _all_pending_result()
+    r.update({k0: 99})
+    r.update([(k1, 98)], **{k2: 97})
+    r |= {k3: 96}
+    assert (r[k0], r[k1], r[k2], r[k3]) == (99, 98, 97, 96)
+    assert dict(r)[k0] == 99 and not r.is_pending(k0)
+    r = _all_pending_result()
+    assert r.setdefault(k0, 'dflt') == ('value', k0) and r.setdefault('new', 5) == 5
+    del r[k1]
+    assert k1 not in r and not r.is_pending(k1) and k1 not in dict(r)
+    r.set_lazy('tail', lambda: 'T')
+    assert r.popitem() == ('tail', 'T')
+    r.clear()
+    assert len(r) == 0 and dict(r) == {}
+    with pytest.raises(TypeError):
+        hash(_all_pending_result())
+
+
 def test_factory_and_constructor_errors():
     from nicr_mt_scene_analysis_amd.model.postprocessing import (
         InstancePostprocessing, get_postprocessing_class)
