@@ -6,6 +6,10 @@ bench.py — Mpix/s of the panoptic hot path on synthetic 640x480 maps.
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N \
         --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
 
+Both launch shapes work for every N: without RANK in the environment `--gpus N>1`
+starts N fresh child ranks itself (torch.distributed.run as a child process, before
+anything in this process touches the GPU) and exits with their return code.
+
 A "step" is one pass of the hot path over one batch that is already resident
 in HBM: center-NMS/top-k -> fused semantic-argmax + offset grouping + class
 votes -> per-instance class/rank -> panoptic paint (BASELINE.json configs[1]:
@@ -15,11 +19,15 @@ independent units, so ranks shard the batch (weak scaling: 32 images per GPU)
 with no data-path collective; only the few-KB metric accumulators are
 all-reduced (RCCL) inside the timed region.
 
-Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").
+Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").  At N=1 the line also
+carries `secondary`: the other BASELINE.json configurations (bf16 logits, configs[2] losses,
+configs[4] shapes + dense cosine loss), measured after the timed region with HIP events.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -43,7 +51,11 @@ def parse_args():
     ap.add_argument('--height', type=int, default=480)
     ap.add_argument('--width', type=int, default=640)
     ap.add_argument('--centers', type=int, default=24)
+    ap.add_argument('--dtype', choices=('f32', 'bf16', 'f16'), default='f32',
+                    help='dtype of the semantic logits (the arithmetic is f32 throughout)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-secondary', action='store_true',
+                    help='skip the other BASELINE configs measured after the timed region (N=1)')
     ap.add_argument('--no-metrics', action='store_true')
     ap.add_argument('--no-side-stream', action='store_true',
                     help='enqueue the metric kernels on the main stream (no overlap)')
@@ -55,6 +67,23 @@ def parse_args():
     ap.add_argument('--streams', type=int, default=2,
                     help='batches in flight: consecutive steps alternate over this many HIP streams')
     return ap.parse_args()
+
+
+def host_cores():
+    """nproc of the node, the cores this process may run on, its cgroup CPU quota, and the
+    thread count the CPU baseline uses: every core the process is actually given"""
+    nproc = os.cpu_count() or 1
+    affinity = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else nproc
+    quota = None
+    try:
+        with open('/sys/fs/cgroup/cpu.max') as f:
+            q, period = f.read().split()
+            if q != 'max':
+                quota = float(q) / float(period)
+    except (OSError, ValueError):
+        pass
+    usable = affinity if quota is None else max(1, min(affinity, int(round(quota))))
+    return {'nproc': nproc, 'affinity': affinity, 'cgroup_quota': quota, 'usable': usable}
 
 
 def cpu_baseline(inp_dev, n_images, C, H, W, metrics=None, reps=3):
@@ -93,8 +122,8 @@ def cpu_baseline(inp_dev, n_images, C, H, W, metrics=None, reps=3):
     # the same chain, one image per task, on the host cores this process may use (the C
     # functions are re-entrant and ctypes releases the GIL): the stronger CPU baseline
     from concurrent.futures import ThreadPoolExecutor
-    threads = max(1, min(16, len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity')
-                         else (os.cpu_count() or 1)))
+    cores = host_cores()
+    threads = cores['usable']
 
     def one_image(b):
         i_, _ = orc.semantic_argmax(logits[b:b + 1])
@@ -112,21 +141,211 @@ def cpu_baseline(inp_dev, n_images, C, H, W, metrics=None, reps=3):
     dt_mt = time.perf_counter() - t0
     assert all(np.array_equal(pans[b], pan[b]) for b in range(n))
     return {'value': round(n_total * H * W / dt_mt / 1e6, 3), 'unit': 'Mpix/s', 'cores': threads,
+            'nproc': cores['nproc'], 'affinity': cores['affinity'],
+            'cgroup_cpu_quota': cores['cgroup_quota'],
             'kind': 'port', 'value_1core': round(one_core, 3),
             'sample': f'{max(1, reps)} passes over {n} images {W}x{H}x{C} of the bench batch, C oracle '
                       f'({what}): {dt:.2f} s on 1 core, {dt_mt:.2f} s with {threads} threads '
                       '(one image per task)'}, (idx, inst, pan)
 
 
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) as a
+    CHILD process tree — this process has not touched the GPU and never execs — forward their
+    output (rank 0 prints the JSON line) and return their exit code."""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def hip_timed(fn, reps, warm):
+    """mean milliseconds per call, HIP events on the stream the kernels are launched on
+    (the ops enqueue on torch's current stream)"""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def _leg(ms, n_px, bytes_px, **extra):
+    gbs = n_px * bytes_px / (ms * 1e-3) / 1e9
+    d = {'ms': round(ms, 4), 'Mpix_s': round(n_px / (ms * 1e-3) / 1e6, 1),
+         'algorithmic_bytes_per_px': bytes_px, 'algorithmic_bytes': n_px * bytes_px,
+         'achieved_GBs': round(gbs, 1), 'frac': round(gbs / HBM_PEAK_GBS, 4)}
+    d.update(extra)
+    return d
+
+
+def secondary_pipeline(ops, syn, dev, B, C, H, W, K, dtype, with_metrics=True):
+    """the panoptic step on another configuration: whole step (HIP events around the five
+    launches + metric updates) and the fused kernel alone (events around that launch)"""
+    from tools import bench_support
+    inp = syn.make_panoptic_inputs_torch(B, C, H, W, n_centers=K, seed=4321, device=dev,
+                                         logits_dtype=dtype)
+    a = (inp['semantic_logits'], inp['instance_center'], inp['instance_offset'],
+         inp['semantic_classes_is_thing'])
+    es = a[0].element_size()
+    m = bench_support.MetricAccumulators(C + 1, dev, inp, 0, side_stream=False) \
+        if with_metrics else None
+    ev = []
+
+    def step():
+        r = ops.panoptic_pipeline(*a, fused_kernel_events=ev)
+        if m is not None:
+            m.update_and_reduce(r['panoptic'])
+    ms = hip_timed(step, reps=20, warm=5)
+    fused_ms = float(np.mean([x.elapsed_time(y) for x, y in ev[5:]]))
+    n_px = B * H * W
+    out = {'shape': f'B={B} C={C} {W}x{H}', 'logits_dtype': str(a[0].dtype).replace('torch.', ''),
+           'step_serial': _leg(ms, n_px, es * C + 21 + (17 if with_metrics else 0),
+                               what='one stream, no batch overlap; pipeline'
+                                    + (' + mIoU/PQ updates' if with_metrics else '')),
+           'k_panoptic_fused': _leg(fused_ms, n_px, es * C + 9)}
+    del inp, a, m
+    torch.cuda.empty_cache()
+    return out
+
+
+def secondary_losses(dev, B=64, C=40, H=480, W=640):
+    """BASELINE configs[2]: CE + center (MSE) + offset (L1) + von Mises orientation on bf16
+    predictions, f32 targets, u8 labels / masks (114 B/px forward, 204 B/px with
+    the backward's gradient writes)"""
+    from nicr_mt_scene_analysis_amd.loss import (CrossEntropyLossSemantic, L1Loss, MSELoss,
+                                                 VonMisesLossBiternion)
+    g = torch.Generator(device=dev).manual_seed(7)
+    dt = torch.bfloat16
+
+    def rnd(*shape):
+        return torch.randn(shape, device=dev, generator=g)
+    logits = (rnd(B, C, H, W) * 3).to(dt).requires_grad_(True)
+    labels = torch.randint(0, C + 1, (B, H, W), device=dev, generator=g).to(torch.uint8)
+    w = torch.rand(C, device=dev, generator=g) + 0.5
+    center = torch.rand((B, H, W), device=dev, generator=g).to(dt).requires_grad_(True)
+    center_t = torch.rand((B, H, W), device=dev, generator=g)
+    offset = rnd(B, 2, H, W).to(dt).requires_grad_(True)
+    offset_t = rnd(B, 2, H, W)
+    ori = rnd(B, 2, H, W).to(dt).requires_grad_(True)
+    ori_t = torch.nn.functional.normalize(rnd(B, 2, H, W), dim=1)
+    m1 = torch.rand((B, H, W), device=dev, generator=g) < 0.7
+    m2 = torch.rand((B, H, W), device=dev, generator=g) < 0.5
+    m3 = torch.rand((B, H, W), device=dev, generator=g) < 0.3
+    ce = CrossEntropyLossSemantic(weights=w)
+    mse, l1, vm = MSELoss(), L1Loss(), VonMisesLossBiternion()
+
+    def fwd():
+        (lc, n), = ce([logits], [labels])
+        a = mse.masked_sum(center, center_t, m1)
+        b = l1.masked_sum(offset, offset_t, m2)
+        c = vm.masked_sum(ori, ori_t, m3)
+        return lc / n + a[0] / a[1] + b[0] / b[1] + c[0] / c[1]
+
+    def fwd_bwd():
+        for t in (logits, center, offset, ori):
+            t.grad = None
+        fwd().backward()
+
+    def ce_fwd_bwd():
+        logits.grad = None
+        (lc, n), = ce([logits], [labels])
+        (lc / n).backward()
+    n_px = B * H * W
+    # bytes this implementation moves per px in forward + backward: forward inputs (2C+34) +
+    # log-sum-exp write 4; CE backward logits 2C + label 1 + lse 4 + gradient 2C; element-wise
+    # backward pred + target + mask + gradient (9 + 17 + 17)
+    moved = (2 * C + 34) + 4 + (2 * C + 1 + 4 + 2 * C) + 9 + 17 + 17
+    with torch.no_grad():
+        ms_f = hip_timed(fwd, reps=10, warm=3)
+    ms_fb = hip_timed(fwd_bwd, reps=10, warm=3)
+    ms_ce = hip_timed(ce_fwd_bwd, reps=10, warm=2)
+    out = {'shape': f'B={B} C={C} {W}x{H}', 'pred_dtype': 'bfloat16',
+           'four_losses_fwd': _leg(ms_f, n_px, 2 * C + 34),
+           'four_losses_fwd_bwd': _leg(
+               ms_fb, n_px, 2 * C + 34 + 2 * C + 2 + 4 + 4,
+               moved_bytes_per_px=moved,
+               frac_of_moved_bytes=round(n_px * moved / (ms_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+               note='algorithmic (SURVEY 8d): inputs once + gradient writes = 204 B/px at C=40; '
+                    'the backward kernels re-read their inputs (CE: logits + saved log-sum-exp), '
+                    'so moved_bytes_per_px is what crosses HBM'),
+           'ce_fwd_bwd': _leg(ms_ce, n_px, (2 * C + 1) + 2 * C,
+                              note='algorithmic: logits + labels read once, gradient written')}
+    return out
+
+
+def secondary_cos_emb(dev, B=8, D=512, H=768, W=1024, L=64):
+    """BASELINE configs[4]: dense visual-embedding cosine loss at the DVEFormer shape
+    (2D+4 B/px forward, +2D gradient write backward, bf16 predictions)"""
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss
+    g = torch.Generator(device=dev).manual_seed(11)
+    pred = torch.empty((B, D, H, W), device=dev, dtype=torch.bfloat16)
+    for b in range(B):                                  # per image: bounds the f32 temporary
+        pred[b] = torch.randn((D, H, W), device=dev, generator=g).to(torch.bfloat16)
+    pred.requires_grad_(True)
+    idx = torch.randint(0, L + 1, (B, H // 16, W // 16), device=dev, generator=g,
+                        dtype=torch.int32)
+    idx = idx.repeat_interleave(16, 1).repeat_interleave(16, 2).contiguous()    # segments
+    lut = torch.nn.functional.normalize(torch.randn((B, L, D), device=dev, generator=g), dim=-1)
+    cos = CosineEmbeddingLoss()
+
+    def fwd():
+        return cos.lut_sum(pred, idx, lut)
+
+    def fwd_bwd():
+        pred.grad = None
+        l, n = cos.lut_sum(pred, idx, lut)
+        (l / n).backward()
+    n_px = B * H * W
+    with torch.no_grad():
+        ms_f = hip_timed(fwd, reps=5, warm=2)
+    ms_fb = hip_timed(fwd_bwd, reps=5, warm=2)
+    return {'shape': f'B={B} D={D} {W}x{H} L={L}', 'pred_dtype': 'bfloat16',
+            'fwd': _leg(ms_f, n_px, 2 * D + 4),
+            'fwd_bwd': _leg(ms_fb, n_px, 2 * D + 4 + 2 * D,
+                            moved_bytes_per_px=3 * 2 * D + 8,
+                            note='the backward re-reads the prediction: 3x2D+8 B/px moved')}
+
+
+def secondary(ops, syn, dev):
+    out = {}
+    legs = (
+        ('cfg2_bf16', lambda: secondary_pipeline(ops, syn, dev, 32, 40, 480, 640, 24,
+                                                 torch.bfloat16)),
+        ('cfg3_losses', lambda: secondary_losses(dev)),
+        ('cfg5_bf16', lambda: secondary_pipeline(ops, syn, dev, 8, 150, 768, 1024, 48,
+                                                 torch.bfloat16)),
+        ('cfg5_cos_emb_D512', lambda: secondary_cos_emb(dev, D=512)),
+        ('cfg5_cos_emb_D768', lambda: secondary_cos_emb(dev, D=768)),
+    )
+    for name, fn in legs:
+        try:
+            out[name] = fn()
+        except Exception as e:                      # a failed leg must not lose the headline
+            out[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+        torch.cuda.empty_cache()
+    return out
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and 'RANK' not in os.environ:
+        sys.exit(launch_ranks(args))
+    launched = 'RANK' in os.environ
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if args.gpus != world and world > 1:
+    if args.gpus != world:
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}')
-    if args.gpus > 1 and world == 1:
-        raise SystemExit('launch N>1 with torch.distributed.run (one rank per GPU)')
 
     from nicr_mt_scene_analysis_amd import ops
     from nicr_mt_scene_analysis_amd.testing import synthetic as syn
@@ -136,7 +355,9 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device('cuda', dev_index)
     dist = None
-    if world > 1:
+    backend = None
+    rccl_ranks = None
+    if launched:                                 # under a launcher also at N=1 (same code path)
         import torch.distributed as dist_
         dist = dist_
         # 'nccl' == RCCL on ROCm.  NMSA_BENCH_BACKEND=gloo is only for rehearsing the
@@ -144,25 +365,28 @@ def main():
         backend = os.environ.get('NMSA_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
             dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+            one = torch.ones((1,), dtype=torch.float64, device=dev)
+            dist.all_reduce(one, op=dist.ReduceOp.SUM)         # an actual RCCL all-reduce
+            rccl_ranks = int(one.item())
+            if rccl_ranks != world:
+                raise SystemExit(f'RCCL all-reduce saw {rccl_ranks} ranks, expected {world}')
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
 
     B, C, H, W = args.batch_per_gpu, args.classes, args.height, args.width
+    logits_dtype = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[args.dtype]
     inp = syn.make_panoptic_inputs_torch(B, C, H, W, n_centers=args.centers,
-                                         seed=1234 + rank, device=dev)
+                                         seed=1234 + rank, device=dev, logits_dtype=logits_dtype)
     logits, center, offset = inp['semantic_logits'], inp['instance_center'], inp['instance_offset']
     is_thing = inp['semantic_classes_is_thing']
     torch.cuda.synchronize()
 
     metrics = None
     if not args.no_metrics:
-        try:
-            from nicr_mt_scene_analysis_amd.metric import bench_support
-            metrics = bench_support.MetricAccumulators(C + 1, dev, inp, rank, world_size=world,
-                                                       side_stream=not args.no_side_stream,
-                                                       sync_every_step=args.metric_sync == 'step')
-        except ImportError:
-            metrics = None
+        from tools import bench_support
+        metrics = bench_support.MetricAccumulators(C + 1, dev, inp, rank, world_size=world,
+                                                   side_stream=not args.no_side_stream,
+                                                   sync_every_step=args.metric_sync == 'step')
 
     events = []
     # consecutive batches are independent: they alternate over `--streams` HIP streams so that
@@ -251,7 +475,8 @@ def main():
         'value': round(value, 1), 'unit': 'Mpix/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
+        'dtype': {torch.float32: 'f32', torch.bfloat16: 'bf16', torch.float16: 'f16'}[logits.dtype],
+        'data': 'synthetic',
         'config': {'workload': 'configs[1]: center-NMS + offset grouping + panoptic merge'
                                + (' + mIoU/PQ accumulators (configs[3])' if metrics else ''),
                    'batch_per_gpu': B, 'global_batch': B * world, 'classes': C,
@@ -259,10 +484,15 @@ def main():
                    'batches_in_flight': len(streams),
                    'parallelism': f'dp{world} (images sharded, accumulators all-reduced '
                                   f'{"every step" if args.metric_sync == "step" else "once per run, timed"})'},
+        'collective': {'backend': ('rccl' if backend == 'nccl' else backend), 'rccl_ranks': rccl_ranks,
+                       'payload_bytes': int(metrics._packed.numel() * 8)
+                       if metrics is not None and metrics._packed is not None else 0}
+        if dist is not None else None,
         'roofline': roofline,
     }
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # contract: rank 0 at N=1 only
+    solo = rank == 0 and world == 1
+    if solo and not args.no_cpu_baseline:                          # contract: rank 0 at N=1 only
         cb, (idx, inst, pan) = cpu_baseline(inp, args.cpu_sample_images, C, H, W, metrics)
         n = idx.shape[0]
         ok = bool((r['semantic_idx_u8'][:n].cpu().numpy() == idx).all()
@@ -272,6 +502,10 @@ def main():
         out['cpu_baseline'] = cb
     elif rank == 0:
         out['cpu_baseline'] = None
+    if solo and not args.no_secondary:
+        del inp, logits, center, offset, r, metrics
+        torch.cuda.empty_cache()
+        out['secondary'] = secondary(ops, syn, dev)
 
     if rank == 0:
         print(json.dumps(out), flush=True)

@@ -604,34 +604,46 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_cos_emb(
 }
 
 // ---- LDS-resident LUT variant (the fast path) ---------------------------------------
-// The per-image LUT [L, D] (<= ~150 KB as fp32) is staged once per workgroup in LDS with a
-// row stride of D+1 words: lanes that need different rows at the same d then hit different
-// banks, lanes that need the same row are a broadcast.  Each lane owns PXT consecutive
-// pixels (16-B plane loads, U planes in flight); the only global traffic is the prediction.
+// The per-image LUT [L, D] is staged in LDS with a row stride of DC+1 words: lanes that need
+// different rows at the same d then hit different banks, lanes that need the same row are a
+// broadcast.  Each lane owns PXT consecutive pixels (16-B plane loads, U planes in flight);
+// the only HBM traffic is the prediction.  A LUT that does not fit (D=768, L=64: 197 KB as
+// fp32, the CU has 160 KB) is staged in `nchunks` column chunks of DC embedding dimensions
+// per pixel tile: the dot products accumulate over the chunks in registers, the restaged
+// bytes come from L2 (L*D*4 per tile of COS_THREADS*PXT px — 1.5 % of the tile's prediction
+// bytes at D=768 bf16).  One chunk (everything up to D=512, L=64) is staged once per
+// workgroup.  The LUT stays fp32: rounding it to 16 bits would cost ~1e-4 relative on the
+// loss, beyond the 1e-5 parity bar.
 constexpr int COS_THREADS = 1024;
 
 template <int DTYPE, int PXT, bool BWD>
 __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
     const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
-    int D, int P, int L, int px_per_block, int vec,
+    int D, int P, int L, int DC, int px_per_block, int vec,
     const float* __restrict__ gscale, void* __restrict__ grad,
     LossPartial* __restrict__ partials, int* __restrict__ status)
 {
-    extern __shared__ float s_lut[];                   // [L][D + 1], then yy[L]
+    extern __shared__ float s_lut[];                   // [L][DC + 1], then yy[L]
     const int b = blockIdx.y;
-    const int ld = D + 1;
+    const int ld = DC + 1;
+    const int nchunks = (D + DC - 1) / DC;
     float* s_yy = s_lut + (size_t)L * ld;
     const float* lut_b = lut + (size_t)b * L * D;
-    for (int i = threadIdx.x; i < L * D; i += COS_THREADS) {
-        const int r = i / D, d = i - r * D;
-        s_lut[r * ld + d] = lut_b[i];
-    }
-    __syncthreads();
-    for (int r = threadIdx.x; r < L; r += COS_THREADS) {
+    // |y|^2 per LUT row straight from global memory: one wave per row, lanes stride over D
+    for (int r = threadIdx.x >> 6; r < L; r += COS_THREADS / 64) {
         float yy = 0.f;
-        for (int d = 0; d < D; ++d) yy = fmaf(s_lut[r * ld + d], s_lut[r * ld + d], yy);
-        s_yy[r] = yy;
+        for (int d = lane_id(); d < D; d += 64) { const float v = lut_b[(size_t)r * D + d]; yy = fmaf(v, v, yy); }
+        yy = wave_reduce_sum(yy);
+        if (lane_id() == 0) s_yy[r] = yy;
     }
+    auto stage = [&](int c) {
+        const int d0 = c * DC, n = min(DC, D - d0);
+        for (int i = threadIdx.x; i < L * n; i += COS_THREADS) {
+            const int r = i / n, d = i - r * n;
+            s_lut[r * ld + d] = lut_b[(size_t)r * D + d0 + d];
+        }
+    };
+    if (nchunks == 1) stage(0);
     __syncthreads();
 
     const float EPS = 1e-12f;
@@ -642,41 +654,50 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
     constexpr int U = (PXT == 4) ? 8 : 4;
     const int start = blockIdx.x * px_per_block;
     const int end = min(start + px_per_block, P);
-    for (int p0 = start + threadIdx.x * PXT; p0 < end; p0 += COS_THREADS * PXT) {
-        const int nvalid = min(PXT, end - p0);
-        int row[PXT];
+    // the trip count is uniform over the workgroup (barriers inside when the LUT is chunked)
+    for (int t0 = start; t0 < end; t0 += COS_THREADS * PXT) {
+        const int p0 = t0 + threadIdx.x * PXT;
+        const int nvalid = max(0, min(PXT, end - p0));
+        int row[PXT], ridx[PXT];
         bool on[PXT];
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
             const int ix = (j < nvalid) ? indices[(size_t)b * P + p0 + j] : 0;
             if (ix < 0 || ix > L) bad = true;
             on[j] = ix > 0 && ix <= L;
-            row[j] = (on[j] ? ix - 1 : 0) * ld;
+            ridx[j] = on[j] ? ix - 1 : 0;
+            row[j] = ridx[j] * ld;
         }
         float xy[PXT], xx[PXT];
 #pragma unroll
         for (int j = 0; j < PXT; ++j) { xy[j] = 0.f; xx[j] = 0.f; }
-        int d = 0;
-        for (; d + U <= D; d += U) {
-            float v[U][PXT];
+        for (int c = 0; c < nchunks; ++c) {
+            if (nchunks > 1) { __syncthreads(); stage(c); __syncthreads(); }
+            if (nvalid == 0) continue;
+            const int d0 = c * DC, n = min(DC, D - d0);
+            const size_t base = img + (size_t)d0 * P + p0;
+            int d = 0;
+            for (; d + U <= n; d += U) {
+                float v[U][PXT];
 #pragma unroll
-            for (int u = 0; u < U; ++u)
-                ldpx<DTYPE, PXT, !BWD>(pred, img + (size_t)(d + u) * P + p0, nvalid, vec, v[u]);
+                for (int u = 0; u < U; ++u)
+                    ldpx<DTYPE, PXT, !BWD>(pred, base + (size_t)(d + u) * P, nvalid, vec, v[u]);
 #pragma unroll
-            for (int u = 0; u < U; ++u)
+                for (int u = 0; u < U; ++u)
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) {
+                        xy[j] = fmaf(v[u][j], s_lut[row[j] + d + u], xy[j]);
+                        xx[j] = fmaf(v[u][j], v[u][j], xx[j]);
+                    }
+            }
+            for (; d < n; ++d) {
+                float v[PXT];
+                ldpx<DTYPE, PXT, !BWD>(pred, base + (size_t)d * P, nvalid, vec, v);
 #pragma unroll
                 for (int j = 0; j < PXT; ++j) {
-                    xy[j] = fmaf(v[u][j], s_lut[row[j] + d + u], xy[j]);
-                    xx[j] = fmaf(v[u][j], v[u][j], xx[j]);
+                    xy[j] = fmaf(v[j], s_lut[row[j] + d], xy[j]);
+                    xx[j] = fmaf(v[j], v[j], xx[j]);
                 }
-        }
-        for (; d < D; ++d) {
-            float v[PXT];
-            ldpx<DTYPE, PXT, !BWD>(pred, img + (size_t)d * P + p0, nvalid, vec, v);
-#pragma unroll
-            for (int j = 0; j < PXT; ++j) {
-                xy[j] = fmaf(v[j], s_lut[row[j] + d], xy[j]);
-                xx[j] = fmaf(v[j], v[j], xx[j]);
             }
         }
         if (!BWD) {
@@ -684,7 +705,7 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
                 if (!on[j]) continue;
-                const float den = sqrtf((xx[j] + EPS) * (s_yy[row[j] / ld] + EPS));
+                const float den = sqrtf((xx[j] + EPS) * (s_yy[ridx[j]] + EPS));
                 part += 1.0f - xy[j] / den;
                 ++cnt;
             }
@@ -694,16 +715,22 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
             float k1[PXT], k2[PXT];
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
-                const float den = sqrtf((xx[j] + EPS) * (s_yy[row[j] / ld] + EPS));
+                const float den = sqrtf((xx[j] + EPS) * (s_yy[ridx[j]] + EPS));
                 k1[j] = on[j] ? -g / den : 0.f;
                 k2[j] = on[j] ? g * xy[j] / ((xx[j] + EPS) * den) : 0.f;
             }
-            for (d = 0; d < D; ++d) {
-                float v[PXT], o[PXT];
-                ldpx<DTYPE, PXT, true>(pred, img + (size_t)d * P + p0, nvalid, vec, v);
+            for (int c = 0; c < nchunks; ++c) {
+                if (nchunks > 1) { __syncthreads(); stage(c); __syncthreads(); }
+                if (nvalid == 0) continue;
+                const int d0 = c * DC, n = min(DC, D - d0);
+                const size_t base = img + (size_t)d0 * P + p0;
+                for (int d = 0; d < n; ++d) {
+                    float v[PXT], o[PXT];
+                    ldpx<DTYPE, PXT, true>(pred, base + (size_t)d * P, nvalid, vec, v);
 #pragma unroll
-                for (int j = 0; j < PXT; ++j) o[j] = fmaf(k2[j], v[j], k1[j] * s_lut[row[j] + d]);
-                stpx<DTYPE, PXT>(grad, img + (size_t)d * P + p0, nvalid, vec, o);
+                    for (int j = 0; j < PXT; ++j) o[j] = fmaf(k2[j], v[j], k1[j] * s_lut[row[j] + d]);
+                    stpx<DTYPE, PXT>(grad, base + (size_t)d * P, nvalid, vec, o);
+                }
             }
         }
     }
@@ -933,7 +960,31 @@ int cos_blocks_per_image(int B, int P, int pxt)
     return per_img;
 }
 
-size_t cos_lds_bytes(int L, int D) { return ((size_t)L * (D + 1) + L) * sizeof(float); }
+// column chunk of the LUT that is LDS-resident at a time: the whole row when it fits in
+// COS_LDS_BUDGET, otherwise D split into the fewest equal chunks that do (multiple of 8);
+// 0 = the LUT has too many rows for a useful chunk -> generic kernel (LUT rows from L2)
+constexpr size_t COS_LDS_BUDGET = 150 * 1024;
+int cos_chunk(int L, int D)
+{
+    const long long dc_max = (long long)(COS_LDS_BUDGET / sizeof(float) - L) / L - 1;
+    if (dc_max < 32) return 0;
+    if (D <= dc_max) return D;
+    int n = (int)((D + dc_max - 1) / dc_max);
+    for (;; ++n) {
+        const int dc = (((D + n - 1) / n) + 7) / 8 * 8;
+        if (dc <= dc_max) return dc;
+    }
+}
+size_t cos_lds_bytes(int L, int DC) { return ((size_t)L * (DC + 1) + L) * sizeof(float); }
+
+// dynamic LDS above the 64 KB default has to be granted per kernel function (once each)
+template <typename K>
+int cos_allow_lds(K kernel, size_t bytes)
+{
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
+                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
+               ? 0 : NMSA_ERR_LAUNCH;
+}
 
 }  // namespace
 
@@ -948,16 +999,18 @@ extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t*
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
     LossPartial* partials = (LossPartial*)workspace;
-    const size_t lds = cos_lds_bytes(L, D);
-    if (lds <= 150 * 1024) {
+    const int DC = cos_chunk(L, D);
+    if (DC > 0) {
+        const size_t lds = cos_lds_bytes(L, DC);
         const int pxt = (dtype == NMSA_F32) ? 4 : 8;
         const int per_img = cos_blocks_per_image(B, P, pxt);
         int ppb = (P + per_img - 1) / per_img;
         ppb = ((ppb + pxt - 1) / pxt) * pxt;                      // keep 16-B alignment of block starts
         const int gx = (P + ppb - 1) / ppb;
         const int vec = (P % pxt == 0) && ((((uintptr_t)pred) & 15) == 0);
-#define COS_FWD(DT, PX) hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, false>), dim3(gx, B), dim3(COS_THREADS), lds, \
-        stream, pred, indices, lut, D, P, L, ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status)
+#define COS_FWD(DT, PX) do { if (cos_allow_lds(k_cos_emb_lds<DT, PX, false>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
+        hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, false>), dim3(gx, B), dim3(COS_THREADS), lds, \
+        stream, pred, indices, lut, D, P, L, DC, ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status); } while (0)
         switch (dtype) {
             case NMSA_F32: COS_FWD(NMSA_F32, 4); break;
             case NMSA_BF16: COS_FWD(NMSA_BF16, 8); break;
@@ -987,16 +1040,18 @@ extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t*
     if (!pred || !indices || !lut || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
     if (bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
     const int P = H * W;
-    const size_t lds = cos_lds_bytes(L, D);
-    if (lds <= 150 * 1024) {
+    const int DC = cos_chunk(L, D);
+    if (DC > 0) {
+        const size_t lds = cos_lds_bytes(L, DC);
         const int pxt = (dtype == NMSA_F32) ? 4 : 8;
         const int per_img = cos_blocks_per_image(B, P, pxt);
         int ppb = (P + per_img - 1) / per_img;
         ppb = ((ppb + pxt - 1) / pxt) * pxt;
         const int gx = (P + ppb - 1) / ppb;
         const int vec = (P % pxt == 0) && ((((uintptr_t)pred | (uintptr_t)grad_pred) & 15) == 0);
-#define COS_BWD(DT, PX) hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, true>), dim3(gx, B), dim3(COS_THREADS), lds, \
-        stream, pred, indices, lut, D, P, L, ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr)
+#define COS_BWD(DT, PX) do { if (cos_allow_lds(k_cos_emb_lds<DT, PX, true>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
+        hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, true>), dim3(gx, B), dim3(COS_THREADS), lds, \
+        stream, pred, indices, lut, D, P, L, DC, ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr); } while (0)
         switch (dtype) {
             case NMSA_F32: COS_BWD(NMSA_F32, 4); break;
             case NMSA_BF16: COS_BWD(NMSA_BF16, 8); break;

@@ -6,3 +6,4 @@ from .focal import CenterFocalLoss
 from .l1 import L1Loss
 from .mse import MSELoss
 from .vonmises import VonMisesLossBiternion
+from ._functional import check_loss_status

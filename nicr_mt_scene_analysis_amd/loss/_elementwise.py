@@ -2,13 +2,15 @@
 
 reduction='sum' (what every task helper uses) on [B,H,W] / [B,C,H,W] inputs runs
 in the HIP kernels k_elem_fwd / k_elem_bwd, optionally with the task helpers'
-`pred*mask` folded in (`masked_sum`).  The 'mean' / 'none' reductions and 2-D
-[N,C] inputs are not on the hot path and use plain on-device torch ops.
+`pred*mask` folded in (`masked_sum`); 'mean' is the same kernel's sum divided by the pixel
+count.  The 'none' reduction and 2-D [N,C] inputs are not on the hot path and use plain
+torch ops on the device.  Host tensors raise: there is no CPU path.
 """
 from typing import Optional, Tuple
 
 import torch
 
+from .. import _lib as L
 from . import _functional as F_
 from .base import LossBase
 
@@ -32,10 +34,16 @@ class _ElementwiseLoss(LossBase):
         return F_.masked_elementwise_sum(input_, target, mask, self._kind)
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor):
-        if self._reduction == 'sum' and input_.ndim in (3, 4) and input_.is_cuda:
+        L.require_device_tensor(input_, 'input_')        # no CPU path: raises for host tensors
+        kernel_ok = input_.ndim in (3, 4) and input_.numel() > 0 and not target.requires_grad
+        if self._reduction in ('sum', 'mean') and kernel_ok:
             loss, _ = F_.masked_elementwise_sum(input_, target, None, self._kind)
-            n_elements = input_.numel() // (input_.shape[1] if input_.ndim == 4 else 1)
-            return loss, n_elements
+            n_px = input_.numel() // (input_.shape[1] if input_.ndim == 4 else 1)
+            if self._reduction == 'mean':
+                return loss / n_px, 1           # mean over all elements == sum_px mean_c / n_px
+            return loss, n_px
+        # per-element losses ('none') and 2-D [N, C] rows are off the hot path: plain torch ops
+        # ON THE DEVICE
         loss = self._pointwise(input_, target.to(input_.device))
         if self._reduction == 'sum':
             if loss.ndim in (2, 4):

@@ -5,7 +5,8 @@ tensors: no `.item()` host sync, unlike reference loss/ce.py:50 and
 task_helper/instance.py:138-139); backward recomputes from the saved inputs and
 scales by the upstream gradient on the device.
 """
-from typing import Optional, Tuple
+import os
+from typing import Dict, Optional, Tuple
 
 import torch
 
@@ -32,6 +33,32 @@ def _scalar_outputs(dev):
             torch.empty((1,), dtype=torch.int64, device=dev))
 
 
+# Out-of-range labels / LUT indices are a device assert in PyTorch.  The kernels skip such
+# pixels and OR a bit into ONE persistent status word per device; `check_loss_status()` reads
+# it (a host sync, so not per call): the task helpers call it at `validation_epoch_end`, and
+# NMSA_CHECK_STATUS=1 checks after every loss call.
+_STATUS: Dict[torch.device, torch.Tensor] = {}
+_CHECK_EVERY_CALL = bool(int(os.environ.get('NMSA_CHECK_STATUS', '0') or 0))
+
+
+def _status_word(dev: torch.device) -> torch.Tensor:
+    st = _STATUS.get(dev)
+    if st is None:
+        st = _STATUS[dev] = torch.zeros((1,), dtype=torch.int32, device=dev)
+    return st
+
+
+def check_loss_status() -> None:
+    """raise IndexError if any loss kernel since the last check saw a label >= C + 1 or a LUT
+    index outside [0, L] (host sync)"""
+    for dev, st in _STATUS.items():
+        v = int(st.item())
+        if v:
+            st.zero_()
+            raise IndexError(f'loss kernels on {dev}: target label / LUT index out of range '
+                             '(PyTorch raises a device-side assert for these)')
+
+
 def _grad_scale(g: torch.Tensor) -> torch.Tensor:
     return g.detach().to(torch.float32).reshape(1).contiguous()
 
@@ -44,14 +71,21 @@ class CrossEntropyFunction(torch.autograd.Function):
         x = L.require_device_tensor(logits, 'input_')
         B, C, H, W = x.shape
         dev = x.device
+        if C > 255:
+            # labels travel as uint8 (0 = void, 1..C; ToTorchTensors keeps semantic uint8):
+            # a wider label would wrap silently
+            raise ValueError(f'{C} classes: the CE kernel takes uint8 labels (C <= 255)')
         t = target.to(dev)
         if t.dtype != torch.uint8:
-            t = t.to(torch.uint8)           # labels 0..C (0 = void), reference: target.long() - 1
+            # labels 0..C (0 = void), reference: target.long() - 1.  Out-of-range values must
+            # not wrap into valid labels: they become 255 (> C) and set the status bit
+            t = torch.where((t < 0) | (t > 255), 255, t).to(torch.uint8) \
+                if t.dtype != torch.bool else t.to(torch.uint8)
         t = t.contiguous()
         w = None if weights is None else weights.to(dev, torch.float32).contiguous()
         s, n = _scalar_outputs(dev)
         wsum = torch.empty((1,), dtype=torch.float64, device=dev)
-        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        status = _status_word(dev)
         ws, nbytes = _workspace(B, H, W, dev)
         # per-pixel log-sum-exp for the backward pass (4 B/px instead of a second read of the
         # logits), only when a gradient can be asked for
@@ -61,6 +95,8 @@ class CrossEntropyFunction(torch.autograd.Function):
             L.ptr(x), L.float_dtype_code(x), L.ptr(t), L.ptr(w), B, C, H, W,
             float(label_smoothing), L.ptr(s), L.ptr(n), L.ptr(wsum), L.ptr(lse2), L.ptr(status),
             L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_ce_fwd')
+        if _CHECK_EVERY_CALL:
+            check_loss_status()
         ctx.save_for_backward(x, t, w if w is not None else torch.empty(0, device=dev),
                               lse2 if lse2 is not None else torch.empty(0, device=dev))
         ctx.has_lse = lse2 is not None
@@ -175,12 +211,14 @@ class CosineEmbeddingLutFunction(torch.autograd.Function):
         lt = lut.to(dev, torch.float32).contiguous()
         Lr = lt.shape[1]
         s, n = _scalar_outputs(dev)
-        status = torch.zeros((1,), dtype=torch.int32, device=dev)
+        status = _status_word(dev)
         ws, nbytes = _workspace(B, H, W, dev)
         L.check(L.lib().nmsa_loss_cos_emb_fwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(idx), L.ptr(lt), B, D, H, W, Lr,
             L.ptr(s), L.ptr(n), L.ptr(status), L.ptr(ws), nbytes, L.stream_ptr(dev)),
             'nmsa_loss_cos_emb_fwd')
+        if _CHECK_EVERY_CALL:
+            check_loss_status()
         ctx.save_for_backward(x, idx, lt)
         loss = s[0].to(torch.float32)
         n_el = n[0]

@@ -3,6 +3,7 @@ from typing import Optional, Tuple
 
 import torch
 
+from .. import _lib as L
 from . import _functional as F_
 from .base import LossBase
 
@@ -22,15 +23,16 @@ class CosineEmbeddingLoss(LossBase):
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor,
                       target_similarity: Optional[torch.Tensor] = None):
+        L.require_device_tensor(input_, 'input_')        # no CPU path: raises for host tensors
         n, d = input_.shape
-        # the HIP kernel covers what the task helper uses: similar pairs (label +1), 'sum';
-        # explicit labels (dissimilar pairs) and the other reductions are ATen's op on the
-        # tensors' own device
+        # the HIP kernel covers similar pairs (label +1) with 'sum' / 'mean' — what the task
+        # helper uses.  Explicit labels (dissimilar pairs), per-row losses ('none') and a target
+        # that itself asks for a gradient are off the hot path: ATen's op ON THE DEVICE.
         labelled = target_similarity is not None
-        if labelled or self._reduction != 'sum' or not input_.is_cuda or n == 0:
+        if labelled or self._reduction == 'none' or n == 0 or target.requires_grad:
             labels = target_similarity if labelled else torch.ones(n, device=input_.device)
-            loss = torch.nn.functional.cosine_embedding_loss(input_, target, labels,
-                                                             reduction='none')
+            loss = torch.nn.functional.cosine_embedding_loss(
+                input_, target.to(input_.device), labels.to(input_.device), reduction='none')
             if self._reduction == 'sum':
                 return loss.sum(), loss.numel()
             if self._reduction == 'mean':
@@ -39,5 +41,7 @@ class CosineEmbeddingLoss(LossBase):
         # rows (n, d): prediction planar (1, d, n, 1); the targets are their own LUT
         x = input_.t().contiguous().view(1, d, n, 1)
         idx = torch.arange(1, n + 1, dtype=torch.int32, device=input_.device).view(1, n, 1)
-        loss, _ = F_.cosine_embedding_lut_sum(x, idx, target.detach().view(1, n, d))
+        loss, _ = F_.cosine_embedding_lut_sum(x, idx, target.view(1, n, d))
+        if self._reduction == 'mean':
+            return loss / n, 1
         return loss, n

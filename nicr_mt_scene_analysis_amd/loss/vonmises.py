@@ -4,6 +4,7 @@ from typing import Optional, Tuple
 
 import torch
 
+from .. import _lib as L
 from . import _functional as F_
 from .base import LossBase
 
@@ -27,9 +28,11 @@ class VonMisesLossBiternion(LossBase):
                 f"expected biternion rows of shape (n, 2), got {tuple(input_.shape)} / "
                 f"{tuple(target.shape)}; permute (b, 2, h, w) to (b, h, w, 2) and flatten to "
                 "(b*h*w, 2) first, or call masked_sum() with the planar tensors")
+        L.require_device_tensor(input_, 'input_')        # no CPU path: raises for host tensors
         n = input_.shape[0]
-        if self._reduction == 'none' or not input_.is_cuda or n == 0:
-            cos = (input_ * target).sum(dim=1, keepdim=True)
+        if self._reduction == 'none' or n == 0 or target.requires_grad:
+            # per-row losses are off the hot path: plain torch ops ON THE DEVICE
+            cos = (input_ * target.to(input_.device)).sum(dim=1, keepdim=True)
             score = 1 - torch.exp(self._kappa * (cos - 1))
             return (score.sum() if self._reduction == 'sum' else score), score.numel()
         # rows (n, 2) -> planar (1, 2, n, 1) for the kernel (autograd carries the transpose)

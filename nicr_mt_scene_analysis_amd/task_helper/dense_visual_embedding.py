@@ -11,6 +11,7 @@ import torch
 from ..data.preprocessing.multiscale_supervision import get_downscale
 from ..data.preprocessing.resize import get_fullres
 from ..data.preprocessing.resize import get_fullres_key
+from ..loss import check_loss_status
 from ..loss import CosineEmbeddingLoss
 from ..loss import L1Loss
 from ..loss import MSELoss
@@ -120,6 +121,7 @@ class DenseVisualEmbeddingTaskHelper(TaskHelperBase):
 
     @append_profile_to_logs('semantic_epoch_end_time')
     def validation_epoch_end(self):
+        check_loss_status()        # out-of-range labels seen by the loss kernels (one host sync)
         miou, ious = self._text_metric_iou.compute(return_ious=True)
         vmiou, vious = self._visual_mean_metric_iou.compute(return_ious=True)
         logs = {'dense_visual_embedding_text_based_miou': miou,

@@ -10,6 +10,7 @@ import torch
 
 from ..data.preprocessing.resize import get_fullres
 from ..data.preprocessing.resize import get_fullres_key
+from ..loss import check_loss_status
 from ..loss import CenterFocalLoss
 from ..loss import L1Loss
 from ..loss import MSELoss
@@ -147,6 +148,7 @@ class InstanceTaskHelper(TaskHelperBase):
 
     @append_profile_to_logs('instance_epoch_end_time')
     def validation_epoch_end(self):
+        check_loss_status()        # out-of-range labels seen by the loss kernels (one host sync)
         artifacts, logs = {}, {}
         for key, value in self._mae_pq_deeplab.compute(suffix="_deeplab").items():
             (logs if value.numel() == 1 else artifacts)[f'instance_{key}'] = value

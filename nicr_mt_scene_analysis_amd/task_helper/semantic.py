@@ -10,6 +10,7 @@ import torch
 
 from ..data.preprocessing.resize import get_fullres
 from ..data.preprocessing.resize import get_fullres_key
+from ..loss import check_loss_status
 from ..loss import CrossEntropyLossSemantic
 from ..metric import MeanIntersectionOverUnion
 from .base import TaskHelperBase
@@ -73,6 +74,7 @@ class SemanticTaskHelper(TaskHelperBase):
 
     @append_profile_to_logs(f'{_TASK}_epoch_end_time')
     def validation_epoch_end(self):
+        check_loss_status()        # out-of-range labels seen by the loss kernels (one host sync)
         miou, ious = self._metric_iou.compute(return_ious=True)
         artifacts = {f'{_TASK}_cm': self._metric_iou.confmat.clone(),
                      f'{_TASK}_ious_per_class': ious.clone()}

@@ -178,6 +178,42 @@ def make_loss_inputs(
     return out
 
 
+def round_to_bf16(a: np.ndarray) -> np.ndarray:
+    """float32 array rounded to the nearest bfloat16 (ties to even), returned as float32 —
+    what a bf16 network output holds; integer arithmetic only, platform-stable"""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(a.shape)
+
+
+def make_embedding_inputs(batch_size: int, embedding_dim: int, height: int, width: int,
+                          n_lut: int, seed: int = 0, block: int = 4, bf16: bool = False
+                          ) -> Dict[str, np.ndarray]:
+    """Dense visual-embedding loss inputs (SURVEY §8d, configs[4]): prediction [B,D,H,W],
+    per-image LUT [B,L,D] of unit rows, index map [B,H,W] int32 in [0, L] (0 = no target) made
+    of `block` x `block` segments with ~15 % of the pixels re-drawn individually, so that lanes
+    of a wave see both shared and distinct LUT rows.  `bf16`: the prediction holds
+    bf16-representable values (as float32)."""
+    rng = np.random.default_rng(seed + 4000)
+    B, D, H, W, L = batch_size, embedding_dim, height, width, n_lut
+    lut = rng.standard_normal((B, L, D))
+    lut = lut / np.sqrt((lut * lut).sum(axis=-1, keepdims=True))
+    coarse = rng.integers(0, L + 1, size=(B, (H + block - 1) // block, (W + block - 1) // block))
+    idx = np.kron(coarse, np.ones((block, block), np.int64))[:, :H, :W]
+    redraw = rng.random((B, H, W)) < 0.15
+    idx = np.where(redraw, rng.integers(0, L + 1, size=(B, H, W)), idx)
+    # prediction: the target row plus noise for most pixels (cosine ~0.5), pure noise elsewhere
+    tgt = np.take_along_axis(lut, np.clip(idx - 1, 0, L - 1).reshape(B, -1, 1), axis=1)
+    tgt = tgt.reshape(B, H, W, D).transpose(0, 3, 1, 2)
+    pred = (tgt * (rng.random((B, 1, H, W)) < 0.8)
+            + rng.standard_normal((B, D, H, W)) / np.sqrt(D)) * 3.0
+    pred = pred.astype(np.float32)
+    if bf16:
+        pred = round_to_bf16(pred)
+    return {'embedding_pred': pred, 'embedding_lut': lut.astype(np.float32),
+            'embedding_indices': idx.astype(np.int32)}
+
+
 def make_label_maps(batch_size, n_classes=41, height=480, width=640, n_instances=30, seed=0,
                     max_id=65535, mixed_fraction=0.3, max_radius=None):
     """Ground-truth style label maps for the target generators.

@@ -547,6 +547,57 @@ def gen_losses(ref):
     save('loss_cases', **out)
 
 
+COS_LARGE_CASES = (
+    # name, B, D, H, W, L, bf16      (kernel path on the GPU, csrc/losses.hip::cos_chunk)
+    ('d512_l64', 2, 512, 24, 32, 64, False),       # one LDS chunk of 131 KB
+    ('d512_l64_bf16', 2, 512, 24, 32, 64, True),
+    ('d768_l64', 2, 768, 24, 32, 64, False),       # 197 KB as fp32: two chunks of 384
+    ('d768_l64_bf16', 2, 768, 24, 32, 64, True),
+    ('d768_l40_ragged', 1, 768, 17, 23, 40, False),  # single chunk, P % 4 != 0 (scalar loads)
+    ('d520_l90', 1, 520, 16, 24, 90, True),        # chunks of 264 + 256, D % chunk != 0
+    ('d48_l1300', 1, 48, 16, 16, 1300, False),     # LUT too tall for LDS: generic kernel
+)
+
+
+def gen_cos_emb_large(ref):
+    """reference CosineEmbeddingLoss with the masking / LUT gather of
+    task_helper/dense_visual_embedding.py:110-171 at the dense-visual-embedding sizes
+    (D = 512 / 768, L up to 64).  Inputs are regenerated from the seed by the tests
+    (`make_embedding_inputs`, digest stored); the full gradient would be 5 MB per case, so the
+    golden keeps it for 96 sampled pixels plus three f64 projections of the whole tensor."""
+    print('cosine embedding at D >= 512 (reference loss + autograd grads)')
+    out = {'names': jdump([c[0] for c in COS_LARGE_CASES])}
+    for seed, (name, B, D, H, W, L, bf16) in enumerate(COS_LARGE_CASES):
+        inp = syn.make_embedding_inputs(B, D, H, W, L, seed=seed, bf16=bf16)
+        x = torch.from_numpy(inp['embedding_pred']).clone().requires_grad_(True)
+        idx = torch.from_numpy(inp['embedding_indices'])
+        lut = torch.from_numpy(inp['embedding_lut'])
+        valid = idx != 0
+        pm_ = x.permute(0, 2, 3, 1)[valid]
+        keep = (idx - 1)[valid].long()
+        bidx = torch.where(valid)[0]
+        parts = [lut[b][keep[bidx == b]] for b in range(B) if int((bidx == b).sum())]
+        tg = torch.cat(parts, 0)
+        (loss, n), = ref.loss_cos_emb.CosineEmbeddingLoss()([pm_], [tg])
+        loss.backward()
+        grad = x.grad.numpy().astype(np.float64)
+        rng = np.random.default_rng(900 + seed)
+        pix = np.sort(rng.choice(B * H * W, size=min(96, B * H * W), replace=False))
+        g_rows = x.grad.permute(0, 2, 3, 1).reshape(-1, D)[torch.from_numpy(pix)].numpy()
+        proj = rng.standard_normal(grad.shape)
+        out[f'{name}__params'] = jdump(dict(B=B, D=D, H=H, W=W, L=L, bf16=bf16, seed=seed))
+        out[f'{name}__digest'] = jdump(syn.input_digest(inp['embedding_pred'], inp['embedding_lut'],
+                                                        inp['embedding_indices']))
+        out[f'{name}__loss'] = np.float32(loss.item())
+        out[f'{name}__n'] = np.int64(n)
+        out[f'{name}__grad_pixels'] = pix.astype(np.int64)
+        out[f'{name}__grad_rows'] = g_rows
+        out[f'{name}__grad_sums'] = np.array([grad.sum(), np.abs(grad).sum(), (grad * proj).sum()])
+        out[f'{name}__proj_seed'] = np.int64(900 + seed)
+        print(f'  {name}: loss {loss.item():.6f} n {n}')
+    save('cos_emb_large', **out)
+
+
 def gen_orientation(ref):
     print('instance orientation (reference _get_instance_orientation)')
     inp = syn.make_panoptic_inputs(2, n_classes=6, height=48, width=64, n_centers=5,
@@ -874,6 +925,8 @@ def main():
         gen_metrics(ref)
     if want('losses'):
         gen_losses(ref)
+    if want('cos_emb_large'):
+        gen_cos_emb_large(ref)
     if want('orientation'):
         gen_orientation(ref)
     if want('fullres'):

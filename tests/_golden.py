@@ -29,3 +29,35 @@ def meta_from_arrays(n, cyx, area, score):
 def ids_from_arrays(n, k, v):
     return [{int(k[b, i]): int(v[b, i]) for i in range(int(n[b]))}
             for b in range(len(n))]
+
+
+def cos_emb_large_cases():
+    """(name, params, inputs, golden) of tests/golden/cos_emb_large.npz: the inputs are
+    regenerated from the seed and checked against the stored digest"""
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+    g = load('cos_emb_large')
+    for name in jload(g['names']):
+        p = jload(g[f'{name}__params'])
+        inp = syn.make_embedding_inputs(p['B'], p['D'], p['H'], p['W'], p['L'], seed=p['seed'],
+                                        bf16=p['bf16'])
+        digest = syn.input_digest(inp['embedding_pred'], inp['embedding_lut'],
+                                  inp['embedding_indices'])
+        assert digest == jload(g[f'{name}__digest']), f'{name}: regenerated inputs differ'
+        yield name, p, inp, g
+
+
+def check_cos_emb_large_grad(name, p, g, grad, rtol, atol, sums_rtol):
+    """full gradient [B,D,H,W] against the golden's sampled pixel rows and the three f64
+    projections of the whole tensor (sum, sum |.|, random projection)"""
+    grad = np.asarray(grad, np.float64)
+    n_px = p['B'] * p['H'] * p['W']
+    rows = grad.transpose(0, 2, 3, 1).reshape(-1, p['D'])[g[f'{name}__grad_pixels']]
+    np.testing.assert_allclose(rows, g[f'{name}__grad_rows'], rtol=rtol, atol=atol, err_msg=name)
+    rng = np.random.default_rng(int(g[f'{name}__proj_seed']))       # replay the generator's draws
+    pix = np.sort(rng.choice(n_px, size=min(96, n_px), replace=False))
+    assert (pix == g[f'{name}__grad_pixels']).all()
+    proj = rng.standard_normal(grad.shape)
+    want = g[f'{name}__grad_sums']
+    scale = want[1]                                  # sum |grad|: the magnitude the sums live on
+    got = np.array([grad.sum(), np.abs(grad).sum(), (grad * proj).sum()])
+    np.testing.assert_allclose(got, want, rtol=0, atol=sums_rtol * scale, err_msg=name)

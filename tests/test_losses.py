@@ -253,3 +253,94 @@ def test_instance_task_helper_accepts_focal_center_loss():
     total = losses['instance_center_total_loss']
     total.backward()
     assert torch.isfinite(total) and float(total) > 0 and center.grad.abs().sum() > 0
+
+
+def test_off_path_reductions_on_device():
+    """'mean' / 'none' reductions, 2-D rows and labelled cosine pairs (reference loss/mse.py:21-41,
+    l1.py:21-41, cos_emb.py:29-56): results on the device, equal to torch's formulas"""
+    from nicr_mt_scene_analysis_amd.loss import (CosineEmbeddingLoss, L1Loss, MSELoss,
+                                                 VonMisesLossBiternion)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x = torch.rand((2, 2, 5, 7), device='cuda', generator=g)
+    y = torch.rand((2, 2, 5, 7), device='cuda', generator=g)
+    for cls, f in ((MSELoss, lambda d: d * d), (L1Loss, torch.abs)):
+        (l, n), = cls('none')([x], [y])
+        assert l.shape == x.shape and n == x.numel() and torch.allclose(l, f(x - y))
+        (l, n), = cls('mean')([x], [y])
+        assert n == 1 and float(l) == pytest.approx(float(f(x - y).mean()), rel=1e-6)
+        (l, n), = cls('sum')([x], [y])
+        assert n == 2 * 5 * 7 and float(l) == pytest.approx(float(f(x - y).mean(1).sum()), rel=1e-6)
+        x2, y2 = x.reshape(-1, 10), y.reshape(-1, 10)          # [N, C] rows
+        (l, n), = cls('sum')([x2], [y2])
+        assert n == x2.shape[0] and float(l) == pytest.approx(float(f(x2 - y2).mean(1).sum()), rel=1e-6)
+    rows = torch.rand((9, 2), device='cuda', generator=g)
+    tg = torch.rand((9, 2), device='cuda', generator=g)
+    (l, n), = VonMisesLossBiternion()([rows], [tg])
+    assert n == 9 and float(l) == pytest.approx(float((1 - torch.exp((rows * tg).sum(1) - 1)).sum()), rel=1e-6)
+    (l, n), = VonMisesLossBiternion(reduction='none')([rows], [tg])
+    assert l.shape == (9, 1) and n == 9
+    minus = -torch.ones(9, device='cuda')
+    l, n = CosineEmbeddingLoss()._compute_loss(rows, tg, target_similarity=minus)
+    want = torch.nn.functional.cosine_embedding_loss(rows, tg, minus, reduction='none')
+    assert n == 9 and float(l) == pytest.approx(float(want.sum()), rel=1e-6)
+    want = torch.nn.functional.cosine_embedding_loss(rows, tg, torch.ones(9, device='cuda'),
+                                                     reduction='none')
+    (l, n), = CosineEmbeddingLoss('mean')([rows], [tg])
+    assert n == 1 and float(l) == pytest.approx(float(want.mean()), rel=1e-5)
+    (l, n), = CosineEmbeddingLoss('none')([rows], [tg])
+    assert n == rows.numel() and torch.allclose(l, want)
+    # a target that asks for a gradient gets one (the reference's op differentiates both sides)
+    tg2 = tg.clone().requires_grad_(True)
+    (l, n), = CosineEmbeddingLoss()([rows], [tg2])
+    l.backward()
+    assert tg2.grad is not None and float(tg2.grad.abs().sum()) > 0
+
+
+@pytest.mark.parametrize('as_bf16', [False, True])
+def test_cos_emb_large_dims_vs_reference_golden(as_bf16):
+    """BASELINE configs[4] sizes: D = 512 (one 131 KB LDS chunk), D = 768 (197 KB as fp32 ->
+    two chunks), ragged P, D % chunk != 0, and a LUT too tall for LDS (generic kernel);
+    forward and gradient against the reference's CosineEmbeddingLoss + autograd.  bf16: the
+    golden's prediction holds bf16-representable values, so the bf16 tensor is the same
+    input and the loss must agree to 1e-5; its gradient is rounded to bf16 once (2^-8)."""
+    from _golden import cos_emb_large_cases, check_cos_emb_large_grad
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss
+    ran = 0
+    for name, p, inp, g in cos_emb_large_cases():
+        if as_bf16 and not p['bf16']:
+            continue
+        x = dev(inp['embedding_pred'])
+        if as_bf16:
+            x = x.to(torch.bfloat16)
+            assert torch.equal(x.float().cpu(), torch.from_numpy(inp['embedding_pred']))
+        x.requires_grad_(True)
+        loss, n = CosineEmbeddingLoss().lut_sum(x, dev(inp['embedding_indices']),
+                                                dev(inp['embedding_lut']))
+        np.testing.assert_allclose(float(loss), g[f'{name}__loss'], rtol=RTOL, err_msg=name)
+        assert int(n) == int(g[f'{name}__n']), name
+        loss.backward()
+        grad = x.grad.float().cpu().numpy()
+        if as_bf16:
+            check_cos_emb_large_grad(name, p, g, grad, rtol=2 ** -7, atol=1e-6, sums_rtol=2e-3)
+        else:
+            check_cos_emb_large_grad(name, p, g, grad, rtol=1e-4, atol=1e-7, sums_rtol=1e-5)
+        ran += 1
+    assert ran >= 3
+
+
+def test_ce_rejects_more_than_255_classes_and_flags_bad_labels():
+    from nicr_mt_scene_analysis_amd.loss import CrossEntropyLossSemantic, check_loss_status
+    x = torch.zeros((1, 300, 4, 4), device='cuda')
+    with pytest.raises(ValueError, match='uint8 labels'):
+        CrossEntropyLossSemantic()([x], [torch.zeros((1, 4, 4), dtype=torch.int64, device='cuda')])
+    check_loss_status()                                  # clean so far
+    x = torch.randn((1, 5, 4, 8), device='cuda')
+    t = torch.randint(0, 6, (1, 4, 8), device='cuda')
+    (l0, n0), = CrossEntropyLossSemantic()([x], [t])
+    check_loss_status()
+    t[0, 0, 0] = 300                                     # wraps to 44 as uint8: must be flagged
+    t[0, 1, 1] = 7                                       # > C
+    CrossEntropyLossSemantic()([x], [t])
+    with pytest.raises(IndexError, match='out of range'):
+        check_loss_status()
+    check_loss_status()                                  # the word was cleared

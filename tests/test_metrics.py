@@ -359,7 +359,7 @@ def test_bench_accumulators_packed_reduce_path():
     """bench.py's MetricAccumulators: the multi-rank path (step-local states -> one packed
     float64 buffer -> [all-reduce] -> totals) gives the same totals as direct accumulation."""
     from nicr_mt_scene_analysis_amd import ops
-    from nicr_mt_scene_analysis_amd.metric.bench_support import MetricAccumulators
+    from tools.bench_support import MetricAccumulators
     from nicr_mt_scene_analysis_amd.testing import synthetic as syn
     inp = syn.make_panoptic_inputs_torch(2, 8, 96, 128, n_centers=6, seed=3, device='cuda')
     a = MetricAccumulators(9, torch.device('cuda'), inp, world_size=1, side_stream=False)
@@ -432,7 +432,7 @@ def test_bench_accumulators_local_accumulation_then_one_reduce():
     """bench.py's default at N > 1: local accumulation, ONE all-reduce in finalize().  A stand-in
     for torch.distributed that doubles the buffer plays two identical ranks."""
     from nicr_mt_scene_analysis_amd import ops
-    from nicr_mt_scene_analysis_amd.metric.bench_support import MetricAccumulators
+    from tools.bench_support import MetricAccumulators
     from nicr_mt_scene_analysis_amd.testing import synthetic as syn
 
     class TwoIdenticalRanks:

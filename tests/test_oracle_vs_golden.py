@@ -230,6 +230,18 @@ def test_losses(oracle):
     np.testing.assert_allclose(grad, g['cos_emb__grad'], rtol=1e-4, atol=1e-6)
 
 
+def test_cosine_embedding_large_dims(oracle):
+    """a9 at the dense-visual-embedding sizes (D = 512 / 768, L up to 64 and a 1300-row LUT):
+    the C oracle against the reference's loss + autograd gradient"""
+    from _golden import cos_emb_large_cases, check_cos_emb_large_grad
+    for name, p, inp, g in cos_emb_large_cases():
+        s, n, grad = oracle.loss_cosine_embedding(inp['embedding_pred'], inp['embedding_indices'],
+                                                  inp['embedding_lut'], True)
+        np.testing.assert_allclose(s, g[f'{name}__loss'], rtol=1e-5, err_msg=name)
+        assert n == g[f'{name}__n']
+        check_cos_emb_large_grad(name, p, g, grad, rtol=1e-4, atol=1e-7, sums_rtol=1e-5)
+
+
 # ---------------------------------------------------------------------------
 # f2: crop + resize to the dataset resolution (dense_base.py:15-58)
 def _fullres_geoms(g):

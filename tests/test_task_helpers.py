@@ -252,3 +252,94 @@ def test_accumulate_losses_zero_elements_warns():
     assert float(out) == 0.0
     out = h.accumulate_losses([torch.zeros((), device='cuda')], [torch.zeros((), dtype=torch.int64, device='cuda')])
     assert float(out) == 0.0
+
+
+def test_four_losses_cfg3_bf16_full_batch(oracle):
+    """BASELINE configs[2]: CE + center (MSE) + offset (L1) + von Mises orientation through
+    SemanticTaskHelper + InstanceTaskHelper.training_step at B=64, 640x480, C=40, bf16
+    predictions.  (a) a 4-image slice equals the C oracle on the same values (1e-5);
+    (b) the full-batch loss values equal the count-weighted combination of the sixteen 4-image
+    slices (additivity of sums and counts over images); (c) backward fills bf16 gradients."""
+    from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper, SemanticTaskHelper
+    B, C, H, W, S = 64, 40, 480, 640, 4
+    dev = torch.device('cuda')
+    g = torch.Generator(device=dev).manual_seed(42)
+
+    def rnd(*shape):
+        return torch.randn(shape, device=dev, generator=g)
+    bf = torch.bfloat16
+    logits = (rnd(B, C, H, W) * 3).to(bf)
+    center = torch.rand((B, 1, H, W), device=dev, generator=g).to(bf)
+    offset = (rnd(B, 2, H, W) * 0.05).to(bf)
+    ori = torch.nn.functional.normalize(rnd(B, 2, H, W), dim=1).to(bf)
+    batch = {
+        'semantic': torch.randint(0, C + 1, (B, H, W), device=dev, generator=g).to(torch.uint8),
+        'instance_center': torch.rand((B, H, W), device=dev, generator=g),
+        'instance_center_mask': torch.rand((B, H, W), device=dev, generator=g) < 0.7,
+        'instance_offset': rnd(B, 2, H, W) * 0.05,
+        'instance_foreground': torch.rand((B, H, W), device=dev, generator=g) < 0.5,
+        'orientation': torch.nn.functional.normalize(rnd(B, 2, H, W), dim=1),
+        'orientation_foreground': torch.rand((B, H, W), device=dev, generator=g) < 0.3,
+    }
+    weights = (torch.rand(C, device=dev, generator=g) + 0.5)
+    sem = SemanticTaskHelper(n_classes=C, class_weights=weights.cpu().numpy())
+    ins = InstanceTaskHelper(semantic_n_classes=C + 1,
+                             semantic_classes_is_thing=(False,) * 21 + (True,) * 20)
+    sem.initialize(dev)
+    ins.initialize(dev)
+
+    def run(lo, hi, grad=False):
+        sl = slice(lo, hi)
+        bt = {k: v[sl] for k, v in batch.items()}
+        x = [t[sl].clone().requires_grad_(grad) for t in (logits, center, offset, ori)]
+        preds = {'semantic_output': x[0], 'semantic_side_outputs': (None, None),
+                 'instance_output': (x[1], x[2], x[3]), 'instance_side_outputs': (None, None)}
+        losses = dict(sem.training_step(bt, 0, preds)[0])
+        losses.update(ins.training_step(bt, 0, preds)[0])
+        return losses, x
+
+    keys = ('semantic_loss_main', 'instance_center_loss_main', 'instance_offset_loss_main',
+            'instance_orientation_loss_main')
+    count_of = {'semantic_loss_main': lambda sl: (batch['semantic'][sl] > 0).sum(),
+                'instance_center_loss_main': lambda sl: batch['instance_center_mask'][sl].sum(),
+                'instance_offset_loss_main': lambda sl: batch['instance_foreground'][sl].sum(),
+                'instance_orientation_loss_main': lambda sl: batch['orientation_foreground'][sl].sum()}
+
+    # (c) + full batch
+    full, x = run(0, B, grad=True)
+    total = sum(full[k.replace('_loss_main', '_total_loss')] for k in keys)
+    total.backward()
+    for t in x:
+        assert t.grad is not None and t.grad.dtype == bf and bool(torch.isfinite(t.grad).all())
+    for k in keys:        # one scale: total == main
+        np.testing.assert_allclose(float(full[k.replace('_loss_main', '_total_loss')]),
+                                   float(full[k]), rtol=1e-6)
+
+    # (b) additivity over sixteen slices of four images
+    acc = {k: [0.0, 0] for k in keys}
+    for lo in range(0, B, S):
+        part, _ = run(lo, lo + S)
+        for k in keys:
+            n = int(count_of[k](slice(lo, lo + S)))
+            acc[k][0] += float(part[k]) * n
+            acc[k][1] += n
+    for k in keys:
+        np.testing.assert_allclose(float(full[k]), acc[k][0] / acc[k][1], rtol=RTOL, err_msg=k)
+        assert acc[k][1] == int(count_of[k](slice(0, B)))
+
+    # (a) first slice against the C oracle (bf16 values as float32: the same numbers)
+    part, _ = run(0, S)
+    f32 = lambda t: t[:S].float().cpu().numpy()                        # noqa: E731
+    npy = lambda t: t[:S].cpu().numpy()                                # noqa: E731
+    s_, n_, _, _ = oracle.loss_ce(f32(logits), npy(batch['semantic']), weights.cpu().numpy())
+    np.testing.assert_allclose(float(part['semantic_loss_main']), s_ / n_, rtol=RTOL)
+    s_, n_, _ = oracle.loss_masked_elementwise(f32(center)[:, 0], npy(batch['instance_center']),
+                                               npy(batch['instance_center_mask']), 'mse')
+    np.testing.assert_allclose(float(part['instance_center_loss_main']), s_ / n_, rtol=RTOL)
+    s_, n_, _ = oracle.loss_masked_elementwise(f32(offset), npy(batch['instance_offset']),
+                                               npy(batch['instance_foreground']), 'l1')
+    np.testing.assert_allclose(float(part['instance_offset_loss_main']), s_ / n_, rtol=RTOL)
+    s_, n_, _ = oracle.loss_vonmises(f32(ori), npy(batch['orientation']),
+                                     npy(batch['orientation_foreground']), 1.0)
+    np.testing.assert_allclose(float(part['instance_orientation_loss_main']), s_ / max(n_, 1),
+                               rtol=RTOL)

@@ -14,9 +14,9 @@ all-reduce) overlap with the next step's streaming kernels.
 """
 import torch
 
-from .. import ops
-from .miou import MeanIntersectionOverUnion
-from .pq import PanopticQuality
+from nicr_mt_scene_analysis_amd import ops
+from nicr_mt_scene_analysis_amd.metric.miou import MeanIntersectionOverUnion
+from nicr_mt_scene_analysis_amd.metric.pq import PanopticQuality
 
 
 class MetricAccumulators:

@@ -8,7 +8,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from nicr_mt_scene_analysis_amd import ops                         # noqa: E402
-from nicr_mt_scene_analysis_amd.metric import bench_support      # noqa: E402
+from tools import bench_support                                   # noqa: E402
 from nicr_mt_scene_analysis_amd.testing import synthetic as syn   # noqa: E402
 
 dev = torch.device('cuda')
