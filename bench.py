@@ -206,6 +206,9 @@ def secondary_pipeline(ops, syn, dev, B, C, H, W, K, dtype, with_metrics=True):
         if m is not None:
             m.update_and_reduce(r['panoptic'])
     ms = hip_timed(step, reps=20, warm=5)
+    if m is not None:
+        m.pq._check_status()                    # table overflow etc. would void the timing
+        m.miou._check_status()
     fused_ms = float(np.mean([x.elapsed_time(y) for x, y in ev[5:]]))
     n_px = B * H * W
     out = {'shape': f'B={B} C={C} {W}x{H}', 'logits_dtype': str(a[0].dtype).replace('torch.', ''),

@@ -362,13 +362,16 @@ int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pred_div,
  *   matches      : i64 [B,match_capacity,2] (gt id, pred id) of the TP pairs in
  *                  ascending intersection-id order, or NULL; n_matches i32 [B]
  *   status       : i32 [1] device word, OR-ed with NMSA_ST_* bits
- *   limits       : <= 2048 distinct ids per image and side, <= 4096 distinct
- *                  intersections per image, num_categories <= 1024
+ *   limits       : <= 2048 distinct ids per image and side, num_categories <= 1024;
+ *                  distinct (target, pred) intersections per image <= cap / 2 with
+ *                  cap = H*W / 48 rounded up to a power of two in [4096, 65536]
+ *                  (640x480: 4096 intersections, 1024x768: 8192); beyond that
+ *                  NMSA_ST_TABLE_OVERFLOW is raised
  *   workspace_is_clean : non-zero when `workspace` was last used by a completed
- *                  nmsa_pq_update of the same B (which leaves the tables empty); the
+ *                  nmsa_pq_update of the same B, H, W (which leaves the tables empty); the
  *                  per-call table initialisation is then skipped
  * ------------------------------------------------------------------------- */
-size_t nmsa_pq_workspace_bytes(int B, int num_categories);
+size_t nmsa_pq_workspace_bytes(int B, int H, int W, int num_categories);
 int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int W,
                    int num_categories, int64_t ignored_label,
                    int64_t max_instances_per_category, int64_t offset,
@@ -443,7 +446,11 @@ int nmsa_pq_update_with_confmat(
  *     where mask != 0 (gather of task_helper/instance.py:186-216), pred/target [B,2,H,W]
  * nmsa_loss_cos_emb_*  CosineEmbeddingLoss  loss/cos_emb.py:21-56 with the LUT gather of
  *     task_helper/dense_visual_embedding.py:110-171: pred [B,D,H,W], indices i32
- *     [B,H,W] (0 = no target), lut f32 [B,L,D]
+ *     [B,H,W] (0 = no target), lut f32 [B,L,D];
+ *     dots f32 [B,2,H,W] (optional, NULL = off; needs H*W % 8 == 0 and 16-B aligned
+ *     pointers, NMSA_ERR_ARG otherwise — see nmsa_loss_cos_emb_can_keep_dots): the forward
+ *     pass stores x.y and |x|^2 per pixel and the backward pass, given the same buffer, reads
+ *     the prediction ONCE (for the gradient) instead of twice
  * ------------------------------------------------------------------------- */
 size_t nmsa_loss_workspace_bytes(int B, int H, int W);
 int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* target, const float* weights,
@@ -470,11 +477,14 @@ int nmsa_loss_vonmises_bwd(const void* pred, int dtype, const float* target, con
                            const float* grad_scale, void* grad_pred, nmsa_stream_t stream);
 int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
                           int B, int D, int H, int W, int L,
-                          double* loss_sum, int64_t* n_rows, int32_t* status,
+                          double* loss_sum, int64_t* n_rows, float* dots_out, int32_t* status,
                           void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
 int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
                           int B, int D, int H, int W, int L,
-                          const float* grad_scale, void* grad_pred, nmsa_stream_t stream);
+                          const float* grad_scale, const float* dots, void* grad_pred,
+                          nmsa_stream_t stream);
+/* 1 when the (L, D, H*W) combination runs the LDS-LUT kernel that can keep `dots` */
+int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
 
 #ifdef __cplusplus
 }

@@ -99,9 +99,10 @@ _SIGNATURES = {
     'nmsa_loss_masked_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'nmsa_loss_vonmises_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_loss_vonmises_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp]),
-    'nmsa_loss_cos_emb_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'nmsa_loss_cos_emb_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
-    'nmsa_pq_workspace_bytes': (_sz, [_i, _i]),
+    'nmsa_loss_cos_emb_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'nmsa_loss_cos_emb_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    'nmsa_loss_cos_emb_can_keep_dots': (_i, [_i, _i, _i, _i]),
+    'nmsa_pq_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'nmsa_pq_update': (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64,
                             _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp]),
 }

@@ -621,7 +621,8 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
     const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
     int D, int P, int L, int DC, int px_per_block, int vec,
     const float* __restrict__ gscale, void* __restrict__ grad,
-    LossPartial* __restrict__ partials, int* __restrict__ status)
+    LossPartial* __restrict__ partials, int* __restrict__ status,
+    float* __restrict__ dots /* [B,2,P]: x.y and |x|^2 per pixel; fwd writes, bwd reads; or null */)
 {
     extern __shared__ float s_lut[];                   // [L][DC + 1], then yy[L]
     const int b = blockIdx.y;
@@ -671,7 +672,19 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
         float xy[PXT], xx[PXT];
 #pragma unroll
         for (int j = 0; j < PXT; ++j) { xy[j] = 0.f; xx[j] = 0.f; }
-        for (int c = 0; c < nchunks; ++c) {
+        // backward with the forward's per-pixel dot products at hand: no first pass over the
+        // prediction (it is read once, for the gradient)
+        const bool have_dots = BWD && dots != nullptr;
+        if (have_dots && nvalid > 0) {
+            float* q = dots + (size_t)b * 2 * P + p0;
+            ldpx<NMSA_F32, 4, true>(q, 0, min(nvalid, 4), vec, xy);
+            ldpx<NMSA_F32, 4, true>(q + P, 0, min(nvalid, 4), vec, xx);
+            if constexpr (PXT == 8) {
+                ldpx<NMSA_F32, 4, true>(q + 4, 0, max(0, nvalid - 4), vec, xy + 4);
+                ldpx<NMSA_F32, 4, true>(q + P + 4, 0, max(0, nvalid - 4), vec, xx + 4);
+            }
+        }
+        for (int c = 0; c < (have_dots ? 0 : nchunks); ++c) {
             if (nchunks > 1) { __syncthreads(); stage(c); __syncthreads(); }
             if (nvalid == 0) continue;
             const int d0 = c * DC, n = min(DC, D - d0);
@@ -701,6 +714,15 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
             }
         }
         if (!BWD) {
+            if (dots != nullptr && nvalid > 0) {
+                float* q = dots + (size_t)b * 2 * P + p0;
+                stpx<NMSA_F32, 4>(q, 0, min(nvalid, 4), vec, xy);
+                stpx<NMSA_F32, 4>(q + P, 0, min(nvalid, 4), vec, xx);
+                if constexpr (PXT == 8) {
+                    stpx<NMSA_F32, 4>(q + 4, 0, max(0, nvalid - 4), vec, xy + 4);
+                    stpx<NMSA_F32, 4>(q + P + 4, 0, max(0, nvalid - 4), vec, xx + 4);
+                }
+            }
             float part = 0.f;
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
@@ -990,7 +1012,8 @@ int cos_allow_lds(K kernel, size_t bytes)
 
 extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t* indices,
                                      const float* lut, int B, int D, int H, int W, int L,
-                                     double* loss_sum, int64_t* n_rows, int32_t* status,
+                                     double* loss_sum, int64_t* n_rows, float* dots_out,
+                                     int32_t* status,
                                      void* workspace, size_t workspace_bytes, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -1008,9 +1031,13 @@ extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t*
         ppb = ((ppb + pxt - 1) / pxt) * pxt;                      // keep 16-B alignment of block starts
         const int gx = (P + ppb - 1) / ppb;
         const int vec = (P % pxt == 0) && ((((uintptr_t)pred) & 15) == 0);
+        // the per-pixel dot products are only kept on the aligned path (16-B float stores)
+        const bool dots_vec = dots_out && vec && ((((uintptr_t)dots_out) & 15) == 0);
+        if (dots_out && !dots_vec) return NMSA_ERR_ARG;
 #define COS_FWD(DT, PX) do { if (cos_allow_lds(k_cos_emb_lds<DT, PX, false>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
         hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, false>), dim3(gx, B), dim3(COS_THREADS), lds, \
-        stream, pred, indices, lut, D, P, L, DC, ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status); } while (0)
+        stream, pred, indices, lut, D, P, L, DC, ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status, \
+        dots_vec ? dots_out : (float*)nullptr); } while (0)
         switch (dtype) {
             case NMSA_F32: COS_FWD(NMSA_F32, 4); break;
             case NMSA_BF16: COS_FWD(NMSA_BF16, 8); break;
@@ -1032,15 +1059,23 @@ extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t*
     return finalize(partials, gx * B, loss_sum, nullptr, n_rows, stream);
 }
 
+extern "C" int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L)
+{
+    if (D <= 0 || L <= 0 || H <= 0 || W <= 0) return 0;
+    return cos_chunk(L, D) > 0 && ((int64_t)H * W) % 8 == 0;
+}
+
 extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t* indices,
                                      const float* lut, int B, int D, int H, int W, int L,
-                                     const float* grad_scale, void* grad_pred, nmsa_stream_t stream_)
+                                     const float* grad_scale, const float* dots, void* grad_pred,
+                                     nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !indices || !lut || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
     if (bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
     const int P = H * W;
     const int DC = cos_chunk(L, D);
+    if (dots && (DC <= 0 || ((uintptr_t)dots & 15) != 0)) return NMSA_ERR_ARG;
     if (DC > 0) {
         const size_t lds = cos_lds_bytes(L, DC);
         const int pxt = (dtype == NMSA_F32) ? 4 : 8;
@@ -1049,9 +1084,11 @@ extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t*
         ppb = ((ppb + pxt - 1) / pxt) * pxt;
         const int gx = (P + ppb - 1) / ppb;
         const int vec = (P % pxt == 0) && ((((uintptr_t)pred | (uintptr_t)grad_pred) & 15) == 0);
+        if (dots && !vec) return NMSA_ERR_ARG;
 #define COS_BWD(DT, PX) do { if (cos_allow_lds(k_cos_emb_lds<DT, PX, true>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
         hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, true>), dim3(gx, B), dim3(COS_THREADS), lds, \
-        stream, pred, indices, lut, D, P, L, DC, ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr); } while (0)
+        stream, pred, indices, lut, D, P, L, DC, ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr, \
+        (float*)dots); } while (0)
         switch (dtype) {
             case NMSA_F32: COS_BWD(NMSA_F32, 4); break;
             case NMSA_BF16: COS_BWD(NMSA_BF16, 8); break;

@@ -194,8 +194,21 @@ __global__ __launch_bounds__(256) void k_confmat_reduce(
 constexpr int64_t KEY_EMPTY = INT64_MIN;
 constexpr int PQ_T_CAP = 2048;      // distinct target ids / image      (LDS, k_pq_match)
 constexpr int PQ_P_CAP = 2048;      // distinct predicted ids / image   (LDS, k_pq_match)
-constexpr int PQ_I_CAP = 4096;      // distinct (target, pred) intersections / image
+constexpr int PQ_I_CAP_MIN = 4096;  // slots of the per-image intersection table: a power of two
+constexpr int PQ_I_CAP_MAX = 65536; //   chosen from the image size (pq_i_cap), kept <= half full
 constexpr int PQ_LI = 1024;         // LDS-privatised intersection table per block
+
+// Slots of the per-image (target, pred) intersection table.  Distinct intersections grow with
+// the total segment boundary length, i.e. with the image size: one slot per 48 px, rounded up
+// to a power of two (640x480 -> 8192, 1024x768 -> 16384; blobby synthetic maps with 150
+// classes hold ~8000 intersections at 1024x768, real label maps a few hundred).  More than
+// cap/2 distinct intersections in one image raise ST_TABLE_OVERFLOW.
+__host__ __device__ inline int pq_i_cap(int64_t P)
+{
+    int cap = PQ_I_CAP_MIN;
+    while (cap < PQ_I_CAP_MAX && (int64_t)cap * 48 < P) cap <<= 1;
+    return cap;
+}
 
 // cheap id hash: one 32-bit multiply per half (64-bit multiplies are quarter rate
 // and dominated the first version of k_pq_count)
@@ -240,25 +253,32 @@ __device__ __forceinline__ int table_find(const int64_t* keys, uint32_t mask, in
     return -1;
 }
 
-__host__ __device__ inline size_t pq_image_bytes()
+// per image: table keys i64[cap] | table counts u32[cap] | the compacted entry list of
+// k_pq_match: keys i64[cap/2] | counts u32[cap/2] | slots u32[cap/2]
+__host__ __device__ inline size_t pq_image_bytes(int cap)
 {
-    return (size_t)PQ_I_CAP * (sizeof(int64_t) + sizeof(uint32_t));
+    return (size_t)cap * (sizeof(int64_t) + sizeof(uint32_t)) +
+           (size_t)(cap / 2) * (sizeof(int64_t) + 2 * sizeof(uint32_t));
 }
-__device__ __forceinline__ int64_t* pq_keys(unsigned char* ws, int b)
+__device__ __forceinline__ int64_t* pq_keys(unsigned char* ws, int b, int cap)
 {
-    return (int64_t*)(ws + (size_t)b * pq_image_bytes());
+    return (int64_t*)(ws + (size_t)b * pq_image_bytes(cap));
 }
-__device__ __forceinline__ uint32_t* pq_cnts(unsigned char* ws, int b)
+__device__ __forceinline__ uint32_t* pq_cnts(unsigned char* ws, int b, int cap)
 {
-    return (uint32_t*)(pq_keys(ws, b) + PQ_I_CAP);
+    return (uint32_t*)(pq_keys(ws, b, cap) + cap);
+}
+__device__ __forceinline__ int64_t* pq_list_keys(unsigned char* ws, int b, int cap)
+{
+    return (int64_t*)(pq_cnts(ws, b, cap) + cap);
 }
 
-__global__ __launch_bounds__(256) void k_pq_init(unsigned char* __restrict__ ws)
+__global__ __launch_bounds__(256) void k_pq_init(unsigned char* __restrict__ ws, int cap)
 {
     const int b = blockIdx.y;
-    int64_t* k = pq_keys(ws, b);
-    uint32_t* c = pq_cnts(ws, b);
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < PQ_I_CAP; i += gridDim.x * blockDim.x) {
+    int64_t* k = pq_keys(ws, b, cap);
+    uint32_t* c = pq_cnts(ws, b, cap);
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += gridDim.x * blockDim.x) {
         k[i] = KEY_EMPTY;
         c[i] = 0;
     }
@@ -282,7 +302,7 @@ template <bool WITH_CM>
 __global__ __launch_bounds__(256) void k_pq_count(
     const int64_t* __restrict__ pred, const int64_t* __restrict__ target,
     int P, int64_t offset, int px_per_block,
-    unsigned char* __restrict__ ws, int* __restrict__ status,
+    unsigned char* __restrict__ ws, int cap, int* __restrict__ status,
     const uint8_t* __restrict__ target_sem, int cm_n, int64_t cm_div, int cm_shift,
     uint32_t* __restrict__ cm_slab, int* __restrict__ cm_status)
 {
@@ -315,8 +335,8 @@ __global__ __launch_bounds__(256) void k_pq_count(
             atomicAdd(&cm_hist_pq[key], weight * (uint32_t)(nxt - l));
         }
     };
-    int64_t* gk = pq_keys(ws, b);
-    uint32_t* gc = pq_cnts(ws, b);
+    int64_t* gk = pq_keys(ws, b, cap);
+    uint32_t* gc = pq_cnts(ws, b, cap);
     const int64_t* pr = pred + (size_t)b * P;
     const int64_t* tg = target + (size_t)b * P;
     const int start = blockIdx.x * px_per_block;
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
         const uint32_t sI = hash_id(iid) & (PQ_LI - 1);
         if (lkI[sI] == iid) { atomicAdd(&lcI[sI], cnt); return; }
         if (!table_add(lkI, lcI, PQ_LI - 1, iid, cnt, 32) &&
-            !table_add(gk, gc, PQ_I_CAP - 1, iid, cnt, PQ_I_CAP)) st |= ST_TABLE_OVERFLOW;
+            !table_add(gk, gc, cap - 1, iid, cnt, 256)) st |= ST_TABLE_OVERFLOW;
     };
     // intersection id with torch's int64 wrap-around arithmetic (pq.py:104); ids that would
     // not decode uniquely (pq.py:83-109 then fails or mixes segments) raise ST_MISSING_KEY
@@ -412,7 +432,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
     }
     // flush the block-private table
     for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x)
-        if (lkI[i] != KEY_EMPTY && !table_add(gk, gc, PQ_I_CAP - 1, lkI[i], lcI[i], PQ_I_CAP))
+        if (lkI[i] != KEY_EMPTY && !table_add(gk, gc, cap - 1, lkI[i], lcI[i], 256))
             st |= ST_TABLE_OVERFLOW;
     if (st) atomicOr(status, st);
 }
@@ -449,19 +469,18 @@ constexpr int PQ_MATCH_THREADS = 1024;
 constexpr int PQ_MAX_CATEGORIES = 1024;
 constexpr int PQ_TP_CAP = 1024;             // matched pairs per image
 
-// One workgroup per image.  The intersection table is copied into LDS as it is (same
-// hash layout -> O(1) probes instead of sorted searches); only the MATCHED pairs (a few
-// dozen) are put in ascending-id order, which is all the reference's fp64 summation
-// order depends on.
+// One workgroup per image.  The image's intersection table stays where k_pq_count built it
+// (global memory, L2-resident: 12 B x cap); its non-empty slots are first compacted into an
+// entry list, every later step walks that list and looks other intersections up in the table
+// with O(1) probes (load factor <= 1/2).  Only the MATCHED pairs (a few dozen) are put in
+// ascending-id order, which is all the reference's fp64 summation order depends on.
 __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
-    unsigned char* __restrict__ ws, int num_categories, int64_t ignored_label,
+    unsigned char* __restrict__ ws, int cap, int num_categories, int64_t ignored_label,
     int64_t max_inst, int64_t offset, int64_t void_segment_id,
     double* __restrict__ img_state /* [B,4,num_categories] */,
     int64_t* __restrict__ matches /* [B,match_cap,2] or null */, int match_cap,
     int32_t* __restrict__ n_matches, int* __restrict__ status)
 {
-    __shared__ int64_t iK[PQ_I_CAP];                   // intersection table (hash layout)
-    __shared__ uint32_t iC[PQ_I_CAP];
     __shared__ int64_t kT[PQ_T_CAP], kP[PQ_P_CAP];     // segment-area tables (marginals)
     __shared__ uint32_t cT[PQ_T_CAP], cP[PQ_P_CAP];
     __shared__ uint8_t fT[PQ_T_CAP], fP[PQ_P_CAP];     // matched flags
@@ -470,33 +489,60 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     __shared__ int16_t tpCat[PQ_TP_CAP], tpCatS[PQ_TP_CAP];
     __shared__ int fnI[PQ_MAX_CATEGORIES], fpI[PQ_MAX_CATEGORIES];
     __shared__ int64_t ignKeys[64];
-    __shared__ int nIgn, nTPs;
+    __shared__ int nIgn, nTPs, nEnt;
 
     const int b = blockIdx.x, tid = threadIdx.x;
-    int64_t* gk = pq_keys(ws, b);
-    uint32_t* gc = pq_cnts(ws, b);
+    int64_t* gk = pq_keys(ws, b, cap);
+    uint32_t* gc = pq_cnts(ws, b, cap);
+    int64_t* eK = pq_list_keys(ws, b, cap);            // entry list: key, count, table slot
+    uint32_t* eC = (uint32_t*)(eK + cap / 2);
+    uint32_t* eS = eC + cap / 2;
+    const int ecap = cap / 2;
     int st = 0;
 
-    // take the image's table into LDS and leave the global copy empty for the next call
-    for (int i = tid; i < PQ_I_CAP; i += PQ_MATCH_THREADS) {
-        const int64_t k = gk[i];
-        iK[i] = k; iC[i] = gc[i];
-        if (k != KEY_EMPTY) { gk[i] = KEY_EMPTY; gc[i] = 0; }
-    }
     for (int i = tid; i < PQ_T_CAP; i += PQ_MATCH_THREADS) {
         fT[i] = 0; fP[i] = 0; kT[i] = KEY_EMPTY; kP[i] = KEY_EMPTY; cT[i] = 0; cP[i] = 0;
     }
     for (int i = tid; i < num_categories; i += PQ_MATCH_THREADS) { fnI[i] = 0; fpI[i] = 0; }
-    if (tid == 0) { nIgn = 0; nTPs = 0; }
+    if (tid == 0) { nIgn = 0; nTPs = 0; nEnt = 0; }
     __syncthreads();
 
+    // ---- 0. compact the non-empty table slots (4 independent loads in flight per thread);
+    //         one LDS atomic per wave reserves the wave's list positions
+    for (int i0 = 0; i0 < cap; i0 += 4 * PQ_MATCH_THREADS) {
+        int64_t k[4];
+        uint32_t c[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * PQ_MATCH_THREADS + tid;
+            k[u] = (i < cap) ? gk[i] : KEY_EMPTY;
+            c[u] = (i < cap) ? gc[i] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool has = k[u] != KEY_EMPTY;
+            const unsigned long long m = __ballot(has);
+            if (m == 0ull) continue;
+            int base = 0;
+            if (lane_id() == 0) base = atomicAdd(&nEnt, __popcll(m));
+            base = __shfl(base, 0);
+            if (has) {
+                const int at = base + __popcll(m & ((1ull << lane_id()) - 1ull));
+                if (at < ecap) { eK[at] = k[u]; eC[at] = c[u]; eS[at] = (uint32_t)(i0 + u * PQ_MATCH_THREADS + tid); }
+            }
+        }
+    }
+    __syncthreads();
+    if (nEnt > ecap) st |= ST_TABLE_OVERFLOW;          // table more than half full
+    const int nE = min(nEnt, ecap);
+    __threadfence_block();
+
     // ---- 1. segment areas = marginals of the intersection table (pq.py:83-84) ------------
-    for (int s = tid; s < PQ_I_CAP; s += PQ_MATCH_THREADS) {
-        const int64_t iid = iK[s];
-        if (iid == KEY_EMPTY) continue;
+    for (int e = tid; e < nE; e += PQ_MATCH_THREADS) {
+        const int64_t iid = eK[e];
         const int64_t gt = floordiv64(iid, offset), pr = floormod64(iid, offset);
-        if (!table_add(kT, cT, PQ_T_CAP - 1, gt, iC[s], PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
-        if (!table_add(kP, cP, PQ_P_CAP - 1, pr, iC[s], PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
+        if (!table_add(kT, cT, PQ_T_CAP - 1, gt, eC[e], PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
+        if (!table_add(kP, cP, PQ_P_CAP - 1, pr, eC[e], PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
     }
     __syncthreads();
     // ignored segments: target ids whose category is the ignored label (pq.py:89-93)
@@ -509,20 +555,20 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     }
 
     // ---- 2. TP decision per intersection (pq.py:119-153), unordered TP list --------------
-    for (int s = tid; s < PQ_I_CAP; s += PQ_MATCH_THREADS) {
-        const int64_t iid = iK[s];
-        if (iid == KEY_EMPTY || iid == void_segment_id) continue;          // :120-121
+    for (int e = tid; e < nE; e += PQ_MATCH_THREADS) {
+        const int64_t iid = eK[e];
+        if (iid == void_segment_id) continue;                               // :120-121
         const int64_t gt = floordiv64(iid, offset), pr = floormod64(iid, offset);
         const int64_t gcat = floordiv64(gt, max_inst), pcat = floordiv64(pr, max_inst);
         if (gcat != pcat) continue;                                         // :128-129
         // prediction_void_overlap (pq.py:35-44)
         const int64_t vid = (int64_t)((uint64_t)void_segment_id * (uint64_t)offset + (uint64_t)pr);
-        const int sV = table_find(iK, PQ_I_CAP - 1, vid);
-        const int64_t r = sV >= 0 ? (int64_t)iC[sV] : 0;
+        const int sV = table_find(gk, cap - 1, vid);
+        const int64_t r = sV >= 0 ? (int64_t)gc[sV] : 0;
         const int sT = table_find(kT, PQ_T_CAP - 1, gt);
         const int sP = table_find(kP, PQ_P_CAP - 1, pr);
         if (sT < 0 || sP < 0) { st |= ST_MISSING_KEY; continue; }
-        const int64_t ia = iC[s];
+        const int64_t ia = eC[e];
         const int64_t uni = (int64_t)cT[sT] + (int64_t)cP[sP] - ia - r;     // :143
         const double iou = (double)ia / (double)uni;                        // :145
         if (iou > 0.5) {                                                    // :147
@@ -573,9 +619,9 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
         if (k == KEY_EMPTY || fP[s]) continue;
         int64_t pio = 0;                                  // prediction_ignored_overlap :47-57
         for (int q = 0; q < min(n_ign, 64); ++q) {
-            const int sI = table_find(iK, PQ_I_CAP - 1,
+            const int sI = table_find(gk, cap - 1,
                                       (int64_t)((uint64_t)ignKeys[q] * (uint64_t)offset + (uint64_t)k));
-            if (sI >= 0) pio += iC[sI];
+            if (sI >= 0) pio += gc[sI];
         }
         if ((double)pio / (double)cP[s] > 0.5) continue;
         const int64_t cat = floordiv64(k, max_inst);
@@ -597,6 +643,14 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     }
     if (tid == 0 && n_matches) n_matches[b] = nTP;
     if (st) atomicOr(status, st);
+    // leave the image's table empty for the next update (no memset per step): the lookups above
+    // are done once every thread has passed this barrier
+    __syncthreads();
+    if (nEnt > ecap) {                                 // overflowed: the list is incomplete
+        for (int i = tid; i < cap; i += PQ_MATCH_THREADS) { gk[i] = KEY_EMPTY; gc[i] = 0; }
+    } else {
+        for (int e = tid; e < nE; e += PQ_MATCH_THREADS) { gk[eS[e]] = KEY_EMPTY; gc[eS[e]] = 0; }
+    }
 }
 
 __global__ __launch_bounds__(64) void k_pq_accumulate(
@@ -702,10 +756,11 @@ extern "C" int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pr
     return check_launch();
 }
 
-extern "C" size_t nmsa_pq_workspace_bytes(int B, int num_categories)
+extern "C" size_t nmsa_pq_workspace_bytes(int B, int H, int W, int num_categories)
 {
-    if (B <= 0 || num_categories <= 0) return 0;
-    return (size_t)B * pq_image_bytes() + (size_t)B * 4 * num_categories * sizeof(double);
+    if (B <= 0 || H <= 0 || W <= 0 || num_categories <= 0) return 0;
+    return (size_t)B * pq_image_bytes(pq_i_cap((int64_t)H * W)) +
+           (size_t)B * 4 * num_categories * sizeof(double);
 }
 
 namespace {
@@ -734,14 +789,15 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
     if (num_categories <= 0 || num_categories > PQ_MAX_CATEGORIES) return NMSA_ERR_ARG;
     if (max_instances_per_category <= 0 || offset <= 0) return NMSA_ERR_ARG;
     if (matches && (match_capacity <= 0 || !n_matches)) return NMSA_ERR_ARG;
-    if (workspace_bytes < nmsa_pq_workspace_bytes(B, num_categories)) return NMSA_ERR_WORKSPACE;
+    if (workspace_bytes < nmsa_pq_workspace_bytes(B, H, W, num_categories)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
+    const int cap = pq_i_cap(P);
     unsigned char* ws = (unsigned char*)workspace;
-    double* img_state = (double*)(ws + (size_t)B * pq_image_bytes());
+    double* img_state = (double*)(ws + (size_t)B * pq_image_bytes(cap));
 
     int rc;
     if (!workspace_is_clean) {
-        hipLaunchKernelGGL(k_pq_init, dim3(2, B), dim3(256), 0, stream, ws);
+        hipLaunchKernelGGL(k_pq_init, dim3(8, B), dim3(256), 0, stream, ws, cap);
         if ((rc = check_launch())) return rc;
     }
     const int px_per_block = pq_px_per_block();
@@ -750,11 +806,11 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
         int shift = -1;
         if ((cm_div & (cm_div - 1)) == 0) shift = __builtin_ctzll((unsigned long long)cm_div);
         hipLaunchKernelGGL(k_pq_count<true>, grid, dim3(256), (size_t)cm_n * cm_n * sizeof(uint32_t),
-                           stream, pred, target, P, offset, px_per_block, ws, status, target_sem, cm_n,
+                           stream, pred, target, P, offset, px_per_block, ws, cap, status, target_sem, cm_n,
                            cm_div, shift, (uint32_t*)cm_workspace, cm_status);
     } else {
         hipLaunchKernelGGL(k_pq_count<false>, grid, dim3(256), 0, stream, pred, target, P, offset,
-                           px_per_block, ws, status, (const uint8_t*)nullptr, 0, (int64_t)1, -1,
+                           px_per_block, ws, cap, status, (const uint8_t*)nullptr, 0, (int64_t)1, -1,
                            (uint32_t*)nullptr, (int*)nullptr);
     }
     rc = check_launch();
@@ -766,7 +822,7 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
                            (unsigned long long*)confmat);
         if ((rc = check_launch())) return rc;
     }
-    hipLaunchKernelGGL(k_pq_match, dim3(B), dim3(PQ_MATCH_THREADS), 0, stream, ws, num_categories,
+    hipLaunchKernelGGL(k_pq_match, dim3(B), dim3(PQ_MATCH_THREADS), 0, stream, ws, cap, num_categories,
                        ignored_label, max_instances_per_category, offset, void_segment_id,
                        img_state, matches, match_capacity, n_matches, status);
     rc = check_launch();

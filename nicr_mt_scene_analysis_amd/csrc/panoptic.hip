@@ -133,9 +133,14 @@ __device__ __noinline__ float2 column_exact(const void* logits, size_t col0, int
 
 // classes c0 .. c0+3 of the 4 pixels of a lane (WITH_SCORE: one rescale per group, see
 // argmax_state.hpp; otherwise the per-class step)
+// `nclasses` < 4: the last, padded group (planes beyond it hold -inf).  The score path takes the
+// padding as it is (exp(-inf) = 0); the argmax-only path must SKIP it: its finite-tracker
+// `nf += v * 0` would turn NaN on the -inf padding and send every pixel through the exact
+// column re-check (measured 5x on the whole kernel at C = 150).
 template <bool WITH_SCORE>
 __device__ __forceinline__ void argmax_quad(ArgmaxState& st, const float4& a, const float4& b,
-                                            const float4& c, const float4& d, int c0)
+                                            const float4& c, const float4& d, int c0,
+                                            int nclasses = 4)
 {
     if (WITH_SCORE) {
         const float p0[4] = {a.x, b.x, c.x, d.x}, p1[4] = {a.y, b.y, c.y, d.y};
@@ -148,6 +153,7 @@ __device__ __forceinline__ void argmax_quad(ArgmaxState& st, const float4& a, co
         const float4 q[4] = {a, b, c, d};
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
+            if (u >= nclasses) break;                     // wave-uniform
             argmax_step<false>(st, 0, q[u].x, c0 + u);
             argmax_step<false>(st, 1, q[u].y, c0 + u);
             argmax_step<false>(st, 2, q[u].z, c0 + u);
@@ -410,7 +416,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
                     v[u] = (c + u < C)
                         ? load_px4<DTYPE, VEC, NT>(logits, img_logits + (size_t)(c + u) * P + p0, nvalid)
                         : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-                argmax_quad<WITH_SCORE>(st, v[0], v[1], v[2], v[3], c);
+                argmax_quad<WITH_SCORE>(st, v[0], v[1], v[2], v[3], c, min(4, C - c));
             }
         }
         if (FIRST) {                            // fill the LDS tables; the only barrier before the flush
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_argmax(
         for (int u = 0; u < 4; ++u)
             v[u] = (c + u < C) ? load_px4<DTYPE, VEC, true>(logits, img + (size_t)(c + u) * P + p0, nvalid)
                                : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
-        argmax_quad<WITH_SCORE>(st, v[0], v[1], v[2], v[3], c);
+        argmax_quad<WITH_SCORE>(st, v[0], v[1], v[2], v[3], c, min(4, C - c));
     }
     int cls[4];
     float sc[4];

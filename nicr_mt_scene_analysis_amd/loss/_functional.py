@@ -213,13 +213,20 @@ class CosineEmbeddingLutFunction(torch.autograd.Function):
         s, n = _scalar_outputs(dev)
         status = _status_word(dev)
         ws, nbytes = _workspace(B, H, W, dev)
+        # x.y and |x|^2 per pixel for the backward pass (8 B/px instead of a second read of the
+        # 2D B/px prediction), only when a gradient can be asked for
+        dots = None
+        if ctx.needs_input_grad[0] and x.data_ptr() % 16 == 0 and \
+                L.lib().nmsa_loss_cos_emb_can_keep_dots(D, H, W, Lr):
+            dots = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
         L.check(L.lib().nmsa_loss_cos_emb_fwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(idx), L.ptr(lt), B, D, H, W, Lr,
-            L.ptr(s), L.ptr(n), L.ptr(status), L.ptr(ws), nbytes, L.stream_ptr(dev)),
-            'nmsa_loss_cos_emb_fwd')
+            L.ptr(s), L.ptr(n), L.ptr(dots), L.ptr(status), L.ptr(ws), nbytes,
+            L.stream_ptr(dev)), 'nmsa_loss_cos_emb_fwd')
         if _CHECK_EVERY_CALL:
             check_loss_status()
-        ctx.save_for_backward(x, idx, lt)
+        ctx.save_for_backward(x, idx, lt, dots if dots is not None else torch.empty(0, device=dev))
+        ctx.has_dots = dots is not None
         loss = s[0].to(torch.float32)
         n_el = n[0]
         ctx.mark_non_differentiable(n_el)
@@ -227,13 +234,14 @@ class CosineEmbeddingLutFunction(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, g_n):
-        x, idx, lt = ctx.saved_tensors
+        x, idx, lt, dots = ctx.saved_tensors
         B, D, H, W = x.shape
         grad = torch.empty_like(x)
         gs = _grad_scale(g_loss)
         L.check(L.lib().nmsa_loss_cos_emb_bwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(idx), L.ptr(lt), B, D, H, W, lt.shape[1],
-            L.ptr(gs), L.ptr(grad), L.stream_ptr(x.device)), 'nmsa_loss_cos_emb_bwd')
+            L.ptr(gs), L.ptr(dots) if ctx.has_dots and grad.data_ptr() % 16 == 0 else None,
+            L.ptr(grad), L.stream_ptr(x.device)), 'nmsa_loss_cos_emb_bwd')
         return grad, None, None
 
 

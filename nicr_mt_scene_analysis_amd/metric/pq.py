@@ -17,7 +17,7 @@ from .base import Metric
 _EPSILON = 1e-10
 _STATUS_MESSAGES = {
     1: 'more distinct segments / intersections per image than the device tables hold '
-       '(2048 ids per side, 4096 intersections)',
+       '(2048 ids per side; intersections: H*W/96 rounded up to a power of two, at least 2048)',
     2: 'segment category outside [0, num_categories) (the reference raises IndexError)',
     4: 'inconsistent segment ids: intersection id decodes to an unknown segment '
        '(offset too small? the reference raises KeyError)',
@@ -82,10 +82,10 @@ class PanopticQuality(Metric):
         t = targets.to(dev, dtype=torch.int64).contiguous()
         B, H, W = p.shape
         lib = L.lib()
-        ws_bytes = lib.nmsa_pq_workspace_bytes(B, self.num_categories)
+        ws_bytes = lib.nmsa_pq_workspace_bytes(B, H, W, self.num_categories)
         # persistent workspace per (batch size, stream): a completed update leaves the hash
         # tables empty, so only the first use pays for the initialisation
-        ws_key = (B, torch.cuda.current_stream(dev).cuda_stream)
+        ws_key = (B, H, W, torch.cuda.current_stream(dev).cuda_stream)
         ws = self._workspaces.get(ws_key)
         clean = ws is not None
         if ws is None:

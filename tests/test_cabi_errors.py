@@ -95,7 +95,7 @@ def test_bad_arguments_return_codes(env):
     assert confmat(n_classes=0) == ERR_ARG
     assert confmat(ws_bytes=8) == ERR_WORKSPACE
 
-    ws_pq = lib.nmsa_pq_workspace_bytes(B, C)
+    ws_pq = lib.nmsa_pq_workspace_bytes(B, H, W, C)
     pq_ws = torch.zeros((ws_pq,), dtype=torch.uint8, device=dev)
 
     def pq(num_categories=C, ws_bytes=ws_pq, offset=256 ** 3):

@@ -235,6 +235,54 @@ def test_pq_full_size_vs_oracle(oracle):
 
 
 @gpu
+def test_pq_many_intersections_cfg5_shape(oracle):
+    """configs[4] shape: 1024x768 maps with 151 categories made of 16-px blocks -> ~6000 distinct
+    (target, pred) intersections per image (the round-1 tables held 4096).  States bit-exact
+    vs the oracle, twice (the second update runs on the tables the first one left clean)."""
+    from nicr_mt_scene_analysis_amd import metric
+    rng = np.random.default_rng(11)
+    H, W, ncat, B = 768, 1024, 151, 2
+    cls = np.repeat(np.repeat(rng.integers(0, ncat, (B, H // 16, W // 16)), 16, 1), 16, 2)
+    ins = np.repeat(np.repeat(rng.integers(0, 3, (B, H // 32, W // 32)), 32, 1), 32, 2)
+    pred = (cls * 65536 + ins * (cls >= 75)).astype(np.int64)
+    tgt = np.roll(pred, (5, 7), axis=(1, 2))
+    tgt[:, :11] = 0
+    n_int = len(np.unique(tgt[0] * 256 ** 3 + pred[0]))
+    assert 4096 < n_int <= 8192, n_int
+    pq = metric.PanopticQuality(ncat, 0, 65536, 256 ** 3, [c >= 75 for c in range(ncat)])
+    state = None
+    for rep in range(2):
+        pq.update(torch.from_numpy(pred), torch.from_numpy(tgt))
+        for b in range(B):
+            *state, _ = oracle.pq_compare_and_accumulate(pred[b], tgt[b], ncat, 0, 65536, 256 ** 3,
+                                                         state=state)
+        got = np.stack([getattr(pq, n).cpu().numpy() for n in
+                        ('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class')])
+        assert (got == np.stack(state)).all(), rep
+    pq.compute()
+
+
+@gpu
+def test_pq_table_overflow_is_reported_and_tables_recover():
+    """per-pixel noise: more distinct intersections than the image's table holds -> ValueError
+    at compute(); the next update on the same workspace is correct again"""
+    from nicr_mt_scene_analysis_amd import metric
+    rng = np.random.default_rng(3)
+    H, W, ncat = 96, 128, 5
+    pq = metric.PanopticQuality(ncat, 0, 65536, 256 ** 3, [False, False, True, True, True])
+    noise = (rng.integers(2, 5, (1, H, W)) * 65536 + rng.integers(0, 2000, (1, H, W))).astype(np.int64)
+    pq.update(torch.from_numpy(noise), torch.from_numpy(np.roll(noise, 1, 2)))
+    with pytest.raises(ValueError, match='more distinct segments'):
+        pq.compute()
+    pq.reset()
+    # the overflowed update left the workspace clean: a small update on it is exact again
+    small = (rng.integers(0, 5, (1, H // 8, W // 8)).repeat(8, 1).repeat(8, 2) * 65536).astype(np.int64)
+    pq.update(torch.from_numpy(small), torch.from_numpy(small))
+    r = pq.compute()
+    assert float(r['all_pq']) == 1.0
+
+
+@gpu
 def test_pq_error_reporting():
     from nicr_mt_scene_analysis_amd import metric
     pq = metric.PanopticQuality(2, 0, 16, 256, [False, True])

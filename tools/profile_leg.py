@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""One leg of bench.py's `secondary` object in a loop, for rocprofv3:
+
+    rocprofv3 --kernel-trace --stats -d out -o leg -- python3 tools/profile_leg.py cfg5_bf16 [reps]
+
+legs: cfg2_f32 cfg2_bf16 cfg5_f32 cfg5_bf16 (pipeline + metric updates), cfg3_losses,
+cos512, cos768"""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench                                                         # noqa: E402
+from nicr_mt_scene_analysis_amd import ops                           # noqa: E402
+from nicr_mt_scene_analysis_amd.testing import synthetic as syn      # noqa: E402
+
+leg = sys.argv[1] if len(sys.argv) > 1 else 'cfg5_bf16'
+dev = torch.device('cuda', 0)
+torch.cuda.set_device(dev)
+shapes = {'cfg2': (32, 40, 480, 640, 24), 'cfg5': (8, 150, 768, 1024, 48)}
+if leg[:4] in shapes:
+    dt = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[leg[5:]]
+    out = bench.secondary_pipeline(ops, syn, dev, *shapes[leg[:4]], dt)
+elif leg == 'cfg3_losses':
+    out = bench.secondary_losses(dev)
+elif leg in ('cos512', 'cos768'):
+    out = bench.secondary_cos_emb(dev, D=int(leg[3:]))
+else:
+    raise SystemExit(f'unknown leg {leg}')
+print(out)
