@@ -364,8 +364,8 @@ int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pred_div,
  *   status       : i32 [1] device word, OR-ed with NMSA_ST_* bits
  *   limits       : <= 2048 distinct ids per image and side, num_categories <= 1024;
  *                  distinct (target, pred) intersections per image <= cap / 2 with
- *                  cap = H*W / 48 rounded up to a power of two in [4096, 65536]
- *                  (640x480: 4096 intersections, 1024x768: 8192); beyond that
+ *                  cap = H*W / 24 rounded up to a power of two in [4096, 131072]
+ *                  (640x480: 8192 intersections, 1024x768: 16384); beyond that
  *                  NMSA_ST_TABLE_OVERFLOW is raised
  *   workspace_is_clean : non-zero when `workspace` was last used by a completed
  *                  nmsa_pq_update of the same B, H, W (which leaves the tables empty); the

@@ -195,18 +195,18 @@ constexpr int64_t KEY_EMPTY = INT64_MIN;
 constexpr int PQ_T_CAP = 2048;      // distinct target ids / image      (LDS, k_pq_match)
 constexpr int PQ_P_CAP = 2048;      // distinct predicted ids / image   (LDS, k_pq_match)
 constexpr int PQ_I_CAP_MIN = 4096;  // slots of the per-image intersection table: a power of two
-constexpr int PQ_I_CAP_MAX = 65536; //   chosen from the image size (pq_i_cap), kept <= half full
+constexpr int PQ_I_CAP_MAX = 131072; //   chosen from the image size (pq_i_cap), kept <= half full
 constexpr int PQ_LI = 1024;         // LDS-privatised intersection table per block
 
 // Slots of the per-image (target, pred) intersection table.  Distinct intersections grow with
-// the total segment boundary length, i.e. with the image size: one slot per 48 px, rounded up
-// to a power of two (640x480 -> 8192, 1024x768 -> 16384; blobby synthetic maps with 150
-// classes hold ~8000 intersections at 1024x768, real label maps a few hundred).  More than
+// the total segment boundary length, i.e. with the image size: one slot per 24 px, rounded up
+// to a power of two (640x480 -> 16384, 1024x768 -> 32768; blobby synthetic maps with 150
+// classes hold ~8500 intersections at 1024x768, real label maps a few hundred).  More than
 // cap/2 distinct intersections in one image raise ST_TABLE_OVERFLOW.
 __host__ __device__ inline int pq_i_cap(int64_t P)
 {
     int cap = PQ_I_CAP_MIN;
-    while (cap < PQ_I_CAP_MAX && (int64_t)cap * 48 < P) cap <<= 1;
+    while (cap < PQ_I_CAP_MAX && (int64_t)cap * 24 < P) cap <<= 1;
     return cap;
 }
 

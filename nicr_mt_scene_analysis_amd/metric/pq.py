@@ -17,7 +17,7 @@ from .base import Metric
 _EPSILON = 1e-10
 _STATUS_MESSAGES = {
     1: 'more distinct segments / intersections per image than the device tables hold '
-       '(2048 ids per side; intersections: H*W/96 rounded up to a power of two, at least 2048)',
+       '(2048 ids per side; intersections: H*W/48 rounded up to a power of two, at least 2048)',
     2: 'segment category outside [0, num_categories) (the reference raises IndexError)',
     4: 'inconsistent segment ids: intersection id decodes to an unknown segment '
        '(offset too small? the reference raises KeyError)',

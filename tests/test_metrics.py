@@ -236,7 +236,7 @@ def test_pq_full_size_vs_oracle(oracle):
 
 @gpu
 def test_pq_many_intersections_cfg5_shape(oracle):
-    """configs[4] shape: 1024x768 maps with 151 categories made of 16-px blocks -> ~6000 distinct
+    """configs[4] shape: 1024x768 maps with 151 categories made of 16-px blocks -> ~8500 distinct
     (target, pred) intersections per image (the round-1 tables held 4096).  States bit-exact
     vs the oracle, twice (the second update runs on the tables the first one left clean)."""
     from nicr_mt_scene_analysis_amd import metric
@@ -248,7 +248,7 @@ def test_pq_many_intersections_cfg5_shape(oracle):
     tgt = np.roll(pred, (5, 7), axis=(1, 2))
     tgt[:, :11] = 0
     n_int = len(np.unique(tgt[0] * 256 ** 3 + pred[0]))
-    assert 4096 < n_int <= 8192, n_int
+    assert 4096 < n_int <= 16384, n_int
     pq = metric.PanopticQuality(ncat, 0, 65536, 256 ** 3, [c >= 75 for c in range(ncat)])
     state = None
     for rep in range(2):
