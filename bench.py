@@ -389,7 +389,8 @@ def main():
         from tools import bench_support
         metrics = bench_support.MetricAccumulators(C + 1, dev, inp, rank, world_size=world,
                                                    side_stream=not args.no_side_stream,
-                                                   sync_every_step=args.metric_sync == 'step')
+                                                   sync_every_step=args.metric_sync == 'step',
+                                                   exercise_collective=launched)
 
     events = []
     # consecutive batches are independent: they alternate over `--streams` HIP streams so that

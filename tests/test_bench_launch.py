@@ -1,0 +1,62 @@
+"""
+GPU tier: the launch shapes of bench.py (contract: `python bench.py --gpus N` and the same
+under torch.distributed.run must both work).
+
+* `python bench.py --gpus 2` WITHOUT a launcher starts two ranks itself (here over gloo, both
+  ranks sharing the one GPU of the test box: RCCL refuses shared devices) and prints one JSON
+  line for the whole job;
+* under torch.distributed.run with one rank the collective leg runs on RCCL: process group
+  'nccl' with device_id, an actual all-reduce (`rccl_ranks`), the packed accumulator
+  all-reduce on the metric side stream.
+"""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ['--steps', '3', '--warmup', '2', '--batch-per-gpu', '2', '--height', '96', '--width', '128',
+         '--classes', '8', '--centers', '4', '--no-secondary', '--no-cpu-baseline']
+
+
+def _json_line(stdout):
+    lines = [ln for ln in stdout.splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_self_launches_two_ranks():
+    env = dict(os.environ, NMSA_BENCH_BACKEND='gloo')
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['scaling'] == 'weak'
+    assert d['collective']['backend'] == 'gloo' and d['collective']['payload_bytes'] > 0
+    assert d['value'] > 0 and d['cpu_baseline'] is None
+
+
+def test_bench_under_launcher_runs_the_rccl_leg():
+    env = dict(os.environ)
+    env.pop('NMSA_BENCH_BACKEND', None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                        '--nproc-per-node=1', '--master-addr', '127.0.0.1', '--master-port', '29533',
+                        os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + SMALL,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    assert d['collective'] == {'backend': 'rccl', 'rccl_ranks': 1,
+                               'payload_bytes': d['collective']['payload_bytes']}
+    assert d['collective']['payload_bytes'] == (9 * 9 + 4 * 9) * 8
+
+
+def test_bench_rejects_a_world_size_mismatch():
+    env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL,
+                       env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)

@@ -22,12 +22,17 @@ from nicr_mt_scene_analysis_amd.metric.pq import PanopticQuality
 class MetricAccumulators:
     def __init__(self, n_classes_with_void: int, device, inputs, rank: int = 0,
                  max_instances_per_category: int = 1 << 16, world_size: int = 1,
-                 side_stream: bool = True, sync_every_step: bool = True) -> None:
+                 side_stream: bool = True, sync_every_step: bool = True,
+                 exercise_collective: bool = False) -> None:
         """sync_every_step=False: ranks accumulate locally and `finalize()` sums the totals
         over the ranks ONCE — the torchmetrics behaviour of the reference (`dist_reduce_fx`
         is applied by `compute()`, metric/miou.py:21-25)."""
         self.max_inst = max_instances_per_category
         self.fused_metrics = not __import__('os').environ.get('NMSA_BENCH_SEPARATE_METRICS')
+        # exercise_collective: take the multi-rank code path (pack, all-reduce, unpack) also in
+        # a 1-rank process group — how a 1-GPU box rehearses the RCCL leg of `bench.py --gpus N`
+        if exercise_collective:
+            world_size = max(world_size, 2)
         self.reduce_world = world_size
         self.world_size = world_size if sync_every_step else 1      # per-step behaviour
         n = n_classes_with_void
