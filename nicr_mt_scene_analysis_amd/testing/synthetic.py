@@ -214,6 +214,67 @@ def make_embedding_inputs(batch_size: int, embedding_dim: int, height: int, widt
             'embedding_indices': idx.astype(np.int32)}
 
 
+def make_training_case(batch_size=2, n_classes=9, height=64, width=96, seed=0,
+                       embedding_dim=16, n_lut=9, scales=(2, 4)):
+    """One training batch for the task helpers (numpy): main output + side outputs at `scales`
+    (every s-th pixel of the main prediction, scaled by 0.9) and the targets of the matching
+    resolutions under the '_down_<s>' batch keys.  -> (batch, preds); per-image LUTs have
+    different row counts (not stackable, like the reference's batches)."""
+    d = make_loss_inputs(batch_size, n_classes, height, width, seed=seed,
+                         embedding_dim=embedding_dim, n_lut=n_lut)
+    rng = np.random.default_rng(seed + 3000)
+    rows = [int(r) for r in rng.integers(max(n_lut // 2, 1), n_lut + 1, size=batch_size)]
+    idx = d['embedding_indices'].copy()
+    for b, r in enumerate(rows):
+        idx[b][idx[b] > r] = 0                           # indices beyond the image's rows: no target
+    batch = {
+        'semantic': d['semantic_target'], 'instance_center': d['center_target'],
+        'instance_center_mask': d['center_mask'], 'instance_offset': d['offset_target'],
+        'instance_foreground': d['offset_mask'], 'orientation': d['orientation_target'],
+        'orientation_foreground': d['orientation_mask'],
+        'dense_visual_embedding_indices': idx,
+    }
+
+    def down(a, s):
+        return np.ascontiguousarray(a[..., ::s, ::s])
+    for s in scales:
+        batch[f'_down_{s}'] = {k: down(v, s) for k, v in batch.items() if isinstance(v, np.ndarray)}
+    luts = [np.ascontiguousarray(d['embedding_lut'][b, :r]) for b, r in enumerate(rows)]
+    batch['dense_visual_embedding_lut'] = luts
+    for s in scales:
+        batch[f'_down_{s}']['dense_visual_embedding_lut'] = luts
+    main = (d['center_pred'][:, None], d['offset_pred'], d['orientation_pred'])
+    f32 = np.float32
+    preds = {
+        'semantic_output': d['semantic_logits'],
+        'semantic_side_outputs': tuple((down(d['semantic_logits'], s) * f32(0.9)) for s in scales),
+        'instance_output': main,
+        'instance_side_outputs': tuple(tuple(down(x, s) * f32(0.9) for x in main) for s in scales),
+        'dense_visual_embedding_output': d['embedding_pred'],
+        'dense_visual_embedding_side_outputs': tuple(down(d['embedding_pred'], s) * f32(0.9)
+                                                     for s in scales),
+    }
+    return batch, preds, d['class_weights']
+
+
+def make_predictions_from_targets(semantic, center, offset, orientation, n_classes, seed=0):
+    """Network-like outputs that mostly agree with the ground truth (so that validation metrics
+    are neither 0 nor 1): logits = 3 * onehot(label - 1) + N(0, 1) (void pixels: pure noise),
+    center / offset / orientation = target + noise.  numpy only, float32 results."""
+    rng = np.random.default_rng(seed + 5000)
+    B, H, W = semantic.shape
+    logits = rng.standard_normal((B, n_classes, H, W))
+    lab = semantic.astype(np.int64) - 1
+    onehot = (np.arange(n_classes)[None, :, None, None] == lab[:, None]).astype(np.float64)
+    logits = logits + 3.0 * onehot
+    c = np.clip(center + 0.03 * rng.standard_normal(center.shape), 0.0, 1.0)
+    o = offset + 0.004 * rng.standard_normal(offset.shape)
+    q = orientation.astype(np.float64) + 0.25 * rng.standard_normal(orientation.shape)
+    q = q / (np.sqrt((q * q).sum(axis=1, keepdims=True)) + 1e-7)
+    return (logits.astype(np.float32), c.astype(np.float32)[:, None], o.astype(np.float32),
+            q.astype(np.float32))
+
+
 def make_label_maps(batch_size, n_classes=41, height=480, width=640, n_instances=30, seed=0,
                     max_id=65535, mixed_fraction=0.3, max_radius=None):
     """Ground-truth style label maps for the target generators.

@@ -12,6 +12,7 @@ oracle/ref_loader.py) on seeded inputs.
 import json
 import os
 import sys
+import types
 
 import numpy as np
 import torch
@@ -547,6 +548,77 @@ def gen_losses(ref):
     save('loss_cases', **out)
 
 
+def gen_argmax_ties(ref):
+    """a1 boundary: the reference takes max(softmax(x)) (model/postprocessing/semantic.py:52-53),
+    the kernels take argmax(x).  Adversarial columns: classes c1 < c2 with x[c2] = x[c1] + k ulp,
+    every other class at least 1 below, |x| from 1e-3 to 16, C = 40, f32.  Stored: the columns,
+    the reference's `semantic_segmentation_idx`, delta = x[c2] - x[c1].  Also the natural rate:
+    the reference vs argmax(x) on 8.4 Mpx of the bench's blobby logits and on 8.4 Mpx of
+    small-magnitude logits (|x| < 0.3, where adjacent floats are < 2^-25 apart)."""
+    print('a1: max(softmax(x)) vs argmax(x) on adversarial near-tie columns')
+    post = ref.post_semantic.SemanticPostprocessing()
+    rng = np.random.default_rng(0)
+    C = 40
+    cols, c1s, c2s = [], [], []
+    for mag in (1e-3, 1e-2, 0.1, 0.25, 0.5, 1, 2, 4, 8, 16):
+        for k in (1, 2, 3, 4, 8, 16, 64):
+            for sign in (1, -1):
+                for _ in range(12):
+                    a = np.float32(sign * mag * (1 + rng.random() * 0.5))
+                    x = np.minimum((rng.standard_normal(C) * 0.5 - 3).astype(np.float32),
+                                   a - np.float32(1.0)).astype(np.float32)
+                    c1, c2 = sorted(rng.choice(C, 2, replace=False))
+                    b = a
+                    for _ in range(k):
+                        b = np.nextafter(b, np.float32(np.inf))
+                    x[c1], x[c2] = a, b
+                    cols.append(x)
+                    c1s.append(c1)
+                    c2s.append(c2)
+    N = len(cols)
+    W = 40
+    assert N % W == 0
+    logits = np.stack(cols).T.reshape(1, C, N // W, W).copy()
+    r = post.postprocess((torch.from_numpy(logits), None),
+                         make_batch(ref, 1, N // W, W), is_training=False)
+    ref_idx = r['semantic_segmentation_idx'].numpy().astype(np.uint8)
+    c1s, c2s = np.array(c1s, np.uint8), np.array(c2s, np.uint8)
+    delta = np.array([float(c[j]) - float(c[i]) for c, i, j in zip(cols, c1s, c2s)])
+    flat = ref_idx.reshape(-1)
+    assert ((flat == c1s) | (flat == c2s)).all()
+    for lo, hi in ((0, 2 ** -25), (2 ** -25, 2 ** -23), (2 ** -23, 1)):
+        m = (delta > lo) & (delta <= hi)
+        print(f'  delta in ({lo:.3g}, {hi:.3g}]: {m.sum()} columns, reference returns the LOWER '
+              f'index in {(flat[m] == c1s[m]).sum()}')
+
+    # natural rate on continuous logits (counts only; the tensors are not stored)
+    def rate(make, n_img):
+        n_px = n_diff = 0
+        for s in range(n_img):
+            x = make(s)
+            pr = post.postprocess((x, None), make_batch(ref, x.shape[0], *x.shape[-2:]),
+                                  is_training=False)['semantic_segmentation_idx']
+            n_diff += int((pr != x.argmax(dim=1)).sum())
+            n_px += pr.numel()
+        return n_px, n_diff
+
+    def blobby(seed):
+        g = torch.Generator().manual_seed(seed)
+        coarse = torch.randn((4, C, 15, 20), generator=g)
+        return 4.0 * torch.nn.functional.interpolate(coarse, size=(480, 640), mode='bilinear',
+                                                     align_corners=False)
+
+    def small(seed):
+        g = torch.Generator().manual_seed(100 + seed)
+        return (torch.rand((4, C, 480, 640), generator=g) - 0.5) * 0.6
+    nb = rate(blobby, 7)
+    ns = rate(small, 7)
+    print(f'  natural rate: blobby logits {nb[1]} of {nb[0]} px differ; |x| < 0.3 logits '
+          f'{ns[1]} of {ns[0]} px differ')
+    save('argmax_ties', logits=logits, ref_idx=ref_idx, c1=c1s, c2=c2s, delta=delta,
+         natural_blobby=np.array(nb, np.int64), natural_small=np.array(ns, np.int64))
+
+
 COS_LARGE_CASES = (
     # name, B, D, H, W, L, bf16      (kernel path on the GPU, csrc/losses.hip::cos_chunk)
     ('d512_l64', 2, 512, 24, 32, 64, False),       # one LDS chunk of 131 KB
@@ -903,6 +975,163 @@ def gen_instance_post(ref):
     save('instance_post_cases', **out)
 
 
+def _to_torch(x):
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(x))
+    if isinstance(x, dict):
+        return {k: _to_torch(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_torch(v) for v in x)
+    return x
+
+
+def _scalars(d):
+    """ordered dict of 0-d tensors / numbers -> (key list, float64 values)"""
+    keys = list(d.keys())
+    return jdump(keys), np.array([float(d[k]) for k in keys], np.float64)
+
+
+VALIDATION_CASE = dict(B=3, C=8, H=64, W=96, n_instances=8, seed=4, max_radius=24, sigma=8)
+
+
+def build_validation_case(ref):
+    """ground truth through the reference's own target generators (per sample, numpy), then
+    network-like predictions derived from it; everything as numpy (stored in the golden)"""
+    c = VALIDATION_CASE
+    B, C, H, W, NC = c['B'], c['C'], c['H'], c['W'], c['C'] + 1
+    maps = syn.make_label_maps(B, NC, H, W, n_instances=c['n_instances'], seed=c['seed'],
+                               max_radius=c['max_radius'])
+    is_thing = tuple(bool(x) for x in maps['semantic_classes_is_thing'])        # incl. void
+    clear = ref.prep_instance.InstanceClearStuffIDs(semantic_classes_is_thing=is_thing)
+    igen = ref.prep_instance.InstanceTargetGenerator(sigma=c['sigma'], semantic_classes_is_thing=is_thing)
+    pgen = ref.prep_panoptic.PanopticTargetGenerator(semantic_classes_is_thing=is_thing)
+    ogen = ref.prep_orientation.OrientationTargetGenerator(semantic_classes_estimate_orientation=is_thing)
+    rng = np.random.default_rng(77)
+    out = {k: [] for k in ('instance', 'instance_center', 'instance_center_mask', 'instance_offset',
+                           'instance_foreground', 'panoptic', 'orientation', 'orientation_foreground')}
+    pan_ids, ori_present = [], []
+    for b in range(B):
+        smp = clear({'semantic': maps['semantic'][b].copy(),
+                     'instance': maps['instance'][b].astype(np.uint16)})
+        ids = [int(i) for i in np.unique(smp['instance']) if i != 0]
+        smp['orientations'] = {i: float(rng.random() * 2 * np.pi) for i in ids if rng.random() < 0.8}
+        smp = ogen(igen(pgen(smp)))
+        out['instance'].append(smp['instance'].astype(np.int32))
+        out['instance_center'].append(smp['instance_center'])
+        out['instance_center_mask'].append(smp['instance_center_mask'])
+        out['instance_offset'].append(np.moveaxis(smp['instance_offset'], -1, 0))
+        out['instance_foreground'].append(smp['instance_foreground'])
+        out['panoptic'].append(smp['panoptic'].astype(np.int64))
+        out['orientation'].append(np.moveaxis(smp['orientation'], -1, 0))
+        out['orientation_foreground'].append(smp['orientation_foreground'])
+        pan_ids.append({int(k): int(v) for k, v in smp['panoptic_ids_to_instance_dict'].items()})
+        ori_present.append({int(k): float(v) for k, v in smp['orientations_present'].items()})
+    gt = {k: np.ascontiguousarray(np.stack(v)) for k, v in out.items()}
+    gt['semantic'] = maps['semantic']
+    return gt, pan_ids, ori_present, is_thing
+
+
+def gen_task_helpers(ref_unused):
+    """a10 / a14: the reference's task helpers themselves (task_helper/{semantic,instance,
+    panoptic,dense_visual_embedding}.py) — loss dicts of a training step with main + 2 side
+    outputs, and two validation steps + validation_epoch_end through the reference's
+    postprocessing.  Stored: every key in order and every value."""
+    from oracle.ref_loader import load_reference as _load
+    ref = _load(task_helpers=True)
+    print('task helpers (reference training_step / validation_step / validation_epoch_end)')
+    cpu = torch.device('cpu')
+    out = {}
+
+    # ---- training: loss dicts ----------------------------------------------------------------
+    batch_np, preds_np, weights = syn.make_training_case()
+    out['train__digest'] = jdump(syn.input_digest(
+        preds_np['semantic_output'], preds_np['instance_output'][1],
+        preds_np['dense_visual_embedding_output'], batch_np['semantic'],
+        batch_np['dense_visual_embedding_indices']))
+    batch, preds = _to_torch(batch_np), _to_torch(preds_np)
+    C = preds_np['semantic_output'].shape[1]
+    is_thing = (False,) * (C // 2 + 1) + (True,) * (C - C // 2)
+    cases = {
+        'sem_plain': ref.th_semantic.SemanticTaskHelper(n_classes=C),
+        'sem_weighted_smooth': ref.th_semantic.SemanticTaskHelper(
+            n_classes=C, class_weights=weights, label_smoothing=0.1),
+        'sem_single_scale': ref.th_semantic.SemanticTaskHelper(
+            n_classes=C, disable_multiscale_supervision=True),
+        'ins_mse': ref.th_instance.InstanceTaskHelper(C + 1, is_thing),
+        'ins_l1': ref.th_instance.InstanceTaskHelper(C + 1, is_thing, loss_name_instance_center='l1'),
+        'dve_cos': ref.th_dve.DenseVisualEmbeddingTaskHelper(n_classes=C, loss_name='cos_emb'),
+    }
+    for name, helper in cases.items():
+        helper.initialize(cpu)
+        losses, logs = helper.training_step(batch, 0, preds)
+        out[f'train__{name}__keys'], out[f'train__{name}__values'] = _scalars(losses)
+        out[f'train__{name}__log_keys'] = jdump(sorted(logs.keys()))
+        print(f'  {name}: {len(losses)} losses, total '
+              f'{[round(float(v), 6) for k, v in losses.items() if k.endswith("total_loss")]}')
+    # instance helper without an orientation head (2-tuple outputs)
+    preds2 = dict(preds, instance_output=preds['instance_output'][:2],
+                  instance_side_outputs=tuple(p[:2] for p in preds['instance_side_outputs']))
+    helper = ref.th_instance.InstanceTaskHelper(C + 1, is_thing)
+    helper.initialize(cpu)
+    losses, _ = helper.training_step(batch, 0, preds2)
+    out['train__ins_no_orientation__keys'], out['train__ins_no_orientation__values'] = _scalars(losses)
+
+    # ---- validation: postprocessing -> helpers -> epoch end ----------------------------------------
+    c = VALIDATION_CASE
+    B, C, H, W = c['B'], c['C'], c['H'], c['W']
+    gt, pan_ids, ori_present, is_thing_nc = build_validation_case(ref)
+    for k, v in gt.items():
+        out[f'val__gt_{k}'] = v
+    n, kk, vv = ids_to_arrays(pan_ids, cap=64)
+    out.update(val__pan_ids_n=n, val__pan_ids_pan=kk, val__pan_ids_ins=vv)
+    out['val__orientations_present'] = jdump([{str(k): v for k, v in d.items()} for d in ori_present])
+    out['val__is_thing_with_void'] = np.array(is_thing_nc)
+    is_thing_c = is_thing_nc[1:]
+    post = ref.post_panoptic.PanopticPostprocessing(
+        semantic_postprocessing=ref.post_semantic.SemanticPostprocessing(),
+        instance_postprocessing=ref.post_instance.InstancePostprocessing(),
+        semantic_classes_is_thing=is_thing_c, semantic_class_has_orientation=is_thing_c)
+    batch = _to_torch(gt)
+    for k in ('semantic', 'instance', 'panoptic'):
+        batch[f'{k}_fullres'] = batch[k]
+    batch['panoptic_ids_to_instance_dict'] = pan_ids
+    batch['orientations_present'] = ori_present
+    batch.update(make_batch(ref, B, H, W))
+    label_list = types.SimpleNamespace(colors=None, classes_is_thing=is_thing_nc, colors_array=None)
+    sem = ref.th_semantic.SemanticTaskHelper(n_classes=C)
+    ins = ref.th_instance.InstanceTaskHelper(C + 1, is_thing_nc)
+    pan = ref.th_panoptic.PanopticTaskHelper(C + 1, is_thing_nc, label_list)
+    for h in (sem, ins, pan):
+        h.initialize(cpu)
+    digests = []
+    for step in range(2):
+        logits, center, offset, ori = syn.make_predictions_from_targets(
+            gt['semantic'], gt['instance_center'], gt['instance_offset'], gt['orientation'], C,
+            seed=step)
+        digests.append(syn.input_digest(logits, center, offset, ori))
+        data = ((torch.from_numpy(logits), (torch.from_numpy(center), torch.from_numpy(offset),
+                                            torch.from_numpy(ori))), ((None, None), (None, None)))
+        r = post.postprocess(data, batch, is_training=False)     # eval mode: side outputs are None
+        if step == 0:
+            out['val__pred_panoptic_step0'] = r['panoptic_segmentation_deeplab_fullres'].numpy()
+        for name, h in (('sem', sem), ('ins', ins), ('pan', pan)):
+            losses, logs = h.validation_step(batch, step, r)
+            out[f'val__{name}__step{step}__loss_keys'], out[f'val__{name}__step{step}__loss_values'] = \
+                _scalars(losses)
+            out[f'val__{name}__step{step}__log_keys'] = jdump(sorted(logs.keys()))
+    out['val__pred_digests'] = jdump(digests)
+    for name, h in (('sem', sem), ('ins', ins), ('pan', pan)):
+        artifacts, examples, logs = h.validation_epoch_end()
+        scal = {k: v for k, v in logs.items() if k.endswith('_time') is False}
+        out[f'val__{name}__log_keys'], out[f'val__{name}__log_values'] = _scalars(scal)
+        out[f'val__{name}__artifact_keys'] = jdump(list(artifacts.keys()))
+        for k, v in artifacts.items():
+            out[f'val__{name}__artifact__{k}'] = v.numpy()
+        print(f'  validation {name}: ' + ', '.join(f'{k}={float(v):.5f}' for k, v in scal.items()
+                                                   if 'pq' in k or 'miou' in k or 'mae' in k)[:300])
+    save('task_helper_cases', **out)
+
+
 def main():
     ref = load_reference()
     only = set(sys.argv[1:])
@@ -925,6 +1154,8 @@ def main():
         gen_metrics(ref)
     if want('losses'):
         gen_losses(ref)
+    if want('argmax_ties'):
+        gen_argmax_ties(ref)
     if want('cos_emb_large'):
         gen_cos_emb_large(ref)
     if want('orientation'):
@@ -937,6 +1168,8 @@ def main():
         gen_instance_post(ref)
     if want('targets'):
         gen_targets(ref)
+    if want('task_helpers'):
+        gen_task_helpers(ref)
 
 
 if __name__ == '__main__':

@@ -18,6 +18,15 @@ Two third-party stand-ins are provided (they are NOT reference code):
                      the hot path never reaches),
   * `torchmetrics` : a 15-line `Metric` (nn.Module + add_state/reset), the only
                      thing `metric/miou.py` and `metric/pq.py` use from it.
+For the task helpers (`load_reference(task_helpers=True)`) two more things are replaced by
+no-ops, neither of which is on the path under test:
+  * the reference's `visualization` sub-package (PIL / matplotlib colourisers the helpers call
+    for the FIRST validation batch to build example images; needs matplotlib + fonts):
+    functions that return None,
+  * `torch.multiprocessing`'s spawn pool inside `metric/pq.py` (its workers would have to
+    re-import the module by name, which only exists in this process): an in-process
+    executor, so `PanopticQuality.update` runs the reference's own `compare_and_accumulate`
+    synchronously and adds the per-image vectors in image order exactly as pq.py:291-296.
 """
 import importlib.util
 import os
@@ -90,6 +99,7 @@ def _install_third_party_standins() -> None:
         ds.__path__ = []
         base = types.ModuleType('nicr_scene_analysis_datasets.dataset_base')
         base.OrientationDict = dict
+        base.SemanticLabelList = list
         ds.dataset_base = base
         sys.modules['nicr_scene_analysis_datasets'] = ds
         sys.modules['nicr_scene_analysis_datasets.dataset_base'] = base
@@ -98,10 +108,81 @@ def _install_third_party_standins() -> None:
 _loaded = None
 
 
-def load_reference():
+class _InlinePool:
+    """stand-in for the spawn pool of metric/pq.py:211-218: same call surface, runs in-process"""
+
+    class _Done:
+        def __init__(self, value):
+            self._value = value
+
+        def get(self):
+            return self._value
+
+    def __init__(self, processes=None):
+        pass
+
+    def apply_async(self, fn, args=()):
+        return self._Done(fn(*args))
+
+    def terminate(self):
+        pass
+
+    close = join = terminate
+
+
+def _load_task_helpers(ns):
+    """task_helper/{base,semantic,instance,panoptic,dense_visual_embedding}.py, unmodified"""
+    # `..loss` / `..metric` package attributes the helpers import by name
+    loss_pkg, metric_pkg = sys.modules[f'{PKG}.loss'], sys.modules[f'{PKG}.metric']
+    loss_pkg.CrossEntropyLossSemantic = ns.loss_ce.CrossEntropyLossSemantic
+    loss_pkg.MSELoss = ns.loss_mse.MSELoss
+    loss_pkg.L1Loss = ns.loss_l1.L1Loss
+    loss_pkg.VonMisesLossBiternion = ns.loss_vonmises.VonMisesLossBiternion
+    loss_pkg.CosineEmbeddingLoss = ns.loss_cos_emb.CosineEmbeddingLoss
+    metric_pkg.MeanIntersectionOverUnion = ns.metric_miou.MeanIntersectionOverUnion
+    metric_pkg.PanopticQuality = ns.metric_pq.PanopticQuality
+    metric_pkg.PanopticQualityWithOrientationMAE = ns.metric_mae.PanopticQualityWithOrientationMAE
+    # in-process executor instead of the spawn pool (see the module docstring)
+    ns.metric_pq.mp = types.SimpleNamespace(
+        cpu_count=lambda: 1,
+        get_context=lambda method: types.SimpleNamespace(Pool=_InlinePool))
+    # no-op visualisation (example images of the first validation batch only)
+    vis = types.ModuleType(f'{PKG}.visualization')
+
+    class PanopticColorGenerator:
+        def __init__(self, *args, **kwargs):
+            pass
+
+    vis.PanopticColorGenerator = PanopticColorGenerator
+    for name in ('visualize_semantic_pil', 'visualize_heatmap_pil', 'visualize_instance_center_pil',
+                 'visualize_instance_offset_pil', 'visualize_instance_pil',
+                 'visualize_instance_orientations_pil', 'visualize_orientation_pil',
+                 'visualize_panoptic_pil'):
+        setattr(vis, name, lambda *a, **k: None)
+    sys.modules[f'{PKG}.visualization'] = vis
+    setattr(sys.modules[PKG], 'visualization', vis)
+
+    utils_pkg = sys.modules[f'{PKG}.utils']
+    u_ori = sys.modules[f'{PKG}.utils._orientation']
+    utils_pkg.np_rad2biternion = u_ori.np_rad2biternion
+    utils_pkg.np_biternion2rad = getattr(u_ori, 'np_biternion2rad', None)
+    _load('data.preprocessing.multiscale_supervision', 'data/preprocessing/multiscale_supervision.py')
+    ns.prep_orientation = _load('data.preprocessing.orientation', 'data/preprocessing/orientation.py')
+    _stub_package(f'{PKG}.task_helper', os.path.join(REF_ROOT, 'task_helper'))
+    setattr(sys.modules[PKG], 'task_helper', sys.modules[f'{PKG}.task_helper'])
+    _load('task_helper.base', 'task_helper/base.py')
+    ns.th_semantic = _load('task_helper.semantic', 'task_helper/semantic.py')
+    ns.th_instance = _load('task_helper.instance', 'task_helper/instance.py')
+    ns.th_panoptic = _load('task_helper.panoptic', 'task_helper/panoptic.py')
+    ns.th_dve = _load('task_helper.dense_visual_embedding', 'task_helper/dense_visual_embedding.py')
+
+
+def load_reference(task_helpers: bool = False):
     """Returns a namespace with the reference hot-path symbols."""
     global _loaded
     if _loaded is not None:
+        if task_helpers and not hasattr(_loaded, 'th_semantic'):
+            _load_task_helpers(_loaded)
         return _loaded
     if not reference_available():
         raise RuntimeError('/root/reference is not mounted here')
@@ -172,6 +253,8 @@ def load_reference():
     ns.metric_mae = _load('metric.mae', 'metric/mae.py')
 
     _loaded = ns
+    if task_helpers:
+        _load_task_helpers(ns)
     return ns
 
 

@@ -359,3 +359,26 @@ def test_graphed_pipeline_matches_eager(ops):
                 assert torch.equal(got[k][:, :n], ref[k][:, :n]), k
             else:
                 assert torch.equal(got[k], ref[k]), k
+
+
+def test_argmax_tie_band_boundary_hip():
+    """the HIP argmax on the adversarial near-tie fixture (see the CPU-tier twin in
+    test_oracle_vs_golden.py): identical to the reference outside the 2^-23 band, the larger
+    logit inside it — for the stand-alone argmax, the with-score variant and the fused kernel"""
+    from nicr_mt_scene_analysis_amd import ops
+    g = load('argmax_ties')
+    x = torch.from_numpy(g['logits']).cuda()
+    ref = g['ref_idx'].reshape(-1)
+    delta, c2 = g['delta'], g['c2']
+    outside = delta > 2.0 ** -23
+    got = [ops.semantic_argmax(x, want_u8=True, want_i64=False, want_score=False)['idx_u8'],
+           ops.semantic_argmax(x, want_u8=True, want_i64=False, want_score=True)['idx_u8']]
+    B, C, H, W = x.shape
+    zeros = torch.zeros((B, 1, H, W), device='cuda')
+    r = ops.panoptic_pipeline(x, zeros, torch.zeros((B, 2, H, W), device='cuda'),
+                              torch.zeros((C,), dtype=torch.bool, device='cuda'))
+    got.append(r['semantic_idx_u8'])
+    for idx in got:
+        idx = idx.cpu().numpy().reshape(-1)
+        assert (idx == c2).all()
+        assert (idx[outside] == ref[outside]).all()

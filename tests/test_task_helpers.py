@@ -343,3 +343,131 @@ def test_four_losses_cfg3_bf16_full_batch(oracle):
                                      npy(batch['orientation_foreground']), 1.0)
     np.testing.assert_allclose(float(part['instance_orientation_loss_main']), s_ / max(n_, 1),
                                rtol=RTOL)
+
+
+# ---- pinned by the reference's own task helpers (tests/golden/task_helper_cases.npz) -------------
+def _to_cuda(x):
+    if isinstance(x, np.ndarray):
+        return torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    if isinstance(x, dict):
+        return {k: _to_cuda(v) for k, v in x.items()}
+    if isinstance(x, (list, tuple)):
+        return type(x)(_to_cuda(v) for v in x)
+    return x
+
+
+def _check_scalars(got: dict, keys, values, what, rtol=RTOL):
+    from _golden import jload
+    keys = jload(keys)
+    assert list(got.keys()) == keys, (what, list(got.keys()), keys)          # same keys, same order
+    for k, v in zip(keys, values):
+        np.testing.assert_allclose(float(got[k]), v, rtol=rtol, atol=1e-9, err_msg=f'{what}: {k}')
+
+
+def test_training_loss_dicts_vs_reference_task_helpers():
+    """a10: loss dicts (every key, in order, and every value) of the reference's
+    SemanticTaskHelper / InstanceTaskHelper / DenseVisualEmbeddingTaskHelper.training_step on a
+    batch with main + 2 side outputs (reference task_helper/semantic.py:57-90,
+    instance.py:92-269, dense_visual_embedding.py:70-193, base.py:161-182)"""
+    from _golden import load, jload
+    from nicr_mt_scene_analysis_amd.task_helper import (DenseVisualEmbeddingTaskHelper,
+                                                        InstanceTaskHelper, SemanticTaskHelper)
+    g = load('task_helper_cases')
+    batch_np, preds_np, weights = syn.make_training_case()
+    assert syn.input_digest(preds_np['semantic_output'], preds_np['instance_output'][1],
+                            preds_np['dense_visual_embedding_output'], batch_np['semantic'],
+                            batch_np['dense_visual_embedding_indices']) == jload(g['train__digest'])
+    batch, preds = _to_cuda(batch_np), _to_cuda(preds_np)
+    C = preds_np['semantic_output'].shape[1]
+    is_thing = (False,) * (C // 2 + 1) + (True,) * (C - C // 2)
+    cases = {
+        'sem_plain': SemanticTaskHelper(n_classes=C),
+        'sem_weighted_smooth': SemanticTaskHelper(n_classes=C, class_weights=weights,
+                                                  label_smoothing=0.1),
+        'sem_single_scale': SemanticTaskHelper(n_classes=C, disable_multiscale_supervision=True),
+        'ins_mse': InstanceTaskHelper(C + 1, is_thing),
+        'ins_l1': InstanceTaskHelper(C + 1, is_thing, loss_name_instance_center='l1'),
+        'dve_cos': DenseVisualEmbeddingTaskHelper(n_classes=C, loss_name='cos_emb'),
+    }
+    dev = torch.device('cuda')
+    for name, helper in cases.items():
+        helper.initialize(dev)
+        losses, logs = helper.training_step(batch, 0, preds)
+        _check_scalars(losses, g[f'train__{name}__keys'], g[f'train__{name}__values'], name)
+        assert sorted(logs.keys()) == jload(g[f'train__{name}__log_keys']), name
+    preds2 = dict(preds, instance_output=preds['instance_output'][:2],
+                  instance_side_outputs=tuple(p[:2] for p in preds['instance_side_outputs']))
+    helper = InstanceTaskHelper(C + 1, is_thing)
+    helper.initialize(dev)
+    losses, _ = helper.training_step(batch, 0, preds2)
+    _check_scalars(losses, g['train__ins_no_orientation__keys'],
+                   g['train__ins_no_orientation__values'], 'ins_no_orientation')
+
+
+def test_validation_chain_vs_reference_task_helpers():
+    """a14: two validation steps + validation_epoch_end of the reference's Semantic / Instance /
+    Panoptic task helpers behind the reference's PanopticPostprocessing, on ground truth made by
+    the reference's target generators: loss dicts per step, log keys, epoch logs (PQ / SQ / RQ,
+    mIoU, MAE) and artifacts (confusion matrices exactly, per-class vectors)."""
+    from _golden import load, jload, ids_from_arrays
+    from nicr_mt_scene_analysis_amd.data.preprocessing import APPLIED_PREPROCESSING_KEY
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    from nicr_mt_scene_analysis_amd.task_helper import (InstanceTaskHelper, PanopticTaskHelper,
+                                                        SemanticTaskHelper)
+    g = load('task_helper_cases')
+    gt = {k[len('val__gt_'):]: g[k] for k in g.files if k.startswith('val__gt_')}
+    B, H, W = gt['semantic'].shape
+    is_thing_nc = tuple(bool(x) for x in g['val__is_thing_with_void'])
+    C = len(is_thing_nc) - 1
+    batch = _to_cuda(gt)
+    for k in ('semantic', 'instance', 'panoptic'):
+        batch[f'{k}_fullres'] = batch[k]
+    batch['panoptic_ids_to_instance_dict'] = ids_from_arrays(
+        g['val__pan_ids_n'], g['val__pan_ids_pan'], g['val__pan_ids_ins'])
+    batch['orientations_present'] = [{int(k): v for k, v in d.items()}
+                                     for d in jload(g['val__orientations_present'])]
+    batch['rgb_fullres'] = torch.zeros((B, 3, H, W))
+    batch[APPLIED_PREPROCESSING_KEY] = [[{'type': 'Resize', 'valid_region_slice_y': slice(0, H),
+                                          'valid_region_slice_x': slice(0, W)}]] * B
+    post = get_postprocessing_class('panoptic')(
+        semantic_postprocessing=get_postprocessing_class('semantic')(),
+        instance_postprocessing=get_postprocessing_class('instance')(),
+        semantic_classes_is_thing=is_thing_nc[1:], semantic_class_has_orientation=is_thing_nc[1:])
+    dev = torch.device('cuda')
+    sem = SemanticTaskHelper(n_classes=C)
+    ins = InstanceTaskHelper(C + 1, is_thing_nc)
+    pan = PanopticTaskHelper(C + 1, is_thing_nc, None)
+    for h in (sem, ins, pan):
+        h.initialize(dev)
+    digests = jload(g['val__pred_digests'])
+    for step in range(2):
+        logits, center, offset, ori = syn.make_predictions_from_targets(
+            gt['semantic'], gt['instance_center'], gt['instance_offset'], gt['orientation'], C,
+            seed=step)
+        assert syn.input_digest(logits, center, offset, ori) == digests[step]
+        data = ((_to_cuda(logits), (_to_cuda(center), _to_cuda(offset), _to_cuda(ori))),
+                ((None, None), (None, None)))
+        r = post.postprocess(data, batch, is_training=False)
+        if step == 0:
+            assert (r['panoptic_segmentation_deeplab_fullres'].cpu().numpy()
+                    == g['val__pred_panoptic_step0']).all()
+        for name, h in (('sem', sem), ('ins', ins), ('pan', pan)):
+            losses, logs = h.validation_step(batch, step, r)
+            _check_scalars(losses, g[f'val__{name}__step{step}__loss_keys'],
+                           g[f'val__{name}__step{step}__loss_values'], f'{name} step {step}')
+            assert sorted(logs.keys()) == jload(g[f'val__{name}__step{step}__log_keys']), name
+    for name, h in (('sem', sem), ('ins', ins), ('pan', pan)):
+        artifacts, examples, logs = h.validation_epoch_end()
+        scal = {k: v for k, v in logs.items() if not k.endswith('_time')}
+        _check_scalars(scal, g[f'val__{name}__log_keys'], g[f'val__{name}__log_values'],
+                       f'{name} epoch logs')
+        assert len([k for k in logs if k.endswith('_time')]) == 1        # the profiling decorator's key
+        want_keys = jload(g[f'val__{name}__artifact_keys'])
+        assert list(artifacts.keys()) == want_keys, (name, list(artifacts.keys()), want_keys)
+        for k in want_keys:
+            got, want = artifacts[k].cpu().numpy(), g[f'val__{name}__artifact__{k}']
+            assert got.shape == want.shape and got.dtype == want.dtype, (k, got.dtype, want.dtype)
+            if np.issubdtype(want.dtype, np.integer):
+                assert (got == want).all(), k
+            else:
+                np.testing.assert_allclose(got, want, rtol=1e-6, atol=1e-12, equal_nan=True, err_msg=k)
