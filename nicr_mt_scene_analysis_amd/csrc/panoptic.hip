@@ -197,7 +197,25 @@ __device__ __forceinline__ float wave_all_min(float v)
 // farther from EVERY pixel than that pixel's nearest center — by the relative margin 1e-5,
 // far outside the sqrt-rounding tie band (2^-22) that the exact search resolves.  A non-finite
 // location switches the culling off for the wave (NaN / inf distances select index 0).
-__device__ __forceinline__ uint64_t wave_candidate_centers(const float2* __restrict__ cen, int n,
+// center tables: LdsCenters = float2 array in LDS (any n); LaneCenters = lane i of the wave holds
+// center i in registers (n <= 64): a wave-uniform index is a v_readlane, no memory access
+struct LdsCenters {
+    const float2* cen;
+    __device__ __forceinline__ float2 at(int i) const { return cen[i]; }
+    __device__ __forceinline__ float2 of_lane(int n) const { return cen[min(lane_id(), n - 1)]; }
+};
+struct LaneCenters {
+    float cy, cx;
+    __device__ __forceinline__ float2 at(int i) const
+    {
+        return make_float2(__int_as_float(__builtin_amdgcn_readlane(__float_as_int(cy), i)),
+                           __int_as_float(__builtin_amdgcn_readlane(__float_as_int(cx), i)));
+    }
+    __device__ __forceinline__ float2 of_lane(int) const { return make_float2(cy, cx); }
+};
+
+template <typename Centers>
+__device__ __forceinline__ uint64_t wave_candidate_centers(const Centers& cen, int n,
                                                            const float ly[4], const float lx[4],
                                                            const bool act[4])
 {
@@ -218,7 +236,7 @@ __device__ __forceinline__ uint64_t wave_candidate_centers(const float2* __restr
     if (!(lo_y < INFINITY)) return 0ull;                 // no active pixel in this wave
     const float hi_y = -nhi_y, hi_x = -nhi_x;
     const int lane = lane_id();
-    const float2 c = cen[min(lane, n - 1)];
+    const float2 c = cen.of_lane(n);
     const float a0 = c.x - lo_y, a1 = hi_y - c.x;         // >= 0 inside the box
     const float b0 = c.y - lo_x, b1 = hi_x - c.y;
     const float near_y = fmaxf(0.f, fmaxf(-a0, -a1)), near_x = fmaxf(0.f, fmaxf(-b0, -b1));
@@ -229,8 +247,8 @@ __device__ __forceinline__ uint64_t wave_candidate_centers(const float2* __restr
     return __ballot(lane < n && lo <= U * 1.00001f) & all;
 }
 
-template <bool CULL = true>
-__device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
+template <bool CULL = true, typename Centers = LdsCenters>
+__device__ __forceinline__ void group4(const Centers& cen, int n,
                                        const float ly[4], const float lx[4],
                                        const bool act[4], int use_thr, float thr,
                                        uint32_t id[4])
@@ -254,7 +272,7 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
         m &= m - 1;
     }
     {
-        const float2 c0 = cen[first];
+        const float2 c0 = cen.at(first);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             smin[j] = sqdist(c0.x, c0.y, ly[j], lx[j]);
@@ -263,7 +281,7 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
         }
     }
     auto visit = [&](const int i) {
-        const float2 c = cen[i];
+        const float2 c = cen.at(i);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float s = sqdist(c.x, c.y, ly[j], lx[j]);
@@ -296,7 +314,7 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
 #pragma unroll
         for (int j = 0; j < 4; ++j) U[j] = sqrt_tie_upper(sqrtf(smin[j]));
         for (int i = n - 1; i >= 0; --i) {
-            const float2 c = cen[i];
+            const float2 c = cen.at(i);
 #pragma unroll
             for (int j = 0; j < 4; ++j)
                 if (sqdist(c.x, c.y, ly[j], lx[j]) <= U[j]) best[j] = i;
@@ -317,8 +335,8 @@ __device__ __forceinline__ void group4(const float2* __restrict__ cen, int n,
 // dynamic LDS: float2 centers[max_centers] | i32 vote_key[FUSED_VOTE_SLOTS] | u32 vote_cnt[..] | u8 thing[256]
 // =================================================================================
 template <int DTYPE, bool VEC, bool WITH_SCORE, int UNROLL = 8, bool NT = true,
-          bool EARLY_OFFSETS = false, bool TILED = false>
-__global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
+          bool EARLY_OFFSETS = false, bool TILED = false, int TILE_LOG2W = 6>
+__global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(WITH_SCORE ? 5 : 7, 8))) void k_panoptic_fused(
     const void* __restrict__ logits, const float* __restrict__ offset,
     const int32_t* __restrict__ centers_yx, const int32_t* __restrict__ n_centers,
     const uint8_t* __restrict__ is_thing,
@@ -335,21 +353,36 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
     int* vote_key = (int*)(cen + max_centers);
     uint32_t* vote_cnt = (uint32_t*)(vote_key + FUSED_VOTE_SLOTS);
     const int NC = C + 1;
-    uint8_t* thing = (uint8_t*)(vote_cnt + FUSED_VOTE_SLOTS);
 
     const int b = blockIdx.y;
     const int P = H * W;
     const int n = min(n_centers[b], max_centers);
 
-    // Everything the first chunk needs from HBM is requested before the first wait: this thread's
-    // row of the center table (not gated on n_centers: rows beyond n are never read) and of the
-    // thing LUT stay in registers, then come the offsets and the first class planes.  The LDS
-    // tables are only needed AFTER the class loop, so they are filled — and the workgroup
-    // barrier sits — behind the first chunk's argmax.
+    // No workgroup barrier between the class stream and the pixel decisions: with n <= 64
+    // centers (top-k 64: the usual case) every wave keeps the whole center table in registers —
+    // lane i holds center i, a wave-uniform index is a v_readlane — and the thing LUT as 64-bit
+    // ballot masks.  Both are requested from HBM/L2 before the first class plane and consumed
+    // behind the class loop.  Only the vote table is shared: cleared here, one barrier at the
+    // START of the kernel (all waves arrive at once), one before the flush.  More than 64
+    // centers (ties at the k-th value): LDS center table + a barrier behind the first chunk.
     static_assert(FUSED_THREADS == 256, "one LUT entry per thread");
     static_assert(FUSED_VOTE_SLOTS == FUSED_THREADS, "one vote slot per thread");
     vote_key[threadIdx.x] = -1;
     vote_cnt[threadIdx.x] = 0;
+    const bool lane_centers = n <= 64;                     // workgroup-uniform
+    // two registers live across the class loop: the lane's center as (y << 16 | x) (image
+    // coordinates < 2^16 — checked by the launcher) and its four thing-LUT bytes
+    uint32_t lane_cyx, thing_b = 0u;
+    {
+        const int2 c2 = *(const int2*)(centers_yx +
+            ((size_t)b * max_centers + min(lane_id(), max_centers - 1)) * 2);
+        lane_cyx = ((uint32_t)c2.x << 16) | ((uint32_t)c2.y & 0xFFFFu);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k * 64 < C)
+                thing_b |= (is_thing[min(k * 64 + lane_id(), C - 1)] != 0 ? 1u : 0u) << k;
+    }
+    __syncthreads();
 
     const size_t img_logits = (size_t)b * C * P;
     const float* offy = offset + (size_t)b * 2 * P;
@@ -362,12 +395,16 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
         constexpr bool FIRST = decltype(first_tag)::value;
         int p0;
         bool active;                            // whole thread out of range in the tail chunk
-        if (TILED) {                            // 64 x 16 pixel tile per workgroup, 64 x 4 per wave
-            const int tiles_x = (W + 63) >> 6;
+        if (TILED) {
+            // a workgroup covers a TW x (1024 / TW) pixel tile; TW = 64: 64 x 4 per wave (four
+            // 128-B row pieces per wave load of 16-bit logits), TW = 128: 128 x 2 per wave (two
+            // 256-B pieces: whole cache-line pairs)
+            constexpr int TW = 1 << TILE_LOG2W, TH = 1024 >> TILE_LOG2W, LPR = TW / 4;
+            const int tiles_x = (W + TW - 1) >> TILE_LOG2W;
             const int tile = blockIdx.x * iters + it;
             const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
-            const int row = ty * 16 + (int)(threadIdx.x >> 4);
-            const int col = tx * 64 + (int)(threadIdx.x & 15) * 4;
+            const int row = ty * TH + (int)threadIdx.x / LPR;
+            const int col = tx * TW + ((int)threadIdx.x % LPR) * 4;
             active = row < H && col < W;        // W % 4 == 0: all 4 pixels or none
             p0 = active ? row * W + col : 0;
         } else {
@@ -386,13 +423,6 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
             ox = load_px4<NMSA_F32, VEC, NT>(offx, (size_t)p0, nvalid);
         }
 
-        int2 my_center = make_int2(0, 0);
-        uint32_t my_thing = 0;
-        if (FIRST) {                            // requested behind the offsets, used behind the classes
-            my_center = *(const int2*)(centers_yx +
-                ((size_t)b * max_centers + min((int)threadIdx.x, max_centers - 1)) * 2);
-            my_thing = is_thing[min((int)threadIdx.x, C - 1)];
-        }
 
         // ---- a1: argmax over classes (first index of the maximum) --------------------
         ArgmaxState st;
@@ -419,16 +449,18 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
                 argmax_quad<WITH_SCORE>(st, v[0], v[1], v[2], v[3], c, min(4, C - c));
             }
         }
-        if (FIRST) {                            // fill the LDS tables; the only barrier before the flush
-            if ((int)threadIdx.x < max_centers)
-                cen[threadIdx.x] = make_float2((float)my_center.x, (float)my_center.y);
-            for (int i = threadIdx.x + FUSED_THREADS; i < max_centers; i += FUSED_THREADS) {
+        if (FIRST && !lane_centers) {           // > 64 centers: LDS table (workgroup-uniform branch)
+            for (int i = threadIdx.x; i < n; i += FUSED_THREADS) {
                 const int2 c2 = *(const int2*)(centers_yx + ((size_t)b * max_centers + i) * 2);
                 cen[i] = make_float2((float)c2.x, (float)c2.y);
             }
-            thing[threadIdx.x] = ((int)threadIdx.x < C) ? (uint8_t)my_thing : (uint8_t)0;
             __syncthreads();
         }
+        // thing LUT as ballot masks: bit c of thing_m[c >> 6] (wave-uniform, SGPRs)
+        uint64_t thing_m[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            thing_m[k] = __ballot(((thing_b >> k) & 1u) != 0u && k * 64 + lane_id() < C);
         // threads beyond the image (tail chunk) stay in the wave: nvalid == 0 keeps them out of
         // every pixel decision, and the wave-level steps below need all lanes
         int cls[4];
@@ -451,14 +483,19 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
             } else if (st.nf[j] != st.nf[j] && j < nvalid) {
                 if (column_degenerate<DTYPE>(logits, img_logits + p0 + j, P, C)) cls[j] = 0;
             }
-            fg[j] = (j < nvalid) && (thing[cls[j]] != 0);               // panoptic.py:123-127
+            uint64_t tm = thing_m[0];
+            if (C > 64) {                                  // workgroup-uniform
+                const int q = cls[j] >> 6;
+                tm = (q == 0) ? thing_m[0] : (q == 1) ? thing_m[1] : (q == 2) ? thing_m[2] : thing_m[3];
+            }
+            fg[j] = (j < nvalid) && ((tm >> (cls[j] & 63)) & 1ull);     // panoptic.py:123-127
             any_fg = any_fg || fg[j];
         }
 
         // ---- a3: offset grouping ------------------------------------------------------
         uint32_t id[4] = {0u, 0u, 0u, 0u};
         if (__any(any_fg) && n > 0) {           // wave-uniform: group4 culls centers per wave
-            if (!EARLY_OFFSETS && any_fg) {
+            if (!EARLY_OFFSETS && any_fg && !(lds_rows & 4)) {
                 oy = load_px4<NMSA_F32, VEC, NT>(offy, (size_t)p0, nvalid);
                 ox = load_px4<NMSA_F32, VEC, NT>(offx, (size_t)p0, nvalid);
             }
@@ -474,7 +511,15 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
                 lx[j] = __fadd_rn((float)x, __fmul_rn(oxv[j], scale_x));
                 if (++x == W) { x = 0; ++y; }
             }
-            group4(cen, n, ly, lx, fg, use_thr, thr, id);
+            if (lds_rows & 2) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) id[j] = fg[j] ? 1u : 0u;
+            } else if (lane_centers) {
+                group4(LaneCenters{(float)(lane_cyx >> 16), (float)(lane_cyx & 0xFFFFu)}, n, ly, lx, fg,
+                       use_thr, thr, id);
+            } else {
+                group4(LdsCenters{cen}, n, ly, lx, fg, use_thr, thr, id);
+            }
         }
 
         // ---- stores --------------------------------------------------------------------
@@ -504,7 +549,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_panoptic_fused(
         // heads in parallel (two ballots, no loop over the distinct keys).  Boundary lanes add
         // their pixels one by one.
         const bool wave_has_inst = __any((id[0] | id[1] | id[2] | id[3]) != 0u);
-        if (wave_has_inst) {
+        if (wave_has_inst && !(lds_rows & 1)) {
             int key[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -783,7 +828,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
                 lx[j] = __fadd_rn((float)x, __fmul_rn(oxv[j], scale_x));
                 if (++x == W) { x = 0; ++y; }
             }
-            group4(cen, n, ly, lx, fg, use_thr, thr, id);
+            group4(LdsCenters{cen}, n, ly, lx, fg, use_thr, thr, id);
         }
         if (VEC && active) {
             *(uchar4*)(inst + (size_t)b * P + p0) =
@@ -1199,7 +1244,7 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     const int iters = fused_iters(P);
     const int chunks = (P + iters * PX_PER_ITER - 1) / (iters * PX_PER_ITER);
     (void)vote_rows_hint;       // the LDS vote table is a fixed-size hash now: no sizing hint needed
-    const int lds_rows = 0;
+    static const int lds_rows = env_int("NMSA_FUSED_ABLATE", 0);   // diagnostics: 1 no votes, 2 no search, 4 no offsets
     const size_t lds = (size_t)max_centers * sizeof(float2) + (size_t)FUSED_VOTE_SLOTS * 8 + 256;
     if (lds > 64 * 1024) return NMSA_ERR_ARG;
     const bool vec = (P % 4 == 0) &&
@@ -1214,12 +1259,27 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     // 16-bit logits (153 vs 183 us with 64 centers, 153 vs 155 with 24); for f32 the four 256-B
     // row pieces per wave load cost more than the hidden search saves (287 vs 278 us)
     static const int tiled = env_int("NMSA_FUSED_TILED", 1);           // 0: never, 1: 16-bit, 2: all
+    static const int tile_w = env_int("NMSA_FUSED_TILE_W", 128);
     if (vec && !score && W % 4 == 0 && (tiled == 2 || (tiled == 1 && DTYPE != NMSA_F32))) {
-        const int tiles = ((W + 63) / 64) * ((H + 15) / 16);
-        hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true>),
-                           dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
-                           centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
-                           use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
+        if (tile_w == 64) {
+            const int tiles = ((W + 63) / 64) * ((H + 15) / 16);
+            hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true, 6>),
+                               dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
+                               centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
+                               use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
+        } else if (tile_w == 256) {
+            const int tiles = ((W + 255) / 256) * ((H + 3) / 4);
+            hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true, 8>),
+                               dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
+                               centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
+                               use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
+        } else {
+            const int tiles = ((W + 127) / 128) * ((H + 7) / 8);
+            hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true, 7>),
+                               dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
+                               centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
+                               use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
+        }
     } else if (vec) { if (score) NMSA_LAUNCH_FUSED(true, true); else NMSA_LAUNCH_FUSED(true, false); }
     else { if (score) NMSA_LAUNCH_FUSED(false, true); else NMSA_LAUNCH_FUSED(false, false); }
 #undef NMSA_LAUNCH_FUSED
@@ -1348,6 +1408,7 @@ extern "C" int nmsa_panoptic_fused(const void* logits, int logits_dtype, const f
     if (!logits || !offset || !centers_yx || !n_centers || !is_thing || !sem_u8 || !inst || !votes)
         return NMSA_ERR_ARG;
     if (bad_dims(B, H, W) || C <= 0 || C > 256 || max_centers <= 0) return NMSA_ERR_ARG;
+    if (H > 65535 || W > 65535) return NMSA_ERR_ARG;      // lane-held centers pack (y, x) in 32 bits
     if (!votes_are_zero) {
         int rc = check_hip(hipMemsetAsync(votes, 0, (size_t)B * 256 * (C + 1) * sizeof(uint32_t), stream));
         if (rc) return rc;
