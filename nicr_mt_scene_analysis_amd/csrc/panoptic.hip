@@ -1255,10 +1255,12 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     hipLaunchKernelGGL((k_panoptic_fused<DTYPE, V, S>), grid, block, lds, stream, logits,    \
                        offset, centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, \
                        sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows)
-    // 64 x 16 pixel tiles per workgroup (compact waves -> effective center culling) pay for
-    // 16-bit logits (153 vs 183 us with 64 centers, 153 vs 155 with 24); for f32 the four 256-B
-    // row pieces per wave load cost more than the hidden search saves (287 vs 278 us)
-    static const int tiled = env_int("NMSA_FUSED_TILED", 1);           // 0: never, 1: 16-bit, 2: all
+    // 128 x 8 pixel tiles per workgroup (a wave covers 128 x 2: compact in the image, so the
+    // center culling leaves 1-3 candidates; every wave load is two whole row pieces of 256 B /
+    // 512 B).  Measured on one box, B=32 640x480 C=40, 24 | 64 centers: 16-bit logits 146 us vs
+    // 153 us with 64 x 16 tiles vs 172 | 203 us with 1024 consecutive pixels; f32 286 | 286 us vs
+    // 299 | 299 (64 x 16) vs 293 | 300 (consecutive).
+    static const int tiled = env_int("NMSA_FUSED_TILED", 2);           // 0: never, 1: 16-bit, 2: all
     static const int tile_w = env_int("NMSA_FUSED_TILE_W", 128);
     if (vec && !score && W % 4 == 0 && (tiled == 2 || (tiled == 1 && DTYPE != NMSA_F32))) {
         if (tile_w == 64) {
