@@ -206,17 +206,41 @@ def secondary_pipeline(ops, syn, dev, B, C, H, W, K, dtype, with_metrics=True):
         if m is not None:
             m.update_and_reduce(r['panoptic'])
     ms = hip_timed(step, reps=20, warm=5)
-    if m is not None:
-        m.pq._check_status()                    # table overflow etc. would void the timing
-        m.miou._check_status()
+    # the headline's schedule: consecutive batches alternate over two streams, metric kernels
+    # on a side stream (the one-workgroup-per-image kernels hide behind the other batch)
+    m2 = bench_support.MetricAccumulators(C + 1, dev, inp, 0, side_stream=True) \
+        if with_metrics else None
+    streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
+
+    def step2(i):
+        with torch.cuda.stream(streams[i % 2]):
+            r = ops.panoptic_pipeline(*a)
+            if m2 is not None:
+                m2.update_and_reduce(r['panoptic'])
+    for i in range(6):
+        step2(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n_rep = 30
+    for i in range(n_rep):
+        step2(i)
+    torch.cuda.synchronize()
+    ms2 = (time.perf_counter() - t0) / n_rep * 1e3
+    for mm in (m, m2):
+        if mm is not None:
+            mm.pq._check_status()               # table overflow etc. would void the timing
+            mm.miou._check_status()
     fused_ms = float(np.mean([x.elapsed_time(y) for x, y in ev[5:]]))
     n_px = B * H * W
     out = {'shape': f'B={B} C={C} {W}x{H}', 'logits_dtype': str(a[0].dtype).replace('torch.', ''),
            'step_serial': _leg(ms, n_px, es * C + 21 + (17 if with_metrics else 0),
                                what='one stream, no batch overlap; pipeline'
                                     + (' + mIoU/PQ updates' if with_metrics else '')),
+           'step_two_batches_in_flight': _leg(ms2, n_px, es * C + 21 + (17 if with_metrics else 0),
+                                              what='wall clock over 30 steps, two streams + metric '
+                                                   'side stream (the headline schedule)'),
            'k_panoptic_fused': _leg(fused_ms, n_px, es * C + 9)}
-    del inp, a, m
+    del inp, a, m, m2
     torch.cuda.empty_cache()
     return out
 
@@ -459,7 +483,8 @@ def main():
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath) and (B, C, H, W) == (32, 40, 480, 640) and esize == 4:
         with open(tpath) as f:
-            traffic = json.load(f).get('k_panoptic_fused', {}).get('hbm_bytes_per_launch')
+            traffic = next((v.get('hbm_bytes_per_launch') for k, v in json.load(f).items()
+                            if k.startswith('k_panoptic_fused')), None)
     roofline = {
         'bound': 'hbm', 'kernel': 'k_panoptic_fused',
         'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',

@@ -18,13 +18,27 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PROF = os.path.join(ROOT, 'profiles')
 
-# kernels whose global loads are 16 B (or 8 B) per lane coalesced streams: FETCH_SIZE x2
-WIDE_STREAM = ('k_panoptic_fused', 'k_paint', 'k_semantic_argmax', 'k_group_offsets',
-               'k_confmat', 'k_pq_count', 'k_loss')
+# kernels whose global loads are wide (8 / 16 B per lane) coalesced streams: FETCH_SIZE x2
+# (MI355X_MICROARCH.md, HBM section).  Exact kernel names or name + '<' (templates): a bare
+# prefix would also catch e.g. k_confmat_reduce (4-B loads) behind k_confmat.
+WIDE_STREAM = ('k_panoptic_fused', 'k_paint', 'k_paint2', 'k_semantic_argmax', 'k_semantic_softmax',
+               'k_semantic_softmax_reg', 'k_group_offsets', 'k_confmat', 'k_pq_count',
+               'k_nms_rows3', 'k_ce_fwd', 'k_ce_bwd', 'k_elem_fwd', 'k_elem_bwd', 'k_vm_fwd',
+               'k_vm_bwd', 'k_cos_emb_lds')
+
+
+def is_wide(kernel):
+    base = kernel.split('<')[0]
+    return base in WIDE_STREAM
 
 
 def short(name):
+    """nmsa::k_x<1, 8, true>(args...) -> k_x<1,8,true>: template arguments stay, they tell the
+    forward from the backward instantiation of one kernel template"""
     name = name.replace('void ', '')
+    head = name.split('(')[0]
+    if 'k_' in head or 'rocclr' in head:
+        return head.split('::')[-1].replace(' ', '')
     for tok in name.replace('(', ' ').replace('<', ' ').split():
         if 'k_' in tok or 'rocclr' in tok:
             return tok.split('::')[-1]
@@ -59,7 +73,7 @@ def main():
         for k, d in agg.items():
             fetch_kb = sum(d['FETCH_SIZE']) / max(len(d['FETCH_SIZE']), 1) if 'FETCH_SIZE' in d else None
             write_kb = sum(d['WRITE_SIZE']) / max(len(d['WRITE_SIZE']), 1) if 'WRITE_SIZE' in d else None
-            wide = any(k.startswith(w_) for w_ in WIDE_STREAM)
+            wide = is_wide(k)
             e = {'FETCH_SIZE_KB_raw': fetch_kb, 'WRITE_SIZE_KB_raw': write_kb,
                  'fetch_correction': 2.0 if wide else 1.0}
             if fetch_kb is not None and write_kb is not None:
