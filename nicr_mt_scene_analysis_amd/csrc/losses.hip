@@ -16,6 +16,7 @@
 // partials are fp64 and are summed in a FIXED order by k_loss_finalize, so results
 // are run-to-run deterministic.  Backward kernels recompute from the inputs and
 // scale by the upstream gradient read from a device scalar (no host sync).
+#include <stdlib.h>
 #include "nmsa_common.hpp"
 
 namespace nmsa {
@@ -267,7 +268,7 @@ __device__ __forceinline__ void ce_scan(const void* logits, size_t img, int P, i
     }
 }
 
-template <int DTYPE, int PXT, bool SMOOTH>
+template <int DTYPE, int PXT, bool SMOOTH, int U>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
@@ -283,7 +284,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
     double acc = 0.0, accw = 0.0;
     long long cnt = 0;
     bool bad = false;
-    constexpr int U = (PXT == 4) ? 8 : 4;
     for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * PXT; p0 < P;
          p0 += gridDim.x * LOSS_THREADS * PXT) {
         const int nvalid = min(PXT, P - p0);
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
 //   grad_j = g * [ (a + bsum) p_j - a [j == t] - b_j ],  a = (1-ls) w_t, b_j = (ls/C) w_j
 // pass 1: max / sum (as forward); pass 2 re-reads the tile (L2) and writes
 // g*((a+bsum) p_j - b_j); the "- a" at the target class is one read-modify-write per px.
-template <int DTYPE, int PXT, bool SMOOTH>
+template <int DTYPE, int PXT, bool SMOOTH, int UB>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
@@ -348,7 +348,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     const float g = *gscale;
     const int b = blockIdx.y;
     const size_t img = (size_t)b * C * P;
-    constexpr int U = (PXT == 4) ? 8 : 4;
+    constexpr int U = (PXT == 4) ? 8 : 4;              // first pass (no saved log-sum-exp)
     for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * PXT; p0 < P;
          p0 += gridDim.x * LOSS_THREADS * PXT) {
         const int nvalid = min(PXT, P - p0);
@@ -386,9 +386,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
             ag[j] = g * a;
             abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;   // p = 2^(x log2e + k0)
         }
-        for (int c = 0; c < C; ++c) {
-            float v[PXT], o[PXT];
-            ldpx<DTYPE, PXT, true>(logits, img + (size_t)c * P + p0, nvalid, vec, v);
+        auto plane = [&](const float v[PXT], int c) {
+            float o[PXT];
             const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
@@ -398,6 +397,21 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
                 o[j] = r;
             }
             stpx<DTYPE, PXT>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
+        };
+        // UB plane loads in flight, then UB plane stores
+        int c = 0;
+        for (; c + UB <= C; c += UB) {
+            float v[UB][PXT];
+#pragma unroll
+            for (int u = 0; u < UB; ++u)
+                ldpx<DTYPE, PXT, true>(logits, img + (size_t)(c + u) * P + p0, nvalid, vec, v[u]);
+#pragma unroll
+            for (int u = 0; u < UB; ++u) plane(v[u], c + u);
+        }
+        for (; c < C; ++c) {
+            float v[PXT];
+            ldpx<DTYPE, PXT, true>(logits, img + (size_t)c * P + p0, nvalid, vec, v);
+            plane(v, c);
         }
     }
 }
@@ -810,6 +824,12 @@ using namespace nmsa;
 
 namespace {
 
+int loss_env_int(const char* name, int dflt)
+{
+    const char* v = getenv(name);
+    return (v && *v) ? atoi(v) : dflt;
+}
+
 int grid_x(int P, int px_per_thread)
 {
     const int64_t per_block = (int64_t)LOSS_THREADS * px_per_thread;
@@ -866,9 +886,12 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
     const int gx = grid_x(P, pxt);
     const bool smooth = label_smoothing != 0.0f;
     LossPartial* partials = (LossPartial*)workspace;
-#define CE_FWD(DT, PX, SM) hipLaunchKernelGGL((k_ce_fwd<DT, PX, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
+    static const int fwd_u = loss_env_int("NMSA_CE_FWD_U", 0);      // tuning knob: 4 | 8 plane loads in flight
+    const int uu = fwd_u ? fwd_u : ((dtype == NMSA_F32) ? 8 : 4);
+#define CE_FWD_U(DT, PX, SM, UU) hipLaunchKernelGGL((k_ce_fwd<DT, PX, SM, UU>), dim3(gx, B), dim3(LOSS_THREADS), \
         C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, partials, status, \
         lse2_out)
+#define CE_FWD(DT, PX, SM) do { if (uu == 8) CE_FWD_U(DT, PX, SM, 8); else CE_FWD_U(DT, PX, SM, 4); } while (0)
     switch (dtype) {
         case NMSA_F32: if (smooth) CE_FWD(NMSA_F32, 4, true); else CE_FWD(NMSA_F32, 4, false); break;
         case NMSA_BF16: if (smooth) CE_FWD(NMSA_BF16, 8, true); else CE_FWD(NMSA_BF16, 8, false); break;
@@ -876,6 +899,7 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
         default: return NMSA_ERR_ARG;
     }
 #undef CE_FWD
+#undef CE_FWD_U
     int rc = check_launch();
     if (rc) return rc;
     return finalize(partials, gx * B, loss_sum, weight_sum, n_elements, stream);
@@ -895,9 +919,13 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
                     ((((uintptr_t)logits | (uintptr_t)grad_logits | (uintptr_t)lse2) & 15) == 0);
     const int gx = grid_x(P, pxt);
     const bool smooth = label_smoothing != 0.0f;
-#define CE_BWD(DT, PX, SM) hipLaunchKernelGGL((k_ce_bwd<DT, PX, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
+    static const int bwd_u = loss_env_int("NMSA_CE_BWD_U", 0);      // tuning knob: 1 | 4 | 8
+    const int ub = bwd_u ? bwd_u : 4;
+#define CE_BWD_U(DT, PX, SM, UU) hipLaunchKernelGGL((k_ce_bwd<DT, PX, SM, UU>), dim3(gx, B), dim3(LOSS_THREADS), \
         C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, grad_scale, \
         grad_logits, lse2)
+#define CE_BWD(DT, PX, SM) do { if (ub == 8) CE_BWD_U(DT, PX, SM, 8); else if (ub == 1) CE_BWD_U(DT, PX, SM, 1); \
+                                else CE_BWD_U(DT, PX, SM, 4); } while (0)
     switch (dtype) {
         case NMSA_F32: if (smooth) CE_BWD(NMSA_F32, 4, true); else CE_BWD(NMSA_F32, 4, false); break;
         case NMSA_BF16: if (smooth) CE_BWD(NMSA_BF16, 8, true); else CE_BWD(NMSA_BF16, 8, false); break;
@@ -905,6 +933,7 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
         default: return NMSA_ERR_ARG;
     }
 #undef CE_BWD
+#undef CE_BWD_U
     return check_launch();
 }
 
