@@ -304,7 +304,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
     int P, int64_t offset, int px_per_block,
     unsigned char* __restrict__ ws, int cap, int* __restrict__ status,
     const uint8_t* __restrict__ target_sem, int cm_n, int64_t cm_div, int cm_shift,
-    uint32_t* __restrict__ cm_slab, int* __restrict__ cm_status)
+    uint32_t* __restrict__ cm_slab, int* __restrict__ cm_status, int ablate)
 {
     __shared__ int64_t lkI[PQ_LI];
     __shared__ uint32_t lcI[PQ_LI];
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
     const uint8_t* ts = WITH_CM ? target_sem + (size_t)b * P : nullptr;
     bool cm_bad = false;
     auto cm_key = [&](int64_t t, int64_t p, bool valid) -> int {
-        if (!valid) return -1;
+        if (!valid || (ablate & 1)) return -1;
         if (p < 0) { cm_bad = true; return -1; }            // bincount rejects negatives
         const int64_t pc = cm_shift >= 0 ? (p >> cm_shift) : (p / cm_div);
         if (t >= cm_n || pc >= cm_n) { cm_bad = true; return -1; }
@@ -345,6 +345,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
 
     // called by MANY lanes at once (one per run of equal pixels)
     auto add = [&](int64_t iid, uint32_t cnt) {
+        if (ablate & 2) return;
         if (iid == KEY_EMPTY) { st |= ST_SENTINEL_KEY; return; }
         // fast path: key already in its home slot -> one LDS read, one LDS atomic
         const uint32_t sI = hash_id(iid) & (PQ_LI - 1);
@@ -427,10 +428,11 @@ __global__ __launch_bounds__(256) void k_pq_count(
     __syncthreads();
     if (WITH_CM) {
         uint32_t* mine = cm_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * cm_bins;
-        for (int i = threadIdx.x; i < cm_bins; i += blockDim.x) mine[i] = cm_hist_pq[i];
+        if (!(ablate & 4)) for (int i = threadIdx.x; i < cm_bins; i += blockDim.x) mine[i] = cm_hist_pq[i];
         if (cm_bad) atomicOr(cm_status, ST_VALUE_RANGE);
     }
     // flush the block-private table
+    if (!(ablate & 8))
     for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x)
         if (lkI[i] != KEY_EMPTY && !table_add(gk, gc, cap - 1, lkI[i], lcI[i], 256))
             st |= ST_TABLE_OVERFLOW;
@@ -801,17 +803,18 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
         if ((rc = check_launch())) return rc;
     }
     const int px_per_block = pq_px_per_block();
+    static const int ablate = getenv("NMSA_PQ_ABLATE") ? atoi(getenv("NMSA_PQ_ABLATE")) : 0;   // diagnostics
     const dim3 grid((P + px_per_block - 1) / px_per_block, B);
     if (target_sem) {
         int shift = -1;
         if ((cm_div & (cm_div - 1)) == 0) shift = __builtin_ctzll((unsigned long long)cm_div);
         hipLaunchKernelGGL(k_pq_count<true>, grid, dim3(256), (size_t)cm_n * cm_n * sizeof(uint32_t),
                            stream, pred, target, P, offset, px_per_block, ws, cap, status, target_sem, cm_n,
-                           cm_div, shift, (uint32_t*)cm_workspace, cm_status);
+                           cm_div, shift, (uint32_t*)cm_workspace, cm_status, ablate);
     } else {
         hipLaunchKernelGGL(k_pq_count<false>, grid, dim3(256), 0, stream, pred, target, P, offset,
                            px_per_block, ws, cap, status, (const uint8_t*)nullptr, 0, (int64_t)1, -1,
-                           (uint32_t*)nullptr, (int*)nullptr);
+                           (uint32_t*)nullptr, (int*)nullptr, ablate);
     }
     rc = check_launch();
     if (rc) return rc;

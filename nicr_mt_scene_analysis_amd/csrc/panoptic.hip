@@ -1277,6 +1277,7 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
                                use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
         } else {
             const int tiles = ((W + 127) / 128) * ((H + 7) / 8);
+            // 8 class planes in flight per lane: 4 / 12 / 20 measured 169 / 166 / 197 us vs 161 (bf16)
             hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true, 7>),
                                dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
                                centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
