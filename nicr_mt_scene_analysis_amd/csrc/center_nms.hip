@@ -196,26 +196,34 @@ __global__ __launch_bounds__(1024) void k_nms_strip(
 // use.  Horizontal neighbours come from the adjacent lanes (two lane shifts per row; the band's
 // outer columns from one extra 4-B load by lanes 0 / 63), vertical neighbours are the other
 // rows' registers.  Eight lanes OR their 4 survivor bits into one 32-bit candidate word.
-constexpr int NR_ROWS = 8;
 
+// HALF: the wave is two 32-lane halves, each a 128-pixel-wide band of its own row group — for
+// widths that are a multiple of 128 but not of 256 (640 = 5 x 128: no idle lanes, where 256-px
+// bands leave half of every third wave empty).
+template <int NR_ROWS, bool HALF>
 __global__ __launch_bounds__(256) void k_nms_rows3(
     const float* __restrict__ center, uint32_t* __restrict__ cand_bits,
     int H, int W, int words_per_image, float thr)
 {
+    constexpr int LPB = HALF ? 32 : 64;                    // lanes per band
+    constexpr int BW = LPB * 4;                            // band width in pixels
     const int b = blockIdx.y;
     const int lane = lane_id();
-    const int bands = (W + 255) >> 8;
+    const int l = lane & (LPB - 1);                        // lane within its band
+    const int sub = HALF ? (lane >> 5) : 0;
+    const int bands = (W + BW - 1) / BW;
     const int wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
     const int seg = wave / bands, band = wave - seg * bands;
-    const int y0 = seg * NR_ROWS;
-    if (y0 >= H) return;                                   // whole wave
-    const int xb = band << 8;
-    const int x0 = xb + 4 * lane;
-    const bool in_x = x0 < W;                              // W % 4 == 0: all 4 pixels or none
+    const int y0 = (seg * (HALF ? 2 : 1) + sub) * NR_ROWS;
+    if ((seg * (HALF ? 2 : 1)) * NR_ROWS >= H) return;     // whole wave
+    const int xb = band * BW;
+    const int x0 = xb + 4 * l;
+    const bool in_x = x0 < W && y0 < H;                    // W % 4 == 0: all 4 pixels or none
     const float* img = center + (size_t)b * H * W;
-    // band edge columns: lane 0 fetches the pixel left of the band, lane 63 the one right of it
-    const int xe = (lane == 0) ? xb - 1 : xb + 256;
-    const bool edge_lane = (lane == 0 || lane == 63) && xe >= 0 && xe < W;
+    // band edge columns: the first lane fetches the pixel left of the band, the last one the
+    // pixel right of it
+    const int xe = (l == 0) ? xb - 1 : xb + BW;
+    const bool edge_lane = (l == 0 || l == LPB - 1) && xe >= 0 && xe < W;
 
     float4 row[NR_ROWS + 2];
     float edge[NR_ROWS + 2];
@@ -231,9 +239,9 @@ __global__ __launch_bounds__(256) void k_nms_rows3(
         e[1] = threshold_m1(v.x, thr); e[2] = threshold_m1(v.y, thr);
         e[3] = threshold_m1(v.z, thr); e[4] = threshold_m1(v.w, thr);
         const float ev = threshold_m1(edge[r], thr);
-        const float l = __shfl_up(e[4], 1), rr = __shfl_down(e[1], 1);
-        e[0] = (lane == 0) ? ev : l;
-        e[5] = (lane == 63) ? ev : rr;
+        const float lf = __shfl_up(e[4], 1), rr = __shfl_down(e[1], 1);
+        e[0] = (l == 0) ? ev : lf;
+        e[5] = (l == LPB - 1) ? ev : rr;
     };
     uint32_t* bits = cand_bits + (size_t)b * words_per_image;
     // hm[j] = max of the three horizontal neighbours around pixel j (NaN ignored): the pooled
@@ -258,7 +266,8 @@ __global__ __launch_bounds__(256) void k_nms_rows3(
         for (int k = 0; k < 4; ++k) { htop[k] = hmid[k]; hmid[k] = hbot[k]; }
         extend(r + 1, bot);                                // wave-uniform: all lanes shift
         hmax3(bot, hbot);
-        if (y >= H) break;                                 // wave-uniform
+        if (__all(y >= H)) break;                          // wave-uniform
+        const bool row_ok = y < H;                         // the halves of a wave differ in y
         const bool border_y = y < 1 || y >= H - 1;
         bool maybe[4];
         bool any_maybe = false;
@@ -267,7 +276,8 @@ __global__ __launch_bounds__(256) void k_nms_rows3(
             const float h = mid[j + 1];
             const float pooled = fmaxf(fmaxf(htop[j], hmid[j]), hbot[j]);
             // NaN h: never a candidate (h >= 0 fails); NaN neighbours are caught by the exact rule
-            maybe[j] = in_x && h >= 0.0f && (border_y || h == pooled || x0 + j < 1 || x0 + j >= W - 1);
+            maybe[j] = in_x && row_ok && h >= 0.0f &&
+                       (border_y || h == pooled || x0 + j < 1 || x0 + j >= W - 1);
             any_maybe = any_maybe || maybe[j];
         }
         uint32_t nib = 0;
@@ -292,7 +302,7 @@ __global__ __launch_bounds__(256) void k_nms_rows3(
         word |= __shfl_xor(word, 1);
         word |= __shfl_xor(word, 2);
         word |= __shfl_xor(word, 4);
-        if ((lane & 7) == 0 && in_x) bits[(y * W + x0) >> 5] = word;
+        if ((lane & 7) == 0 && in_x && row_ok) bits[(y * W + x0) >> 5] = word;
     }
 }
 
@@ -492,9 +502,20 @@ extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
     const size_t strip_lds = (size_t)(R + 2 * pad) * (W + 2 * pad) * sizeof(float);
     static const int rows3_env = getenv("NMSA_NMS_ROWS3") ? atoi(getenv("NMSA_NMS_ROWS3")) : 1;
     if (pad == 1 && (W % 32) == 0 && rows3_env) {
-        const int waves = ((W + 255) / 256) * ((H + NR_ROWS - 1) / NR_ROWS);
-        hipLaunchKernelGGL(k_nms_rows3, dim3((waves + 3) / 4, B), dim3(256), 0, stream, center, bits,
-                           H, W, words, threshold);
+        // rows per wave: 4 (6 row loads in flight, 1.5x the bytes requested, mostly L2 hits on the
+        // neighbour's halo) measured 13.8-14.0 us vs 15.8 (6 rows), 17.6-17.8 (8), 20.5 (12),
+        // 22.8 (16) at B=32 640x480: the kernel is a one-shot bound by latency and wave count
+        static const int nr = getenv("NMSA_NMS_NR") ? atoi(getenv("NMSA_NMS_NR")) : 4;
+        static const int half_env = getenv("NMSA_NMS_HALF") ? atoi(getenv("NMSA_NMS_HALF")) : -1;
+        const bool half = half_env >= 0 ? (half_env != 0 && W % 128 == 0) : (W % 256 != 0 && W % 128 == 0);
+#define NMSA_ROWS3(NR) do { if (half) { const int waves = (W / 128) * ((H + 2 * NR - 1) / (2 * NR));     \
+        hipLaunchKernelGGL((k_nms_rows3<NR, true>), dim3((waves + 3) / 4, B), dim3(256), 0, stream, center,  \
+                           bits, H, W, words, threshold); } else {                                         \
+        const int waves = ((W + 255) / 256) * ((H + NR - 1) / NR);                                          \
+        hipLaunchKernelGGL((k_nms_rows3<NR, false>), dim3((waves + 3) / 4, B), dim3(256), 0, stream, center, \
+                           bits, H, W, words, threshold); } } while (0)
+        if (nr == 8) NMSA_ROWS3(8); else NMSA_ROWS3(4);
+#undef NMSA_ROWS3
     } else if ((W % 32) == 0 && pad <= NMS_PAD_MAX && strip_lds <= 64 * 1024) {
         dim3 grid((H + R - 1) / R, B);
         // one thread per column when the row fits a workgroup (every wave fully used)
