@@ -358,3 +358,32 @@ def test_crop_and_resize_host_side():
     with pytest.raises(NotImplementedError):
         post._crop_to_valid_region_and_resize_prediction(ids, (slice(1, 5), slice(0, 8)), (8, 16),
                                                          mode='bicubic')
+
+
+def test_bench_self_launch_command_and_host_cores(monkeypatch):
+    """`python bench.py --gpus N` without a launcher: N fresh ranks through torch.distributed.run as
+    a CHILD process (no exec), the user's arguments forwarded, rendezvous on 127.0.0.1"""
+    import importlib
+    import sys
+    bench = importlib.import_module('bench')
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen['cmd'], seen['env'] = cmd, env
+        return 7
+    monkeypatch.setattr(bench.subprocess, 'call', fake_call)
+    monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '9', '--warmup', '2'])
+    monkeypatch.delenv('RANK', raising=False)
+    args = bench.parse_args()
+    assert bench.launch_ranks(args) == 7                        # the child's return code
+    cmd = seen['cmd']
+    assert cmd[0] == sys.executable and cmd[1:3] == ['-m', 'torch.distributed.run']
+    assert '--nnodes=1' in cmd and '--nproc-per-node=4' in cmd
+    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
+    assert 0 < int(cmd[cmd.index('--master-port') + 1]) < 65536
+    script = cmd.index(bench.os.path.abspath(bench.__file__))
+    assert cmd[script + 1:] == ['--gpus', '4', '--steps', '9', '--warmup', '2']
+    assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') is not None
+    cores = bench.host_cores()
+    assert 1 <= cores['usable'] <= cores['affinity'] <= max(cores['nproc'], cores['affinity'])
+    assert cores['cgroup_quota'] is None or cores['usable'] <= max(1, round(cores['cgroup_quota']))
