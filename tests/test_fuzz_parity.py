@@ -510,6 +510,86 @@ def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype):
 @settings(max_examples=_n(40), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
                                  HealthCheck.data_too_large])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 2),
+       D=st.sampled_from([2, 7, 64, 255, 384, 512, 520, 599, 600, 768, 900]),   # D = 1: cos = +-1, its gradient is rounding noise
+       L=st.sampled_from([1, 3, 40, 64, 65, 90, 130, 1300]),
+       hw=st.sampled_from([(1, 1), (3, 5), (8, 8), (8, 16), (16, 24), (7, 23), (32, 32)]),
+       dtype=st.sampled_from(['float32', 'bfloat16', 'float16']))
+def test_fuzz_cosine_embedding_large_dims_vs_oracle(oracle, seed, B, D, L, hw, dtype):
+    """a9 at embedding sizes around the LDS chunk boundaries of k_cos_emb_lds (one chunk, two,
+    three; D not a multiple of the chunk), pixel counts with and without the per-pixel dot
+    buffer (H*W % 8), LUTs too tall for LDS (generic kernel): forward + gradient vs the oracle"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    if D * L > 300_000:
+        L = max(1, 300_000 // D)                        # keep the oracle's LUT small
+    H, W = hw
+    rng = np.random.default_rng(seed)
+    tdt = getattr(torch, dtype)
+    lut = rng.standard_normal((B, L, D)).astype(np.float32)
+    lut /= np.maximum(np.linalg.norm(lut, axis=-1, keepdims=True), 1e-3)
+    idx = rng.integers(0, L + 1, (B, H, W)).astype(np.int32)
+    tgt = np.take_along_axis(lut, np.clip(idx - 1, 0, L - 1).reshape(B, -1, 1), axis=1)
+    pred = tgt.reshape(B, H, W, D).transpose(0, 3, 1, 2) + rng.standard_normal((B, D, H, W)) / np.sqrt(D)
+    x = dev(pred.astype(np.float32)).to(tdt).requires_grad_(True)
+    loss, n = F_.cosine_embedding_lut_sum(x, dev(idx), dev(lut))
+    loss.backward()
+    s_ref, n_ref, g_ref = oracle.loss_cosine_embedding(x.detach().float().cpu().numpy(), idx, lut,
+                                                       want_grad=True)
+    assert int(n) == n_ref
+    _EFFECTIVE['cos_large'] = _EFFECTIVE.get('cos_large', 0) + 1
+    np.testing.assert_allclose(float(loss.detach()), s_ref, rtol=1e-5, atol=1e-5)
+    got = x.grad.float().cpu().numpy()
+    if dtype == 'float32':
+        np.testing.assert_allclose(got, g_ref, rtol=2e-3, atol=2e-6)
+    else:                                               # the gradient is rounded to 16 bits once
+        np.testing.assert_allclose(got, g_ref, rtol=2 ** -7, atol=1e-5)
+
+
+@settings(max_examples=_n(25), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
+                                 HealthCheck.data_too_large])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3),
+       hw=st.sampled_from([(96, 128), (120, 200), (240, 320), (250, 333), (480, 640)]),
+       n_cat=st.integers(2, 60), cell=st.sampled_from([4, 8, 16, 32]), twice=st.booleans())
+def test_fuzz_pq_many_segments_vs_oracle(oracle, seed, B, hw, n_cat, cell, twice):
+    """a12 on larger maps with many segments (hundreds to thousands of distinct intersections:
+    block-private LDS tables overflow into the image's global table, different table capacities
+    per image size); states bit-exact vs the oracle, also on a second update that starts from
+    the tables the first one left clean"""
+    from nicr_mt_scene_analysis_amd import metric
+    H, W = hw
+    rng = np.random.default_rng(seed)
+    cls = np.kron(rng.integers(0, n_cat, (B, (H + cell - 1) // cell, (W + cell - 1) // cell)),
+                  np.ones((cell, cell), np.int64))[:, :H, :W]
+    ins = np.kron(rng.integers(0, 5, (B, (H + 2 * cell - 1) // (2 * cell), (W + 2 * cell - 1) // (2 * cell))),
+                  np.ones((2 * cell, 2 * cell), np.int64))[:, :H, :W]
+    is_thing = rng.random(n_cat) < 0.5
+    pred = (cls * 65536 + ins * is_thing[cls]).astype(np.int64)
+    tgt = np.roll(pred, (int(rng.integers(0, 6)), int(rng.integers(0, 6))), axis=(1, 2))
+    tgt[:, :int(rng.integers(0, 9))] = 0
+    n_int = max(len(np.unique(tgt[b] * 256 ** 3 + pred[b])) for b in range(B))
+    cap = 4096
+    while cap * 24 < H * W:
+        cap *= 2
+    if n_int > cap // 2:
+        return                                           # beyond the table: reported, other test
+    _EFFECTIVE['pq_many'] = _EFFECTIVE.get('pq_many', 0) + 1
+    pq = metric.PanopticQuality(n_cat, 0, 65536, 256 ** 3, [bool(t) for t in is_thing])
+    state = None
+    for _ in range(2 if twice else 1):
+        pq.update(torch.from_numpy(pred), torch.from_numpy(tgt))
+        for b in range(B):
+            *state, _ = oracle.pq_compare_and_accumulate(pred[b], tgt[b], n_cat, 0, 65536, 256 ** 3,
+                                                         state=state)
+    got = np.stack([getattr(pq, n).cpu().numpy() for n in
+                    ('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class')])
+    assert (got == np.stack(state)).all()
+    pq.compute()
+
+
+@settings(max_examples=_n(40), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
+                                 HealthCheck.data_too_large])
 @given(p=cases(medium=True))
 def test_fuzz_compute_scores_vs_oracle(oracle, p):
     """f3: score maps / per-instance mean semantic score of random pipelines vs the oracle"""
@@ -701,6 +781,6 @@ def test_fuzz_standalone_grouping_vs_oracle(oracle, p, p_fg, blocky):
 
 def test_fuzz_effective_cases():
     """runs last: the fuzz tests that may skip a draw must still have exercised the kernels"""
-    for name in ('scores', 'grouping'):
+    for name in ('scores', 'grouping', 'cos_large', 'pq_many'):
         if name in _EFFECTIVE:
             assert _EFFECTIVE[name] >= 10, _EFFECTIVE
