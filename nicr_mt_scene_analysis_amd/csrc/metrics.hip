@@ -355,8 +355,12 @@ __global__ __launch_bounds__(256) void k_pq_count(
     };
     // intersection id with torch's int64 wrap-around arithmetic (pq.py:104); ids that would
     // not decode uniquely (pq.py:83-109 then fails or mixes segments) raise ST_MISSING_KEY
+    // (offset is a power of two in practice — 256^3, task_helper/panoptic.py:57-63 — then the
+    // 64-bit multiply is a shift; same wrap-around either way)
+    const int off_shift = ((offset & (offset - 1)) == 0) ? (63 - __clzll((long long)offset)) : -1;
     auto iid_of = [&](int64_t t, int64_t p, bool valid) -> int64_t {
         if (valid && (t < 0 || p < 0 || p >= offset)) st |= ST_MISSING_KEY;
+        if (off_shift >= 0) return (int64_t)(((uint64_t)t << off_shift) + (uint64_t)p);
         return (int64_t)((uint64_t)t * (uint64_t)offset + (uint64_t)p);
     };
     // One (target, pred) pair per lane, lanes = consecutive pixels.  Neighbouring pixels
@@ -399,20 +403,24 @@ __global__ __launch_bounds__(256) void k_pq_count(
                 for (int u = 0; u < PQ_UNROLL; ++u) {
                     const int k0 = cm_key(sv[u] & 0xFFu, pv[u].x, ok[u]);
                     const int k1 = cm_key(sv[u] >> 8, pv[u].y, ok[u]);
-                    if (__all(k0 == k1)) cm_runs(k0, 2u);
-                    else { cm_runs(k0, 1u); cm_runs(k1, 1u); }
+                    // lanes whose two pixels agree form the runs (one LDS atomic per run); the
+                    // others — segment boundaries, or every lane when the maps are incoherent —
+                    // add their two pixels themselves: ONE run pass per load either way
+                    const bool same = k0 == k1;
+                    if (__any(same && k0 >= 0)) cm_runs(same ? k0 : -1, 2u);
+                    if (!same) {
+                        if (k0 >= 0) atomicAdd(&cm_hist_pq[k0], 1u);
+                        if (k1 >= 0) atomicAdd(&cm_hist_pq[k1], 1u);
+                    }
                 }
             }
 #pragma unroll
             for (int u = 0; u < PQ_UNROLL; ++u) {
                 const int64_t i0 = iid_of(tv[u].x, pv[u].x, ok[u]);
                 const int64_t i1 = iid_of(tv[u].y, pv[u].y, ok[u]);
-                if (__all(i0 == i1 || !ok[u])) {
-                    wave_runs(ok[u], i0, 2u);                   // both px of every lane agree
-                } else {
-                    wave_runs(ok[u], i0, 1u);
-                    wave_runs(ok[u], i1, 1u);
-                }
+                const bool same = i0 == i1;
+                if (__any(ok[u] && same)) wave_runs(ok[u] && same, i0, 2u);
+                if (ok[u] && !same) { add(i0, 1u); add(i1, 1u); }     // boundary lanes
             }
         }
     } else {
