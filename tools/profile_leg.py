@@ -22,7 +22,7 @@ torch.cuda.set_device(dev)
 shapes = {'cfg2': (32, 40, 480, 640, 24), 'cfg5': (8, 150, 768, 1024, 48)}
 if leg[:4] in shapes:
     dt = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[leg[5:]]
-    out = bench.secondary_pipeline(ops, syn, dev, *shapes[leg[:4]], dt)
+    out = bench.secondary_pipeline(ops, syn, dev, *shapes[leg[:4]], dt, overlap=False)
 elif leg == 'cfg3_losses':
     out = bench.secondary_losses(dev)
 elif leg in ('cos512', 'cos768'):

@@ -34,11 +34,13 @@ summarize() {           # <name> <tag suffix> [bench log]
     (cd "$ROOT" && python3 tools/summarize_profile.py "$TAG$suffix" "$stats" "$fetch" "$write" $log)
 }
 
+if [ -z "$LEGS_ONLY" ]; then
 mkdir -p "$OUT/headline"
 three_passes headline "$ROOT/bench.py" --steps 30 --warmup 10 --no-cpu-baseline --no-secondary
 echo "[profile] plain bench"
 (cd "$ROOT" && timeout -k 10 400 python3 bench.py > "$OUT/bench.log" 2> "$OUT/bench.err")
 summarize headline "" "$OUT/bench.log"
+fi
 for leg in $LEGS; do
     mkdir -p "$OUT/$leg"
     three_passes "$leg" "$ROOT/tools/profile_leg.py" "$leg"
@@ -46,4 +48,4 @@ for leg in $LEGS; do
 done
 mkdir -p "$ROOT/gpurun_out/profiles_$TAG"
 cp "$ROOT"/profiles/${TAG}_* "$ROOT/gpurun_out/profiles_$TAG/"
-tail -c 600 "$OUT/bench.log"
+[ -z "$LEGS_ONLY" ] && tail -c 600 "$OUT/bench.log" || true
