@@ -865,34 +865,90 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
 // =================================================================================
 // a5: per-instance class (mode, smallest on ties) + running per-class counter
 // =================================================================================
-__global__ __launch_bounds__(256) void k_assign(
+// The image's vote table [256 x NC] is staged through LDS in blocks of whole rows with
+// coalesced loads (thread-per-row global reads are 64 different cache lines per wave load:
+// 46 us at NC = 151, 10 us at NC = 41); non-zero words are zeroed on the way (the table is left
+// clean for the next call); thread r then scans row r in LDS (row stride NC words).
+constexpr int ASSIGN_LDS_WORDS = 36 * 1024;       // 144 KB of dynamic LDS
+constexpr int ASSIGN_THREADS = 1024;
+__global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(
     uint32_t* __restrict__ votes, int NC, int clear_votes, int64_t max_inst, int64_t void_label,
     int64_t* __restrict__ pan_of_inst, int32_t* __restrict__ area,
     int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins, int32_t* __restrict__ n_ids)
 {
+    extern __shared__ uint32_t s_rows[];  // rows_per_pass x NC
     __shared__ int s_vcls[256];          // classes of the valid instances, ascending id
     __shared__ int s_wcnt[4];
+    __shared__ uint32_t s_total[256];
+    __shared__ int s_cls[256];
     const int b = blockIdx.x, t = threadIdx.x;
-    uint32_t* row = votes + ((size_t)b * 256 + t) * NC;
-    uint32_t total = 0;
-    int64_t bestc = -1;
-    int cls = 0;
-    for (int c = 0; c < NC; ++c) {
-        const uint32_t v = row[c];
-        total += v;
-        if ((int64_t)v > bestc) { bestc = v; cls = c; }      // torch.mode: smallest value on ties
+    uint32_t* tab = votes + (size_t)b * 256 * NC;
+    const int rows_per_pass = min(256, ASSIGN_LDS_WORDS / NC);
+    for (int r0 = 0; r0 < 256; r0 += rows_per_pass) {
+        const int nr = min(rows_per_pass, 256 - r0);
+        const int nwords = nr * NC;
+        uint32_t* src = tab + (size_t)r0 * NC;
+        // 4 independent loads in flight per thread (a load -> LDS store chain per word would pay
+        // one memory latency per iteration)
+        for (int i0 = t; i0 < nwords; i0 += 4 * ASSIGN_THREADS) {
+            uint32_t v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * ASSIGN_THREADS;
+                v[u] = (i < nwords) ? src[i] : 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * ASSIGN_THREADS;
+                if (i < nwords) {
+                    s_rows[i] = v[u];
+                    if (clear_votes && v[u]) src[i] = 0;
+                }
+            }
+        }
+        __syncthreads();
+        // four lanes per row: each scans a contiguous quarter of the classes, then the quarters
+        // are combined (larger count wins, equal counts -> the smaller class = torch.mode)
+        {
+            const int r = t >> 2, part = t & 3;
+            const int q = (NC + 3) >> 2;
+            const int c0 = part * q, c1 = min(c0 + q, NC);
+            uint32_t tot = 0;
+            int64_t bestc = -1;
+            int c_best = 0;
+            if (r < nr) {
+                const uint32_t* row = s_rows + r * NC;
+                for (int c = c0; c < c1; ++c) {
+                    const uint32_t v = row[c];
+                    tot += v;
+                    if ((int64_t)v > bestc) { bestc = v; c_best = c; }
+                }
+            }
+#pragma unroll
+            for (int o = 1; o <= 2; o <<= 1) {
+                const uint32_t tot_o = __shfl_xor(tot, o);
+                const int64_t best_o = __shfl_xor(bestc, o);
+                const int c_o = __shfl_xor(c_best, o);
+                tot += tot_o;
+                if (best_o > bestc || (best_o == bestc && c_o < c_best)) { bestc = best_o; c_best = c_o; }
+            }
+            if (part == 0 && r < nr) { s_total[r0 + r] = tot; s_cls[r0 + r] = c_best; }
+        }
+        __syncthreads();
     }
-    // leave the table zeroed for the next call (saves the caller a memset per step)
-    if (clear_votes && total) for (int c = 0; c < NC; ++c) row[c] = 0;
+    // the ordered compaction below is one thread per row (threads 256.. only keep the barriers)
+    const bool rowt = t < 256;
+    const uint32_t total = rowt ? s_total[t] : 0u;
+    const int cls = rowt ? s_cls[t] : 0;
     // skip id 0, empty masks (panoptic_merge.py:195-200) and void majority (:203-204)
-    const bool valid = (t > 0) && (total > 0) && (cls != 0);
+    const bool valid = rowt && (t > 0) && (total > 0) && (cls != 0);
     // order-preserving compaction of the valid instances (ballot + popcount)
     const unsigned long long m = __ballot(valid);
     const int w = t >> 6, l = t & 63;
-    if (l == 0) s_wcnt[w] = __popcll(m);
+    if (l == 0 && w < 4) s_wcnt[w] = __popcll(m);
     __syncthreads();
     int pos = __popcll(m & ((1ull << l) - 1ull));
-    for (int k = 0; k < w; ++k) pos += s_wcnt[k];
+    for (int k = 0; k < min(w, 4); ++k) pos += s_wcnt[k];
     if (valid) s_vcls[pos] = cls;
     __syncthreads();
     // running per-class counter in ascending instance-id order (:206-207)
@@ -900,8 +956,8 @@ __global__ __launch_bounds__(256) void k_assign(
     if (valid)
         for (int j = 0; j < pos; ++j) rank += (s_vcls[j] == cls);
     const int64_t pid = (int64_t)cls * max_inst + rank;        // :208
-    pan_of_inst[(size_t)b * 256 + t] = valid ? pid : void_label;
-    if (area) area[(size_t)b * 256 + t] = (t > 0) ? (int32_t)total : 0;
+    if (rowt) pan_of_inst[(size_t)b * 256 + t] = valid ? pid : void_label;
+    if (area && rowt) area[(size_t)b * 256 + t] = (t > 0) ? (int32_t)total : 0;
     if (valid) {
         ids_pan[(size_t)b * 256 + pos] = pid;                   // dict insertion order (:209)
         ids_ins[(size_t)b * 256 + pos] = t;
@@ -1223,6 +1279,18 @@ int env_int(const char* name, int dflt)
     return v ? atoi(v) : dflt;
 }
 
+// dynamic LDS of k_assign: whole rows of the vote table, at most ASSIGN_LDS_WORDS words; the
+// grant above 64 KB is requested once
+size_t assign_lds_bytes(int NC)
+{
+    static const bool granted = hipFuncSetAttribute(
+        reinterpret_cast<const void*>(k_assign), hipFuncAttributeMaxDynamicSharedMemorySize,
+        ASSIGN_LDS_WORDS * (int)sizeof(uint32_t)) == hipSuccess;
+    (void)granted;
+    const int rows = 256 < ASSIGN_LDS_WORDS / NC ? 256 : ASSIGN_LDS_WORDS / NC;
+    return (size_t)rows * NC * sizeof(uint32_t);
+}
+
 int fused_iters(int P)
 {
     // 1024 px per workgroup: 300 workgroups per 640x480 image -> 9600 at B=32, >> 256 CUs x 8
@@ -1441,8 +1509,8 @@ extern "C" int nmsa_panoptic_assign(uint32_t* votes, int B, int n_vote_classes, 
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!votes || !pan_of_inst || !ids_pan || !ids_ins || !n_ids) return NMSA_ERR_ARG;
-    if (B <= 0 || n_vote_classes <= 0) return NMSA_ERR_ARG;
-    hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_vote_classes, clear_votes,
+    if (B <= 0 || n_vote_classes <= 0 || n_vote_classes > 4096) return NMSA_ERR_ARG;
+    hipLaunchKernelGGL(k_assign, dim3(B), dim3(ASSIGN_THREADS), assign_lds_bytes(n_vote_classes), stream, votes, n_vote_classes, clear_votes,
                        max_instances_per_category, void_label, pan_of_inst, area,
                        ids_pan, ids_ins, n_ids);
     return check_launch();
@@ -1486,7 +1554,7 @@ extern "C" int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* i
     if (!sem || !ins || !thing_seg || !is_thing_class || !votes || !pan_of_inst || !pan ||
         !ids_pan || !ids_ins || !n_ids)
         return NMSA_ERR_ARG;
-    if (bad_dims(B, H, W) || n_classes <= 0) return NMSA_ERR_ARG;
+    if (bad_dims(B, H, W) || n_classes <= 0 || n_classes > 4096) return NMSA_ERR_ARG;
     if (sem_dtype < NMSA_U8 || sem_dtype > NMSA_I64 || ins_dtype < NMSA_U8 || ins_dtype > NMSA_I64)
         return NMSA_ERR_ARG;
     const int P = H * W;
@@ -1504,7 +1572,7 @@ extern "C" int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* i
                             ins_dtype, thing_seg, n_classes, P, votes);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_assign, dim3(B), dim3(256), 0, stream, votes, n_classes, 0,
+    hipLaunchKernelGGL(k_assign, dim3(B), dim3(ASSIGN_THREADS), assign_lds_bytes(n_classes), stream, votes, n_classes, 0,
                        max_instances_per_category, void_label, pan_of_inst, (int32_t*)nullptr,
                        ids_pan, ids_ins, n_ids);
     rc = check_launch();
