@@ -11,6 +11,7 @@ under torch.distributed.run must both work).
 """
 import json
 import os
+import socket
 import subprocess
 import sys
 
@@ -44,8 +45,11 @@ def test_bench_self_launches_two_ranks():
 def test_bench_under_launcher_runs_the_rccl_leg():
     env = dict(os.environ)
     env.pop('NMSA_BENCH_BACKEND', None)
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
     r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-                        '--nproc-per-node=1', '--master-addr', '127.0.0.1', '--master-port', '29533',
+                        '--nproc-per-node=1', '--master-addr', '127.0.0.1', '--master-port', str(port),
                         os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + SMALL,
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
