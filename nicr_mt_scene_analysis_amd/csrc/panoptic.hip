@@ -9,7 +9,7 @@
 // Data flow (B images, P = H*W pixels each, C classes):
 //   k_panoptic_fused  reads  logits 4C B/px (f32) + offset 8 B/px
 //                     writes sem u8 1 B/px + inst u8 1 B/px (+ votes, tiny)
-//   k_assign          256 threads / image over the [256 x (C+1)] vote table
+//   k_assign          1024 threads / image over the [256 x (C+1)] vote table (staged in LDS)
 //   k_paint           reads sem+inst 2 B/px, writes panoptic i64 8 B/px
 // All three are HBM-bound streaming kernels: 16-B loads per lane, >= 8 loads
 // in flight per lane, no LDS staging of the big tensors (each byte is used
@@ -332,7 +332,9 @@ __device__ __forceinline__ void group4(const Centers& cen, int n,
 
 // =================================================================================
 // fused: argmax + fg + grouping + class votes
-// dynamic LDS: float2 centers[max_centers] | i32 vote_key[FUSED_VOTE_SLOTS] | u32 vote_cnt[..] | u8 thing[256]
+// dynamic LDS: float2 centers[max_centers] (used with > 64 centers only) | i32 vote_key[FUSED_VOTE_SLOTS]
+//              | u32 vote_cnt[FUSED_VOTE_SLOTS]
+// `ablate`: diagnostics only (NMSA_FUSED_ABLATE; bits 1 no votes, 2 no search, 4 no offset loads)
 // =================================================================================
 template <int DTYPE, bool VEC, bool WITH_SCORE, int UNROLL = 8, bool NT = true,
           bool EARLY_OFFSETS = false, bool TILED = false, int TILE_LOG2W = 6>
@@ -343,7 +345,7 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(W
     int C, int H, int W, int max_centers, int iters,
     float scale_y, float scale_x, int use_thr, float thr,
     uint8_t* __restrict__ sem_u8, uint8_t* __restrict__ inst, uint8_t* __restrict__ fg_out,
-    float* __restrict__ score, uint32_t* __restrict__ votes, int lds_rows)
+    float* __restrict__ score, uint32_t* __restrict__ votes, int ablate)
 {
     extern __shared__ __align__(16) unsigned char smem[];
     float2* cen = (float2*)smem;
@@ -495,7 +497,7 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(W
         // ---- a3: offset grouping ------------------------------------------------------
         uint32_t id[4] = {0u, 0u, 0u, 0u};
         if (__any(any_fg) && n > 0) {           // wave-uniform: group4 culls centers per wave
-            if (!EARLY_OFFSETS && any_fg && !(lds_rows & 4)) {
+            if (!EARLY_OFFSETS && any_fg && !(ablate & 4)) {
                 oy = load_px4<NMSA_F32, VEC, NT>(offy, (size_t)p0, nvalid);
                 ox = load_px4<NMSA_F32, VEC, NT>(offx, (size_t)p0, nvalid);
             }
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(W
                 lx[j] = __fadd_rn((float)x, __fmul_rn(oxv[j], scale_x));
                 if (++x == W) { x = 0; ++y; }
             }
-            if (lds_rows & 2) {
+            if (ablate & 2) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) id[j] = fg[j] ? 1u : 0u;
             } else if (lane_centers) {
@@ -549,7 +551,7 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(W
         // heads in parallel (two ballots, no loop over the distinct keys).  Boundary lanes add
         // their pixels one by one.
         const bool wave_has_inst = __any((id[0] | id[1] | id[2] | id[3]) != 0u);
-        if (wave_has_inst && !(lds_rows & 1)) {
+        if (wave_has_inst && !(ablate & 1)) {
             int key[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -1312,7 +1314,7 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
     const int iters = fused_iters(P);
     const int chunks = (P + iters * PX_PER_ITER - 1) / (iters * PX_PER_ITER);
     (void)vote_rows_hint;       // the LDS vote table is a fixed-size hash now: no sizing hint needed
-    static const int lds_rows = env_int("NMSA_FUSED_ABLATE", 0);   // diagnostics: 1 no votes, 2 no search, 4 no offsets
+    static const int ablate = env_int("NMSA_FUSED_ABLATE", 0);   // diagnostics: 1 no votes, 2 no search, 4 no offsets
     const size_t lds = (size_t)max_centers * sizeof(float2) + (size_t)FUSED_VOTE_SLOTS * 8 + 256;
     if (lds > 64 * 1024) return NMSA_ERR_ARG;
     const bool vec = (P % 4 == 0) &&
@@ -1322,7 +1324,7 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
 #define NMSA_LAUNCH_FUSED(V, S)                                                              \
     hipLaunchKernelGGL((k_panoptic_fused<DTYPE, V, S>), grid, block, lds, stream, logits,    \
                        offset, centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, \
-                       sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows)
+                       sy, sx, use_thr, thr, sem_u8, inst, fg_out, score, votes, ablate)
     // 128 x 8 pixel tiles per workgroup (a wave covers 128 x 2: compact in the image, so the
     // center culling leaves 1-3 candidates; every wave load is two whole row pieces of 256 B /
     // 512 B).  Measured on one box, B=32 640x480 C=40, 24 | 64 centers: 16-bit logits 146 us vs
@@ -1336,20 +1338,20 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
             hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true, 6>),
                                dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
                                centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
-                               use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
+                               use_thr, thr, sem_u8, inst, fg_out, score, votes, ablate);
         } else if (tile_w == 256) {
             const int tiles = ((W + 255) / 256) * ((H + 3) / 4);
             hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true, 8>),
                                dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
                                centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
-                               use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
+                               use_thr, thr, sem_u8, inst, fg_out, score, votes, ablate);
         } else {
             const int tiles = ((W + 127) / 128) * ((H + 7) / 8);
             // 8 class planes in flight per lane: 4 / 12 / 20 measured 169 / 166 / 197 us vs 161 (bf16)
             hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, false, 8, true, false, true, 7>),
                                dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
                                centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
-                               use_thr, thr, sem_u8, inst, fg_out, score, votes, lds_rows);
+                               use_thr, thr, sem_u8, inst, fg_out, score, votes, ablate);
         }
     } else if (vec) { if (score) NMSA_LAUNCH_FUSED(true, true); else NMSA_LAUNCH_FUSED(true, false); }
     else { if (score) NMSA_LAUNCH_FUSED(false, true); else NMSA_LAUNCH_FUSED(false, false); }
