@@ -872,7 +872,9 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_group_offsets(
 // 46 us at NC = 151, 10 us at NC = 41); non-zero words are zeroed on the way (the table is left
 // clean for the next call); thread r then scans row r in LDS (row stride NC words).
 constexpr int ASSIGN_LDS_WORDS = 36 * 1024;       // 144 KB of dynamic LDS
-constexpr int ASSIGN_THREADS = 1024;
+// 256 threads: a 1024-thread workgroup does not fit next to the other batch's fused kernel (7 of
+// 8 wave slots per SIMD taken) and waits for it to drain — the step lost 9 % with it
+constexpr int ASSIGN_THREADS = 256;
 __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(
     uint32_t* __restrict__ votes, int NC, int clear_votes, int64_t max_inst, int64_t void_label,
     int64_t* __restrict__ pan_of_inst, int32_t* __restrict__ area,
@@ -890,17 +892,17 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(
         const int nr = min(rows_per_pass, 256 - r0);
         const int nwords = nr * NC;
         uint32_t* src = tab + (size_t)r0 * NC;
-        // 4 independent loads in flight per thread (a load -> LDS store chain per word would pay
+        // 8 independent loads in flight per thread (a load -> LDS store chain per word would pay
         // one memory latency per iteration)
-        for (int i0 = t; i0 < nwords; i0 += 4 * ASSIGN_THREADS) {
-            uint32_t v[4];
+        for (int i0 = t; i0 < nwords; i0 += 8 * ASSIGN_THREADS) {
+            uint32_t v[8];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * ASSIGN_THREADS;
                 v[u] = (i < nwords) ? src[i] : 0u;
             }
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
+            for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * ASSIGN_THREADS;
                 if (i < nwords) {
                     s_rows[i] = v[u];
@@ -911,8 +913,8 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(
         __syncthreads();
         // four lanes per row: each scans a contiguous quarter of the classes, then the quarters
         // are combined (larger count wins, equal counts -> the smaller class = torch.mode)
-        {
-            const int r = t >> 2, part = t & 3;
+        for (int rb = 0; rb < nr; rb += ASSIGN_THREADS / 4) {          // uniform trip count
+            const int r = rb + (t >> 2), part = t & 3;
             const int q = (NC + 3) >> 2;
             const int c0 = part * q, c1 = min(c0 + q, NC);
             uint32_t tot = 0;
