@@ -351,10 +351,10 @@ def secondary(ops, syn, dev):
         ('cfg2_bf16', lambda: secondary_pipeline(ops, syn, dev, 32, 40, 480, 640, 24,
                                                  torch.bfloat16)),
         ('cfg3_losses', lambda: secondary_losses(dev)),
-        ('cfg5_bf16', lambda: secondary_pipeline(ops, syn, dev, 8, 150, 768, 1024, 48,
+        ('cfg5_bf16', lambda: secondary_pipeline(ops, syn, dev, 16, 150, 768, 1024, 48,
                                                  torch.bfloat16)),
-        ('cfg5_cos_emb_D512', lambda: secondary_cos_emb(dev, D=512)),
-        ('cfg5_cos_emb_D768', lambda: secondary_cos_emb(dev, D=768)),
+        ('cfg5_cos_emb_D512', lambda: secondary_cos_emb(dev, B=16, D=512)),
+        ('cfg5_cos_emb_D768', lambda: secondary_cos_emb(dev, B=16, D=768)),
     )
     for name, fn in legs:
         try:

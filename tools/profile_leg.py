@@ -19,14 +19,14 @@ from nicr_mt_scene_analysis_amd.testing import synthetic as syn      # noqa: E40
 leg = sys.argv[1] if len(sys.argv) > 1 else 'cfg5_bf16'
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
-shapes = {'cfg2': (32, 40, 480, 640, 24), 'cfg5': (8, 150, 768, 1024, 48)}
+shapes = {'cfg2': (32, 40, 480, 640, 24), 'cfg5': (16, 150, 768, 1024, 48)}
 if leg[:4] in shapes:
     dt = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[leg[5:]]
     out = bench.secondary_pipeline(ops, syn, dev, *shapes[leg[:4]], dt, overlap=False)
 elif leg == 'cfg3_losses':
     out = bench.secondary_losses(dev)
 elif leg in ('cos512', 'cos768'):
-    out = bench.secondary_cos_emb(dev, D=int(leg[3:]))
+    out = bench.secondary_cos_emb(dev, B=16, D=int(leg[3:]))
 else:
     raise SystemExit(f'unknown leg {leg}')
 print(out)
