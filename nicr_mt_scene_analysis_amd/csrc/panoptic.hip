@@ -371,9 +371,9 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(W
     static_assert(FUSED_VOTE_SLOTS == FUSED_THREADS, "one vote slot per thread");
     vote_key[threadIdx.x] = -1;
     vote_cnt[threadIdx.x] = 0;
-    const bool lane_centers = n <= 64;                     // workgroup-uniform
+    const bool lane_centers = n <= 64 && H <= 65535 && W <= 65535;   // workgroup-uniform; (y, x) packed in 32 bits
     // two registers live across the class loop: the lane's center as (y << 16 | x) (image
-    // coordinates < 2^16 — checked by the launcher) and its four thing-LUT bytes
+    // sides < 2^16, else the LDS table is used) and its four thing-LUT bytes
     uint32_t lane_cyx, thing_b = 0u;
     {
         const int2 c2 = *(const int2*)(centers_yx +
@@ -1483,7 +1483,6 @@ extern "C" int nmsa_panoptic_fused(const void* logits, int logits_dtype, const f
     if (!logits || !offset || !centers_yx || !n_centers || !is_thing || !sem_u8 || !inst || !votes)
         return NMSA_ERR_ARG;
     if (bad_dims(B, H, W) || C <= 0 || C > 256 || max_centers <= 0) return NMSA_ERR_ARG;
-    if (H > 65535 || W > 65535) return NMSA_ERR_ARG;      // lane-held centers pack (y, x) in 32 bits
     if (!votes_are_zero) {
         int rc = check_hip(hipMemsetAsync(votes, 0, (size_t)B * 256 * (C + 1) * sizeof(uint32_t), stream));
         if (rc) return rc;

@@ -382,3 +382,29 @@ def test_argmax_tie_band_boundary_hip():
         idx = idx.cpu().numpy().reshape(-1)
         assert (idx == c2).all()
         assert (idx[outside] == ref[outside]).all()
+
+
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+def test_pipeline_image_side_beyond_16_bits(ops, oracle, dtype):
+    """an image side > 65535: the lane-held center table of the fused kernel packs (y, x) in 32
+    bits, so it must fall back to the LDS table — ids still bit-exact vs the oracle"""
+    B, C, H, W = 1, 3, 2, 70000
+    rng = np.random.default_rng(5)
+    logits = rng.integers(0, 5, (B, C, H, W)).astype(np.float32)
+    heat = np.zeros((B, 1, H, W), np.float32)
+    xs = np.array([100, 30000, 65600, 69990])
+    heat[0, 0, 1, xs] = [0.9, 0.8, 0.7, 0.6]
+    off_px = rng.integers(-6, 7, (B, 2, H, W)).astype(np.float32)
+    offset = np.stack([off_px[:, 0] / H, off_px[:, 1] / W], 1).astype(np.float32)
+    is_thing = np.array([False, True, True])
+    x = dev(logits).to(getattr(torch, dtype))
+    r = ops.panoptic_pipeline(x, dev(heat), dev(offset), dev(is_thing), kernel_size=1)
+    torch.cuda.synchronize()
+    idx, _ = oracle.semantic_argmax(x.float().cpu().numpy())
+    fg = is_thing[idx]
+    cyx, n, _, _ = oracle.center_nms_topk(heat, ksize=1, max_centers=256)
+    inst, _ = oracle.group_offsets(offset, fg, cyx, n, scale_y=H, scale_x=W)
+    pan, _ = oracle.deeplab_merge(idx + 1, inst, fg, 1 << 16, np.where(is_thing)[0] + 1, 0)
+    assert int(n[0]) == 4 and (r['n_centers'].cpu().numpy() == n).all()
+    assert (r['instance'].cpu().numpy() == inst).all()
+    assert (r['panoptic'].cpu().numpy() == pan).all()
