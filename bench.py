@@ -345,6 +345,54 @@ def secondary_cos_emb(dev, B=8, D=512, H=768, W=1024, L=64):
                             note='the backward re-reads the prediction: 3x2D+8 B/px moved')}
 
 
+def secondary_next_rows(ops, syn, dev, B=32, C=40, H=480, W=640):
+    """SURVEY §8(f) rows that sit either side of the headline path, each as one HIP-event-timed
+    call on B=32 640x480 inputs: f2 the full-resolution step (crop + bilinear resize + softmax
+    + max fused, 640x480 -> 730x530 and -> 1024x768; the nearest resize of the panoptic map),
+    f3 `compute_scores`, f4 on-device target generation.  Algorithmic bytes per OUTPUT pixel
+    for f2 (source logits read once + index / score written), per pixel otherwise."""
+    out = {}
+    inp = syn.make_panoptic_inputs_torch(B, C, H, W, n_centers=24, seed=99, device=dev)
+    x = inp['semantic_logits']
+    p = ops.panoptic_pipeline(x, inp['instance_center'], inp['instance_offset'],
+                              inp['semantic_classes_is_thing'], want_score=True)
+    n_px = B * H * W
+    in_bytes = x.numel() * x.element_size()
+    for size in ((530, 730), (768, 1024)):
+        n_out = B * size[0] * size[1]
+        ms = hip_timed(lambda: ops.semantic_argmax_resized(x, size, None, want_score=False),
+                       reps=10, warm=3)
+        out[f'f2_argmax_resized_{size[1]}x{size[0]}'] = _leg(
+            ms, n_out, round((in_bytes + n_out * 8) / n_out, 2),
+            what='fused crop + bilinear + softmax + max, int64 index out (semantic.py:61-80); '
+                 'VALU / LDS-issue bound, not HBM-bound')
+        ms = hip_timed(lambda: ops.resize_nearest(p['panoptic'], size, None), reps=10, warm=3)
+        out[f'f2_nearest_i64_{size[1]}x{size[0]}'] = _leg(
+            ms, n_out, round((n_px * 8 + n_out * 8) / n_out, 2), what='dense_base.py:15-58')
+    tab = torch.zeros((B, 256), dtype=torch.float32, device=dev)
+    tab[:, 1:] = p['center_scores'][:, :255]
+    ms = hip_timed(lambda: ops.panoptic_scores(x, p['semantic_idx_u8'], p['semantic_score'],
+                                               p['instance'], p['panoptic'], p['pan_of_inst'],
+                                               tab, 1 << 16), reps=10, warm=3)
+    out['f3_compute_scores'] = _leg(ms, n_px, 4 + 1 + 1 + 8 + 4 + 4 + 1 + 8 + 8,
+                                    what='panoptic.py:171-239: two kernels')
+    m = syn.make_label_maps(2, C + 1, H, W, 30, seed=2)
+    reps = (B + 1) // 2
+    sem = torch.from_numpy(np.tile(m['semantic'], (reps, 1, 1))[:B]).to(dev)
+    ins = torch.from_numpy(np.tile(m['instance'], (reps, 1, 1))[:B]).to(dev)
+    th = torch.from_numpy(m['semantic_classes_is_thing'].astype(np.uint8)).to(dev)
+    st = torch.from_numpy((~m['semantic_classes_is_thing']).astype(np.uint8)).to(dev)
+    ops.instance_clear_stuff(sem, ins, st)
+    ms = hip_timed(lambda: ops.instance_targets(sem, ins, C + 1, th, st, 8, True), reps=10, warm=3)
+    out['f4_instance_targets'] = _leg(ms, n_px, 1 + 4 + 4 + 8 + 1 + 1,
+                                      what='data/preprocessing/instance.py:97-286 per batch: labels '
+                                           'in, center / offset / masks out; latency-bound passes')
+    ms = hip_timed(lambda: ops.panoptic_targets(sem, ins, C + 1, th, 1 << 16), reps=10, warm=3)
+    out['f4_panoptic_targets'] = _leg(ms, n_px, 1 + 4 + 8,
+                                      what='data/preprocessing/panoptic.py:16-85 per batch')
+    return out
+
+
 def secondary(ops, syn, dev):
     out = {}
     legs = (
@@ -355,6 +403,7 @@ def secondary(ops, syn, dev):
                                                  torch.bfloat16)),
         ('cfg5_cos_emb_D512', lambda: secondary_cos_emb(dev, B=16, D=512)),
         ('cfg5_cos_emb_D768', lambda: secondary_cos_emb(dev, B=16, D=768)),
+        ('next_rows', lambda: secondary_next_rows(ops, syn, dev)),
     )
     for name, fn in legs:
         try:
