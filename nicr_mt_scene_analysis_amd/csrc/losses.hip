@@ -1057,7 +1057,8 @@ int cos_chunk(int L, int D)
 }
 size_t cos_lds_bytes(int L, int DC) { return ((size_t)L * (DC + 1) + L) * sizeof(float); }
 
-// dynamic LDS above the 64 KB default has to be granted per kernel function (once each)
+// dynamic LDS above the 64 KB default is granted per kernel function, once per process (the
+// launch macros keep the result in a function-local static)
 template <typename K>
 int cos_allow_lds(K kernel, size_t bytes)
 {
@@ -1092,7 +1093,8 @@ extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t*
         // the per-pixel dot products are only kept on the aligned path (16-B float stores)
         const bool dots_vec = dots_out && vec && ((((uintptr_t)dots_out) & 15) == 0);
         if (dots_out && !dots_vec) return NMSA_ERR_ARG;
-#define COS_FWD(DT, PX) do { if (cos_allow_lds(k_cos_emb_lds<DT, PX, false>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
+#define COS_FWD(DT, PX) do { static const int denied = cos_allow_lds(k_cos_emb_lds<DT, PX, false>, COS_LDS_BUDGET + 1024); \
+        if (denied) return NMSA_ERR_LAUNCH; \
         hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, false>), dim3(gx, B), dim3(COS_THREADS), lds, \
         stream, pred, indices, lut, D, P, L, DC, ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status, \
         dots_vec ? dots_out : (float*)nullptr); } while (0)
@@ -1143,7 +1145,8 @@ extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t*
         const int gx = (P + ppb - 1) / ppb;
         const int vec = (P % pxt == 0) && ((((uintptr_t)pred | (uintptr_t)grad_pred) & 15) == 0);
         if (dots && !vec) return NMSA_ERR_ARG;
-#define COS_BWD(DT, PX) do { if (cos_allow_lds(k_cos_emb_lds<DT, PX, true>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
+#define COS_BWD(DT, PX) do { static const int denied = cos_allow_lds(k_cos_emb_lds<DT, PX, true>, COS_LDS_BUDGET + 1024); \
+        if (denied) return NMSA_ERR_LAUNCH; \
         hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, true>), dim3(gx, B), dim3(COS_THREADS), lds, \
         stream, pred, indices, lut, D, P, L, DC, ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr, \
         (float*)dots); } while (0)
