@@ -161,6 +161,10 @@ __global__ __launch_bounds__(FIN_THREADS) void k_loss_finalize(
 // target logit x_t is fetched with one gather per pixel after the loop (the tile was just
 // streamed, the gather hits L2) instead of a compare/select per class.
 // =================================================================================
+#ifndef NMSA_GRAD_NT
+#define NMSA_GRAD_NT 1
+#endif
+constexpr bool GRAD_NT = NMSA_GRAD_NT != 0;     // gradient planes are written once: streaming stores
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float LN2 = 0.6931471805599453f;
 
@@ -191,12 +195,15 @@ __device__ __forceinline__ void ldpx(const void* base, size_t off, int nvalid, b
     }
 }
 
-template <int DTYPE, int PXT>
+template <int DTYPE, int PXT, bool NT = false>
 __device__ __forceinline__ void stpx(void* base, size_t off, int nvalid, bool vec, const float v[PXT])
 {
     if (DTYPE == NMSA_F32) {
         float* p = (float*)base + off;
-        if (vec) *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
+        if (vec) {
+            const f32x4_s w = {v[0], v[1], v[2], v[3]};
+            if (NT) __builtin_nontemporal_store(w, (f32x4_s*)p); else *(f32x4_s*)p = w;
+        }
         else for (int j = 0; j < nvalid; ++j) p[j] = v[j];
     } else {
         uint16_t* p = (uint16_t*)base + off;
@@ -204,10 +211,10 @@ __device__ __forceinline__ void stpx(void* base, size_t off, int nvalid, bool ve
 #pragma unroll
         for (int j = 0; j < PXT; ++j) h[j] = (DTYPE == NMSA_BF16) ? f32_to_bf16(v[j]) : f32_to_f16(v[j]);
         if (vec) {
-            uint4 w;
+            u32x4_s w;
             w.x = h[0] | ((uint32_t)h[1] << 16); w.y = h[2] | ((uint32_t)h[3] << 16);
             w.z = h[4] | ((uint32_t)h[5] << 16); w.w = h[6] | ((uint32_t)h[7] << 16);
-            *(uint4*)p = w;
+            if (NT) __builtin_nontemporal_store(w, (u32x4_s*)p); else *(u32x4_s*)p = w;
         } else {
             for (int j = 0; j < nvalid; ++j) p[j] = h[j];
         }
@@ -396,7 +403,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
                 r -= (t[j] == c) ? ag[j] : 0.f;
                 o[j] = r;
             }
-            stpx<DTYPE, PXT>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
+            stpx<DTYPE, PXT, GRAD_NT>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
         };
         // UB plane loads in flight, then UB plane stores
         int c = 0;
@@ -786,7 +793,7 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
 #pragma unroll
                         for (int j = 0; j < PXT; ++j)
                             o[j] = fmaf(k2[j], v[u][j], k1[j] * s_lut[row[j] + d + u]);
-                        stpx<DTYPE, PXT>(grad, base + (size_t)(d + u) * P, nvalid, vec, o);
+                        stpx<DTYPE, PXT, GRAD_NT>(grad, base + (size_t)(d + u) * P, nvalid, vec, o);
                     }
                 }
                 for (; d < n; ++d) {
@@ -794,7 +801,7 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
                     ldpx<DTYPE, PXT, true>(pred, base + (size_t)d * P, nvalid, vec, v);
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) o[j] = fmaf(k2[j], v[j], k1[j] * s_lut[row[j] + d]);
-                    stpx<DTYPE, PXT>(grad, base + (size_t)d * P, nvalid, vec, o);
+                    stpx<DTYPE, PXT, GRAD_NT>(grad, base + (size_t)d * P, nvalid, vec, o);
                 }
             }
         }
