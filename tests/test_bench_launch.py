@@ -64,3 +64,19 @@ def test_bench_rejects_a_world_size_mismatch():
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL,
                        env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and 'WORLD_SIZE' in (r.stderr + r.stdout)
+
+
+def test_metric_sync_on_rccl():
+    """`Metric.sync()` (dist_reduce_fx='sum' of reference metric/miou.py:21-25, pq.py:228-246) on
+    the RCCL backend with device-resident int64 / float64 states, one rank"""
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.pop('NMSA_BENCH_BACKEND', None)
+    r = subprocess.run([sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
+                        '--nproc-per-node=1', '--master-addr', '127.0.0.1', '--master-port', str(port),
+                        os.path.join(ROOT, 'tests', '_nccl_sync_worker.py')],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert 'RCCL_SYNC_OK rank 0 of 1' in r.stdout, r.stdout[-2000:]
