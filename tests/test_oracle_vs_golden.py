@@ -371,3 +371,57 @@ def test_target_cases(oracle):
     assert [list(d.items()) for d in dicts] == [list(d.items()) for d in want]
     keys = [g['dve_keys'][b, :g['dve_n'][b]] for b in range(len(sem))]
     assert np.array_equal(oracle.dve_indices(g['panoptic'], keys), g['dve_indices'])
+
+
+def test_task_helper_loss_dicts_from_oracle_pieces(oracle):
+    """a10 on the CPU tier: the reference task helpers' loss dicts (tests/golden/task_helper_cases)
+    rebuilt from the C oracle's loss functions with the helpers' conventions — per-scale
+    `loss / n`, total = sum(loss) / sum(n) (task_helper/base.py:161-182), center `pred * mask` with
+    n = sum(mask) (instance.py:129-139), offset n = sum(foreground) (:154-167), orientation
+    n = max(sum(mask), 1) (:206-211)"""
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+    g = load('task_helper_cases')
+    batch, preds, weights = syn.make_training_case()
+    scales = [('main', None), ('down_2', 2), ('down_4', 4)]
+
+    def want(name):
+        return dict(zip(jload(g[f'train__{name}__keys']), g[f'train__{name}__values']))
+
+    def tgt(key, s):
+        return batch[key] if s is None else batch[f'_down_{s}'][key]
+
+    def pred(key, s, i=None):
+        x = preds[key] if s is None else preds[key.replace('_output', '_side_outputs')][scales_idx[s]]
+        return x if i is None else x[i]
+    scales_idx = {2: 0, 4: 1}
+
+    # semantic: plain and weighted + label smoothing
+    for name, kw in (('sem_plain', {}), ('sem_weighted_smooth', dict(weights=weights, label_smoothing=0.1))):
+        w, tot_l, tot_n = want(name), 0.0, 0
+        for key, s in scales:
+            l, n, _, _ = oracle.loss_ce(pred('semantic_output', s), tgt('semantic', s), **kw)
+            np.testing.assert_allclose(l / n, w[f'semantic_loss_{key}'], rtol=1e-5, err_msg=f'{name} {key}')
+            tot_l, tot_n = tot_l + l, tot_n + n
+        np.testing.assert_allclose(tot_l / tot_n, w['semantic_total_loss'], rtol=1e-5)
+
+    # instance: center (mse / l1), offset (l1), orientation (von Mises)
+    for name, kind in (('ins_mse', 'mse'), ('ins_l1', 'l1')):
+        w = want(name)
+        acc = {k: [0.0, 0] for k in ('center', 'offset', 'orientation')}
+        for key, s in scales:
+            l, n, _ = oracle.loss_masked_elementwise(pred('instance_output', s, 0)[:, 0],
+                                                     tgt('instance_center', s),
+                                                     tgt('instance_center_mask', s), kind)
+            np.testing.assert_allclose(l / n, w[f'instance_center_loss_{key}'], rtol=1e-5)
+            acc['center'][0] += l; acc['center'][1] += n
+            l, n, _ = oracle.loss_masked_elementwise(pred('instance_output', s, 1), tgt('instance_offset', s),
+                                                     tgt('instance_foreground', s), 'l1')
+            np.testing.assert_allclose(l / n, w[f'instance_offset_loss_{key}'], rtol=1e-5)
+            acc['offset'][0] += l; acc['offset'][1] += n
+            l, n, _ = oracle.loss_vonmises(pred('instance_output', s, 2), tgt('orientation', s),
+                                           tgt('orientation_foreground', s), 1.0)
+            n = max(n, 1)
+            np.testing.assert_allclose(l / n, w[f'instance_orientation_loss_{key}'], rtol=1e-5)
+            acc['orientation'][0] += l; acc['orientation'][1] += n
+        for k, (l, n) in acc.items():
+            np.testing.assert_allclose(l / n, w[f'instance_{k}_total_loss'], rtol=1e-5, err_msg=f'{name} {k}')
