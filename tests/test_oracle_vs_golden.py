@@ -425,3 +425,63 @@ def test_task_helper_loss_dicts_from_oracle_pieces(oracle):
             acc['orientation'][0] += l; acc['orientation'][1] += n
         for k, (l, n) in acc.items():
             np.testing.assert_allclose(l / n, w[f'instance_{k}_total_loss'], rtol=1e-5, err_msg=f'{name} {k}')
+
+
+def test_validation_logs_from_oracle_pieces(oracle):
+    """a14 on the CPU tier: the reference's SemanticTaskHelper / PanopticTaskHelper validation
+    artifacts and logs (two steps + epoch end, tests/golden/task_helper_cases) rebuilt from the
+    C oracle: argmax -> center NMS -> grouping -> merge, confusion matrices (bit-exact), PQ states
+    and the PQ / SQ / RQ / mIoU values computed from them"""
+    import torch
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+    g = load('task_helper_cases')
+    gt = {k[len('val__gt_'):]: g[k] for k in g.files if k.startswith('val__gt_')}
+    is_thing_nc = g['val__is_thing_with_void']
+    NC = len(is_thing_nc)
+    C = NC - 1
+    is_thing = is_thing_nc[1:]
+    B, H, W = gt['semantic'].shape
+    cm_sem = np.zeros((C, C), np.int64)
+    cm_pan = np.zeros((NC, NC), np.int64)
+    state = None
+    for step in range(2):
+        logits, center, offset, _ = syn.make_predictions_from_targets(
+            gt['semantic'], gt['instance_center'], gt['instance_offset'], gt['orientation'], C, seed=step)
+        idx, _ = oracle.semantic_argmax(logits)
+        # SemanticTaskHelper.validation_step (semantic.py:124-128): void pixels masked out
+        m = gt['semantic'] != 0
+        cm_sem = oracle.confmat_update(idx[m], gt['semantic'][m] - 1, C, cm_sem)
+        fg = is_thing[idx]
+        cyx, n, _, _ = oracle.center_nms_topk(center, max_centers=256)
+        inst, _ = oracle.group_offsets(offset, fg, cyx, n, scale_y=H, scale_x=W)
+        pan, _ = oracle.deeplab_merge(idx + 1, inst, fg, 1 << 16, np.where(is_thing)[0] + 1, 0)
+        if step == 0:
+            assert (pan == g['val__pred_panoptic_step0']).all()
+        # PanopticTaskHelper.validation_step (panoptic.py:104-126)
+        for b in range(B):
+            *state, _ = oracle.pq_compare_and_accumulate(pan[b], gt['panoptic'][b], NC, 0, 1 << 16,
+                                                         256 ** 3, state=state)
+        cm_pan = oracle.confmat_update(pan // 65536, gt['semantic'], NC, cm_pan)
+    assert (cm_sem == g['val__sem__artifact__semantic_cm']).all()
+    assert (cm_pan == g['val__pan__artifact__panoptic_deeplab_semantic_cm']).all()
+
+    logs = dict(zip(jload(g['val__sem__log_keys']), g['val__sem__log_values']))
+    miou = MeanIntersectionOverUnion(C, device='cpu')
+    miou.confmat += torch.from_numpy(cm_sem)
+    np.testing.assert_allclose(float(miou.compute()), logs['semantic_miou'], rtol=1e-6)
+
+    logs = dict(zip(jload(g['val__pan__log_keys']), g['val__pan__log_values']))
+    miou = MeanIntersectionOverUnion(NC, ignore_first_class=True, device='cpu')
+    miou.confmat += torch.from_numpy(cm_pan)
+    np.testing.assert_allclose(float(miou.compute()), logs['panoptic_deeplab_semantic_miou'], rtol=1e-6)
+    pq = PanopticQuality(NC, 0, 1 << 16, 256 ** 3, [bool(t) for t in is_thing_nc], device='cpu')
+    for name, vec in zip(('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class'), state):
+        getattr(pq, name).add_(torch.from_numpy(vec))
+    res = pq.compute(suffix='_deeplab')
+    for k, v in logs.items():
+        short = k[len('panoptic_'):]
+        if short in res:
+            np.testing.assert_allclose(float(res[short]), v, rtol=1e-12, err_msg=k)
+    for k in ('sq_per_class', 'rq_per_class', 'pq_per_class'):
+        np.testing.assert_allclose(res[k].numpy(), g[f'val__pan__artifact__panoptic_{k}'], rtol=1e-12)
