@@ -1355,6 +1355,13 @@ int launch_fused(const void* logits, const float* offset, const int32_t* centers
                                centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
                                use_thr, thr, sem_u8, inst, fg_out, score, votes, ablate);
         }
+    } else if (vec && score && W % 4 == 0 && tiled == 2 && env_int("NMSA_FUSED_SCORE_TILED", 1)) {
+        // the with-score variant on the same 128 x 8 tiles
+        const int tiles = ((W + 127) / 128) * ((H + 7) / 8);
+        hipLaunchKernelGGL((k_panoptic_fused<DTYPE, true, true, 8, true, false, true, 7>),
+                           dim3((tiles + iters - 1) / iters, B), block, lds, stream, logits, offset,
+                           centers_yx, n_centers, is_thing, C, H, W, max_centers, iters, sy, sx,
+                           use_thr, thr, sem_u8, inst, fg_out, score, votes, ablate);
     } else if (vec) { if (score) NMSA_LAUNCH_FUSED(true, true); else NMSA_LAUNCH_FUSED(true, false); }
     else { if (score) NMSA_LAUNCH_FUSED(false, true); else NMSA_LAUNCH_FUSED(false, false); }
 #undef NMSA_LAUNCH_FUSED

@@ -28,8 +28,9 @@ if 'stuff' in flags:                    # no thing pixel at all
     logits[:, 0] = 5
 a = (logits, center, inp['instance_offset'], inp['semantic_classes_is_thing'])
 ev = []
+want_score = 'score' in flags
 for _ in range(25):
-    r = ops.panoptic_pipeline(*a, fused_kernel_events=ev)
+    r = ops.panoptic_pipeline(*a, fused_kernel_events=ev, want_score=want_score)
 torch.cuda.synchronize()
 ms = float(np.mean([x.elapsed_time(y) for x, y in ev[5:]]))
 es = logits.element_size()
