@@ -24,6 +24,7 @@ carries `secondary`: the other BASELINE.json configurations (bf16 logits, config
 configs[4] shapes + dense cosine loss), measured after the timed region with HIP events.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -489,6 +490,8 @@ def main():
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
+    gc.collect()
+    gc.disable()                               # no collector pause inside the (few-ms) timed region
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = step(i, True)
@@ -499,6 +502,7 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    gc.enable()
 
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64,
