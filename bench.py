@@ -510,6 +510,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # after the timed region: every rank must hold the same reduced accumulators (checksum of
+    # the confusion matrix and the PQ vectors, gathered over the ranks)
+    totals_identical = None
+    if dist is not None and metrics is not None:
+        metrics.wait()
+        torch.cuda.synchronize()
+        chk = torch.stack([metrics.total_confmat.sum().double(),
+                           metrics.total_pq.double().sum()]).to(dev)
+        if dist.get_backend() != 'nccl':
+            chk = chk.cpu()
+        gathered = [torch.zeros_like(chk) for _ in range(world)]
+        dist.all_gather(gathered, chk)
+        totals_identical = bool(all(torch.equal(g, gathered[0]) for g in gathered))
+
     n_px_step = B * H * W * world
     ms_per_step = elapsed / args.steps * 1e3
     value = n_px_step / (elapsed / args.steps) / 1e6
@@ -570,7 +584,8 @@ def main():
                                   f'{"every step" if args.metric_sync == "step" else "once per run, timed"})'},
         'collective': {'backend': ('rccl' if backend == 'nccl' else backend), 'rccl_ranks': rccl_ranks,
                        'payload_bytes': int(metrics._packed.numel() * 8)
-                       if metrics is not None and metrics._packed is not None else 0}
+                       if metrics is not None and metrics._packed is not None else 0,
+                       'totals_identical_on_all_ranks': totals_identical}
         if dist is not None else None,
         'roofline': roofline,
     }

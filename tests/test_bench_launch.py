@@ -39,6 +39,7 @@ def test_bench_self_launches_two_ranks():
     d = _json_line(r.stdout)
     assert d['n_gpus'] == 2 and d['config']['global_batch'] == 4 and d['scaling'] == 'weak'
     assert d['collective']['backend'] == 'gloo' and d['collective']['payload_bytes'] > 0
+    assert d['collective']['totals_identical_on_all_ranks'] is True
     assert d['value'] > 0 and d['cpu_baseline'] is None
 
 
@@ -54,9 +55,9 @@ def test_bench_under_launcher_runs_the_rccl_leg():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     d = _json_line(r.stdout)
-    assert d['collective'] == {'backend': 'rccl', 'rccl_ranks': 1,
-                               'payload_bytes': d['collective']['payload_bytes']}
-    assert d['collective']['payload_bytes'] == (9 * 9 + 4 * 9) * 8
+    c = d['collective']
+    assert c['backend'] == 'rccl' and c['rccl_ranks'] == 1
+    assert c['payload_bytes'] == (9 * 9 + 4 * 9) * 8 and c['totals_identical_on_all_ranks'] is True
 
 
 def test_bench_rejects_a_world_size_mismatch():
