@@ -81,3 +81,31 @@ def test_metric_sync_on_rccl():
                        env=env, capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr[-3000:]
     assert 'RCCL_SYNC_OK rank 0 of 1' in r.stdout, r.stdout[-2000:]
+
+
+def test_bench_secondary_legs_run_on_small_shapes():
+    """every leg of bench.py's `secondary` object (the other BASELINE configurations and the
+    "next" rows) on tiny shapes: no exception, the fields the driver reads are there"""
+    import importlib
+    import torch
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module('bench')
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
+    dev = torch.device('cuda', 0)
+    legs = {
+        'pipeline_bf16': bench.secondary_pipeline(ops, syn, dev, 2, 8, 96, 128, 4, torch.bfloat16),
+        'pipeline_f32_serial': bench.secondary_pipeline(ops, syn, dev, 2, 150, 64, 128, 4, None,
+                                                        overlap=False),
+        'losses': bench.secondary_losses(dev, B=2, C=8, H=64, W=96),
+        'cos': bench.secondary_cos_emb(dev, B=1, D=64, H=32, W=32, L=8),
+        'next_rows': bench.secondary_next_rows(ops, syn, dev, B=2, C=8, H=96, W=128),
+    }
+    n = 0
+    for name, leg in legs.items():
+        for key, entry in leg.items():
+            if isinstance(entry, dict):
+                n += 1
+                assert entry['ms'] == entry['ms'] or key == 'step_two_batches_in_flight', (name, key)
+                assert entry['algorithmic_bytes'] > 0 and 'frac' in entry, (name, key)
+    assert n >= 17
