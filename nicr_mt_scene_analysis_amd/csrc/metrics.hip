@@ -407,10 +407,12 @@ __global__ __launch_bounds__(256) void k_pq_count(
                     // others — segment boundaries, or every lane when the maps are incoherent —
                     // add their two pixels themselves: ONE run pass per load either way
                     const bool same = k0 == k1;
-                    if (__any(same && k0 >= 0)) cm_runs(same ? k0 : -1, 2u);
-                    if (!same) {
-                        if (k0 >= 0) atomicAdd(&cm_hist_pq[k0], 1u);
-                        if (k1 >= 0) atomicAdd(&cm_hist_pq[k1], 1u);
+                    const int kf = __builtin_amdgcn_readfirstlane(k0);
+                    if (__all(same && k0 == kf)) {                    // the wave sits on one bin
+                        if (lane_id() == 0 && kf >= 0) atomicAdd(&cm_hist_pq[kf], 128u);
+                    } else {
+                        if (k0 >= 0) atomicAdd(&cm_hist_pq[k0], same ? 2u : 1u);
+                        if (!same && k1 >= 0) atomicAdd(&cm_hist_pq[k1], 1u);
                     }
                 }
             }
@@ -419,8 +421,19 @@ __global__ __launch_bounds__(256) void k_pq_count(
                 const int64_t i0 = iid_of(tv[u].x, pv[u].x, ok[u]);
                 const int64_t i1 = iid_of(tv[u].y, pv[u].y, ok[u]);
                 const bool same = i0 == i1;
-                if (__any(ok[u] && same)) wave_runs(ok[u] && same, i0, 2u);
-                if (ok[u] && !same) { add(i0, 1u); add(i1, 1u); }     // boundary lanes
+                // Insertion per LANE, not per run: cutting the wave into runs (shuffles, two
+                // ballots, per-lane 64-bit mask arithmetic) cost more issue slots than the LDS
+                // atomics it saved (47 -> 41 us on the bench's 30-60 px segments).  Only a wave
+                // that sits on ONE pair — the inside of a large segment, where 64 lanes would
+                // hit one LDS address — sends a single lane with the whole weight.
+                const int64_t f0 = (int64_t)(((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(i0 >> 32)) << 32) |
+                                             (uint32_t)__builtin_amdgcn_readfirstlane((int)i0));
+                if (__all(ok[u] && same && i0 == f0)) {
+                    if (lane_id() == 0) add(f0, 128u);
+                } else {
+                    if (ok[u]) add(i0, same ? 2u : 1u);
+                    if (ok[u] && !same) add(i1, 1u);
+                }
             }
         }
     } else {
