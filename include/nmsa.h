@@ -444,6 +444,23 @@ int nmsa_pq_update_with_confmat(
  *     n_mask then counts the positive (target == 1) masked pixels
  * nmsa_loss_vonmises_* VonMisesLossBiternion  loss/vonmises.py:27-51 over the px
  *     where mask != 0 (gather of task_helper/instance.py:186-216), pred/target [B,2,H,W]
+ * nmsa_loss_*_fwd_grad / nmsa_loss_*_bwd_unless  forward and gradient in ONE pass:
+ *     the reference's losses are sums that the caller divides (`loss / n`,
+ *     task_helper/base.py:161-182: sum_scales loss / sum_scales n), so the upstream gradient
+ *     of a loss sum is known before backward runs once n is (nmsa_count_u8 over the labels /
+ *     mask, 1 B/px).  *_fwd_grad takes that EXPECTED scale as a device scalar and writes
+ *     expected * d loss_sum / d pred into grad_* while it computes the forward sum: the
+ *     prediction is read once and the gradient written once (CE at C = 40, bf16: 162 B/px
+ *     instead of 250).  Backward then calls *_bwd_unless with the real upstream gradient:
+ *     when *grad_scale is bit-equal to *computed_for the gradient buffer is already right and
+ *     the kernel returns at once (counters[0]++), otherwise it recomputes the gradient from
+ *     the inputs (counters[1]++), so the result never depends on the expectation.
+ *     The CE variant keeps a pixel's whole class column in registers: C <= 48
+ *     (nmsa_loss_ce_fwd_grad_supported), NMSA_ERR_UNSUPPORTED above.
+ * nmsa_count_u8        *count = #{i : lo <= values[i] <= hi}  (labels 1..C, mask bytes 1..255);
+ *     *mean_scale (optional) = weight / (float)count, the correctly rounded fp32 division
+ *     autograd performs for `weight * loss_sum / count`;
+ *     workspace: nmsa_count_workspace_bytes()
  * nmsa_loss_cos_emb_*  CosineEmbeddingLoss  loss/cos_emb.py:21-56 with the LUT gather of
  *     task_helper/dense_visual_embedding.py:110-171: pred [B,D,H,W], indices i32
  *     [B,H,W] (0 = no target), lut f32 [B,L,D];
@@ -461,6 +478,21 @@ int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* target, const
                      int B, int C, int H, int W, float label_smoothing,
                      const float* grad_scale, const float* lse2, void* grad_logits,
                      nmsa_stream_t stream);
+int nmsa_loss_ce_fwd_grad_supported(int dtype, int C);
+int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_t* target, const float* weights,
+                          int B, int C, int H, int W, float label_smoothing,
+                          const float* expected_grad_scale,
+                          double* loss_sum, int64_t* n_elements, double* weight_sum,
+                          void* grad_logits, int32_t* status,
+                          void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_loss_ce_bwd_unless(const void* logits, int dtype, const uint8_t* target,
+                            const float* weights, int B, int C, int H, int W,
+                            float label_smoothing, const float* grad_scale, void* grad_logits,
+                            const float* computed_for, int32_t* counters, nmsa_stream_t stream);
+size_t nmsa_count_workspace_bytes(void);
+int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, int64_t* count,
+                  float* mean_scale, float weight,
+                  void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
 int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
                          int B, int C, int H, int W, int kind,
                          double* loss_sum, int64_t* n_mask,
@@ -468,6 +500,15 @@ int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* target, const
 int nmsa_loss_masked_bwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
                          int B, int C, int H, int W, int kind,
                          const float* grad_scale, void* grad_pred, nmsa_stream_t stream);
+int nmsa_loss_masked_fwd_grad(const void* pred, int dtype, const float* target,
+                              const uint8_t* mask, int B, int C, int H, int W, int kind,
+                              const float* expected_grad_scale,
+                              double* loss_sum, int64_t* n_mask, void* grad_pred,
+                              void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_loss_masked_bwd_unless(const void* pred, int dtype, const float* target,
+                                const uint8_t* mask, int B, int C, int H, int W, int kind,
+                                const float* grad_scale, void* grad_pred,
+                                const float* computed_for, int32_t* counters, nmsa_stream_t stream);
 int nmsa_loss_vonmises_fwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
                            int B, int H, int W, float kappa,
                            double* loss_sum, int64_t* n_rows,
@@ -475,6 +516,16 @@ int nmsa_loss_vonmises_fwd(const void* pred, int dtype, const float* target, con
 int nmsa_loss_vonmises_bwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
                            int B, int H, int W, float kappa,
                            const float* grad_scale, void* grad_pred, nmsa_stream_t stream);
+int nmsa_loss_vonmises_fwd_grad(const void* pred, int dtype, const float* target,
+                                const uint8_t* mask, int B, int H, int W, float kappa,
+                                const float* expected_grad_scale,
+                                double* loss_sum, int64_t* n_rows, void* grad_pred,
+                                void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_loss_vonmises_bwd_unless(const void* pred, int dtype, const float* target,
+                                  const uint8_t* mask, int B, int H, int W, float kappa,
+                                  const float* grad_scale, void* grad_pred,
+                                  const float* computed_for, int32_t* counters,
+                                  nmsa_stream_t stream);
 int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
                           int B, int D, int H, int W, int L,
                           double* loss_sum, int64_t* n_rows, float* dots_out, int32_t* status,

@@ -149,6 +149,22 @@ __global__ __launch_bounds__(FIN_THREADS) void k_loss_finalize(
     }
 }
 
+// Speculative gradients (k_*_fused below write the gradient in the forward pass for an EXPECTED
+// upstream scale).  The backward kernels are then launched with `computed_for` = that expected
+// scale: when the real upstream gradient is bit-equal, the gradient buffer is already right and
+// every workgroup returns at once; otherwise the kernel recomputes it.  counters[0] / [1] count
+// the two outcomes.
+__device__ __forceinline__ bool grad_already_computed(const float* __restrict__ gscale,
+                                                      const float* __restrict__ computed_for,
+                                                      int* __restrict__ counters)
+{
+    if (!computed_for) return false;
+    const bool same = __float_as_uint(*gscale) == __float_as_uint(*computed_for);
+    if (counters && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        atomicAdd(&counters[same ? 0 : 1], 1);
+    return same;
+}
+
 // =================================================================================
 // a6: cross entropy (weights, ignore void, label smoothing)
 //   per px (t = label-1 >= 0):  (1-ls)*w_t*(lse - x_t) + (ls/C)*(lse*W - sum_c w_c x_c)
@@ -345,9 +361,11 @@ template <int DTYPE, int PXT, bool SMOOTH, int UB>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
-    const float* __restrict__ gscale, void* __restrict__ grad, const float* __restrict__ lse2)
+    const float* __restrict__ gscale, void* __restrict__ grad, const float* __restrict__ lse2,
+    const float* __restrict__ computed_for, int* __restrict__ counters)
 {
     extern __shared__ float s_w[];
+    if (grad_already_computed(gscale, computed_for, counters)) return;
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
     float wsum = 0.f;
@@ -423,6 +441,258 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     }
 }
 
+// ---- forward + gradient in ONE pass over the logits ------------------------------------------
+// The gradient of the summed loss needs the upstream scale g, which autograd hands over only
+// in backward.  The callers know what it is going to be (1 / n for a mean, w / sum_scales n in
+// the task helpers; n comes from a 1 B/px count over the labels, k_count_u8), so the forward
+// kernel writes g_expected * d loss / d logits right away and the backward launch only confirms
+// it (grad_already_computed).  Per px: logits 2C|4C read once + gradient written once instead
+// of forward read + log-sum-exp write + backward read + log-sum-exp read + gradient write.
+//
+// A lane keeps its pixels' WHOLE class column in registers (8 B per plane and lane: 4 px of a
+// 16-bit dtype, 2 px of f32; 8*NG planes -> 16*NG VGPRs), so the maximum, the sum of
+// exponentials and the softmax each walk registers, not memory.  C <= 48 (NG <= 6); larger C
+// falls back to the two-kernel path.
+typedef unsigned int u32x2_s __attribute__((ext_vector_type(2)));
+
+template <int DTYPE>
+__device__ __forceinline__ u32x2_s ld_plane8(const void* base, size_t off, int nvalid, bool vec)
+{
+    if (DTYPE == NMSA_F32) {
+        const float* p = (const float*)base + off;
+        if (vec) return __builtin_nontemporal_load((const u32x2_s*)p);
+        u32x2_s r = {0u, 0u};
+        if (nvalid > 0) r.x = __float_as_uint(p[0]);
+        if (nvalid > 1) r.y = __float_as_uint(p[1]);
+        return r;
+    }
+    const uint16_t* p = (const uint16_t*)base + off;
+    if (vec) return __builtin_nontemporal_load((const u32x2_s*)p);
+    uint16_t h[4] = {0, 0, 0, 0};
+    for (int j = 0; j < 4; ++j) if (j < nvalid) h[j] = p[j];
+    u32x2_s r = {h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16)};
+    return r;
+}
+
+template <int DTYPE>
+__device__ __forceinline__ float plane_px(const u32x2_s r, int j)
+{
+    if (DTYPE == NMSA_F32) return __uint_as_float(j == 0 ? r.x : r.y);
+    const uint32_t w = (j < 2) ? r.x : r.y;
+    if (DTYPE == NMSA_BF16) return __uint_as_float((j & 1) ? (w & 0xFFFF0000u) : (w << 16));
+    return f16_to_f32((uint16_t)((j & 1) ? (w >> 16) : (w & 0xFFFFu)));
+}
+
+template <int DTYPE>
+__device__ __forceinline__ void st_plane8(void* base, size_t off, int nvalid, bool vec, const float* v)
+{
+    if (DTYPE == NMSA_F32) {
+        float* p = (float*)base + off;
+        if (vec) {
+            const u32x2_s w = {__float_as_uint(v[0]), __float_as_uint(v[1])};
+            if (GRAD_NT) __builtin_nontemporal_store(w, (u32x2_s*)p); else *(u32x2_s*)p = w;
+        } else {
+            for (int j = 0; j < nvalid; ++j) p[j] = v[j];
+        }
+        return;
+    }
+    uint16_t* p = (uint16_t*)base + off;
+    uint16_t h[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) h[j] = (DTYPE == NMSA_BF16) ? f32_to_bf16(v[j]) : f32_to_f16(v[j]);
+    if (vec) {
+        const u32x2_s w = {h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16)};
+        if (GRAD_NT) __builtin_nontemporal_store(w, (u32x2_s*)p); else *(u32x2_s*)p = w;
+    } else {
+        for (int j = 0; j < nvalid; ++j) p[j] = h[j];
+    }
+}
+
+constexpr int CE_FUSED_MAX_C = 48;
+#ifndef NMSA_CE_FUSED_KEEP_PACKED
+#define NMSA_CE_FUSED_KEEP_PACKED 1
+#endif
+
+// Between the three walks over the register tile the compiler would rather keep the UNPACKED
+// fp32 values of a 16-bit tile (4 px x 40 planes = 160 more VGPRs, 1-2 waves per SIMD) than
+// unpack again (one shift / and per element); this makes the tile opaque so it stays packed.
+template <int NP>
+__device__ __forceinline__ void keep_packed(u32x2_s (&r)[NP])
+{
+#if NMSA_CE_FUSED_KEEP_PACKED
+#pragma unroll
+    for (int c = 0; c < NP; ++c) { asm volatile("" : "+v"(r[c].x), "+v"(r[c].y)); }
+#endif
+}
+
+template <int DTYPE, int NG, bool SMOOTH>
+__global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
+    const void* __restrict__ logits, const uint8_t* __restrict__ target,
+    const float* __restrict__ weights, int C, int P, float ls, int vec,
+    const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials, int* __restrict__ status)
+{
+    constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
+    constexpr int NP = 8 * NG;
+    extern __shared__ float s_w[];
+    for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
+    __syncthreads();
+    float wsum = 0.f;
+    if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
+    const float g = *expected_gscale;
+    const int b = blockIdx.y;
+    const size_t img = (size_t)b * C * P;
+    double acc = 0.0, accw = 0.0;
+    long long cnt = 0;
+    bool bad = false;
+    const int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * PXT;
+    if (p0 < P) {
+        const int nvalid = min(PXT, P - p0);
+        u32x2_s r[NP];
+#pragma unroll
+        for (int c = 0; c < NP; ++c)
+            if (c < C) r[c] = ld_plane8<DTYPE>(logits, img + (size_t)c * P + p0, nvalid, vec);
+        int t[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j)
+            t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;       // ce.py:46
+        float m[PXT], s[PXT], swx[PXT], xt[PXT], k0[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) { m[j] = -INFINITY; s[j] = 0.f; swx[j] = 0.f; xt[j] = 0.f; }
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            if (c < C) {
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) m[j] = fmaxf(m[j], plane_px<DTYPE>(r[c], j));
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) k0[j] = -m[j] * LOG2E;
+        if (DTYPE != NMSA_F32) keep_packed(r);
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            if (c < C) {
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    const float x = plane_px<DTYPE>(r[c], j);
+                    s[j] += __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                    if (SMOOTH) swx[j] = fmaf(s_w[c], x, swx[j]);
+                }
+            }
+        }
+        float ag[PXT], abg[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));                   // p = 2^(x log2e + k0)
+            const bool on = t[j] >= 0 && t[j] < C;
+            const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
+            ag[j] = g * a;
+            abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
+        }
+        if (DTYPE != NMSA_F32) keep_packed(r);
+#pragma unroll
+        for (int c = 0; c < NP; ++c) {
+            if (c < C) {
+                float o[PXT];
+                const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    const float x = plane_px<DTYPE>(r[c], j);
+                    const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                    float q = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
+                    const bool hit = t[j] == c;
+                    q -= hit ? ag[j] : 0.f;
+                    xt[j] = hit ? x : xt[j];
+                    o[j] = q;
+                }
+                st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
+            }
+        }
+        float part = 0.f, partw = 0.f;
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            if (t[j] < 0) continue;                                         // void: ignore_index
+            if (t[j] >= C) { bad = true; continue; }
+            const float lse = fmaf(__log2f(s[j]), LN2, m[j]);
+            const float wt = s_w[t[j]];
+            float l = (1.0f - ls) * wt * (lse - xt[j]);
+            if (SMOOTH) l += (ls / C) * (lse * wsum - swx[j]);
+            part += l;
+            partw += wt;
+            ++cnt;
+        }
+        acc = part; accw = partw;
+    }
+    if (bad) atomicOr(status, 8);
+    block_partial(acc, accw, cnt, partials);
+}
+
+// number of bytes v with lo <= v <= hi (labels 1..C, mask bytes != 0): the element count a loss
+// is going to be divided by, known BEFORE the loss kernel runs (1 B/px).  One partial per
+// workgroup, summed by k_count_finalize (thousands of atomics on one address cost 10 ns each).
+constexpr int COUNT_MAX_BLOCKS = 512;
+
+__global__ __launch_bounds__(LOSS_THREADS) void k_count_u8(
+    const uint8_t* __restrict__ v, long long n, int lo, int hi, int vec,
+    long long* __restrict__ partials)
+{
+    __shared__ long long s_cnt[LOSS_THREADS / 64];
+    long long cnt = 0;
+    const long long stride = (long long)gridDim.x * LOSS_THREADS;
+    const long long tid = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x;
+    const long long n16 = vec ? n / 16 : 0;
+    const unsigned span = (unsigned)(hi - lo);
+    auto count16 = [&](const u32x4_s w) {
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        int c = 0;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c += ((((ww[k] >> (8 * j)) & 0xFF) - (unsigned)lo) <= span);
+        }
+        return c;
+    };
+    long long i = tid;
+    for (; i + 3 * stride < n16; i += 4 * stride) {            // 4 x 16 B in flight per lane
+        u32x4_s w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load((const u32x4_s*)v + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += count16(w[u]);
+    }
+    for (; i < n16; i += stride) cnt += count16(__builtin_nontemporal_load((const u32x4_s*)v + i));
+    for (long long k = n16 * 16 + tid; k < n; k += stride) cnt += (((unsigned)v[k] - (unsigned)lo) <= span);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long c = 0;
+        for (int k = 0; k < LOSS_THREADS / 64; ++k) c += s_cnt[k];
+        partials[blockIdx.x] = c;
+    }
+}
+
+// *count = sum of the partials; *mean_scale (optional) = weight / count as fp32: the
+// correctly rounded division ATen's `weight / count` performs
+__global__ __launch_bounds__(COUNT_MAX_BLOCKS) void k_count_finalize(
+    const long long* __restrict__ partials, int n, long long* __restrict__ count,
+    float* __restrict__ mean_scale, float weight)
+{
+    __shared__ long long s_cnt[COUNT_MAX_BLOCKS / 64];
+    long long c = (threadIdx.x < n) ? partials[threadIdx.x] : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long t = 0;
+        for (int k = 0; k < COUNT_MAX_BLOCKS / 64; ++k) t += s_cnt[k];
+        *count = t;
+        if (mean_scale) *mean_scale = weight / (float)t;
+    }
+}
+
 // =================================================================================
 // a7: masked MSE / L1 with channel mean (C = 1: center, C = 2: offset)
 //   loss = sum_px mean_c f(pred*mask - target);  n = sum(mask)
@@ -485,8 +755,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_fwd(
 template <int DTYPE, int KIND>
 __global__ __launch_bounds__(LOSS_THREADS) void k_elem_bwd(
     const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
-    int C, int P, int vec, const float* __restrict__ gscale, void* __restrict__ grad)
+    int C, int P, int vec, const float* __restrict__ gscale, void* __restrict__ grad,
+    const float* __restrict__ computed_for, int* __restrict__ counters)
 {
+    if (grad_already_computed(gscale, computed_for, counters)) return;
     const int b = blockIdx.y;
     const float g = *gscale / C;
     for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * LOSS_THREADS * 4) {
@@ -509,6 +781,49 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_bwd(
             st4<DTYPE>(grad, off, nvalid, vec, o);
         }
     }
+}
+
+// forward + gradient for the expected upstream scale (see k_ce_fused)
+template <int DTYPE, int KIND>
+__global__ __launch_bounds__(LOSS_THREADS) void k_elem_fused(
+    const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
+    int C, int P, int vec, const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials)
+{
+    const int b = blockIdx.y;
+    double acc = 0.0; long long cnt = 0;
+    const float invC = 1.0f / C;
+    const float g = *expected_gscale / C;
+    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * LOSS_THREADS * 4) {
+        const int nvalid = min(4, P - p0);
+        bool mk[4];
+        ld_mask4(mask, (size_t)b * P + p0, nvalid, vec, mk);
+        float part = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const size_t off = ((size_t)b * C + c) * P + p0;
+            const float4 x = ld4<DTYPE>(pred, off, nvalid, vec);
+            const float4 y = ld4<NMSA_F32>(target, off, nvalid, vec);
+            const float xv[4] = {x.x, x.y, x.z, x.w}, yv[4] = {y.x, y.y, y.z, y.w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = (mk[j] ? xv[j] : 0.f) - yv[j];       // pred*mask - target
+                const float dd = (KIND == 2) ? focal_grad(xv[j], yv[j])
+                               : (KIND == 0) ? 2.0f * d : (float)((d > 0.f) - (d < 0.f));
+                o[j] = mk[j] ? g * dd : 0.f;
+                if (j >= nvalid) continue;
+                if (KIND == 2) {
+                    if (mk[j]) { part += focal_value(xv[j], yv[j]); cnt += (yv[j] == 1.0f); }
+                    continue;
+                }
+                part += (KIND == 0) ? d * d : fabsf(d);
+            }
+            st4<DTYPE>(grad, off, nvalid, vec, o);
+        }
+        acc += part * invC;
+        if (KIND != 2) for (int j = 0; j < 4; ++j) cnt += (j < nvalid) && mk[j];
+    }
+    block_partial(acc, 0.0, cnt, partials);
 }
 
 // =================================================================================
@@ -547,8 +862,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_vm_fwd(
 template <int DTYPE>
 __global__ __launch_bounds__(LOSS_THREADS) void k_vm_bwd(
     const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
-    int P, float kappa, int vec, const float* __restrict__ gscale, void* __restrict__ grad)
+    int P, float kappa, int vec, const float* __restrict__ gscale, void* __restrict__ grad,
+    const float* __restrict__ computed_for, int* __restrict__ counters)
 {
+    if (grad_already_computed(gscale, computed_for, counters)) return;
     const int b = blockIdx.y;
     const float g = *gscale;
     for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * LOSS_THREADS * 4) {
@@ -570,6 +887,42 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_vm_bwd(
         st4<DTYPE>(grad, o0, nvalid, vec, g0);
         st4<DTYPE>(grad, o1, nvalid, vec, g1);
     }
+}
+
+// forward + gradient for the expected upstream scale (see k_ce_fused)
+template <int DTYPE>
+__global__ __launch_bounds__(LOSS_THREADS) void k_vm_fused(
+    const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
+    int P, float kappa, int vec, const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials)
+{
+    const int b = blockIdx.y;
+    const float g = *expected_gscale;
+    double acc = 0.0; long long cnt = 0;
+    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * LOSS_THREADS * 4) {
+        const int nvalid = min(4, P - p0);
+        bool mk[4];
+        ld_mask4(mask, (size_t)b * P + p0, nvalid, vec, mk);
+        const size_t o0 = ((size_t)b * 2) * P + p0, o1 = o0 + P;
+        const float4 x0 = ld4<DTYPE>(pred, o0, nvalid, vec), x1 = ld4<DTYPE>(pred, o1, nvalid, vec);
+        const float4 y0 = ld4<NMSA_F32>(target, o0, nvalid, vec), y1 = ld4<NMSA_F32>(target, o1, nvalid, vec);
+        const float a0[4] = {x0.x, x0.y, x0.z, x0.w}, a1[4] = {x1.x, x1.y, x1.z, x1.w};
+        const float b0[4] = {y0.x, y0.y, y0.z, y0.w}, b1[4] = {y1.x, y1.y, y1.z, y1.w};
+        float g0[4], g1[4];
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float dot = fmaf(a1[j], b1[j], a0[j] * b0[j]);
+            const float ex = __expf(kappa * (dot - 1.0f));
+            const float e = mk[j] ? -g * kappa * ex : 0.f;
+            g0[j] = e * b0[j]; g1[j] = e * b1[j];
+            if (mk[j]) { part += 1.0f - ex; ++cnt; }
+        }
+        acc += part;
+        st4<DTYPE>(grad, o0, nvalid, vec, g0);
+        st4<DTYPE>(grad, o1, nvalid, vec, g1);
+    }
+    block_partial(acc, 0.0, cnt, partials);
 }
 
 // =================================================================================
@@ -912,10 +1265,11 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
     return finalize(partials, gx * B, loss_sum, weight_sum, n_elements, stream);
 }
 
-extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* target,
-                                const float* weights, int B, int C, int H, int W,
-                                float label_smoothing, const float* grad_scale, const float* lse2,
-                                void* grad_logits, nmsa_stream_t stream_)
+static int ce_bwd_impl(const void* logits, int dtype, const uint8_t* target,
+                       const float* weights, int B, int C, int H, int W,
+                       float label_smoothing, const float* grad_scale, const float* lse2,
+                       void* grad_logits, const float* computed_for, int32_t* counters,
+                       nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!logits || !target || !grad_scale || !grad_logits) return NMSA_ERR_ARG;
@@ -930,7 +1284,7 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
     const int ub = bwd_u ? bwd_u : 4;
 #define CE_BWD_U(DT, PX, SM, UU) hipLaunchKernelGGL((k_ce_bwd<DT, PX, SM, UU>), dim3(gx, B), dim3(LOSS_THREADS), \
         C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, grad_scale, \
-        grad_logits, lse2)
+        grad_logits, lse2, computed_for, counters)
 #define CE_BWD(DT, PX, SM) do { if (ub == 8) CE_BWD_U(DT, PX, SM, 8); else if (ub == 1) CE_BWD_U(DT, PX, SM, 1); \
                                 else CE_BWD_U(DT, PX, SM, 4); } while (0)
     switch (dtype) {
@@ -942,6 +1296,94 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
 #undef CE_BWD
 #undef CE_BWD_U
     return check_launch();
+}
+
+extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* target,
+                                const float* weights, int B, int C, int H, int W,
+                                float label_smoothing, const float* grad_scale, const float* lse2,
+                                void* grad_logits, nmsa_stream_t stream)
+{
+    return ce_bwd_impl(logits, dtype, target, weights, B, C, H, W, label_smoothing, grad_scale, lse2,
+                       grad_logits, nullptr, nullptr, stream);
+}
+
+extern "C" int nmsa_loss_ce_bwd_unless(const void* logits, int dtype, const uint8_t* target,
+                                       const float* weights, int B, int C, int H, int W,
+                                       float label_smoothing, const float* grad_scale,
+                                       void* grad_logits, const float* computed_for,
+                                       int32_t* counters, nmsa_stream_t stream)
+{
+    if (!computed_for) return NMSA_ERR_ARG;
+    return ce_bwd_impl(logits, dtype, target, weights, B, C, H, W, label_smoothing, grad_scale,
+                       nullptr, grad_logits, computed_for, counters, stream);
+}
+
+extern "C" size_t nmsa_count_workspace_bytes(void)
+{
+    return (size_t)COUNT_MAX_BLOCKS * sizeof(long long);
+}
+
+extern "C" int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, int64_t* count,
+                             float* mean_scale, float weight, void* workspace,
+                             size_t workspace_bytes, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!values || !count || !workspace || n < 0 || lo < 0 || hi > 255 || lo > hi) return NMSA_ERR_ARG;
+    if (workspace_bytes < nmsa_count_workspace_bytes()) return NMSA_ERR_WORKSPACE;
+    const int vec = (((uintptr_t)values) & 15) == 0;
+    int64_t blocks = (n / 16 + LOSS_THREADS * 4 - 1) / (LOSS_THREADS * 4);       // ~4 loads per lane
+    if (blocks < 1) blocks = 1;
+    if (blocks > COUNT_MAX_BLOCKS) blocks = COUNT_MAX_BLOCKS;
+    long long* partials = (long long*)workspace;
+    hipLaunchKernelGGL(k_count_u8, dim3((unsigned)blocks), dim3(LOSS_THREADS), 0, stream, values,
+                       (long long)n, lo, hi, vec, partials);
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_count_finalize, dim3(1), dim3(COUNT_MAX_BLOCKS), 0, stream, partials,
+                       (int)blocks, (long long*)count, mean_scale, weight);
+    return check_launch();
+}
+
+extern "C" int nmsa_loss_ce_fwd_grad_supported(int dtype, int C)
+{
+    return (dtype == NMSA_F32 || dtype == NMSA_BF16 || dtype == NMSA_F16) && C >= 1 &&
+           C <= CE_FUSED_MAX_C;
+}
+
+extern "C" int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_t* target,
+                                     const float* weights, int B, int C, int H, int W,
+                                     float label_smoothing, const float* expected_grad_scale,
+                                     double* loss_sum, int64_t* n_elements, double* weight_sum,
+                                     void* grad_logits, int32_t* status, void* workspace,
+                                     size_t workspace_bytes, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!logits || !target || !loss_sum || !n_elements || !status || !workspace ||
+        !expected_grad_scale || !grad_logits) return NMSA_ERR_ARG;
+    if (bad_shape(B, H, W) || C <= 0 || C > 4096) return NMSA_ERR_ARG;
+    if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return NMSA_ERR_ARG;
+    if (!nmsa_loss_ce_fwd_grad_supported(dtype, C)) return NMSA_ERR_UNSUPPORTED;   // column > registers
+    if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
+    const int P = H * W;
+    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
+    const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 7) == 0);
+    const int gx = grid_x(P, pxt);
+    const bool smooth = label_smoothing != 0.0f;
+    LossPartial* partials = (LossPartial*)workspace;
+    const int ng = (C <= 24) ? 3 : (C <= 40) ? 5 : 6;
+#define CE_FUSED_L(DT, NG, SM) hipLaunchKernelGGL((k_ce_fused<DT, NG, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
+        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, \
+        expected_grad_scale, grad_logits, partials, status)
+#define CE_FUSED_NG(DT, SM) do { if (ng == 3) CE_FUSED_L(DT, 3, SM); else if (ng == 5) CE_FUSED_L(DT, 5, SM); \
+                                 else CE_FUSED_L(DT, 6, SM); } while (0)
+#define CE_FUSED(DT) do { if (smooth) CE_FUSED_NG(DT, true); else CE_FUSED_NG(DT, false); } while (0)
+    NMSA_DISPATCH_DTYPE(dtype, CE_FUSED)
+#undef CE_FUSED
+#undef CE_FUSED_NG
+#undef CE_FUSED_L
+    int rc = check_launch();
+    if (rc) return rc;
+    return finalize(partials, gx * B, loss_sum, weight_sum, n_elements, stream);
 }
 
 extern "C" int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* target,
@@ -971,9 +1413,10 @@ extern "C" int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* ta
     return finalize(partials, gx * B, loss_sum, nullptr, n_mask, stream);
 }
 
-extern "C" int nmsa_loss_masked_bwd(const void* pred, int dtype, const float* target,
-                                    const uint8_t* mask, int B, int C, int H, int W, int kind,
-                                    const float* grad_scale, void* grad_pred, nmsa_stream_t stream_)
+static int masked_bwd_impl(const void* pred, int dtype, const float* target,
+                           const uint8_t* mask, int B, int C, int H, int W, int kind,
+                           const float* grad_scale, void* grad_pred, const float* computed_for,
+                           int32_t* counters, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !target || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
@@ -984,15 +1427,68 @@ extern "C" int nmsa_loss_masked_bwd(const void* pred, int dtype, const float* ta
     const int gx = grid_x(P, 8);
 #define CALL(DT)                                                                                     \
     if (kind == 0) hipLaunchKernelGGL((k_elem_bwd<DT, 0>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, \
-                                      pred, target, mask, C, P, vec, grad_scale, grad_pred);         \
+                                      pred, target, mask, C, P, vec, grad_scale, grad_pred,          \
+                                      computed_for, counters);                                       \
     else if (kind == 1) hipLaunchKernelGGL((k_elem_bwd<DT, 1>), dim3(gx, B), dim3(LOSS_THREADS), 0,   \
                                            stream, pred, target, mask, C, P, vec, grad_scale,        \
-                                           grad_pred);                                               \
+                                           grad_pred, computed_for, counters);                       \
     else hipLaunchKernelGGL((k_elem_bwd<DT, 2>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, pred,    \
-                            target, mask, C, P, vec, grad_scale, grad_pred)
+                            target, mask, C, P, vec, grad_scale, grad_pred, computed_for, counters)
     NMSA_DISPATCH_DTYPE(dtype, CALL)
 #undef CALL
     return check_launch();
+}
+
+extern "C" int nmsa_loss_masked_bwd(const void* pred, int dtype, const float* target,
+                                    const uint8_t* mask, int B, int C, int H, int W, int kind,
+                                    const float* grad_scale, void* grad_pred, nmsa_stream_t stream)
+{
+    return masked_bwd_impl(pred, dtype, target, mask, B, C, H, W, kind, grad_scale, grad_pred,
+                           nullptr, nullptr, stream);
+}
+
+extern "C" int nmsa_loss_masked_bwd_unless(const void* pred, int dtype, const float* target,
+                                           const uint8_t* mask, int B, int C, int H, int W, int kind,
+                                           const float* grad_scale, void* grad_pred,
+                                           const float* computed_for, int32_t* counters,
+                                           nmsa_stream_t stream)
+{
+    if (!computed_for) return NMSA_ERR_ARG;
+    return masked_bwd_impl(pred, dtype, target, mask, B, C, H, W, kind, grad_scale, grad_pred,
+                           computed_for, counters, stream);
+}
+
+extern "C" int nmsa_loss_masked_fwd_grad(const void* pred, int dtype, const float* target,
+                                         const uint8_t* mask, int B, int C, int H, int W, int kind,
+                                         const float* expected_grad_scale,
+                                         double* loss_sum, int64_t* n_mask, void* grad_pred,
+                                         void* workspace, size_t workspace_bytes,
+                                         nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!pred || !target || !loss_sum || !n_mask || !workspace || !expected_grad_scale || !grad_pred)
+        return NMSA_ERR_ARG;
+    if (bad_shape(B, H, W) || C <= 0 || kind < 0 || kind > 2) return NMSA_ERR_ARG;
+    if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
+    const int P = H * W;
+    const int vec = (P % 4 == 0) &&
+                    ((((uintptr_t)pred | (uintptr_t)target | (uintptr_t)mask | (uintptr_t)grad_pred) & 15) == 0);
+    const int gx = grid_x(P, 8);
+    LossPartial* partials = (LossPartial*)workspace;
+#define CALL(DT)                                                                                       \
+    if (kind == 0) hipLaunchKernelGGL((k_elem_fused<DT, 0>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, \
+                                      pred, target, mask, C, P, vec, expected_grad_scale, grad_pred,   \
+                                      partials);                                                       \
+    else if (kind == 1) hipLaunchKernelGGL((k_elem_fused<DT, 1>), dim3(gx, B), dim3(LOSS_THREADS), 0,   \
+                                           stream, pred, target, mask, C, P, vec, expected_grad_scale, \
+                                           grad_pred, partials);                                       \
+    else hipLaunchKernelGGL((k_elem_fused<DT, 2>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, pred,    \
+                            target, mask, C, P, vec, expected_grad_scale, grad_pred, partials)
+    NMSA_DISPATCH_DTYPE(dtype, CALL)
+#undef CALL
+    int rc = check_launch();
+    if (rc) return rc;
+    return finalize(partials, gx * B, loss_sum, nullptr, n_mask, stream);
 }
 
 extern "C" int nmsa_loss_vonmises_fwd(const void* pred, int dtype, const float* target,
@@ -1017,9 +1513,10 @@ extern "C" int nmsa_loss_vonmises_fwd(const void* pred, int dtype, const float* 
     return finalize(partials, gx * B, loss_sum, nullptr, n_rows, stream);
 }
 
-extern "C" int nmsa_loss_vonmises_bwd(const void* pred, int dtype, const float* target,
-                                      const uint8_t* mask, int B, int H, int W, float kappa,
-                                      const float* grad_scale, void* grad_pred, nmsa_stream_t stream_)
+static int vonmises_bwd_impl(const void* pred, int dtype, const float* target,
+                             const uint8_t* mask, int B, int H, int W, float kappa,
+                             const float* grad_scale, void* grad_pred, const float* computed_for,
+                             int32_t* counters, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !target || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
@@ -1029,10 +1526,56 @@ extern "C" int nmsa_loss_vonmises_bwd(const void* pred, int dtype, const float* 
                     ((((uintptr_t)pred | (uintptr_t)target | (uintptr_t)mask | (uintptr_t)grad_pred) & 15) == 0);
     const int gx = grid_x(P, 8);
 #define CALL(DT) hipLaunchKernelGGL((k_vm_bwd<DT>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, pred, \
-                                    target, mask, P, kappa, vec, grad_scale, grad_pred)
+                                    target, mask, P, kappa, vec, grad_scale, grad_pred, computed_for, \
+                                    counters)
     NMSA_DISPATCH_DTYPE(dtype, CALL)
 #undef CALL
     return check_launch();
+}
+
+extern "C" int nmsa_loss_vonmises_bwd(const void* pred, int dtype, const float* target,
+                                      const uint8_t* mask, int B, int H, int W, float kappa,
+                                      const float* grad_scale, void* grad_pred, nmsa_stream_t stream)
+{
+    return vonmises_bwd_impl(pred, dtype, target, mask, B, H, W, kappa, grad_scale, grad_pred,
+                             nullptr, nullptr, stream);
+}
+
+extern "C" int nmsa_loss_vonmises_bwd_unless(const void* pred, int dtype, const float* target,
+                                             const uint8_t* mask, int B, int H, int W, float kappa,
+                                             const float* grad_scale, void* grad_pred,
+                                             const float* computed_for, int32_t* counters,
+                                             nmsa_stream_t stream)
+{
+    if (!computed_for) return NMSA_ERR_ARG;
+    return vonmises_bwd_impl(pred, dtype, target, mask, B, H, W, kappa, grad_scale, grad_pred,
+                             computed_for, counters, stream);
+}
+
+extern "C" int nmsa_loss_vonmises_fwd_grad(const void* pred, int dtype, const float* target,
+                                           const uint8_t* mask, int B, int H, int W, float kappa,
+                                           const float* expected_grad_scale,
+                                           double* loss_sum, int64_t* n_rows, void* grad_pred,
+                                           void* workspace, size_t workspace_bytes,
+                                           nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!pred || !target || !loss_sum || !n_rows || !workspace || !expected_grad_scale || !grad_pred)
+        return NMSA_ERR_ARG;
+    if (bad_shape(B, H, W)) return NMSA_ERR_ARG;
+    if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
+    const int P = H * W;
+    const int vec = (P % 4 == 0) &&
+                    ((((uintptr_t)pred | (uintptr_t)target | (uintptr_t)mask | (uintptr_t)grad_pred) & 15) == 0);
+    const int gx = grid_x(P, 8);
+    LossPartial* partials = (LossPartial*)workspace;
+#define CALL(DT) hipLaunchKernelGGL((k_vm_fused<DT>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, pred, \
+                                    target, mask, P, kappa, vec, expected_grad_scale, grad_pred, partials)
+    NMSA_DISPATCH_DTYPE(dtype, CALL)
+#undef CALL
+    int rc = check_launch();
+    if (rc) return rc;
+    return finalize(partials, gx * B, loss_sum, nullptr, n_rows, stream);
 }
 
 namespace {

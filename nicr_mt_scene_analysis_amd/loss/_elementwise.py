@@ -28,17 +28,26 @@ class _ElementwiseLoss(LossBase):
         return d * d if self._kind == 'mse' else d.abs()
 
     def masked_sum(self, input_: torch.Tensor, target: torch.Tensor,
-                   mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+                   mask: Optional[torch.Tensor], expected_scale=None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
         """(sum_px mean_c f(input_*mask - target), sum(mask)) — the masking of
-        task_helper/instance.py:129-139,154-167 without materialising input_*mask."""
-        return F_.masked_elementwise_sum(input_, target, mask, self._kind)
+        task_helper/instance.py:129-139,154-167 without materialising input_*mask.
+        `expected_scale`: see LossBase.forward; default = 1 / sum(mask)."""
+        if expected_scale is None and mask is not None and self._kind != 'focal' and \
+                input_.is_cuda and F_.mean_speculation_enabled() and F_.wants_gradient(input_):
+            mask = F_._u8(mask.to(input_.device))
+            _, expected_scale = F_.count_u8(mask, with_mean_scale=True)
+        return F_.masked_elementwise_sum(input_, target, mask, self._kind, expected_scale)
 
-    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor):
+    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor, expected_scale=None):
         L.require_device_tensor(input_, 'input_')        # no CPU path: raises for host tensors
         kernel_ok = input_.ndim in (3, 4) and input_.numel() > 0 and not target.requires_grad
         if self._reduction in ('sum', 'mean') and kernel_ok:
-            loss, _ = F_.masked_elementwise_sum(input_, target, None, self._kind)
             n_px = input_.numel() // (input_.shape[1] if input_.ndim == 4 else 1)
+            if expected_scale is None and self._kind != 'focal' and \
+                    F_.mean_speculation_enabled() and F_.wants_gradient(input_):
+                expected_scale = F_.expected_scale(n_px, device=input_.device)   # loss / n_px
+            loss, _ = F_.masked_elementwise_sum(input_, target, None, self._kind, expected_scale)
             if self._reduction == 'mean':
                 return loss / n_px, 1           # mean over all elements == sum_px mean_c / n_px
             return loss, n_px

@@ -4,9 +4,22 @@ Forward returns device scalars (loss sum as fp32 0-d tensor, counts as int64 0-d
 tensors: no `.item()` host sync, unlike reference loss/ce.py:50 and
 task_helper/instance.py:138-139); backward recomputes from the saved inputs and
 scales by the upstream gradient on the device.
+
+Speculative gradients.  Every loss here is a SUM the caller divides by a count that depends
+on the targets only (`loss / n`; task_helper/base.py:161-182 divides the sum over the scales
+by the summed counts), so the gradient that autograd is going to hand to the loss sum is
+known before the forward kernel runs: `count_u8` counts the labels / mask bytes (1 B/px) and
+`expected_scale` forms the very division autograd will do.  Given that expectation the forward
+kernel also writes the finished gradient (prediction read once, gradient written once); the
+backward launch compares the real upstream gradient with the expectation ON THE DEVICE and
+recomputes only when they differ bit-wise, so results never depend on the expectation being
+right.  `speculation_stats()` counts both outcomes.  NMSA_SPECULATIVE_GRAD=0 turns it off.
 """
 import os
+import warnings
 from typing import Dict, Optional, Tuple
+
+import ctypes as C
 
 import torch
 
@@ -37,26 +50,123 @@ def _scalar_outputs(dev):
 # pixels and OR a bit into ONE persistent status word per device; `check_loss_status()` reads
 # it (a host sync, so not per call): the task helpers call it at `validation_epoch_end`, and
 # NMSA_CHECK_STATUS=1 checks after every loss call.
-_STATUS: Dict[torch.device, torch.Tensor] = {}
+_STATUS: Dict[torch.device, torch.Tensor] = {}      # int32 [status, confirmed, recomputed, -]
 _CHECK_EVERY_CALL = bool(int(os.environ.get('NMSA_CHECK_STATUS', '0') or 0))
+_SPECULATE = bool(int(os.environ.get('NMSA_SPECULATIVE_GRAD', '1') or 0))
+_SPEC_TOTALS = {'confirmed': 0, 'recomputed': 0}
+_MEAN_SPECULATION = {'on': True, 'warned': False}
 
 
 def _status_word(dev: torch.device) -> torch.Tensor:
     st = _STATUS.get(dev)
     if st is None:
-        st = _STATUS[dev] = torch.zeros((1,), dtype=torch.int32, device=dev)
+        st = _STATUS[dev] = torch.zeros((4,), dtype=torch.int32, device=dev)
     return st
+
+
+def _counters_ptr(dev: torch.device):
+    return C.c_void_p(_status_word(dev).data_ptr() + 4)
+
+
+def _drain_status():
+    """read and clear the per-device words (host sync) -> {device: status bits}"""
+    bits = {}
+    for dev, st in _STATUS.items():
+        status, confirmed, recomputed, _ = (int(v) for v in st.tolist())
+        st.zero_()
+        bits[dev] = status
+        _SPEC_TOTALS['confirmed'] += confirmed
+        _SPEC_TOTALS['recomputed'] += recomputed
+    if _MEAN_SPECULATION['on'] and _SPEC_TOTALS['recomputed'] >= 8 and \
+            _SPEC_TOTALS['recomputed'] > _SPEC_TOTALS['confirmed']:
+        # the default expectation (`loss_sum / n` of the same call) keeps missing: stop paying
+        # for gradients that get recomputed.  Explicit `expected_scale=` arguments stay honoured.
+        _MEAN_SPECULATION['on'] = False
+        if not _MEAN_SPECULATION['warned']:
+            _MEAN_SPECULATION['warned'] = True
+            warnings.warn('loss gradients written for `loss_sum / n` were recomputed in most '
+                          'backward passes; default speculation is off from here on (pass '
+                          'expected_scale= or set backward_scale on the task helper).')
+    return bits
 
 
 def check_loss_status() -> None:
     """raise IndexError if any loss kernel since the last check saw a label >= C + 1 or a LUT
     index outside [0, L] (host sync)"""
-    for dev, st in _STATUS.items():
-        v = int(st.item())
+    for dev, v in _drain_status().items():
         if v:
-            st.zero_()
             raise IndexError(f'loss kernels on {dev}: target label / LUT index out of range '
                              '(PyTorch raises a device-side assert for these)')
+
+
+def speculation_stats() -> Dict[str, int]:
+    """backward passes that found their gradient already written by the forward kernel
+    ('confirmed') / had to recompute it ('recomputed') since the process started (host sync;
+    pending status bits are kept for check_loss_status)"""
+    pending = {dev: int(st[0].item()) for dev, st in _STATUS.items()}
+    _drain_status()
+    for dev, v in pending.items():
+        if v:
+            _STATUS[dev][0] = v
+    return dict(_SPEC_TOTALS)
+
+
+def speculation_enabled() -> bool:
+    return _SPECULATE
+
+
+def mean_speculation_enabled() -> bool:
+    """default expectation of the loss classes: the caller divides this call's sum by this
+    call's count"""
+    return _SPECULATE and _MEAN_SPECULATION['on']
+
+
+def count_u8(values: torch.Tensor, lo: int = 1, hi: int = 255, with_mean_scale: bool = False):
+    """number of bytes in [lo, hi] as an int64 0-d device tensor (labels 1..C, mask != 0);
+    `with_mean_scale`: also 1 / count as the fp32 [1] tensor `expected_scale(count)` gives"""
+    v = L.require_device_tensor(values, 'values')
+    if v.dtype == torch.bool:
+        v = v.contiguous().view(torch.uint8)
+    assert v.dtype == torch.uint8
+    v = v.contiguous()
+    dev = v.device
+    out = torch.empty((1,), dtype=torch.int64, device=dev)
+    scale = torch.empty((1,), dtype=torch.float32, device=dev) if with_mean_scale else None
+    nbytes = L.lib().nmsa_count_workspace_bytes()
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    L.check(L.lib().nmsa_count_u8(L.ptr(v), v.numel(), int(lo), int(hi), L.ptr(out), L.ptr(scale),
+                                  1.0, L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_count_u8')
+    return (out[0], scale) if with_mean_scale else out[0]
+
+
+_ONES: Dict[Tuple[torch.device, float], torch.Tensor] = {}
+
+
+def expected_scale(count, weight: float = 1.0, device=None) -> torch.Tensor:
+    """the gradient autograd hands to `loss_sum` in `weight * loss_sum / count`: the same ATen
+    division, so the value is bit-equal to the one backward receives"""
+    dev = count.device if isinstance(count, torch.Tensor) else torch.device(device)
+    key = (dev, float(weight))
+    one = _ONES.get(key)
+    if one is None:
+        one = _ONES[key] = torch.full((), float(weight), dtype=torch.float32, device=dev)
+    return (one / count).reshape(1)
+
+
+def labels_u8(target: torch.Tensor, dev) -> torch.Tensor:
+    """labels 0..C (0 = void) as contiguous uint8 on `dev`; out-of-range values must not wrap
+    into valid labels: they become 255 (> C) and set the status bit in the kernel"""
+    t = target.to(dev)
+    if t.dtype != torch.uint8:
+        t = torch.where((t < 0) | (t > 255), 255, t).to(torch.uint8) \
+            if t.dtype != torch.bool else t.to(torch.uint8)
+    return t.contiguous()
+
+
+def _expected(hint, dev) -> Optional[torch.Tensor]:
+    if hint is None or not _SPECULATE:
+        return None
+    return hint.detach().to(dev, torch.float32).reshape(1).contiguous()
 
 
 def _grad_scale(g: torch.Tensor) -> torch.Tensor:
@@ -67,34 +177,41 @@ class CrossEntropyFunction(torch.autograd.Function):
     """sum over non-void px of the (weighted, label-smoothed) CE; also n and sum w[label]."""
 
     @staticmethod
-    def forward(ctx, logits, target, weights, label_smoothing):
+    def forward(ctx, logits, target, weights, label_smoothing, expected=None):
         x = L.require_device_tensor(logits, 'input_')
-        B, C, H, W = x.shape
+        B, C_, H, W = x.shape
         dev = x.device
-        if C > 255:
+        if C_ > 255:
             # labels travel as uint8 (0 = void, 1..C; ToTorchTensors keeps semantic uint8):
             # a wider label would wrap silently
-            raise ValueError(f'{C} classes: the CE kernel takes uint8 labels (C <= 255)')
-        t = target.to(dev)
-        if t.dtype != torch.uint8:
-            # labels 0..C (0 = void), reference: target.long() - 1.  Out-of-range values must
-            # not wrap into valid labels: they become 255 (> C) and set the status bit
-            t = torch.where((t < 0) | (t > 255), 255, t).to(torch.uint8) \
-                if t.dtype != torch.bool else t.to(torch.uint8)
-        t = t.contiguous()
+            raise ValueError(f'{C_} classes: the CE kernel takes uint8 labels (C <= 255)')
+        t = labels_u8(target, dev)
         w = None if weights is None else weights.to(dev, torch.float32).contiguous()
         s, n = _scalar_outputs(dev)
         wsum = torch.empty((1,), dtype=torch.float64, device=dev)
         status = _status_word(dev)
         ws, nbytes = _workspace(B, H, W, dev)
-        # per-pixel log-sum-exp for the backward pass (4 B/px instead of a second read of the
-        # logits), only when a gradient can be asked for
-        lse2 = torch.empty((B, H, W), dtype=torch.float32, device=dev) \
-            if ctx.needs_input_grad[0] else None
-        L.check(L.lib().nmsa_loss_ce_fwd(
-            L.ptr(x), L.float_dtype_code(x), L.ptr(t), L.ptr(w), B, C, H, W,
-            float(label_smoothing), L.ptr(s), L.ptr(n), L.ptr(wsum), L.ptr(lse2), L.ptr(status),
-            L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_ce_fwd')
+        code = L.float_dtype_code(x)
+        exp = _expected(expected, dev) if ctx.needs_input_grad[0] else None
+        if exp is not None and not L.lib().nmsa_loss_ce_fwd_grad_supported(code, C_):
+            exp = None                               # class column does not fit the registers
+        lse2 = grad = None
+        if exp is not None:
+            # forward sum + the gradient for the expected upstream scale in one pass
+            grad = torch.empty_like(x)
+            L.check(L.lib().nmsa_loss_ce_fwd_grad(
+                L.ptr(x), code, L.ptr(t), L.ptr(w), B, C_, H, W, float(label_smoothing),
+                L.ptr(exp), L.ptr(s), L.ptr(n), L.ptr(wsum), L.ptr(grad), L.ptr(status),
+                L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_ce_fwd_grad')
+        else:
+            # per-pixel log-sum-exp for the backward pass (4 B/px instead of a second read of
+            # the logits), only when a gradient can be asked for
+            lse2 = torch.empty((B, H, W), dtype=torch.float32, device=dev) \
+                if ctx.needs_input_grad[0] else None
+            L.check(L.lib().nmsa_loss_ce_fwd(
+                L.ptr(x), code, L.ptr(t), L.ptr(w), B, C_, H, W,
+                float(label_smoothing), L.ptr(s), L.ptr(n), L.ptr(wsum), L.ptr(lse2),
+                L.ptr(status), L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_ce_fwd')
         if _CHECK_EVERY_CALL:
             check_loss_status()
         ctx.save_for_backward(x, t, w if w is not None else torch.empty(0, device=dev),
@@ -102,6 +219,7 @@ class CrossEntropyFunction(torch.autograd.Function):
         ctx.has_lse = lse2 is not None
         ctx.has_w = w is not None
         ctx.ls = float(label_smoothing)
+        ctx.spec = (grad, exp) if grad is not None else None
         loss = s[0].to(torch.float32)
         n_el = n[0]
         wsum_ = wsum[0]
@@ -111,39 +229,57 @@ class CrossEntropyFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_n, g_w):
         x, t, w, lse2 = ctx.saved_tensors
-        B, C, H, W = x.shape
-        grad = torch.empty_like(x)
+        B, C_, H, W = x.shape
         gs = _grad_scale(g_loss)
+        spec, ctx.spec = ctx.spec, None          # a second backward recomputes
+        if spec is not None:
+            grad, exp = spec
+            L.check(L.lib().nmsa_loss_ce_bwd_unless(
+                L.ptr(x), L.float_dtype_code(x), L.ptr(t), L.ptr(w) if ctx.has_w else None,
+                B, C_, H, W, ctx.ls, L.ptr(gs), L.ptr(grad), L.ptr(exp),
+                _counters_ptr(x.device), L.stream_ptr(x.device)), 'nmsa_loss_ce_bwd_unless')
+            return grad, None, None, None, None
+        grad = torch.empty_like(x)
         L.check(L.lib().nmsa_loss_ce_bwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(t), L.ptr(w) if ctx.has_w else None,
-            B, C, H, W, ctx.ls, L.ptr(gs), L.ptr(lse2) if ctx.has_lse else None, L.ptr(grad),
+            B, C_, H, W, ctx.ls, L.ptr(gs), L.ptr(lse2) if ctx.has_lse else None, L.ptr(grad),
             L.stream_ptr(x.device)), 'nmsa_loss_ce_bwd')
-        return grad, None, None, None
+        return grad, None, None, None, None
 
 
 class MaskedElementwiseFunction(torch.autograd.Function):
     """sum_px mean_c f(pred*mask - target) and n = sum(mask); kind 0 = MSE, 1 = L1."""
 
     @staticmethod
-    def forward(ctx, pred, target, mask, kind):
+    def forward(ctx, pred, target, mask, kind, expected=None):
         x = L.require_device_tensor(pred, 'input_')
         dev = x.device
         if x.ndim == 3:
             B, H, W = x.shape
-            C = 1
+            C_ = 1
         else:
-            B, C, H, W = x.shape
+            B, C_, H, W = x.shape
         y = target.to(dev, torch.float32).contiguous()
         m = _u8(None if mask is None else mask.to(dev))
         s, n = _scalar_outputs(dev)
         ws, nbytes = _workspace(B, H, W, dev)
-        L.check(L.lib().nmsa_loss_masked_fwd(
-            L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m), B, C, H, W, int(kind),
-            L.ptr(s), L.ptr(n), L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_masked_fwd')
+        exp = _expected(expected, dev) if ctx.needs_input_grad[0] else None
+        grad = None
+        if exp is not None:
+            grad = torch.empty_like(x)
+            L.check(L.lib().nmsa_loss_masked_fwd_grad(
+                L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m), B, C_, H, W, int(kind),
+                L.ptr(exp), L.ptr(s), L.ptr(n), L.ptr(grad), L.ptr(ws), nbytes,
+                L.stream_ptr(dev)), 'nmsa_loss_masked_fwd_grad')
+        else:
+            L.check(L.lib().nmsa_loss_masked_fwd(
+                L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m), B, C_, H, W, int(kind),
+                L.ptr(s), L.ptr(n), L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_masked_fwd')
         ctx.save_for_backward(x, y, m if m is not None else torch.empty(0, device=dev))
         ctx.has_m = m is not None
         ctx.kind = int(kind)
-        ctx.dims = (B, C, H, W)
+        ctx.dims = (B, C_, H, W)
+        ctx.spec = (grad, exp) if grad is not None else None
         loss = s[0].to(torch.float32)
         n_el = n[0]
         ctx.mark_non_differentiable(n_el)
@@ -152,21 +288,29 @@ class MaskedElementwiseFunction(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, g_n):
         x, y, m = ctx.saved_tensors
-        B, C, H, W = ctx.dims
-        grad = torch.empty_like(x)
+        B, C_, H, W = ctx.dims
         gs = _grad_scale(g_loss)
+        spec, ctx.spec = ctx.spec, None
+        if spec is not None:
+            grad, exp = spec
+            L.check(L.lib().nmsa_loss_masked_bwd_unless(
+                L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m) if ctx.has_m else None,
+                B, C_, H, W, ctx.kind, L.ptr(gs), L.ptr(grad), L.ptr(exp),
+                _counters_ptr(x.device), L.stream_ptr(x.device)), 'nmsa_loss_masked_bwd_unless')
+            return grad, None, None, None, None
+        grad = torch.empty_like(x)
         L.check(L.lib().nmsa_loss_masked_bwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m) if ctx.has_m else None,
-            B, C, H, W, ctx.kind, L.ptr(gs), L.ptr(grad), L.stream_ptr(x.device)),
+            B, C_, H, W, ctx.kind, L.ptr(gs), L.ptr(grad), L.stream_ptr(x.device)),
             'nmsa_loss_masked_bwd')
-        return grad, None, None, None
+        return grad, None, None, None, None
 
 
 class VonMisesFunction(torch.autograd.Function):
     """sum over masked px of 1 - exp(kappa (x.y - 1)); pred/target planar [B,2,H,W]."""
 
     @staticmethod
-    def forward(ctx, pred, target, mask, kappa):
+    def forward(ctx, pred, target, mask, kappa, expected=None):
         x = L.require_device_tensor(pred, 'input_')
         dev = x.device
         B, two, H, W = x.shape
@@ -175,12 +319,22 @@ class VonMisesFunction(torch.autograd.Function):
         m = _u8(None if mask is None else mask.to(dev))
         s, n = _scalar_outputs(dev)
         ws, nbytes = _workspace(B, H, W, dev)
-        L.check(L.lib().nmsa_loss_vonmises_fwd(
-            L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m), B, H, W, float(kappa),
-            L.ptr(s), L.ptr(n), L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_vonmises_fwd')
+        exp = _expected(expected, dev) if ctx.needs_input_grad[0] else None
+        grad = None
+        if exp is not None:
+            grad = torch.empty_like(x)
+            L.check(L.lib().nmsa_loss_vonmises_fwd_grad(
+                L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m), B, H, W, float(kappa),
+                L.ptr(exp), L.ptr(s), L.ptr(n), L.ptr(grad), L.ptr(ws), nbytes,
+                L.stream_ptr(dev)), 'nmsa_loss_vonmises_fwd_grad')
+        else:
+            L.check(L.lib().nmsa_loss_vonmises_fwd(
+                L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m), B, H, W, float(kappa),
+                L.ptr(s), L.ptr(n), L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_vonmises_fwd')
         ctx.save_for_backward(x, y, m if m is not None else torch.empty(0, device=dev))
         ctx.has_m = m is not None
         ctx.kappa = float(kappa)
+        ctx.spec = (grad, exp) if grad is not None else None
         loss = s[0].to(torch.float32)
         n_el = n[0]
         ctx.mark_non_differentiable(n_el)
@@ -190,13 +344,21 @@ class VonMisesFunction(torch.autograd.Function):
     def backward(ctx, g_loss, g_n):
         x, y, m = ctx.saved_tensors
         B, _, H, W = x.shape
-        grad = torch.empty_like(x)
         gs = _grad_scale(g_loss)
+        spec, ctx.spec = ctx.spec, None
+        if spec is not None:
+            grad, exp = spec
+            L.check(L.lib().nmsa_loss_vonmises_bwd_unless(
+                L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m) if ctx.has_m else None,
+                B, H, W, ctx.kappa, L.ptr(gs), L.ptr(grad), L.ptr(exp),
+                _counters_ptr(x.device), L.stream_ptr(x.device)), 'nmsa_loss_vonmises_bwd_unless')
+            return grad, None, None, None, None
+        grad = torch.empty_like(x)
         L.check(L.lib().nmsa_loss_vonmises_bwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(m) if ctx.has_m else None,
             B, H, W, ctx.kappa, L.ptr(gs), L.ptr(grad), L.stream_ptr(x.device)),
             'nmsa_loss_vonmises_bwd')
-        return grad, None, None, None
+        return grad, None, None, None, None
 
 
 class CosineEmbeddingLutFunction(torch.autograd.Function):
@@ -245,17 +407,32 @@ class CosineEmbeddingLutFunction(torch.autograd.Function):
         return grad, None, None
 
 
-def cross_entropy_sum(logits, target, weights=None, label_smoothing=0.0
+def cross_entropy_sum(logits, target, weights=None, label_smoothing=0.0, expected_scale=None
                       ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
-    return CrossEntropyFunction.apply(logits, target, weights, label_smoothing)
+    return CrossEntropyFunction.apply(logits, target, weights, label_smoothing, expected_scale)
 
 
-def masked_elementwise_sum(pred, target, mask, kind: str) -> Tuple[torch.Tensor, torch.Tensor]:
-    return MaskedElementwiseFunction.apply(pred, target, mask, {'mse': 0, 'l1': 1, 'focal': 2}[kind])
+_KINDS = {'mse': 0, 'l1': 1, 'focal': 2}
 
 
-def vonmises_sum(pred, target, mask, kappa: float = 1.0) -> Tuple[torch.Tensor, torch.Tensor]:
-    return VonMisesFunction.apply(pred, target, mask, kappa)
+def masked_elementwise_sum(pred, target, mask, kind: str, expected_scale=None
+                           ) -> Tuple[torch.Tensor, torch.Tensor]:
+    return MaskedElementwiseFunction.apply(pred, target, mask, _KINDS[kind], expected_scale)
+
+
+def vonmises_sum(pred, target, mask, kappa: float = 1.0, expected_scale=None
+                 ) -> Tuple[torch.Tensor, torch.Tensor]:
+    return VonMisesFunction.apply(pred, target, mask, kappa, expected_scale)
+
+
+def wants_gradient(pred: torch.Tensor) -> bool:
+    return torch.is_grad_enabled() and pred.requires_grad
+
+
+def ce_forward_can_write_gradient(logits: torch.Tensor) -> bool:
+    """the class column of a pixel fits the registers of k_ce_fused (C <= 48)"""
+    return logits.is_cuda and logits.ndim == 4 and bool(
+        L.lib().nmsa_loss_ce_fwd_grad_supported(L.float_dtype_code(logits), logits.shape[1]))
 
 
 def cosine_embedding_lut_sum(pred, indices, lut) -> Tuple[torch.Tensor, torch.Tensor]:

@@ -9,8 +9,16 @@ class LossBase(torch.nn.Module):
         """one scale -> (loss, number of loss elements)"""
         raise NotImplementedError(f'{type(self).__name__} must define _compute_loss')
 
-    def forward(self, input_tensors, target_tensors):
+    def forward(self, input_tensors, target_tensors, expected_scales=None):
+        """`expected_scales` (extension, optional): per scale the gradient the caller's
+        reduction is going to send back to that scale's loss sum (a device scalar, see
+        loss/_functional.py `expected_scale`); losses that can write their gradient in the
+        forward pass do so, the others ignore it"""
         pairs = []
-        for prediction, target in zip(input_tensors, target_tensors):
-            pairs.append(self._compute_loss(prediction, target))
+        for i, (prediction, target) in enumerate(zip(input_tensors, target_tensors)):
+            if expected_scales is None or expected_scales[i] is None:
+                pairs.append(self._compute_loss(prediction, target))
+            else:
+                pairs.append(self._compute_loss(prediction, target,
+                                                expected_scale=expected_scales[i]))
         return tuple(pairs)

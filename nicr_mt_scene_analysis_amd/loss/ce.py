@@ -23,10 +23,17 @@ class CrossEntropyLossSemantic(LossBase):
         if weighted_reduction:
             assert self._weights is not None
 
-    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor
+    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor, expected_scale=None
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
+        if expected_scale is None and not self._weighted_reduction and \
+                F_.mean_speculation_enabled() and F_.wants_gradient(input_) and \
+                F_.ce_forward_can_write_gradient(input_):
+            # callers divide the sum by the count of this very call (`loss / n_elements`): count
+            # the non-void labels first (1 B/px) so the forward kernel can write the gradient
+            target = F_.labels_u8(target, input_.device)
+            _, expected_scale = F_.count_u8(target, 1, min(input_.shape[1], 255), with_mean_scale=True)
         loss, n_elements, weight_sum = F_.cross_entropy_sum(
-            input_, target, self._weights, self._label_smoothing)
+            input_, target, self._weights, self._label_smoothing, expected_scale)
         if self._weighted_reduction:
             # sum(loss) / sum_c n_c * w_c  (ce.py:57-68): the divisor is the sum of the
             # label weights over the non-void pixels

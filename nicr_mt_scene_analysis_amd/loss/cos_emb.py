@@ -22,7 +22,9 @@ class CosineEmbeddingLoss(LossBase):
         return F_.cosine_embedding_lut_sum(input_, indices, lut)
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor,
-                      target_similarity: Optional[torch.Tensor] = None):
+                      target_similarity: Optional[torch.Tensor] = None, expected_scale=None):
+        # expected_scale: accepted for LossBase.forward, unused (the embedding column does not
+        # fit the registers; the backward kernel reads the saved dot products instead)
         L.require_device_tensor(input_, 'input_')        # no CPU path: raises for host tensors
         n, d = input_.shape
         # the HIP kernel covers similar pairs (label +1) with 'sum' / 'mean' — what the task

@@ -23,10 +23,11 @@ class CenterFocalLoss(LossBase):
         assert reduction == 'sum'
 
     def masked_sum(self, input_: torch.Tensor, target: torch.Tensor,
-                   mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+                   mask: Optional[torch.Tensor], expected_scale=None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
         """(loss sum over the masked pixels, max(#positive masked pixels, 1))"""
-        loss, n_pos = F_.masked_elementwise_sum(input_, target, mask, 'focal')
+        loss, n_pos = F_.masked_elementwise_sum(input_, target, mask, 'focal', expected_scale)
         return loss, n_pos.clamp(min=1)
 
-    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor):
-        return self.masked_sum(input_, target, None)
+    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor, expected_scale=None):
+        return self.masked_sum(input_, target, None, expected_scale)

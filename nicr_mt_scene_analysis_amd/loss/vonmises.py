@@ -17,12 +17,18 @@ class VonMisesLossBiternion(LossBase):
         self._reduction = reduction
 
     def masked_sum(self, input_: torch.Tensor, target: torch.Tensor,
-                   mask: Optional[torch.Tensor]) -> Tuple[torch.Tensor, torch.Tensor]:
+                   mask: Optional[torch.Tensor], expected_scale=None
+                   ) -> Tuple[torch.Tensor, torch.Tensor]:
         """planar [B,2,H,W] prediction/target + [B,H,W] mask: the permute + boolean
-        gather of task_helper/instance.py:186-216 folded into the kernel."""
-        return F_.vonmises_sum(input_, target, mask, self._kappa)
+        gather of task_helper/instance.py:186-216 folded into the kernel.
+        `expected_scale`: see LossBase.forward; default = 1 / sum(mask)."""
+        if expected_scale is None and mask is not None and input_.is_cuda and \
+                F_.mean_speculation_enabled() and F_.wants_gradient(input_):
+            mask = F_._u8(mask.to(input_.device))
+            _, expected_scale = F_.count_u8(mask, with_mean_scale=True)
+        return F_.vonmises_sum(input_, target, mask, self._kappa, expected_scale)
 
-    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor):
+    def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor, expected_scale=None):
         if input_.ndim != 2 or target.ndim != 2:
             raise ValueError(
                 f"expected biternion rows of shape (n, 2), got {tuple(input_.shape)} / "
@@ -38,5 +44,7 @@ class VonMisesLossBiternion(LossBase):
         # rows (n, 2) -> planar (1, 2, n, 1) for the kernel (autograd carries the transpose)
         x = input_.t().contiguous().view(1, 2, n, 1)
         y = target.t().contiguous().view(1, 2, n, 1)
-        loss, _ = F_.vonmises_sum(x, y, None, self._kappa)
+        if expected_scale is None and F_.mean_speculation_enabled() and F_.wants_gradient(input_):
+            expected_scale = F_.expected_scale(n, device=input_.device)             # loss / n
+        loss, _ = F_.vonmises_sum(x, y, None, self._kappa, expected_scale)
         return loss, n

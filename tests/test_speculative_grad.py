@@ -1,0 +1,266 @@
+"""
+GPU tier: forward kernels that also write the gradient for an EXPECTED upstream scale
+(csrc/losses.hip k_ce_fused / k_elem_fused / k_vm_fused, loss/_functional.py).
+
+ * confirmed expectation: loss sum and gradient equal torch's fp32 autograd on the same
+   tensors (relative 1e-5 on the scalars; gradients to fp32 / 16-bit rounding) and the
+   two-kernel path of this library, and the backward launch only confirms;
+ * wrong expectation: the backward launch recomputes — the gradient is the one the
+   unspeculated path gives, whatever the expectation was;
+ * the default expectation of the loss classes (`loss_sum / n` of the same call) is confirmed
+   by autograd's own division, and the task helpers' sum-over-scales reduction is too.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _gen(seed=0):
+    return torch.Generator(device='cuda').manual_seed(seed)
+
+
+def _stats():
+    from nicr_mt_scene_analysis_amd.loss import speculation_stats
+    return speculation_stats()
+
+
+def _delta(before):
+    now = _stats()
+    return now['confirmed'] - before['confirmed'], now['recomputed'] - before['recomputed']
+
+
+def _grad_tol(dtype):
+    # outputs are rounded to the prediction dtype: half an ulp of 8 / 11 significand bits
+    return {torch.float32: 2e-5, torch.bfloat16: 2 ** -7, torch.float16: 2 ** -9}[dtype]
+
+
+def _ce_case(B, C, H, W, dtype, seed, void_frac=0.2):
+    g = _gen(seed)
+    x = (torch.randn((B, C, H, W), device='cuda', generator=g) * 3).to(dtype)
+    t = torch.randint(1, C + 1, (B, H, W), device='cuda', generator=g)
+    t[torch.rand((B, H, W), device='cuda', generator=g) < void_frac] = 0
+    w = torch.rand(C, device='cuda', generator=g) + 0.5
+    return x, t.to(torch.uint8), w
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16, torch.float16])
+@pytest.mark.parametrize('C', [1, 5, 19, 24, 25, 40, 41, 48])
+@pytest.mark.parametrize('label_smoothing', [0.0, 0.1])
+def test_ce_forward_writes_gradient(dtype, C, label_smoothing):
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    x, t, w = _ce_case(2, C, 24, 36, dtype, seed=C)
+    n = F_.count_u8(t, 1, C)
+    assert int(n) == int((t != 0).sum())
+    scale = F_.expected_scale(n)
+
+    xs = x.clone().requires_grad_(True)
+    before = _stats()
+    loss, n_el, _ = F_.cross_entropy_sum(xs, t, w, label_smoothing, expected_scale=scale)
+    (loss / n_el).backward()
+    assert _delta(before) == (1, 0)                     # the forward's gradient was the right one
+
+    xu = x.clone().requires_grad_(True)                 # two-kernel path of this library
+    loss_u, n_u, _ = F_.cross_entropy_sum(xu, t, w, label_smoothing)
+    (loss_u / n_u).backward()
+    assert int(n_el) == int(n_u) == int(n)
+    # C = 1: the true loss is 0 and what is left is the fp32 rounding of x*log2(e) per pixel
+    atol = 1e-4 if C == 1 else 0.0
+    np.testing.assert_allclose(float(loss), float(loss_u), rtol=RTOL, atol=atol)
+
+    xr = x.double().requires_grad_(True)                # torch autograd, fp64
+    ref = torch.nn.functional.cross_entropy(xr, t.long() - 1, weight=w.double(), reduction='sum',
+                                            ignore_index=-1, label_smoothing=label_smoothing)
+    (ref / int(n)).backward()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL, atol=atol)
+    tol = _grad_tol(dtype)
+    # p - 1 at the target class cancels in fp32: absolute error ~ 1e-6 of the term g * w
+    atol = max(tol * float(xr.grad.abs().max()) * 0.05, 4e-6 * float(w.max()) / int(n))
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(),
+                               rtol=tol, atol=atol)
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xu.grad.double().cpu().numpy(),
+                               rtol=tol, atol=atol)
+
+
+@pytest.mark.parametrize('shape', [(1, 7, 9), (3, 5, 11), (2, 16, 18), (1, 1, 3)])
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_ce_ragged_sizes_and_unaligned_views(shape, dtype):
+    """pixel counts that are no multiple of the 8-B lane tile, and a base pointer that is not
+    8-B aligned (the scalar tail path of k_ce_fused)"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    B, H, W = shape
+    C = 13
+    x, t, w = _ce_case(B, C, H, W, dtype, seed=H * W)
+    flat = torch.zeros(x.numel() + 1, device='cuda', dtype=dtype)
+    flat[1:] = x.flatten()
+    x_off = flat[1:].view(B, C, H, W)                   # element-aligned only
+    assert x_off.is_contiguous()
+    for src in (x, x_off):
+        xs = src.detach().clone().requires_grad_(True) if src is x else src.detach().requires_grad_(True)
+        n = F_.count_u8(t, 1, C)
+        loss, n_el, _ = F_.cross_entropy_sum(xs, t, w, 0.0, expected_scale=F_.expected_scale(n))
+        (loss / n_el).backward()
+        xr = x.double().requires_grad_(True)
+        ref = torch.nn.functional.cross_entropy(xr, t.long() - 1, weight=w.double(),
+                                                reduction='sum', ignore_index=-1)
+        (ref / max(int(n), 1)).backward()
+        np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL, atol=1e-6)
+        if int(n):
+            tol = _grad_tol(dtype)
+            np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(),
+                                       rtol=tol, atol=tol * float(xr.grad.abs().max()) * 0.05)
+
+
+def test_wrong_expectation_is_recomputed():
+    """the result never depends on the expectation: a wrong one costs a recomputation"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    x, t, w = _ce_case(2, 40, 48, 64, torch.bfloat16, seed=3)
+    wrong = torch.full((1,), 0.125, device='cuda')
+    xs = x.clone().requires_grad_(True)
+    before = _stats()
+    loss, n_el, _ = F_.cross_entropy_sum(xs, t, w, 0.0, expected_scale=wrong)
+    (3.0 * loss / n_el).backward()
+    assert _delta(before) == (0, 1)
+    xu = x.clone().requires_grad_(True)
+    loss_u, n_u, _ = F_.cross_entropy_sum(xu, t, w, 0.0)
+    (3.0 * loss_u / n_u).backward()
+    np.testing.assert_allclose(float(loss), float(loss_u), rtol=RTOL)
+    # same formula, same upstream scale; the log-sum-exp is summed in another order
+    np.testing.assert_allclose(xs.grad.float().cpu().numpy(), xu.grad.float().cpu().numpy(),
+                               rtol=2 ** -7, atol=1e-9)
+    # a second backward through the same graph recomputes as well
+    xs2 = x.clone().requires_grad_(True)
+    loss2, n2, _ = F_.cross_entropy_sum(xs2, t, w, 0.0, expected_scale=F_.expected_scale(n_u))
+    out = loss2 / n2
+    out.backward(retain_graph=True)
+    first = xs2.grad.clone()
+    xs2.grad = None
+    out.backward()
+    np.testing.assert_allclose(xs2.grad.float().cpu().numpy(), first.float().cpu().numpy(),
+                               rtol=2 ** -7, atol=1e-9)
+
+
+def test_more_classes_than_registers_falls_back():
+    from nicr_mt_scene_analysis_amd import _lib as L
+    from nicr_mt_scene_analysis_amd.loss import CrossEntropyLossSemantic
+    assert L.lib().nmsa_loss_ce_fwd_grad_supported(L.float_dtype_code(torch.zeros(1).bfloat16()), 48)
+    assert not L.lib().nmsa_loss_ce_fwd_grad_supported(1, 49)
+    x, t, w = _ce_case(1, 150, 24, 32, torch.bfloat16, seed=5)
+    xs = x.clone().requires_grad_(True)
+    before = _stats()
+    (loss, n), = CrossEntropyLossSemantic(weights=w)([xs], [t])
+    (loss / n).backward()
+    assert _delta(before) == (0, 0)                     # no speculation took place
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t.long() - 1, weight=w.double(), reduction='sum',
+                                            ignore_index=-1)
+    (ref / int(n)).backward()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL)
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(),
+                               rtol=2 ** -7, atol=float(xr.grad.abs().max()) * 1e-4)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_loss_classes_expect_the_mean_by_default(dtype):
+    """`loss / n` of every loss class confirms its forward-written gradient; gradients equal
+    torch's on the same tensors"""
+    from nicr_mt_scene_analysis_amd.loss import (CrossEntropyLossSemantic, L1Loss, MSELoss,
+                                                 VonMisesLossBiternion)
+    g = _gen(11)
+    B, H, W = 2, 40, 52
+    x, t, w = _ce_case(B, 40, H, W, dtype, seed=1)
+    center = torch.rand((B, H, W), device='cuda', generator=g).to(dtype)
+    center_t = torch.rand((B, H, W), device='cuda', generator=g)
+    offset = torch.randn((B, 2, H, W), device='cuda', generator=g).to(dtype)
+    offset_t = torch.randn((B, 2, H, W), device='cuda', generator=g)
+    ori = torch.randn((B, 2, H, W), device='cuda', generator=g).to(dtype)
+    ori_t = torch.nn.functional.normalize(torch.randn((B, 2, H, W), device='cuda', generator=g), dim=1)
+    m1 = torch.rand((B, H, W), device='cuda', generator=g) < 0.7
+    m2 = torch.rand((B, H, W), device='cuda', generator=g) < 0.5
+    m3 = torch.rand((B, H, W), device='cuda', generator=g) < 0.3
+
+    leaves = [v.clone().requires_grad_(True) for v in (x, center, offset, ori)]
+    before = _stats()
+    (lc, n), = CrossEntropyLossSemantic(weights=w)([leaves[0]], [t])
+    a = MSELoss().masked_sum(leaves[1], center_t, m1)
+    b = L1Loss().masked_sum(leaves[2], offset_t, m2)
+    c = VonMisesLossBiternion().masked_sum(leaves[3], ori_t, m3)
+    total = lc / n + a[0] / a[1] + b[0] / b[1] + c[0] / c[1]
+    total.backward()
+    assert _delta(before) == (4, 0)
+
+    ref_leaves = [v.double().requires_grad_(True) for v in (x, center, offset, ori)]
+    r_ce = torch.nn.functional.cross_entropy(ref_leaves[0], t.long() - 1, weight=w.double(),
+                                             reduction='sum', ignore_index=-1) / int(n)
+    r_a = ((ref_leaves[1] * m1) - center_t.double()).pow(2).sum() / int(m1.sum())
+    r_b = ((ref_leaves[2] * m2.unsqueeze(1)) - offset_t.double()).abs().mean(dim=1).sum() / int(m2.sum())
+    dot = (ref_leaves[3] * ori_t.double()).sum(dim=1)
+    r_c = (1 - torch.exp(dot - 1))[m3].sum() / int(m3.sum())
+    ref_total = r_ce + r_a + r_b + r_c
+    ref_total.backward()
+    np.testing.assert_allclose(float(total), float(ref_total), rtol=RTOL)
+    tol = _grad_tol(dtype)
+    for got, ref in zip(leaves, ref_leaves):
+        np.testing.assert_allclose(got.grad.double().cpu().numpy(), ref.grad.cpu().numpy(),
+                                   rtol=tol, atol=tol * float(ref.grad.abs().max()) * 0.05)
+
+
+@pytest.mark.parametrize('cls_name', ['MSELoss', 'L1Loss'])
+def test_unmasked_sum_and_mean_reductions(cls_name):
+    """`loss / n_px` (python int) and reduction='mean' are expected too"""
+    from nicr_mt_scene_analysis_amd import loss as losses
+    g = _gen(2)
+    x = torch.randn((2, 2, 20, 28), device='cuda', generator=g)
+    y = torch.randn((2, 2, 20, 28), device='cuda', generator=g)
+    for reduction in ('sum', 'mean'):
+        xs = x.clone().requires_grad_(True)
+        before = _stats()
+        (l, n), = getattr(losses, cls_name)(reduction=reduction)([xs], [y])
+        (l / n).backward()
+        assert _delta(before) == (1, 0), reduction
+        xr = x.double().requires_grad_(True)
+        d = xr - y.double()
+        ref = (d * d if cls_name == 'MSELoss' else d.abs()).mean(dim=1).sum() / (2 * 20 * 28)
+        ref.backward()
+        np.testing.assert_allclose(float(l / n), float(ref), rtol=RTOL)
+        np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(),
+                                   rtol=2e-5, atol=1e-9)
+
+
+def test_sum_without_division_recomputes_and_is_right():
+    """backward on the bare sum (upstream gradient 1.0) misses the default expectation"""
+    from nicr_mt_scene_analysis_amd.loss import L1Loss, VonMisesLossBiternion
+    g = _gen(4)
+    p = torch.randn((2, 2, 24, 32), device='cuda', generator=g)
+    y = torch.nn.functional.normalize(torch.randn((2, 2, 24, 32), device='cuda', generator=g), dim=1)
+    m = torch.rand((2, 24, 32), device='cuda', generator=g) > 0.5
+    for loss_obj, ref_fn in (
+            (L1Loss(), lambda q: ((q * m.unsqueeze(1)) - y.double()).abs().mean(dim=1).sum()),
+            (VonMisesLossBiternion(),
+             lambda q: (1 - torch.exp((q * y.double()).sum(dim=1) - 1))[m].sum())):
+        ps = p.clone().requires_grad_(True)
+        before = _stats()
+        l, n = loss_obj.masked_sum(ps, y, m)
+        l.backward()
+        assert _delta(before) == (0, 1)
+        pr = p.double().requires_grad_(True)
+        ref = ref_fn(pr)
+        ref.backward()
+        np.testing.assert_allclose(float(l), float(ref), rtol=RTOL)
+        np.testing.assert_allclose(ps.grad.double().cpu().numpy(), pr.grad.cpu().numpy(),
+                                   rtol=2e-5, atol=1e-9)
+
+
+def test_no_gradient_is_written_without_autograd():
+    """under no_grad / for predictions that do not require a gradient the plain forward runs"""
+    from nicr_mt_scene_analysis_amd.loss import CrossEntropyLossSemantic
+    x, t, w = _ce_case(1, 40, 24, 32, torch.bfloat16, seed=8)
+    before = _stats()
+    with torch.no_grad():
+        (l0, n0), = CrossEntropyLossSemantic(weights=w)([x.clone().requires_grad_(True)], [t])
+    (l1, n1), = CrossEntropyLossSemantic(weights=w)([x], [t])
+    assert not l0.requires_grad and not l1.requires_grad
+    np.testing.assert_allclose(float(l0), float(l1), rtol=1e-7)
+    assert _delta(before) == (0, 0)
