@@ -291,10 +291,19 @@ def secondary_losses(dev, B=64, C=40, H=480, W=640):
         (lc, n), = ce([logits], [labels])
         (lc / n).backward()
     n_px = B * H * W
-    # bytes this implementation moves per px in forward + backward: forward inputs (2C+34) +
-    # log-sum-exp write 4; CE backward logits 2C + label 1 + lse 4 + gradient 2C; element-wise
-    # backward pred + target + mask + gradient (9 + 17 + 17)
-    moved = (2 * C + 34) + 4 + (2 * C + 1 + 4 + 2 * C) + 9 + 17 + 17
+    from nicr_mt_scene_analysis_amd.loss import _functional as loss_f, speculation_stats
+    if loss_f.mean_speculation_enabled():
+        # forward kernels that also write the gradient: per loss the element count
+        # (labels / mask, 1 B/px) + inputs once + gradient once; backward launches only confirm
+        moved = (1 + 2 * C + 1 + 2 * C) + (1 + 7 + 2) + 2 * (1 + 13 + 4)
+        how = ('forward kernels write the gradient for the expected upstream scale 1/n (count '
+               'pass 1 B/px per loss); the backward launches confirm it on the device')
+    else:
+        # two-kernel path: forward inputs (2C+34) + log-sum-exp write 4; CE backward logits 2C +
+        # label 1 + lse 4 + gradient 2C; element-wise backward pred + target + mask + gradient
+        moved = (2 * C + 34) + 4 + (2 * C + 1 + 4 + 2 * C) + 9 + 17 + 17
+        how = ('the backward kernels re-read their inputs (CE: logits + saved log-sum-exp)')
+    spec0 = speculation_stats()
     with torch.no_grad():
         ms_f = hip_timed(fwd, reps=10, warm=3)
     ms_fb = hip_timed(fwd_bwd, reps=10, warm=3)
@@ -306,10 +315,11 @@ def secondary_losses(dev, B=64, C=40, H=480, W=640):
                moved_bytes_per_px=moved,
                frac_of_moved_bytes=round(n_px * moved / (ms_fb * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                note='algorithmic (SURVEY 8d): inputs once + gradient writes = 204 B/px at C=40; '
-                    'the backward kernels re-read their inputs (CE: logits + saved log-sum-exp), '
-                    'so moved_bytes_per_px is what crosses HBM'),
+                    + how + '; moved_bytes_per_px is what crosses HBM'),
            'ce_fwd_bwd': _leg(ms_ce, n_px, (2 * C + 1) + 2 * C,
                               note='algorithmic: logits + labels read once, gradient written')}
+    spec1 = speculation_stats()
+    out['backward_launches'] = {k: spec1[k] - spec0[k] for k in spec1}
     return out
 
 

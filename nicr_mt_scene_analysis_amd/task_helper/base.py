@@ -67,8 +67,33 @@ def _last_dim(output):
 
 
 class TaskHelperBase(torch.nn.Module):
+    # Extension: the factor the trainer multiplies this task's total loss with before calling
+    # backward.  The HIP losses write their gradient in the forward pass for
+    # `backward_scale / sum_scales(n)` — what autograd sends back through accumulate_losses —
+    # and re-do it in backward only when the real upstream gradient differs, so a wrong value
+    # costs time, never correctness (loss/_functional.py).  A dict gives one factor per total
+    # ('instance_center', 'instance_offset', 'instance_orientation', 'semantic'; default 1).
+    backward_scale = 1.0
+
     def initialize(self, device):
         """create losses / metrics on `device`"""
+
+    def expected_scale_for_total(self, counts, predictions, name=None):
+        """the gradient `backward_scale * accumulate_losses(sums, counts)` hands to each loss
+        sum of the total `name`, or None when no gradient is going to be asked for"""
+        from ..loss import _functional as F_
+        if not F_.speculation_enabled() or not torch.is_grad_enabled():
+            return None
+        if not any(isinstance(p, torch.Tensor) and p.requires_grad for p in predictions):
+            return None
+        count = sum(counts)
+        if not isinstance(count, torch.Tensor):
+            return None
+        # accumulate_losses: loss_sum / count.clamp(min=1).to(float32)
+        weight = self.backward_scale
+        if isinstance(weight, dict):
+            weight = weight.get(name, 1.0)
+        return F_.expected_scale(count.clamp(min=1).to(torch.float32), float(weight))
 
     # ---- pairing predictions and targets over the supervision scales ---------------------
     def collect_predictions_for_loss(self, predictions_post, predictions_post_key,

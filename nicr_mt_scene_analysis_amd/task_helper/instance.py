@@ -10,6 +10,7 @@ import torch
 
 from ..data.preprocessing.resize import get_fullres
 from ..data.preprocessing.resize import get_fullres_key
+from ..loss import _functional as F_
 from ..loss import check_loss_status
 from ..loss import CenterFocalLoss
 from ..loss import L1Loss
@@ -70,14 +71,27 @@ class InstanceTaskHelper(TaskHelperBase):
         def targets(key):
             return self.collect_targets_for_loss(batch, batch_key=key, downscales=downscales)
 
+        def expected(name, preds_, masks, clamp=False):
+            """per scale: the gradient the total over the scales sends back (None: not asked)"""
+            if not (torch.is_grad_enabled() and F_.speculation_enabled()) or \
+                    not any(p.requires_grad for p in preds_):
+                return [None] * len(preds_), masks
+            masks = [F_._u8(m.to(p.device)) for m, p in zip(masks, preds_)]
+            counts = [F_.count_u8(m) for m in masks]
+            if clamp:
+                counts = [c.clamp(min=1) for c in counts]
+            return [self.expected_scale_for_total(counts, preds_, name)] * len(preds_), masks
+
         # center: pred*mask vs target, n = sum(mask)            (instance.py:115-139)
-        out_center = [self._loss_center.masked_sum(p.contiguous(), t, m)
-                      for p, t, m in zip(preds_center, targets('instance_center'),
-                                         targets('instance_center_mask'))]
+        center_focal = self._loss_name_instance_center == 'focal'     # n = #positives: no count
+        exp, masks = ([None] * len(preds_center), targets('instance_center_mask')) if center_focal \
+            else expected('instance_center', preds_center, targets('instance_center_mask'))
+        out_center = [self._loss_center.masked_sum(p.contiguous(), t, m, expected_scale=e)
+                      for p, t, m, e in zip(preds_center, targets('instance_center'), masks, exp)]
         # offset: pred*foreground vs target, n = sum(foreground)  (instance.py:141-167)
-        out_offset = [self._loss_offset.masked_sum(p.contiguous(), t, m)
-                      for p, t, m in zip(preds_offset, targets('instance_offset'),
-                                         targets('instance_foreground'))]
+        exp, masks = expected('instance_offset', preds_offset, targets('instance_foreground'))
+        out_offset = [self._loss_offset.masked_sum(p.contiguous(), t, m, expected_scale=e)
+                      for p, t, m, e in zip(preds_offset, targets('instance_offset'), masks, exp)]
         loss_dict = {}
         loss_dict.update({f'instance_center_loss_{k}': l / n
                           for k, (l, n) in zip(keys, out_center)})
@@ -92,9 +106,10 @@ class InstanceTaskHelper(TaskHelperBase):
         if self._with_orientation:
             # masked rows, n = max(sum(mask), 1)                 (instance.py:170-216)
             out_ori = []
-            for p, t, m in zip(preds_orientation, targets('orientation'),
-                               targets('orientation_foreground')):
-                l, n = self._loss_orientation.masked_sum(p.contiguous(), t, m)
+            exp, masks = expected('instance_orientation', preds_orientation,
+                                  targets('orientation_foreground'), clamp=True)
+            for p, t, m, e in zip(preds_orientation, targets('orientation'), masks, exp):
+                l, n = self._loss_orientation.masked_sum(p.contiguous(), t, m, expected_scale=e)
                 out_ori.append((l, n.clamp(min=1)))
             loss_dict.update({f'instance_orientation_loss_{k}': l / n
                               for k, (l, n) in zip(keys, out_ori)})

@@ -10,6 +10,7 @@ import torch
 
 from ..data.preprocessing.resize import get_fullres
 from ..data.preprocessing.resize import get_fullres_key
+from ..loss import _functional as F_
 from ..loss import check_loss_status
 from ..loss import CrossEntropyLossSemantic
 from ..metric import MeanIntersectionOverUnion
@@ -47,7 +48,17 @@ class SemanticTaskHelper(TaskHelperBase):
         predictions, targets, scale_names = self.collect_predictions_and_targets_for_loss(
             batch=batch, batch_key=_TASK, predictions_post=predictions_post,
             predictions_post_key=f'{_TASK}_output', side_outputs_key=side_key)
-        per_scale = self._loss(input_tensors=predictions, target_tensors=targets)
+        expected = None
+        if torch.is_grad_enabled() and F_.speculation_enabled() and \
+                any(p.requires_grad and F_.ce_forward_can_write_gradient(p) for p in predictions):
+            # non-void pixels per scale first (1 B/px): the total's divisor, hence the gradient
+            # of every scale's sum, is known before the loss kernels run
+            targets = [F_.labels_u8(t, p.device) for t, p in zip(targets, predictions)]
+            counts = [F_.count_u8(t, 1, min(self._n_classes, 255)) for t in targets]
+            scale = self.expected_scale_for_total(counts, predictions, _TASK)
+            expected = [scale] * len(predictions)
+        per_scale = self._loss(input_tensors=predictions, target_tensors=targets,
+                               expected_scales=expected)
         sums = [loss_sum for loss_sum, _ in per_scale]
         counts = [count for _, count in per_scale]
         losses = {f'{_TASK}_loss_{name}': s / n for name, s, n in zip(scale_names, sums, counts)}

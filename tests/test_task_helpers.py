@@ -110,6 +110,51 @@ def test_instance_task_helper_losses():
         assert x.grad is not None and torch.isfinite(x.grad).all()
 
 
+def test_task_helper_totals_confirm_forward_written_gradients(monkeypatch):
+    """the helpers tell the loss kernels what `weight * total` is going to send back (sum over
+    the scales of the counts): every backward launch confirms, and the gradients are those of
+    the two-kernel path"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    from nicr_mt_scene_analysis_amd.loss import speculation_stats
+    from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper, SemanticTaskHelper
+    weights = {'semantic': 0.75, 'instance_center': 2.0, 'instance_offset': 1.0,
+               'instance_orientation': 0.5}
+
+    def run():
+        batch, preds, t = make_loss_batch()
+        preds['semantic_side_outputs'] = tuple(
+            x.detach().requires_grad_(True) for x in preds['semantic_side_outputs'])
+        preds['instance_side_outputs'] = tuple(
+            tuple(x.detach().requires_grad_(True) for x in side)
+            for side in preds['instance_side_outputs'])
+        sem = SemanticTaskHelper(n_classes=9, class_weights=t['class_weights'].cpu().numpy())
+        ins = InstanceTaskHelper(semantic_n_classes=10,
+                                 semantic_classes_is_thing=(False,) * 5 + (True,) * 5)
+        sem.backward_scale = weights['semantic']
+        ins.backward_scale = weights
+        losses = {}
+        for helper in (sem, ins):
+            helper.initialize(torch.device('cuda'))
+            losses.update(helper.training_step(batch, 0, preds)[0])
+        total = sum(w * losses[f'{k}_total_loss'] for k, w in weights.items())
+        total.backward()
+        leaves = [preds['semantic_output'], *preds['semantic_side_outputs'],
+                  *preds['instance_output'], *(x for s in preds['instance_side_outputs'] for x in s)]
+        return float(total), [x.grad.clone() for x in leaves]
+
+    before = speculation_stats()
+    total, grads = run()
+    after = speculation_stats()
+    assert after['recomputed'] == before['recomputed']
+    assert after['confirmed'] - before['confirmed'] == 3 + 3 * 3       # scales x (CE + 3 instance)
+    monkeypatch.setattr(F_, '_SPECULATE', False)
+    total_plain, grads_plain = run()
+    assert speculation_stats() == after
+    np.testing.assert_allclose(total, total_plain, rtol=1e-6)
+    for a, b in zip(grads, grads_plain):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-5, atol=1e-9)
+
+
 def test_panoptic_and_semantic_validation(oracle):
     from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
     from nicr_mt_scene_analysis_amd.task_helper import PanopticTaskHelper, SemanticTaskHelper
