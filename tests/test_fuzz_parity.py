@@ -430,13 +430,20 @@ def test_fuzz_orientation_wide_ids(oracle, seed, B, H, W, n_rect, with_mask):
 
 @settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
-@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), C=st.integers(1, 11), H=st.integers(1, 19),
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3),
+       C=st.one_of(st.integers(1, 11), st.integers(12, 52)), H=st.integers(1, 19),
        W=st.integers(1, 23), weighted=st.booleans(), ls=st.sampled_from([0.0, 0.1, 0.5]),
-       dtype=st.sampled_from(['float32', 'bfloat16']))
-def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype):
-    """every loss kernel (sum, count, gradient) on random odd shapes against the C oracle"""
+       dtype=st.sampled_from(['float32', 'bfloat16']),
+       expect=st.sampled_from(['nothing', 'right', 'wrong']))
+def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype, expect):
+    """every loss kernel (sum, count, gradient) on random odd shapes against the C oracle;
+    `expect`: the forward kernel writes the gradient for the upstream scale it is told to expect
+    (right: backward confirms; wrong: backward recomputes; nothing: two-kernel path)"""
     from nicr_mt_scene_analysis_amd.loss import _functional as F_
     rng = np.random.default_rng(seed)
+    # `loss.backward()` below sends 1.0 to the loss sum
+    exp = {'nothing': None, 'right': torch.ones(1, device='cuda'),
+           'wrong': torch.full((1,), 0.5, device='cuda')}[expect]
     tdt = getattr(torch, dtype)
     # gradients are O(1); the exp2-domain softmax carries ~|x| * 1e-7 of absolute error
     tol = dict(rtol=2e-5, atol=1e-5) if dtype == 'float32' else dict(rtol=2e-2, atol=2e-2)
@@ -451,7 +458,7 @@ def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype):
     x = leaf((rng.standard_normal((B, C, H, W)) * 3).astype(np.float32))
     t = rng.integers(0, C + 1, (B, H, W)).astype(np.uint8)              # 0 = void
     w = (rng.random(C) + 0.5).astype(np.float32) if weighted else None
-    loss, n, wsum = F_.cross_entropy_sum(x, dev(t), None if w is None else dev(w), ls)
+    loss, n, wsum = F_.cross_entropy_sum(x, dev(t), None if w is None else dev(w), ls, exp)
     loss.backward()
     s_ref, n_ref, w_ref, g_ref = oracle.loss_ce(as_f32(x), t, w, ls, want_grad=True)
     assert int(n) == n_ref
@@ -469,7 +476,7 @@ def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype):
         p = leaf(rng.standard_normal(shape).astype(np.float32))
         y = rng.standard_normal(shape).astype(np.float32)
         m = rng.random((B, H, W)) < 0.6
-        loss, n = F_.masked_elementwise_sum(p, dev(y), dev(m), kind)
+        loss, n = F_.masked_elementwise_sum(p, dev(y), dev(m), kind, exp)
         loss.backward()
         s_ref, n_ref, g_ref = oracle.loss_masked_elementwise(as_f32(p), y, m, kind, want_grad=True)
         assert int(n) == n_ref
@@ -482,7 +489,7 @@ def test_fuzz_losses_vs_oracle(oracle, seed, B, C, H, W, weighted, ls, dtype):
     p = leaf(unit(rng.standard_normal((B, 2, H, W))).astype(np.float32))
     y = unit(rng.standard_normal((B, 2, H, W))).astype(np.float32)
     m = rng.random((B, H, W)) < 0.5
-    loss, n = F_.vonmises_sum(p, dev(y), dev(m), 1.0)
+    loss, n = F_.vonmises_sum(p, dev(y), dev(m), 1.0, exp)
     loss.backward()
     s_ref, n_ref, g_ref = oracle.loss_vonmises(as_f32(p), y, m, 1.0, want_grad=True)
     assert int(n) == n_ref
