@@ -104,7 +104,10 @@ def test_bench_secondary_legs_run_on_small_shapes():
     n = 0
     for name, leg in legs.items():
         for key, entry in leg.items():
-            if isinstance(entry, dict):
+            if key == 'backward_launches':
+                # the loss leg's forward-written gradients must all have been confirmed
+                assert entry['confirmed'] > 0 and entry['recomputed'] == 0, entry
+            elif isinstance(entry, dict):
                 n += 1
                 assert entry['ms'] == entry['ms'] or key == 'step_two_batches_in_flight', (name, key)
                 assert entry['algorithmic_bytes'] > 0 and 'frac' in entry, (name, key)
