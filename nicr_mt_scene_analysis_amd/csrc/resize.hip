@@ -483,11 +483,21 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
         r0[j] = (iy0 - ys0) * P;
         r1[j] = (iy1 - ys0) * P;
     }
-    auto corner = [&](const void* L, int cc, int j, int which) -> float {
-        // which: 0 a (row0,x0)  1 b (row0,x1)  2 c (row1,x0)  3 d (row1,x1); cc * PLANE folds
-        // into the ds_read immediate offset
-        const int i = ((which & 2) ? r1[j] : r0[j]) + ((which & 1) ? cx1 : cx0);
-        return lds_elem<DTYPE>(L, cc * PLANE + i);
+    // A wave owns 4 whole output rows, so the source rows of its pixels are WAVE-UNIFORM: the
+    // horizontal interpolation of a source row (2 LDS reads + mul + fma per class) is shared by
+    // every output row that touches it — when upscaling, the 8 (row0, row1) slots of the 4
+    // output rows name only 3-5 distinct source rows.  The vertical step keeps ATen's order
+    // (width first, then `fma(t0, wy0, t1 * wy1)`), so results are unchanged.
+    int ur0[4], ur1[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        ur0[j] = __builtin_amdgcn_readfirstlane(r0[j]);
+        ur1[j] = __builtin_amdgcn_readfirstlane(r1[j]);
+    }
+    auto hlerp = [&](const void* L, int cc, int row) -> float {
+        // cc * PLANE folds into the ds_read immediate offset
+        return __fmaf_rn(lds_elem<DTYPE>(L, cc * PLANE + row + cx0), wx0,
+                         __fmul_rn(lds_elem<DTYPE>(L, cc * PLANE + row + cx1), wx1));
     };
 
     // ---- staging slots: piece e of the window -> source offset (the tail lanes of the last
@@ -527,14 +537,35 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
         __syncthreads();          // vmcnt(0) + barrier: chunk c0 has landed, the other buffer is free
         if (c0 + LT_CH < C) stage(c0 + LT_CH, buf ^ 1);
         const void* L = lds_raw + (size_t)buf * LT_CH * PLANE * ESZ;
+        float h0[LT_CH], h1[LT_CH];       // horizontal interpolations of source rows have0 / have1
+        int have0 = -1, have1 = -1;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
+            if (ur0[j] != have0) {                              // wave-uniform branches
+                if (ur0[j] == have1) {
+#pragma unroll
+                    for (int cc = 0; cc < LT_CH; ++cc) h0[cc] = h1[cc];
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < LT_CH; ++cc) h0[cc] = hlerp(L, cc, ur0[j]);
+                }
+                have0 = ur0[j];
+            }
+            if (ur1[j] != have1) {
+                if (ur1[j] == have0) {
+#pragma unroll
+                    for (int cc = 0; cc < LT_CH; ++cc) h1[cc] = h0[cc];
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < LT_CH; ++cc) h1[cc] = hlerp(L, cc, ur1[j]);
+                }
+                have1 = ur1[j];
+            }
             float v[LT_CH];
 #pragma unroll
             for (int cc = 0; cc < LT_CH; ++cc) {
-                const float val = round_to_storage<DTYPE>(bilerp(
-                    corner(L, cc, j, 0), corner(L, cc, j, 1), corner(L, cc, j, 2), corner(L, cc, j, 3),
-                    wx0, wx1, wy0[j], wy1[j]));
+                const float val = round_to_storage<DTYPE>(
+                    __fmaf_rn(h0[cc], wy0[j], __fmul_rn(h1[cc], wy1[j])));
                 v[cc] = (cc < nch) ? val : -INFINITY;          // tail chunk: stale LDS, ignored
             }
             if (MODE == LT_MODE_MATERIALISE) {
