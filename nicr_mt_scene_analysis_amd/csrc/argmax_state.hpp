@@ -29,7 +29,9 @@ __device__ __forceinline__ void argmax_step(ArgmaxState& s, int j, float v, int 
         const float e = (v == -INFINITY) ? 0.f : __expf(-fabsf(v - s.m[j]));
         s.se[j] = (v > s.m[j]) ? fmaf(s.se[j], e, 1.0f) : (s.se[j] + e);
     }
-    if (v > s.m[j]) { s.m[j] = v; s.am[j] = c; }
+    const bool above = v > s.m[j];             // selects, not a branch: 1 compare + 2 cndmask
+    s.am[j] = above ? c : s.am[j];
+    s.m[j] = above ? v : s.m[j];
 }
 
 // Four classes c0..c0+3 of pixel j at once (values already in registers): one running-max

@@ -25,6 +25,7 @@
 // Integer maps take the reference's float32 round trip (dense_base.py:38-40), which is
 // the identity below 2^24 and reproduced above it.
 #include <stdlib.h>
+#include <type_traits>
 #include "nmsa_common.hpp"
 #include "argmax_state.hpp"
 
@@ -530,6 +531,8 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     };
     ArgmaxState st;
     argmax_init(st);
+    // (three buffers — two chunks in flight — were tried: 48 KB of LDS per workgroup leave 3
+    // instead of 5 workgroups per CU and the kernel lost 3-11 %)
     stage(0, 0);
     int buf = 0;
     for (int c0 = 0; c0 < C; c0 += LT_CH, buf ^= 1) {
@@ -537,57 +540,64 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
         __syncthreads();          // vmcnt(0) + barrier: chunk c0 has landed, the other buffer is free
         if (c0 + LT_CH < C) stage(c0 + LT_CH, buf ^ 1);
         const void* L = lds_raw + (size_t)buf * LT_CH * PLANE * ESZ;
-        float h0[LT_CH], h1[LT_CH];       // horizontal interpolations of source rows have0 / have1
-        int have0 = -1, have1 = -1;
+        // FULL: all LT_CH classes of the chunk exist (every chunk but possibly the last) — no
+        // per-class bounds checks in the unrolled body
+        auto chunk = [&](auto full_tag) {
+            constexpr bool FULL = decltype(full_tag)::value;
+            float h0[LT_CH], h1[LT_CH];   // horizontal interpolations of source rows have0 / have1
+            int have0 = -1, have1 = -1;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (ur0[j] != have0) {                              // wave-uniform branches
-                if (ur0[j] == have1) {
+            for (int j = 0; j < 4; ++j) {
+                if (ur0[j] != have0) {                              // wave-uniform branches
+                    if (ur0[j] == have1) {
 #pragma unroll
-                    for (int cc = 0; cc < LT_CH; ++cc) h0[cc] = h1[cc];
-                } else {
+                        for (int cc = 0; cc < LT_CH; ++cc) h0[cc] = h1[cc];
+                    } else {
 #pragma unroll
-                    for (int cc = 0; cc < LT_CH; ++cc) h0[cc] = hlerp(L, cc, ur0[j]);
-                }
-                have0 = ur0[j];
-            }
-            if (ur1[j] != have1) {
-                if (ur1[j] == have0) {
-#pragma unroll
-                    for (int cc = 0; cc < LT_CH; ++cc) h1[cc] = h0[cc];
-                } else {
-#pragma unroll
-                    for (int cc = 0; cc < LT_CH; ++cc) h1[cc] = hlerp(L, cc, ur1[j]);
-                }
-                have1 = ur1[j];
-            }
-            float v[LT_CH];
-#pragma unroll
-            for (int cc = 0; cc < LT_CH; ++cc) {
-                const float val = round_to_storage<DTYPE>(
-                    __fmaf_rn(h0[cc], wy0[j], __fmul_rn(h1[cc], wy1[j])));
-                v[cc] = (cc < nch) ? val : -INFINITY;          // tail chunk: stale LDS, ignored
-            }
-            if (MODE == LT_MODE_MATERIALISE) {
-                if (x < g.Wo && yy[j] < g.Ho) {
-#pragma unroll
-                    for (int cc = 0; cc < LT_CH; ++cc) {
-                        if (cc >= nch) break;
-                        const size_t o = ((size_t)(p_begin + c0 + cc) * g.Ho + yy[j]) * g.Wo + x;
-                        if (DTYPE == NMSA_F32) __builtin_nontemporal_store(v[cc], (float*)dst + o);
-                        else if (DTYPE == NMSA_BF16) ((uint16_t*)dst)[o] = f32_to_bf16_bits(v[cc]);
-                        else ((uint16_t*)dst)[o] = f32_to_f16_bits(v[cc]);
+                        for (int cc = 0; cc < LT_CH; ++cc) h0[cc] = hlerp(L, cc, ur0[j]);
                     }
+                    have0 = ur0[j];
                 }
-            } else if (MODE == LT_MODE_ARGMAX_SCORE) {
-                static_assert(LT_CH == 4, "argmax_group4_score");
-                argmax_group4_score(st, j, v, c0);
-            } else {
+                if (ur1[j] != have1) {
+                    if (ur1[j] == have0) {
 #pragma unroll
-                for (int cc = 0; cc < LT_CH; ++cc)
-                    if (cc < nch) argmax_step<false>(st, j, v[cc], c0 + cc);
+                        for (int cc = 0; cc < LT_CH; ++cc) h1[cc] = h0[cc];
+                    } else {
+#pragma unroll
+                        for (int cc = 0; cc < LT_CH; ++cc) h1[cc] = hlerp(L, cc, ur1[j]);
+                    }
+                    have1 = ur1[j];
+                }
+                float v[LT_CH];
+#pragma unroll
+                for (int cc = 0; cc < LT_CH; ++cc) {
+                    const float val = round_to_storage<DTYPE>(
+                        __fmaf_rn(h0[cc], wy0[j], __fmul_rn(h1[cc], wy1[j])));
+                    v[cc] = (FULL || cc < nch) ? val : -INFINITY;  // tail chunk: stale LDS, ignored
+                }
+                if (MODE == LT_MODE_MATERIALISE) {
+                    if (x < g.Wo && yy[j] < g.Ho) {
+#pragma unroll
+                        for (int cc = 0; cc < LT_CH; ++cc) {
+                            if (!FULL && cc >= nch) break;
+                            const size_t o = ((size_t)(p_begin + c0 + cc) * g.Ho + yy[j]) * g.Wo + x;
+                            if (DTYPE == NMSA_F32) __builtin_nontemporal_store(v[cc], (float*)dst + o);
+                            else if (DTYPE == NMSA_BF16) ((uint16_t*)dst)[o] = f32_to_bf16_bits(v[cc]);
+                            else ((uint16_t*)dst)[o] = f32_to_f16_bits(v[cc]);
+                        }
+                    }
+                } else if (MODE == LT_MODE_ARGMAX_SCORE) {
+                    static_assert(LT_CH == 4, "argmax_group4_score");
+                    argmax_group4_score(st, j, v, c0);
+                } else {
+#pragma unroll
+                    for (int cc = 0; cc < LT_CH; ++cc)
+                        if (FULL || cc < nch) argmax_step<false>(st, j, v[cc], c0 + cc);
+                }
             }
-        }
+        };
+        if (nch == LT_CH) chunk(std::true_type{});
+        else chunk(std::false_type{});
     }
     if (MODE == LT_MODE_MATERIALISE) return;
     if (x >= g.Wo) return;
