@@ -505,6 +505,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         r = step(i, True)
+    host_issue = time.perf_counter() - t0      # the host is done queueing; the GPU is not
     if metrics is not None:
         metrics.finalize(dist)                 # --metric-sync end: the one all-reduce, timed
     torch.cuda.synchronize()
@@ -582,6 +583,8 @@ def main():
         'metric': 'Mpix/s panoptic merge+metrics, 640x480xB',
         'value': round(value, 1), 'unit': 'Mpix/s', 'n_gpus': world,
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
+        # host time to queue one step (this rank): below ms_per_step = the GPU sets the pace
+        'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 4),
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {torch.float32: 'f32', torch.bfloat16: 'bf16', torch.float16: 'f16'}[logits.dtype],
         'data': 'synthetic',
