@@ -53,4 +53,19 @@ __device__ __forceinline__ void argmax_group4_score(ArgmaxState& s, int j, const
     s.m[j] = nm;
 }
 
+// ---- max(softmax(x)) vs argmax(x): the probability-tie trigger (see panoptic.hip) ----------
+template <int DTYPE>
+__device__ __forceinline__ float tie_band_magnitude()
+{
+    // f32: spacing 2^-25 in [0.25, 0.5); bf16 (8-bit significand): below 2^-17; f16: its finest
+    // spacing is 2^-24, never
+    return (DTYPE == NMSA_F32) ? 0.5f : (DTYPE == NMSA_BF16) ? 0x1p-17f : 0.0f;
+}
+
+template <int DTYPE>
+__device__ __forceinline__ bool may_tie_in_probability(float m)
+{
+    return fabsf(m) < tie_band_magnitude<DTYPE>();
+}
+
 }  // namespace nmsa

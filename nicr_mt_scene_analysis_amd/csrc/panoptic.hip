@@ -82,28 +82,41 @@ __device__ __forceinline__ float4 load_px4(const void* base, size_t elem_off, in
     }
 }
 
-// Exact rule for a column that holds a non-finite logit (rare, re-reads the column):
-// softmax of a column with a NaN, a +inf, or nothing but -inf is all-NaN and torch.max then
-// returns index 0 (semantic.py:52-53); a column with some -inf entries is an ordinary one.
+// The reference takes max(softmax(x)) (semantic.py:52-53), the kernels argmax(x).  They differ
+// on two kinds of columns, both re-evaluated exactly by the functions below (rare, re-read):
+//  * a NaN, a +inf, or nothing but -inf: softmax is all-NaN and torch.max returns index 0;
+//    a column with some -inf entries is an ordinary one;
+//  * classes within 2^-25 of the maximum: exp(x_c - max) rounds to exactly 1.0f, so they share
+//    the maximum's probability and the LOWEST such index wins.  Two distinct logits can only be
+//    that close where the format's spacing is <= 2^-25, i.e. for |max| < tie_band_magnitude —
+//    the trigger, one compare per pixel.  (Gaps in (2^-25, 2^-23] collapse or not with ATen's
+//    exp / division rounding, build- and device-dependent: the larger logit is kept)
+// class of one column by the reference's rule
 template <int DTYPE>
-__device__ __noinline__ bool column_degenerate(const void* logits, size_t col0, int P, int C)
+__device__ __noinline__ int column_class(const void* logits, size_t col0, int P, int C)
 {
+    auto ld = [&](int c) -> float {
+        if (DTYPE == NMSA_F32) return ((const float*)logits)[col0 + (size_t)c * P];
+        const uint16_t h = ((const uint16_t*)logits)[col0 + (size_t)c * P];
+        return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
+    };
     bool nan_or_pinf = false, any_finite = false;
+    float m = -INFINITY;
+    int am = 0;
     for (int c = 0; c < C; ++c) {
-        float v;
-        if (DTYPE == NMSA_F32) v = ((const float*)logits)[col0 + (size_t)c * P];
-        else {
-            const uint16_t h = ((const uint16_t*)logits)[col0 + (size_t)c * P];
-            v = (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
-        }
+        const float v = ld(c);
         if (v != v || v == INFINITY) nan_or_pinf = true;
         if (fabsf(v) < INFINITY) any_finite = true;
+        if (v > m) { m = v; am = c; }
     }
-    return nan_or_pinf || !any_finite;
+    if (nan_or_pinf || !any_finite) return 0;
+    for (int c = 0; c < am; ++c)
+        if (__fsub_rn(ld(c), m) >= -0x1p-25f) return c;
+    return am;
 }
 
-// Exact argmax + score of one column (rare: the group-wise fast path of the WITH_SCORE kernels
-// came out with a NaN denominator): the reference's softmax -> max incl. its degenerate columns.
+// Exact argmax + score of one column (the group-wise fast path of the WITH_SCORE kernels came
+// out with a NaN denominator, or the maximum is small enough for a probability tie).
 // returns (score, class index as int bits): by value, so that no scratch slot is needed
 template <int DTYPE>
 __device__ __noinline__ float2 column_exact(const void* logits, size_t col0, int P, int C)
@@ -124,11 +137,13 @@ __device__ __noinline__ float2 column_exact(const void* logits, size_t col0, int
     }
     if (nan_or_pinf || !any_finite) return make_float2(__int_as_float(0x7fc00000), __int_as_float(0));
     float se = 0.f;
+    int first = am;
     for (int c = 0; c < C; ++c) {
         const float v = ld(c);
         se += (v == -INFINITY) ? 0.f : __expf(v - m);
+        if (c < first && __fsub_rn(v, m) >= -0x1p-25f) first = c;
     }
-    return make_float2(1.0f / se, __int_as_float(am));
+    return make_float2(1.0f / se, __int_as_float(first));
 }
 
 // classes c0 .. c0+3 of the 4 pixels of a lane (WITH_SCORE: one rescale per group, see
@@ -476,14 +491,14 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(W
             cls[j] = st.am[j];
             if (WITH_SCORE) {
                 float sc = 1.0f / st.se[j];
-                if (st.se[j] != st.se[j] && j < nvalid) {
+                if ((st.se[j] != st.se[j] || may_tie_in_probability<DTYPE>(st.m[j])) && j < nvalid) {
                     const float2 ex = column_exact<DTYPE>(logits, img_logits + p0 + j, P, C);
                     sc = ex.x;
                     cls[j] = __float_as_int(ex.y);
                 }
                 st.se[j] = sc;
-            } else if (st.nf[j] != st.nf[j] && j < nvalid) {
-                if (column_degenerate<DTYPE>(logits, img_logits + p0 + j, P, C)) cls[j] = 0;
+            } else if ((st.nf[j] != st.nf[j] || may_tie_in_probability<DTYPE>(st.m[j])) && j < nvalid) {
+                cls[j] = column_class<DTYPE>(logits, img_logits + p0 + j, P, C);
             }
             uint64_t tm = thing_m[0];
             if (C > 64) {                                  // workgroup-uniform
@@ -622,13 +637,13 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_argmax(
         sc[j] = 0.f;
         if (WITH_SCORE) {
             sc[j] = 1.0f / st.se[j];
-            if (st.se[j] != st.se[j] && j < nvalid) {
+            if ((st.se[j] != st.se[j] || may_tie_in_probability<DTYPE>(st.m[j])) && j < nvalid) {
                 const float2 ex = column_exact<DTYPE>(logits, img + p0 + j, P, C);
                 sc[j] = ex.x;
                 cls[j] = __float_as_int(ex.y);
             }
-        } else if (st.nf[j] != st.nf[j] && j < nvalid) {
-            if (column_degenerate<DTYPE>(logits, img + p0 + j, P, C)) cls[j] = 0;
+        } else if ((st.nf[j] != st.nf[j] || may_tie_in_probability<DTYPE>(st.m[j])) && j < nvalid) {
+            cls[j] = column_class<DTYPE>(logits, img + p0 + j, P, C);
         }
     }
     const size_t o = (size_t)b * P + p0;

@@ -275,22 +275,9 @@ __global__ __launch_bounds__(256) void k_resize_bilinear(
 constexpr int RZ_TW = 64, RZ_TH = 4, RZ_UNROLL = 4;
 
 template <int DTYPE>
-__device__ __noinline__ bool resized_column_degenerate(
+__device__ float2 resized_column_exact(
     const void* logits, size_t o00, size_t o01, size_t o10, size_t o11, size_t plane_stride,
-    int C, float wx0, float wx1, float wy0, float wy1)
-{
-    bool nan_or_pinf = false, any_finite = false;
-    for (int c = 0; c < C; ++c) {
-        const size_t pc = (size_t)c * plane_stride;
-        const float v = round_to_storage<DTYPE>(bilerp(
-            ld_elem<DTYPE>(logits, pc + o00), ld_elem<DTYPE>(logits, pc + o01),
-            ld_elem<DTYPE>(logits, pc + o10), ld_elem<DTYPE>(logits, pc + o11),
-            wx0, wx1, wy0, wy1));
-        if (v != v || v == INFINITY) nan_or_pinf = true;
-        if (fabsf(v) < INFINITY) any_finite = true;
-    }
-    return nan_or_pinf || !any_finite;
-}
+    int C, float wx0, float wx1, float wy0, float wy1);
 
 template <int DTYPE, bool WITH_SCORE, bool PAIR>
 __global__ __launch_bounds__(RZ_TW * RZ_TH) void k_argmax_resized(
@@ -355,15 +342,20 @@ __global__ __launch_bounds__(RZ_TW * RZ_TH) void k_argmax_resized(
             wx0, wx1, wy0, wy1)), c);
     }
     if (!valid) return;
-    bool degenerate = false;
-    if (st.nf[0] != st.nf[0])
-        degenerate = resized_column_degenerate<DTYPE>(logits, o00, o01, o10, o11, plane_stride,
+    // non-finite column, or a maximum small enough for two classes to share its probability
+    // (panoptic.hip): exact re-evaluation
+    int cls = st.am[0];
+    float sc = WITH_SCORE ? (1.0f / st.se[0]) : 0.f;
+    if (st.nf[0] != st.nf[0] || may_tie_in_probability<DTYPE>(st.m[0])) {
+        const float2 ex = resized_column_exact<DTYPE>(logits, o00, o01, o10, o11, plane_stride,
                                                       C, wx0, wx1, wy0, wy1);
-    const int cls = degenerate ? 0 : st.am[0];
+        sc = ex.x;
+        cls = __float_as_int(ex.y);
+    }
     const size_t o = ((size_t)b * g.Ho + y) * g.Wo + x;
     if (idx_u8) idx_u8[o] = (uint8_t)cls;
     if (idx_i64) idx_i64[o] = cls;
-    if (WITH_SCORE) score[o] = degenerate ? __int_as_float(0x7fc00000) : (1.0f / st.se[0]);
+    if (WITH_SCORE) score[o] = sc;
 }
 
 // =================================================================================
@@ -423,6 +415,7 @@ __device__ __noinline__ float2 resized_column_exact(
     }
     if (nan_or_pinf || !any_finite) return make_float2(__int_as_float(0x7fc00000), __int_as_float(0));
     float se = 0.f;
+    int first = am;           // lowest class whose probability equals the maximum's (panoptic.hip)
     for (int c = 0; c < C; ++c) {
         const size_t pc = (size_t)c * plane_stride;
         const float v = round_to_storage<DTYPE>(bilerp(
@@ -430,8 +423,9 @@ __device__ __noinline__ float2 resized_column_exact(
             ld_elem<DTYPE>(logits, pc + o10), ld_elem<DTYPE>(logits, pc + o11),
             wx0, wx1, wy0, wy1));
         se += (v == -INFINITY) ? 0.f : __expf(v - m);
+        if (c < first && __fsub_rn(v, m) >= -0x1p-25f) first = c;
     }
-    return make_float2(1.0f / se, __int_as_float(am));
+    return make_float2(1.0f / se, __int_as_float(first));
 }
 
 template <int DTYPE, int MODE, int K16>
@@ -606,8 +600,9 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
         if (yy[j] >= g.Ho) continue;
         int cls = st.am[j];
         float sc = 0.f;
-        const bool suspicious = (MODE == LT_MODE_ARGMAX_SCORE) ? (st.se[j] != st.se[j])
-                                                               : (st.nf[j] != st.nf[j]);
+        const bool suspicious = ((MODE == LT_MODE_ARGMAX_SCORE) ? (st.se[j] != st.se[j])
+                                                                : (st.nf[j] != st.nf[j])) ||
+                                may_tie_in_probability<DTYPE>(st.m[j]);
         if (MODE == LT_MODE_ARGMAX_SCORE) sc = 1.0f / st.se[j];
         if (suspicious) {
             const size_t img = (size_t)p_begin * plane_stride;

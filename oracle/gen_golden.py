@@ -615,8 +615,34 @@ def gen_argmax_ties(ref):
     ns = rate(small, 7)
     print(f'  natural rate: blobby logits {nb[1]} of {nb[0]} px differ; |x| < 0.3 logits '
           f'{ns[1]} of {ns[0]} px differ')
+    def grid_map():
+        # 4 random classes per pixel on a grid of 2^-26 (gaps of 0..11 steps: inside the 2^-25
+        # band, between the bands and outside), the other classes far below
+        x = (-1.0 - rng.random((1, C, 48, 64))).astype(np.float32)
+        for _ in range(4):
+            c = rng.integers(0, C, (48, 64))
+            v = (rng.integers(0, 12, (48, 64)) * 2.0 ** -26).astype(np.float32)
+            np.put_along_axis(x[0], c[None], v[None], axis=0)
+        return x
+
+    # whole maps in the regime where probabilities tie by themselves, through the reference
+    # (network resolution and the full-resolution resize): every class within 2^-25 of the
+    # maximum ('tiny': all of them -> index 0) and a map on a 2^-26 grid ('small')
+    key_full = 'semantic_segmentation_idx_fullres'
+    extra = {}
+    for name, x, full in (
+            ('tiny', (rng.standard_normal((1, C, 24, 40)) * 1e-9).astype(np.float32), (36, 60)),
+            ('small', grid_map(), (72, 96))):
+        r = post.postprocess((torch.from_numpy(x), None), make_batch(ref, x.shape[0], *full),
+                             is_training=False)
+        extra[f'{name}_logits'] = x
+        extra[f'{name}_ref_idx'] = r['semantic_segmentation_idx'].numpy().astype(np.uint8)
+        extra[f'{name}_ref_idx_fullres'] = r[key_full].numpy().astype(np.uint8)
+        am = torch.from_numpy(x).argmax(dim=1).numpy()
+        print(f'  {name}: reference differs from argmax(x) on '
+              f'{int((extra[f"{name}_ref_idx"] != am).sum())} of {am.size} px')
     save('argmax_ties', logits=logits, ref_idx=ref_idx, c1=c1s, c2=c2s, delta=delta,
-         natural_blobby=np.array(nb, np.int64), natural_small=np.array(ns, np.int64))
+         natural_blobby=np.array(nb, np.int64), natural_small=np.array(ns, np.int64), **extra)
 
 
 COS_LARGE_CASES = (

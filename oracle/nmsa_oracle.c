@@ -30,10 +30,14 @@ int orc_version(void) { return 1; }
 /* ------------------------------------------------------------------------- */
 /* a1  SemanticPostprocessing._postprocess_inference                          */
 /*     model/postprocessing/semantic.py:52-53  softmax(dim=1) -> max(dim=1)    */
-/* idx  : first index attaining the maximum (torch.max tie rule).  The maximum */
-/*        is searched on the logits; softmax is monotone, so this equals the   */
-/*        reference unless two *distinct* logits round to the same fp32        */
-/*        probability (sub-ulp gaps, see DESIGN.md "argmax boundary").          */
+/* idx  : first index attaining the maximum PROBABILITY (torch.max tie rule). */
+/*        softmax is monotone, so that is the first maximum of the logits —    */
+/*        except that exp(x_c - max) is exactly 1.0f for every class within    */
+/*        2^-25 of the maximum (exp(-d) rounds to 1 for d <= 2^-25): those      */
+/*        classes share the maximum's probability and the LOWEST such index    */
+/*        wins.  Gaps in (2^-25, 2^-23] collapse or not depending on ATen's    */
+/*        exp / division rounding (build- and device-dependent): there the     */
+/*        larger logit is kept (DESIGN.md "argmax boundary").                  */
 /*        Non-finite maximum (NaN anywhere, +inf, or all -inf) makes every     */
 /*        softmax output NaN in the reference -> torch.max returns index 0.    */
 /* score: 1 / sum_c exp(x_c - max)  (fp64 accumulate, rounded once).           */
@@ -61,6 +65,10 @@ int orc_semantic_argmax(const float* logits, int B, int C, int H, int W,
             double s = 0.0;
             for (int c = 0; c < C; ++c)
                 s += exp((double)lb[(int64_t)c * P + p] - (double)m);
+            for (int c = 0; c < am; ++c) {
+                const volatile float d = lb[(int64_t)c * P + p] - m;      /* fp32, as ATen */
+                if (d >= -0x1p-25f) { am = c; break; }
+            }
             if (idx) idx[b * P + p] = am;
             if (score) score[b * P + p] = (float)(1.0 / s);
         }

@@ -61,3 +61,19 @@ def check_cos_emb_large_grad(name, p, g, grad, rtol, atol, sums_rtol):
     scale = want[1]                                  # sum |grad|: the magnitude the sums live on
     got = np.array([grad.sum(), np.abs(grad).sum(), (grad * proj).sum()])
     np.testing.assert_allclose(got, want, rtol=0, atol=sums_rtol * scale, err_msg=name)
+
+
+def probability_tie_rule(logits):
+    """a1, numpy restatement of the rule oracle and kernels implement for max(softmax(x)):
+    per pixel the LOWEST class within 2^-25 (fp32 subtraction) of the maximum logit.
+    -> (rule index, mask of pixels where a lower-indexed class sits between 2^-25 and 2^-23
+    below the maximum: there the reference's own answer depends on ATen's rounding)"""
+    import numpy as np
+    x = np.asarray(logits, np.float32)
+    m = x.max(axis=1, keepdims=True)
+    d = (x - m).astype(np.float32)                           # <= 0, fp32 like ATen's x - max
+    C = x.shape[1]
+    cls = np.arange(C).reshape(1, C, 1, 1)
+    rule = np.where(d >= -np.float32(2.0 ** -25), cls, C).min(axis=1)
+    between = (d < -np.float32(2.0 ** -25)) & (d >= -np.float32(2.0 ** -23)) & (cls < rule[:, None])
+    return rule.astype(np.uint8), between.any(axis=1)

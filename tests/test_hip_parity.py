@@ -361,27 +361,56 @@ def test_graphed_pipeline_matches_eager(ops):
                 assert torch.equal(got[k], ref[k]), k
 
 
-def test_argmax_tie_band_boundary_hip():
-    """the HIP argmax on the adversarial near-tie fixture (see the CPU-tier twin in
-    test_oracle_vs_golden.py): identical to the reference outside the 2^-23 band, the larger
-    logit inside it — for the stand-alone argmax, the with-score variant and the fused kernel"""
+def test_argmax_tie_band_boundary_hip(oracle):
+    """the HIP argmax on the reference-run near-tie fixture (CPU-tier twin with the details:
+    test_oracle_vs_golden.py): the lowest class within 2^-25 of the maximum — the reference's
+    answer wherever it is forced —, the larger logit between 2^-25 and 2^-23; for the
+    stand-alone argmax, the with-score variant, the fused kernel and the full-resolution path"""
+    from _golden import probability_tie_rule
     from nicr_mt_scene_analysis_amd import ops
     g = load('argmax_ties')
+
+    def all_paths(x):
+        out = [ops.semantic_argmax(x, want_u8=True, want_i64=False, want_score=False)['idx_u8'],
+               ops.semantic_argmax(x, want_u8=True, want_i64=False, want_score=True)['idx_u8']]
+        B, C, H, W = x.shape
+        zeros = torch.zeros((B, 1, H, W), device='cuda')
+        r = ops.panoptic_pipeline(x, zeros, torch.zeros((B, 2, H, W), device='cuda'),
+                                  torch.zeros((C,), dtype=torch.bool, device='cuda'))
+        out.append(r['semantic_idx_u8'])
+        return [o.cpu().numpy() for o in out]
+
     x = torch.from_numpy(g['logits']).cuda()
     ref = g['ref_idx'].reshape(-1)
-    delta, c2 = g['delta'], g['c2']
-    outside = delta > 2.0 ** -23
-    got = [ops.semantic_argmax(x, want_u8=True, want_i64=False, want_score=False)['idx_u8'],
-           ops.semantic_argmax(x, want_u8=True, want_i64=False, want_score=True)['idx_u8']]
-    B, C, H, W = x.shape
-    zeros = torch.zeros((B, 1, H, W), device='cuda')
-    r = ops.panoptic_pipeline(x, zeros, torch.zeros((B, 2, H, W), device='cuda'),
-                              torch.zeros((C,), dtype=torch.bool, device='cuda'))
-    got.append(r['semantic_idx_u8'])
-    for idx in got:
-        idx = idx.cpu().numpy().reshape(-1)
-        assert (idx == c2).all()
-        assert (idx[outside] == ref[outside]).all()
+    delta, c1, c2 = g['delta'], g['c1'], g['c2']
+    forced = (delta > 2.0 ** -23) | (delta <= 2.0 ** -25)
+    want = np.where(delta <= 2.0 ** -25, c1, c2)
+    for idx in all_paths(x):
+        idx = idx.reshape(-1)
+        assert (idx == want).all()
+        assert (idx[forced] == ref[forced]).all()
+    for name in ('tiny', 'small'):
+        xn = g[f'{name}_logits']
+        rule, between = probability_tie_rule(xn)
+        for idx in all_paths(torch.from_numpy(xn).cuda()):
+            assert (idx == rule).all(), name
+            assert (idx[~between] == g[f'{name}_ref_idx'][~between]).all(), name
+        # full resolution: the rule on the interpolated logits
+        ref_full = g[f'{name}_ref_idx_fullres']
+        size = ref_full.shape[-2:]
+        up = oracle.resize_bilinear(xn, size, None)
+        rule_f, between_f = probability_tie_rule(up)
+        for want_score in (False, True):
+            got = ops.semantic_argmax_resized(torch.from_numpy(xn).cuda(), size, None, want_u8=True,
+                                              want_i64=False, want_score=want_score
+                                              )['idx_u8'].cpu().numpy()
+            assert (got == rule_f).all(), (name, want_score)
+            assert (got[~between_f] == ref_full[~between_f]).all(), (name, want_score)
+    # 16-bit logits: values that close exist only below 2^-17 (bf16) / never (f16)
+    xb = (torch.randn((1, 12, 16, 24), device='cuda') * 2.0 ** -40).to(torch.bfloat16)
+    rule_b, _ = probability_tie_rule(xb.float().cpu().numpy())
+    for idx in all_paths(xb):
+        assert (idx == rule_b).all()
 
 
 @pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
