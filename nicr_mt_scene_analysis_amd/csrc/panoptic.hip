@@ -91,9 +91,10 @@ __device__ __forceinline__ float4 load_px4(const void* base, size_t elem_off, in
 //    that close where the format's spacing is <= 2^-25, i.e. for |max| < tie_band_magnitude —
 //    the trigger, one compare per pixel.  (Gaps in (2^-25, 2^-23] collapse or not with ATen's
 //    exp / division rounding, build- and device-dependent: the larger logit is kept)
-// class of one column by the reference's rule
+// class of one column by the reference's rule, given its maximum m (the running maximum of the
+// fast path; with a NaN / +inf in the column the answer is 0 whatever m is): one walk
 template <int DTYPE>
-__device__ __noinline__ int column_class(const void* logits, size_t col0, int P, int C)
+__device__ __noinline__ int column_class(const void* logits, size_t col0, int P, int C, float m)
 {
     auto ld = [&](int c) -> float {
         if (DTYPE == NMSA_F32) return ((const float*)logits)[col0 + (size_t)c * P];
@@ -101,18 +102,26 @@ __device__ __noinline__ int column_class(const void* logits, size_t col0, int P,
         return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
     };
     bool nan_or_pinf = false, any_finite = false;
-    float m = -INFINITY;
-    int am = 0;
-    for (int c = 0; c < C; ++c) {
-        const float v = ld(c);
-        if (v != v || v == INFINITY) nan_or_pinf = true;
-        if (fabsf(v) < INFINITY) any_finite = true;
-        if (v > m) { m = v; am = c; }
+    int first = C;
+    int c = 0;
+    for (; c + 4 <= C; c += 4) {                    // 4 loads in flight
+        float v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = ld(c + u);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            nan_or_pinf |= (v[u] != v[u]) || (v[u] == INFINITY);
+            any_finite |= fabsf(v[u]) < INFINITY;
+            if (first == C && __fsub_rn(v[u], m) >= -0x1p-25f) first = c + u;
+        }
     }
-    if (nan_or_pinf || !any_finite) return 0;
-    for (int c = 0; c < am; ++c)
-        if (__fsub_rn(ld(c), m) >= -0x1p-25f) return c;
-    return am;
+    for (; c < C; ++c) {
+        const float v = ld(c);
+        nan_or_pinf |= (v != v) || (v == INFINITY);
+        any_finite |= fabsf(v) < INFINITY;
+        if (first == C && __fsub_rn(v, m) >= -0x1p-25f) first = c;
+    }
+    return (nan_or_pinf || !any_finite || first == C) ? 0 : first;
 }
 
 // Exact argmax + score of one column (the group-wise fast path of the WITH_SCORE kernels came
@@ -498,7 +507,7 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(W
                 }
                 st.se[j] = sc;
             } else if ((st.nf[j] != st.nf[j] || may_tie_in_probability<DTYPE>(st.m[j])) && j < nvalid) {
-                cls[j] = column_class<DTYPE>(logits, img_logits + p0 + j, P, C);
+                cls[j] = column_class<DTYPE>(logits, img_logits + p0 + j, P, C, st.m[j]);
             }
             uint64_t tm = thing_m[0];
             if (C > 64) {                                  // workgroup-uniform
@@ -643,7 +652,7 @@ __global__ __launch_bounds__(FUSED_THREADS) void k_semantic_argmax(
                 cls[j] = __float_as_int(ex.y);
             }
         } else if ((st.nf[j] != st.nf[j] || may_tie_in_probability<DTYPE>(st.m[j])) && j < nvalid) {
-            cls[j] = column_class<DTYPE>(logits, img + p0 + j, P, C);
+            cls[j] = column_class<DTYPE>(logits, img + p0 + j, P, C, st.m[j]);
         }
     }
     const size_t o = (size_t)b * P + p0;
