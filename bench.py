@@ -296,7 +296,9 @@ def secondary_losses(dev, B=64, C=40, H=480, W=640):
         (lc, n), = ce([logits], [labels])
         (lc / n).backward()
     n_px = B * H * W
-    from nicr_mt_scene_analysis_amd.loss import _functional as loss_f, speculation_stats
+    from nicr_mt_scene_analysis_amd.loss import (_functional as loss_f, reset_speculation_state,
+                                                 speculation_stats)
+    reset_speculation_state()                  # history of whatever ran before in this process
     if loss_f.mean_speculation_enabled():
         # forward kernels that also write the gradient: per loss the element count
         # (labels / mask, 1 B/px) + inputs once + gradient once; backward launches only confirm

@@ -7,4 +7,5 @@ from .l1 import L1Loss
 from .mse import MSELoss
 from .vonmises import VonMisesLossBiternion
 from ._functional import check_loss_status
+from ._functional import reset_speculation_state
 from ._functional import speculation_stats

@@ -111,6 +111,15 @@ def speculation_stats() -> Dict[str, int]:
     return dict(_SPEC_TOTALS)
 
 
+def reset_speculation_state() -> None:
+    """forget the confirmed / recomputed history (host sync) and switch the default expectation
+    of the loss classes back on — a new training run, a test, a benchmark leg"""
+    speculation_stats()                     # drains the counters, keeps pending status bits
+    _SPEC_TOTALS['confirmed'] = _SPEC_TOTALS['recomputed'] = 0
+    _MEAN_SPECULATION['on'] = True
+    _MEAN_SPECULATION['warned'] = False
+
+
 def speculation_enabled() -> bool:
     return _SPECULATE
 

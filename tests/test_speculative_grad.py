@@ -18,6 +18,15 @@ pytestmark = pytest.mark.gpu
 RTOL = 1e-5
 
 
+@pytest.fixture(autouse=True)
+def fresh_speculation_state():
+    """the default expectation switches itself off after a history of misses (other test files
+    call backward on bare sums): every test here starts from a clean history"""
+    from nicr_mt_scene_analysis_amd.loss import reset_speculation_state
+    reset_speculation_state()
+    yield
+
+
 def _gen(seed=0):
     return torch.Generator(device='cuda').manual_seed(seed)
 
@@ -264,3 +273,36 @@ def test_no_gradient_is_written_without_autograd():
     assert not l0.requires_grad and not l1.requires_grad
     np.testing.assert_allclose(float(l0), float(l1), rtol=1e-7)
     assert _delta(before) == (0, 0)
+
+
+def test_default_expectation_switches_itself_off_after_misses():
+    """a caller whose reduction is not `loss / n` (here: backward on the bare sum) makes every
+    default expectation miss; after 8 misses in the majority the loss classes stop writing
+    gradients nobody confirms (one warning), explicit expectations stay honoured"""
+    from nicr_mt_scene_analysis_amd.loss import L1Loss, check_loss_status
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    g = _gen(9)
+    p = torch.randn((1, 2, 16, 20), device='cuda', generator=g)
+    y = torch.randn((1, 2, 16, 20), device='cuda', generator=g)
+    m = torch.rand((1, 16, 20), device='cuda', generator=g) > 0.5
+    loss = L1Loss()
+    assert F_.mean_speculation_enabled()
+    for _ in range(9):
+        ps = p.clone().requires_grad_(True)
+        loss.masked_sum(ps, y, m)[0].backward()
+    with pytest.warns(UserWarning, match='recomputed'):
+        check_loss_status()
+    assert not F_.mean_speculation_enabled()
+    before = _stats()
+    ps = p.clone().requires_grad_(True)
+    l, n = loss.masked_sum(ps, y, m)
+    (l / n).backward()
+    assert _delta(before) == (0, 0)                      # plain two-kernel path now
+    ps = p.clone().requires_grad_(True)
+    l, n = loss.masked_sum(ps, y, m, expected_scale=F_.expected_scale(F_.count_u8(m)))
+    (l / n).backward()
+    assert _delta(before) == (1, 0)
+    pr = p.double().requires_grad_(True)
+    ((pr * m.unsqueeze(1) - y.double()).abs().mean(dim=1).sum() / int(m.sum())).backward()
+    np.testing.assert_allclose(ps.grad.double().cpu().numpy(), pr.grad.cpu().numpy(),
+                               rtol=2e-5, atol=1e-9)

@@ -115,8 +115,9 @@ def test_task_helper_totals_confirm_forward_written_gradients(monkeypatch):
     the scales of the counts): every backward launch confirms, and the gradients are those of
     the two-kernel path"""
     from nicr_mt_scene_analysis_amd.loss import _functional as F_
-    from nicr_mt_scene_analysis_amd.loss import speculation_stats
+    from nicr_mt_scene_analysis_amd.loss import reset_speculation_state, speculation_stats
     from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper, SemanticTaskHelper
+    reset_speculation_state()
     weights = {'semantic': 0.75, 'instance_center': 2.0, 'instance_offset': 1.0,
                'instance_orientation': 0.5}
 
