@@ -122,3 +122,78 @@ def test_wrappers_raise_the_reference_exception_types(env):
         get_postprocessing_class('instance')(heatmap_nms_kernel_size=2)
     with pytest.raises(ValueError):
         get_postprocessing_class('nope')
+
+
+def test_forward_written_gradient_entry_points_return_codes(env):
+    """nmsa_count_u8 / nmsa_loss_*_fwd_grad / nmsa_loss_*_bwd_unless: null pointers, unknown
+    dtype codes, short workspaces, a class column that does not fit the registers"""
+    L, lib, dev, (B, C, H, W), t = env
+    p, st = L.ptr, L.stream_ptr(dev)
+    ERR_UNSUPPORTED = -4
+    x = t['logits']
+    grad = torch.empty_like(x)
+    labels = torch.randint(0, C + 1, (B, H, W), dtype=torch.uint8, device=dev)
+    one = torch.ones((1,), device=dev)
+    s = torch.zeros((1,), dtype=torch.float64, device=dev)
+    n = torch.zeros((1,), dtype=torch.int64, device=dev)
+    ws_b = lib.nmsa_loss_workspace_bytes(B, H, W)
+    cnt_b = lib.nmsa_count_workspace_bytes()
+    assert cnt_b > 0
+
+    def count(values=labels, nbytes=cnt_b, lo=1, hi=C, out=n):
+        return lib.nmsa_count_u8(p(values), values.numel() if values is not None else 0, lo, hi,
+                                 p(out), None, 1.0, p(t['ws']), nbytes, st)
+    assert count() == 0 and int(n) == int((labels != 0).sum())
+    assert count(values=None) == ERR_ARG
+    assert count(out=None) == ERR_ARG
+    assert count(lo=3, hi=2) == ERR_ARG
+    assert count(hi=256) == ERR_ARG
+    assert count(nbytes=cnt_b - 1) == ERR_WORKSPACE
+
+    def ce(logits=x, dtype=0, c=C, expected=one, g=grad, nbytes=ws_b):
+        return lib.nmsa_loss_ce_fwd_grad(p(logits), dtype, p(labels), None, B, c, H, W, 0.0,
+                                         p(expected), p(s), p(n), None, p(g), p(t['status']),
+                                         p(t['ws']), nbytes, st)
+    assert ce() == 0
+    assert ce(logits=None) == ERR_ARG
+    assert ce(expected=None) == ERR_ARG
+    assert ce(g=None) == ERR_ARG
+    assert ce(dtype=7) == ERR_ARG
+    assert ce(c=0) == ERR_ARG
+    assert ce(c=49) == ERR_UNSUPPORTED                   # > 48 planes: two-kernel path
+    assert ce(nbytes=ws_b - 1) == ERR_WORKSPACE
+    assert lib.nmsa_loss_ce_fwd_grad_supported(0, 48) == 1
+    assert lib.nmsa_loss_ce_fwd_grad_supported(0, 49) == 0
+    assert lib.nmsa_loss_ce_fwd_grad_supported(9, 8) == 0
+
+    def ce_bwd(computed_for=one, g=grad):
+        return lib.nmsa_loss_ce_bwd_unless(p(x), 0, p(labels), None, B, C, H, W, 0.0, p(one), p(g),
+                                           p(computed_for), None, st)
+    assert ce_bwd() == 0
+    assert ce_bwd(computed_for=None) == ERR_ARG
+    assert ce_bwd(g=None) == ERR_ARG
+
+    pred, tgt = t['offset'], torch.zeros_like(t['offset'])
+    gp = torch.empty_like(pred)
+
+    def masked(kind=1, expected=one, g=gp, nbytes=ws_b):
+        return lib.nmsa_loss_masked_fwd_grad(p(pred), 0, p(tgt), p(t['fg']), B, 2, H, W, kind,
+                                             p(expected), p(s), p(n), p(g), p(t['ws']), nbytes, st)
+    assert masked() == 0
+    assert masked(kind=3) == ERR_ARG
+    assert masked(expected=None) == ERR_ARG
+    assert masked(g=None) == ERR_ARG
+    assert masked(nbytes=8) == ERR_WORKSPACE
+    assert lib.nmsa_loss_masked_bwd_unless(p(pred), 0, p(tgt), p(t['fg']), B, 2, H, W, 1, p(one),
+                                           p(gp), None, None, st) == ERR_ARG
+
+    def vm(expected=one, g=gp, nbytes=ws_b):
+        return lib.nmsa_loss_vonmises_fwd_grad(p(pred), 0, p(tgt), p(t['fg']), B, H, W, 1.0,
+                                               p(expected), p(s), p(n), p(g), p(t['ws']), nbytes, st)
+    assert vm() == 0
+    assert vm(expected=None) == ERR_ARG
+    assert vm(g=None) == ERR_ARG
+    assert vm(nbytes=8) == ERR_WORKSPACE
+    assert lib.nmsa_loss_vonmises_bwd_unless(p(pred), 0, p(tgt), p(t['fg']), B, H, W, 1.0, p(one),
+                                             p(gp), None, None, st) == ERR_ARG
+    torch.cuda.synchronize()
