@@ -455,8 +455,9 @@ int nmsa_pq_update_with_confmat(
  *     when *grad_scale is bit-equal to *computed_for the gradient buffer is already right and
  *     the kernel returns at once (counters[0]++), otherwise it recomputes the gradient from
  *     the inputs (counters[1]++), so the result never depends on the expectation.
- *     The CE variant keeps a pixel's whole class column in registers: C <= 48
- *     (nmsa_loss_ce_fwd_grad_supported), NMSA_ERR_UNSUPPORTED above.
+ *     The CE variant keeps a pixel's whole class column in registers up to C = 48; above
+ *     that the same launch walks the column twice (the second walk is served by the caches).
+ *     nmsa_loss_ce_fwd_grad_supported(dtype, C): 1 for every valid dtype and C <= 4096.
  * nmsa_count_u8        *count = #{i : lo <= values[i] <= hi}  (labels 1..C, mask bytes 1..255);
  *     *mean_scale (optional) = weight / (float)count, the correctly rounded fp32 division
  *     autograd performs for `weight * loss_sum / count`;

@@ -357,15 +357,24 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
 //   grad_j = g * [ (a + bsum) p_j - a [j == t] - b_j ],  a = (1-ls) w_t, b_j = (ls/C) w_j
 // pass 1: max / sum (as forward); pass 2 re-reads the tile (L2) and writes
 // g*((a+bsum) p_j - b_j); the "- a" at the target class is one read-modify-write per px.
-template <int DTYPE, int PXT, bool SMOOTH, int UB>
+// LOSS: the same two walks also produce the forward sum (block partials as k_ce_fwd) — forward +
+// gradient for an expected upstream scale in ONE launch for class counts whose column does not
+// fit the registers of k_ce_fused (C > 48): the second walk re-reads the tile through the
+// Infinity Cache at ~40 % of a first read (tools/diag_two_pass.py) instead of a second kernel
+// reading it from HBM plus a log-sum-exp round trip.
+template <int DTYPE, int PXT, bool SMOOTH, int UB, bool LOSS = false>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
     const float* __restrict__ gscale, void* __restrict__ grad, const float* __restrict__ lse2,
-    const float* __restrict__ computed_for, int* __restrict__ counters)
+    const float* __restrict__ computed_for, int* __restrict__ counters,
+    LossPartial* __restrict__ partials = nullptr, int* __restrict__ status = nullptr)
 {
     extern __shared__ float s_w[];
-    if (grad_already_computed(gscale, computed_for, counters)) return;
+    if (!LOSS && grad_already_computed(gscale, computed_for, counters)) return;
+    double acc = 0.0, accw = 0.0;
+    long long cnt = 0;
+    bool bad = false;
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
     float wsum = 0.f;
@@ -399,10 +408,26 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
             }
         } else {
             // pass 1 with regular loads (the tile may still be in L2 / MALL for pass 2)
-            ce_scan<DTYPE, PXT, U, false, false, false>(logits, img, P, p0, nvalid, vec, C, s_w, t,
-                                                        m, s, swx, xts);
+            ce_scan<DTYPE, PXT, U, LOSS && SMOOTH, LOSS, false>(logits, img, P, p0, nvalid, vec, C,
+                                                                s_w, t, m, s, swx, xts);
 #pragma unroll
             for (int j = 0; j < PXT; ++j) k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));
+            if (LOSS) {
+                float part = 0.f, partw = 0.f;
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    if (t[j] < 0) continue;                                 // void: ignore_index
+                    if (t[j] >= C) { bad = true; continue; }
+                    const float lse = fmaf(__log2f(s[j]), LN2, m[j]);
+                    const float wt = s_w[t[j]];
+                    float l = (1.0f - ls) * wt * (lse - xts[j]);
+                    if (SMOOTH) l += (ls / C) * (lse * wsum - swx[j]);
+                    part += l;
+                    partw += wt;
+                    ++cnt;
+                }
+                acc += part; accw += partw;
+            }
         }
 #pragma unroll
         for (int j = 0; j < PXT; ++j) {
@@ -438,6 +463,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
             ldpx<DTYPE, PXT, true>(logits, img + (size_t)c * P + p0, nvalid, vec, v);
             plane(v, c);
         }
+    }
+    if (LOSS) {
+        if (bad) atomicOr(status, 8);
+        block_partial(acc, accw, cnt, partials);
     }
 }
 
@@ -1346,8 +1375,8 @@ extern "C" int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, i
 
 extern "C" int nmsa_loss_ce_fwd_grad_supported(int dtype, int C)
 {
-    return (dtype == NMSA_F32 || dtype == NMSA_BF16 || dtype == NMSA_F16) && C >= 1 &&
-           C <= CE_FUSED_MAX_C;
+    // C <= 48: register-resident column (k_ce_fused); above: two walks in one launch
+    return (dtype == NMSA_F32 || dtype == NMSA_BF16 || dtype == NMSA_F16) && C >= 1 && C <= 4096;
 }
 
 extern "C" int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_t* target,
@@ -1362,9 +1391,29 @@ extern "C" int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_
         !expected_grad_scale || !grad_logits) return NMSA_ERR_ARG;
     if (bad_shape(B, H, W) || C <= 0 || C > 4096) return NMSA_ERR_ARG;
     if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return NMSA_ERR_ARG;
-    if (!nmsa_loss_ce_fwd_grad_supported(dtype, C)) return NMSA_ERR_UNSUPPORTED;   // column > registers
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
+    if (C > CE_FUSED_MAX_C) {
+        // column > registers: the two-walk backward kernel also sums the loss
+        const int pxt = (dtype == NMSA_F32) ? 4 : 8;
+        const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 15) == 0);
+        const int gx = grid_x(P, pxt);
+        LossPartial* partials = (LossPartial*)workspace;
+#define CE_TWO(DT, PX, SM) hipLaunchKernelGGL((k_ce_bwd<DT, PX, SM, 4, true>), dim3(gx, B), dim3(LOSS_THREADS), \
+        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, \
+        expected_grad_scale, grad_logits, (const float*)nullptr, (const float*)nullptr, (int*)nullptr, \
+        partials, status)
+        const bool smooth2 = label_smoothing != 0.0f;
+        switch (dtype) {
+            case NMSA_F32: if (smooth2) CE_TWO(NMSA_F32, 4, true); else CE_TWO(NMSA_F32, 4, false); break;
+            case NMSA_BF16: if (smooth2) CE_TWO(NMSA_BF16, 8, true); else CE_TWO(NMSA_BF16, 8, false); break;
+            default: if (smooth2) CE_TWO(NMSA_F16, 8, true); else CE_TWO(NMSA_F16, 8, false); break;
+        }
+#undef CE_TWO
+        int rc2 = check_launch();
+        if (rc2) return rc2;
+        return finalize(partials, gx * B, loss_sum, weight_sum, n_elements, stream);
+    }
     const int pxt = (dtype == NMSA_F32) ? 2 : 4;
     const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 7) == 0);
     const int gx = grid_x(P, pxt);

@@ -203,7 +203,7 @@ class CrossEntropyFunction(torch.autograd.Function):
         code = L.float_dtype_code(x)
         exp = _expected(expected, dev) if ctx.needs_input_grad[0] else None
         if exp is not None and not L.lib().nmsa_loss_ce_fwd_grad_supported(code, C_):
-            exp = None                               # class column does not fit the registers
+            exp = None                               # no such kernel for this dtype / C
         lse2 = grad = None
         if exp is not None:
             # forward sum + the gradient for the expected upstream scale in one pass
@@ -439,7 +439,8 @@ def wants_gradient(pred: torch.Tensor) -> bool:
 
 
 def ce_forward_can_write_gradient(logits: torch.Tensor) -> bool:
-    """the class column of a pixel fits the registers of k_ce_fused (C <= 48)"""
+    """the library has a forward kernel that also writes the gradient for these logits
+    (register-resident column up to C = 48, two walks in one launch above)"""
     return logits.is_cuda and logits.ndim == 4 and bool(
         L.lib().nmsa_loss_ce_fwd_grad_supported(L.float_dtype_code(logits), logits.shape[1]))
 

@@ -98,6 +98,7 @@ def test_bench_secondary_legs_run_on_small_shapes():
         'pipeline_f32_serial': bench.secondary_pipeline(ops, syn, dev, 2, 150, 64, 128, 4, None,
                                                         overlap=False),
         'losses': bench.secondary_losses(dev, B=2, C=8, H=64, W=96),
+        'ce_many_classes': bench.secondary_ce(dev, B=1, C=60, H=32, W=48),
         'cos': bench.secondary_cos_emb(dev, B=1, D=64, H=32, W=32, L=8),
         'next_rows': bench.secondary_next_rows(ops, syn, dev, B=2, C=8, H=96, W=128),
     }
@@ -111,4 +112,4 @@ def test_bench_secondary_legs_run_on_small_shapes():
                 n += 1
                 assert entry['ms'] == entry['ms'] or key == 'step_two_batches_in_flight', (name, key)
                 assert entry['algorithmic_bytes'] > 0 and 'frac' in entry, (name, key)
-    assert n >= 17
+    assert n >= 19

@@ -126,10 +126,9 @@ def test_wrappers_raise_the_reference_exception_types(env):
 
 def test_forward_written_gradient_entry_points_return_codes(env):
     """nmsa_count_u8 / nmsa_loss_*_fwd_grad / nmsa_loss_*_bwd_unless: null pointers, unknown
-    dtype codes, short workspaces, a class column that does not fit the registers"""
+    dtype codes, short workspaces, impossible class counts"""
     L, lib, dev, (B, C, H, W), t = env
     p, st = L.ptr, L.stream_ptr(dev)
-    ERR_UNSUPPORTED = -4
     x = t['logits']
     grad = torch.empty_like(x)
     labels = torch.randint(0, C + 1, (B, H, W), dtype=torch.uint8, device=dev)
@@ -160,10 +159,11 @@ def test_forward_written_gradient_entry_points_return_codes(env):
     assert ce(g=None) == ERR_ARG
     assert ce(dtype=7) == ERR_ARG
     assert ce(c=0) == ERR_ARG
-    assert ce(c=49) == ERR_UNSUPPORTED                   # > 48 planes: two-kernel path
+    assert ce(c=4097) == ERR_ARG
     assert ce(nbytes=ws_b - 1) == ERR_WORKSPACE
     assert lib.nmsa_loss_ce_fwd_grad_supported(0, 48) == 1
-    assert lib.nmsa_loss_ce_fwd_grad_supported(0, 49) == 0
+    assert lib.nmsa_loss_ce_fwd_grad_supported(0, 49) == 1     # two walks in one launch
+    assert lib.nmsa_loss_ce_fwd_grad_supported(0, 4097) == 0
     assert lib.nmsa_loss_ce_fwd_grad_supported(9, 8) == 0
 
     def ce_bwd(computed_for=one, g=grad):
