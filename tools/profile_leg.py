@@ -4,7 +4,8 @@
     rocprofv3 --kernel-trace --stats -d out -o leg -- python3 tools/profile_leg.py cfg5_bf16 [reps]
 
 legs: cfg2_f32 cfg2_bf16 cfg5_f32 cfg5_bf16 (pipeline + metric updates), cfg3_losses,
-cos512, cos768, next_rows (f2 full resolution, f3 scores, f4 targets)"""
+ce150 (cross entropy at 150 classes), cos512, cos768, next_rows (f2 full resolution, f3 scores,
+f4 targets)"""
 import os
 import sys
 
@@ -27,6 +28,8 @@ elif leg == 'cfg3_losses':
     out = bench.secondary_losses(dev)
 elif leg == 'next_rows':
     out = bench.secondary_next_rows(ops, syn, dev)
+elif leg == 'ce150':
+    out = bench.secondary_ce(dev)
 elif leg in ('cos512', 'cos768'):
     out = bench.secondary_cos_emb(dev, B=16, D=int(leg[3:]))
 else:
