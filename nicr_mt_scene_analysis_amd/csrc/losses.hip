@@ -1399,8 +1399,15 @@ extern "C" int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_
         const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 15) == 0);
         const int gx = grid_x(P, pxt);
         LossPartial* partials = (LossPartial*)workspace;
+        // Fewer workgroups per CU keep more of the tiles between their two walks inside the
+        // Infinity Cache: 50 KB of (unused) dynamic LDS admit 3 workgroups = 12 waves per CU —
+        // B=16 C=150 1024x768: 2.02 ms unpadded, 1.89 (32 KB), 1.75 (50 KB), 1.76 (64 KB);
+        // C=64: 0.592 / 0.582 / 0.576 / 0.610.  NMSA_CE_TWO_LDS overrides (bytes).
+        static const int lds_pad = loss_env_int("NMSA_CE_TWO_LDS", 50000);
+        const size_t lds_two = (size_t)C * sizeof(float) > (size_t)lds_pad ? (size_t)C * sizeof(float)
+                                                                           : (size_t)lds_pad;
 #define CE_TWO(DT, PX, SM) hipLaunchKernelGGL((k_ce_bwd<DT, PX, SM, 4, true>), dim3(gx, B), dim3(LOSS_THREADS), \
-        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, \
+        lds_two, stream, logits, target, weights, C, P, label_smoothing, vec, \
         expected_grad_scale, grad_logits, (const float*)nullptr, (const float*)nullptr, (int*)nullptr, \
         partials, status)
         const bool smooth2 = label_smoothing != 0.0f;
