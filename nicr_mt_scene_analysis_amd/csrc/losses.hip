@@ -1357,7 +1357,8 @@ extern "C" int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, i
                              size_t workspace_bytes, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!values || !count || !workspace || n < 0 || lo < 0 || hi > 255 || lo > hi) return NMSA_ERR_ARG;
+    if ((!values && n > 0) || !count || !workspace || n < 0 || lo < 0 || hi > 255 || lo > hi)
+        return NMSA_ERR_ARG;                                        // an empty input counts 0
     if (workspace_bytes < nmsa_count_workspace_bytes()) return NMSA_ERR_WORKSPACE;
     const int vec = (((uintptr_t)values) & 15) == 0;
     int64_t blocks = (n / 16 + LOSS_THREADS * 4 - 1) / (LOSS_THREADS * 4);       // ~4 loads per lane

@@ -143,7 +143,8 @@ def test_forward_written_gradient_entry_points_return_codes(env):
         return lib.nmsa_count_u8(p(values), values.numel() if values is not None else 0, lo, hi,
                                  p(out), None, 1.0, p(t['ws']), nbytes, st)
     assert count() == 0 and int(n) == int((labels != 0).sum())
-    assert count(values=None) == ERR_ARG
+    assert lib.nmsa_count_u8(None, 5, 1, C, p(n), None, 1.0, p(t['ws']), cnt_b, st) == ERR_ARG
+    assert lib.nmsa_count_u8(None, 0, 1, C, p(n), None, 1.0, p(t['ws']), cnt_b, st) == 0 and int(n) == 0
     assert count(out=None) == ERR_ARG
     assert count(lo=3, hi=2) == ERR_ARG
     assert count(hi=256) == ERR_ARG

@@ -321,3 +321,26 @@ def test_default_expectation_switches_itself_off_after_misses():
     ((pr * m.unsqueeze(1) - y.double()).abs().mean(dim=1).sum() / int(m.sum())).backward()
     np.testing.assert_allclose(ps.grad.double().cpu().numpy(), pr.grad.cpu().numpy(),
                                rtol=2e-5, atol=1e-9)
+
+
+def test_count_u8_ranges_sizes_and_alignments():
+    """k_count_u8: empty input, sizes around the 16-B vector width and the per-block tile,
+    unaligned base pointers (scalar path), every kind of [lo, hi] range, bool masks"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    g = _gen(21)
+    base = torch.randint(0, 256, (300_000,), device='cuda', generator=g, dtype=torch.int32).to(torch.uint8)
+    host = base.cpu().numpy()
+    for n in (0, 1, 15, 16, 17, 255, 4096, 16 * 1024 + 3, 262_144, 299_999):
+        for off in (0, 1, 7, 16):
+            if off + n > base.numel():
+                continue
+            view = base[off:off + n]
+            for lo, hi in ((1, 255), (1, 40), (0, 0), (255, 255), (7, 7), (0, 255)):
+                want = int(((host[off:off + n] >= lo) & (host[off:off + n] <= hi)).sum())
+                assert int(F_.count_u8(view, lo, hi)) == want, (n, off, lo, hi)
+    mask = torch.rand((3, 37, 53), device='cuda', generator=g) < 0.3
+    cnt, inv = F_.count_u8(mask, with_mean_scale=True)
+    assert int(cnt) == int(mask.sum())
+    assert torch.equal(inv, torch.ones(1, device='cuda') / cnt)        # the division autograd does
+    with pytest.raises(Exception):
+        F_.count_u8(mask.cpu())
