@@ -344,3 +344,36 @@ def test_count_u8_ranges_sizes_and_alignments():
     assert torch.equal(inv, torch.ones(1, device='cuda') / cnt)        # the division autograd does
     with pytest.raises(Exception):
         F_.count_u8(mask.cpu())
+
+
+def test_nothing_selected_gives_zero_gradients():
+    """all labels void / all mask bytes 0: n = 0, the expected scale is 1 / 0 = inf — the same inf
+    autograd sends back for `loss / n` — and the written gradient is all zeros, not NaN"""
+    from nicr_mt_scene_analysis_amd.loss import CrossEntropyLossSemantic, L1Loss, VonMisesLossBiternion
+    g = _gen(5)
+    x = torch.randn((2, 7, 12, 20), device='cuda', generator=g).requires_grad_(True)
+    t = torch.zeros((2, 12, 20), dtype=torch.uint8, device='cuda')
+    before = _stats()
+    (l, n), = CrossEntropyLossSemantic()([x], [t])
+    assert int(n) == 0 and float(l) == 0.0
+    (l / n).backward()
+    assert _delta(before) == (1, 0)
+    assert torch.count_nonzero(x.grad) == 0
+    p = torch.randn((2, 2, 12, 20), device='cuda', generator=g).requires_grad_(True)
+    y = torch.randn((2, 2, 12, 20), device='cuda', generator=g)
+    m = torch.zeros((2, 12, 20), dtype=torch.bool, device='cuda')
+    for loss in (L1Loss(), VonMisesLossBiternion()):
+        p.grad = None
+        l, n = loss.masked_sum(p, y, m)
+        assert int(n) == 0
+        (l / n).backward()
+        assert torch.count_nonzero(p.grad) == 0 and torch.isfinite(p.grad).all()
+    # the task helper's guarded reduction (count.clamp(min=1)) sends 1.0 instead of inf
+    from nicr_mt_scene_analysis_amd.task_helper.base import TaskHelperBase
+    helper = TaskHelperBase()
+    p.grad = None
+    l, n = L1Loss().masked_sum(p, y, m, expected_scale=helper.expected_scale_for_total([n], [p]))
+    total = helper.accumulate_losses([l], [n])
+    assert float(total) == float(l)          # masked-out pixels still count |0 - target| (instance.py:129-139)
+    total.backward()
+    assert torch.count_nonzero(p.grad) == 0
