@@ -375,8 +375,15 @@ def test_argmax_tie_band_boundary_hip(oracle):
                ops.semantic_argmax(x, want_u8=True, want_i64=False, want_score=True)['idx_u8']]
         B, C, H, W = x.shape
         zeros = torch.zeros((B, 1, H, W), device='cuda')
+        for want_score in (False, True):                  # both instantiations of the fused kernel
+            r = ops.panoptic_pipeline(x, zeros, torch.zeros((B, 2, H, W), device='cuda'),
+                                      torch.zeros((C,), dtype=torch.bool, device='cuda'),
+                                      want_score=want_score)
+            out.append(r['semantic_idx_u8'])
+        # foreground-masked heat-map: the argmax runs first as its own kernel
         r = ops.panoptic_pipeline(x, zeros, torch.zeros((B, 2, H, W), device='cuda'),
-                                  torch.zeros((C,), dtype=torch.bool, device='cuda'))
+                                  torch.ones((C,), dtype=torch.bool, device='cuda'),
+                                  apply_foreground_mask=True)
         out.append(r['semantic_idx_u8'])
         return [o.cpu().numpy() for o in out]
 
