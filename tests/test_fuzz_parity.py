@@ -59,7 +59,10 @@ def cases(draw, medium=False):
     n_thing = draw(st.integers(0, C))
     dtype = draw(st.sampled_from(['float32', 'bfloat16', 'float16']))
     specials = draw(st.sampled_from([False, False, False, True]))
-    return dict(specials=specials, dtype=dtype, B=B, C=C, H=H, W=W, seed=seed, levels=levels, heat_levels=heat_levels, off_q=off_q,
+    # f32 only: logit levels 2^-26 apart instead of 1 apart — neighbouring levels get the SAME
+    # softmax probability and the lowest index wins (a1 probability ties)
+    near_ties = draw(st.sampled_from([False, False, True])) and dtype == 'float32'
+    return dict(near_ties=near_ties, specials=specials, dtype=dtype, B=B, C=C, H=H, W=W, seed=seed, levels=levels, heat_levels=heat_levels, off_q=off_q,
                 ksize=ksize, topk=topk, thr=thr, apply_fg=apply_fg, dist_thr=dist_thr, n_thing=n_thing)
 
 
@@ -67,6 +70,8 @@ def make_inputs(p):
     rng = np.random.default_rng(p['seed'])
     B, C, H, W = p['B'], p['C'], p['H'], p['W']
     logits = rng.integers(0, p['levels'], (B, C, H, W)).astype(np.float32)
+    if p.get('near_ties'):
+        logits = (logits * np.float32(2.0 ** -26)).astype(np.float32)
     heat = (rng.integers(0, p['heat_levels'], (B, 1, H, W)) / (p['heat_levels'] - 1)).astype(np.float32)
     # offsets: multiples of off_q pixels, normalised by (H, W) like the network head
     off_px = rng.integers(-8, 9, (B, 2, H, W)) * p['off_q']
@@ -255,8 +260,9 @@ def test_fuzz_resize_vs_oracle(oracle, seed, Hs, Ws, Ho, Wo, C):
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), Hs=st.integers(20, 90), Ws=st.integers(70, 200),
        fy=st.floats(1.0, 2.6), fx=st.floats(1.0, 2.6), C=st.integers(1, 13),
-       dtype=st.sampled_from(['float32', 'bfloat16', 'float16']), cropped=st.booleans())
-def test_fuzz_upscaling_tiles_vs_oracle(oracle, seed, Hs, Ws, fy, fx, C, dtype, cropped):
+       dtype=st.sampled_from(['float32', 'bfloat16', 'float16']), cropped=st.booleans(),
+       near_ties=st.sampled_from([False, False, True]))
+def test_fuzz_upscaling_tiles_vs_oracle(oracle, seed, Hs, Ws, fy, fx, C, dtype, cropped, near_ties):
     """upscaling geometries wide enough for the LDS-staged tile kernels (64 x 16 output tiles,
     windows shifted at the right border, one or two staging slots): resized logits bit-exact,
     fused argmax / score == argmax of the resized logits, for all three logit dtypes"""
@@ -272,6 +278,10 @@ def test_fuzz_upscaling_tiles_vs_oracle(oracle, seed, Hs, Ws, fy, fx, C, dtype, 
     tdt = getattr(torch, dtype)
     # few levels -> exact ties between classes; all levels exact in bf16 / f16
     x = (rng.integers(-8, 9, (2, C, Hs, Ws)) * 0.375).astype(np.float32)
+    if near_ties and dtype == 'float32':
+        # interpolated values a few 2^-27 apart: classes that share the maximum's fp32
+        # probability (a1 probability ties) — the lowest index wins
+        x = (x * np.float32(2.0 ** -25)).astype(np.float32)
     if rng.random() < 0.2:
         x[0, rng.integers(C), rng.integers(Hs), rng.integers(Ws)] = np.nan
     xd = dev(x).to(tdt)
