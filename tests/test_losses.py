@@ -340,7 +340,12 @@ def test_ce_rejects_more_than_255_classes_and_flags_bad_labels():
     check_loss_status()
     t[0, 0, 0] = 300                                     # wraps to 44 as uint8: must be flagged
     t[0, 1, 1] = 7                                       # > C
-    CrossEntropyLossSemantic()([x], [t])
-    with pytest.raises(IndexError, match='out of range'):
-        check_loss_status()
+    try:
+        CrossEntropyLossSemantic()([x], [t])
+        raised_at_call = False
+    except IndexError:                                   # NMSA_CHECK_STATUS=1 checks per call
+        raised_at_call = True
+    if not raised_at_call:
+        with pytest.raises(IndexError, match='out of range'):
+            check_loss_status()
     check_loss_status()                                  # the word was cleared
