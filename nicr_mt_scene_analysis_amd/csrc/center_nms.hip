@@ -569,12 +569,13 @@ extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
     }
     rc = check_launch();
     if (rc) return rc;
-    if (words <= SEL_LDS_WORDS) {
-        static const bool granted = hipFuncSetAttribute(
-            reinterpret_cast<const void*>(k_select_compact<true>),
-            hipFuncAttributeMaxDynamicSharedMemorySize, SEL_LDS_WORDS * (int)sizeof(uint32_t)) == hipSuccess;
-        (void)granted;
-        hipLaunchKernelGGL(k_select_compact<true>, dim3(B), dim3(SEL_THREADS), (size_t)words * sizeof(uint32_t),
+    // the LDS copy of the candidate mask needs a grant above 64 KB for large images; without
+    // it (denied, another device) the global-memory variant runs instead
+    const size_t sel_lds = (size_t)words * sizeof(uint32_t);
+    if (words <= SEL_LDS_WORDS &&
+        (sel_lds <= 48 * 1024 ||
+         allow_dynamic_lds(k_select_compact<true>, SEL_LDS_WORDS * sizeof(uint32_t)) == NMSA_OK)) {
+        hipLaunchKernelGGL(k_select_compact<true>, dim3(B), dim3(SEL_THREADS), sel_lds,
                            stream, center, apply_fg ? fg : nullptr, bits, H, W, words, topk, apply_fg,
                            max_centers, centers_yx, n_centers, scores, center_mask);
     } else {

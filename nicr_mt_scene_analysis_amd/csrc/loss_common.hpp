@@ -1,0 +1,73 @@
+// loss_common.hpp — pieces shared by the loss kernels (losses.hip: streaming kernels,
+// losses_tile.hip: LDS-resident pixel tiles, losses_multi.hip: one launch for several losses).
+#pragma once
+#include "nmsa_common.hpp"
+
+namespace nmsa {
+
+constexpr int LOSS_THREADS = 256;
+
+// one per workgroup; summed in a FIXED order by k_loss_finalize (deterministic results)
+struct LossPartial { double sum; double aux; long long count; long long pad; };
+
+typedef float f32x4_s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4_s __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2_s __attribute__((ext_vector_type(2)));
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float LN2 = 0.6931471805599453f;
+
+__device__ __forceinline__ uint16_t f32_to_bf16(float f)
+{
+    // round-to-nearest-even via the hardware conversion (keeps NaN a NaN)
+    return __builtin_bit_cast(uint16_t, (__bf16)f);
+}
+__device__ __forceinline__ uint16_t f32_to_f16(float f)
+{
+    return __builtin_bit_cast(uint16_t, (_Float16)f);
+}
+
+// element j (0..1) of a dword holding two 16-bit values / the dword itself for f32
+template <int DTYPE>
+__device__ __forceinline__ float unpack16(uint32_t w, int j)
+{
+    if (DTYPE == NMSA_BF16) return __uint_as_float(j ? (w & 0xFFFF0000u) : (w << 16));
+    return f16_to_f32((uint16_t)(j ? (w >> 16) : (w & 0xFFFFu)));
+}
+template <int DTYPE>
+__device__ __forceinline__ uint32_t pack16(float a, float b)
+{
+    if (DTYPE == NMSA_BF16) return (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+    return (uint32_t)f32_to_f16(a) | ((uint32_t)f32_to_f16(b) << 16);
+}
+
+// Speculative gradients (forward kernels write the gradient for an EXPECTED upstream scale).
+// The backward kernels are launched with `computed_for` = that expected scale: when the real
+// upstream gradient is bit-equal, the gradient buffer is already right and every workgroup
+// returns at once; otherwise the kernel recomputes it.  counters[0] / [1] count the outcomes.
+__device__ __forceinline__ bool grad_already_computed(const float* __restrict__ gscale,
+                                                      const float* __restrict__ computed_for,
+                                                      int* __restrict__ counters)
+{
+    if (!computed_for) return false;
+    const bool same = __float_as_uint(*gscale) == __float_as_uint(*computed_for);
+    if (counters && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+        atomicAdd(&counters[same ? 0 : 1], 1);
+    return same;
+}
+
+// host side, defined in losses.hip
+int loss_finalize(const LossPartial* partials, int n, double* sum, double* aux, int64_t* count,
+                  hipStream_t stream);
+int loss_env_int(const char* name, int dflt);
+bool loss_bad_shape(int B, int H, int W);
+
+
+// losses_tile.hip: LDS-resident pixel tiles for class columns beyond the registers (C > 48)
+bool ce_tile_supported(const void* logits, const void* grad, int dtype, int C, int P, float ls);
+int ce_tile_launch(bool loss, const void* logits, int dtype, const uint8_t* target, const float* weights,
+                   int B, int C, int P, float ls, const float* gscale, const float* computed_for,
+                   int* counters, void* grad, LossPartial* partials, int* status, int* n_blocks,
+                   int max_blocks_per_image, hipStream_t stream);
+
+}  // namespace nmsa

@@ -17,13 +17,9 @@
 // are run-to-run deterministic.  Backward kernels recompute from the inputs and
 // scale by the upstream gradient read from a device scalar (no host sync).
 #include <stdlib.h>
-#include "nmsa_common.hpp"
+#include "loss_common.hpp"
 
 namespace nmsa {
-
-constexpr int LOSS_THREADS = 256;
-
-struct LossPartial { double sum; double aux; long long count; long long pad; };
 
 // ---- typed 4-px helpers --------------------------------------------------------------
 template <int DTYPE>
@@ -49,19 +45,6 @@ __device__ __forceinline__ float4 ld4(const void* base, size_t off, int nvalid, 
         }
     }
     return r;
-}
-
-typedef float f32x4_s __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x4_s __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ uint16_t f32_to_bf16(float f)
-{
-    // round-to-nearest-even via the hardware conversion (keeps NaN a NaN)
-    return __builtin_bit_cast(uint16_t, (__bf16)f);
-}
-__device__ __forceinline__ uint16_t f32_to_f16(float f)
-{
-    return __builtin_bit_cast(uint16_t, (_Float16)f);
 }
 
 template <int DTYPE>
@@ -149,22 +132,6 @@ __global__ __launch_bounds__(FIN_THREADS) void k_loss_finalize(
     }
 }
 
-// Speculative gradients (k_*_fused below write the gradient in the forward pass for an EXPECTED
-// upstream scale).  The backward kernels are then launched with `computed_for` = that expected
-// scale: when the real upstream gradient is bit-equal, the gradient buffer is already right and
-// every workgroup returns at once; otherwise the kernel recomputes it.  counters[0] / [1] count
-// the two outcomes.
-__device__ __forceinline__ bool grad_already_computed(const float* __restrict__ gscale,
-                                                      const float* __restrict__ computed_for,
-                                                      int* __restrict__ counters)
-{
-    if (!computed_for) return false;
-    const bool same = __float_as_uint(*gscale) == __float_as_uint(*computed_for);
-    if (counters && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
-        atomicAdd(&counters[same ? 0 : 1], 1);
-    return same;
-}
-
 // =================================================================================
 // a6: cross entropy (weights, ignore void, label smoothing)
 //   per px (t = label-1 >= 0):  (1-ls)*w_t*(lse - x_t) + (ls/C)*(lse*W - sum_c w_c x_c)
@@ -181,8 +148,6 @@ __device__ __forceinline__ bool grad_already_computed(const float* __restrict__ 
 #define NMSA_GRAD_NT 1
 #endif
 constexpr bool GRAD_NT = NMSA_GRAD_NT != 0;     // gradient planes are written once: streaming stores
-constexpr float LOG2E = 1.4426950408889634f;
-constexpr float LN2 = 0.6931471805599453f;
 
 template <int DTYPE, int PXT, bool NT = true>
 __device__ __forceinline__ void ldpx(const void* base, size_t off, int nvalid, bool vec, float out[PXT])
@@ -482,7 +447,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
 // 16-bit dtype, 2 px of f32; 8*NG planes -> 16*NG VGPRs), so the maximum, the sum of
 // exponentials and the softmax each walk registers, not memory.  C <= 48 (NG <= 6); larger C
 // falls back to the two-kernel path.
-typedef unsigned int u32x2_s __attribute__((ext_vector_type(2)));
 
 template <int DTYPE>
 __device__ __forceinline__ u32x2_s ld_plane8(const void* base, size_t off, int nvalid, bool vec)
@@ -554,16 +518,22 @@ __device__ __forceinline__ void keep_packed(u32x2_s (&r)[NP])
 #endif
 }
 
-template <int DTYPE, int NG, bool SMOOTH>
+// LOSS = false: the confirming backward launch — returns at once when the gradient written by
+// the forward launch was computed for the real upstream scale, otherwise recomputes it with the
+// same single pass (a miss costs one read of the logits + one gradient write, no more than the
+// backward of the two-kernel path)
+template <int DTYPE, int NG, bool SMOOTH, bool LOSS = true>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
     const float* __restrict__ expected_gscale, void* __restrict__ grad,
-    LossPartial* __restrict__ partials, int* __restrict__ status)
+    LossPartial* __restrict__ partials, int* __restrict__ status,
+    const float* __restrict__ computed_for = nullptr, int* __restrict__ counters = nullptr)
 {
     constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
     constexpr int NP = 8 * NG;
     extern __shared__ float s_w[];
+    if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
     float wsum = 0.f;
@@ -652,8 +622,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
         }
         acc = part; accw = partw;
     }
-    if (bad) atomicOr(status, 8);
-    block_partial(acc, accw, cnt, partials);
+    if (LOSS) {
+        if (bad) atomicOr(status, 8);
+        block_partial(acc, accw, cnt, partials);
+    }
 }
 
 // number of bytes v with lo <= v <= hi (labels 1..C, mask bytes != 0): the element count a loss
@@ -691,6 +663,42 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_count_u8(
     }
     for (; i < n16; i += stride) cnt += count16(__builtin_nontemporal_load((const u32x4_s*)v + i));
     for (long long k = n16 * 16 + tid; k < n; k += stride) cnt += (((unsigned)v[k] - (unsigned)lo) <= span);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long c = 0;
+        for (int k = 0; k < LOSS_THREADS / 64; ++k) c += s_cnt[k];
+        partials[blockIdx.x] = c;
+    }
+}
+
+// the same for int32 values (LUT indices of the embedding loss: 1..L are valid targets)
+__global__ __launch_bounds__(LOSS_THREADS) void k_count_i32(
+    const int32_t* __restrict__ v, long long n, int lo, int hi, int vec,
+    long long* __restrict__ partials)
+{
+    __shared__ long long s_cnt[LOSS_THREADS / 64];
+    long long cnt = 0;
+    const long long stride = (long long)gridDim.x * LOSS_THREADS;
+    const long long tid = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x;
+    const long long n4 = vec ? n / 4 : 0;
+    const unsigned span = (unsigned)(hi - lo);
+    auto count4 = [&](const u32x4_s w) {
+        return (int)((w.x - (unsigned)lo) <= span) + (int)((w.y - (unsigned)lo) <= span) +
+               (int)((w.z - (unsigned)lo) <= span) + (int)((w.w - (unsigned)lo) <= span);
+    };
+    long long i = tid;
+    for (; i + 3 * stride < n4; i += 4 * stride) {
+        u32x4_s w[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load((const u32x4_s*)v + i + u * stride);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) cnt += count4(w[u]);
+    }
+    for (; i < n4; i += stride) cnt += count4(__builtin_nontemporal_load((const u32x4_s*)v + i));
+    for (long long k = n4 * 4 + tid; k < n; k += stride) cnt += (((unsigned)v[k] - (unsigned)lo) <= span);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
@@ -1211,13 +1219,30 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
 
 using namespace nmsa;
 
-namespace {
+namespace nmsa {
 
 int loss_env_int(const char* name, int dflt)
 {
     const char* v = getenv(name);
     return (v && *v) ? atoi(v) : dflt;
 }
+
+bool loss_bad_shape(int B, int H, int W)
+{
+    return B <= 0 || H <= 0 || W <= 0 || (int64_t)H * W > ((int64_t)1 << 30) || B > 65535;
+}
+
+int loss_finalize(const LossPartial* partials, int n, double* sum, double* aux, int64_t* count,
+                  hipStream_t stream)
+{
+    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(FIN_THREADS), 0, stream, partials, n, sum, aux,
+                       (long long*)count);
+    return check_launch();
+}
+
+}  // namespace nmsa
+
+namespace {
 
 int grid_x(int P, int px_per_thread)
 {
@@ -1227,17 +1252,12 @@ int grid_x(int P, int px_per_thread)
     return (int)g;
 }
 
-bool bad_shape(int B, int H, int W)
-{
-    return B <= 0 || H <= 0 || W <= 0 || (int64_t)H * W > ((int64_t)1 << 30) || B > 65535;
-}
+bool bad_shape(int B, int H, int W) { return loss_bad_shape(B, H, W); }
 
 int finalize(const LossPartial* partials, int n, double* sum, double* aux, int64_t* count,
              hipStream_t stream)
 {
-    hipLaunchKernelGGL(k_loss_finalize, dim3(1), dim3(FIN_THREADS), 0, stream, partials, n, sum, aux,
-                       (long long*)count);
-    return check_launch();
+    return loss_finalize(partials, n, sum, aux, count, stream);
 }
 
 }  // namespace
@@ -1336,13 +1356,44 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
                        grad_logits, nullptr, nullptr, stream);
 }
 
+static int ce_fused_ng(int C) { return (C <= 24) ? 3 : (C <= 40) ? 5 : 6; }
+
 extern "C" int nmsa_loss_ce_bwd_unless(const void* logits, int dtype, const uint8_t* target,
                                        const float* weights, int B, int C, int H, int W,
                                        float label_smoothing, const float* grad_scale,
                                        void* grad_logits, const float* computed_for,
-                                       int32_t* counters, nmsa_stream_t stream)
+                                       int32_t* counters, nmsa_stream_t stream_)
 {
     if (!computed_for) return NMSA_ERR_ARG;
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!logits || !target || !grad_scale || !grad_logits) return NMSA_ERR_ARG;
+    if (bad_shape(B, H, W) || C <= 0 || C > 4096) return NMSA_ERR_ARG;
+    if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return NMSA_ERR_ARG;
+    const int P = H * W;
+    const bool smooth = label_smoothing != 0.0f;
+    // a miss recomputes with the SAME single-pass kernels that wrote the expected gradient
+    // (logits read once, gradient written once): never dearer than the two-kernel backward
+    if (C <= CE_FUSED_MAX_C) {
+        const int pxt = (dtype == NMSA_F32) ? 2 : 4;
+        const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 7) == 0);
+        const int gx = grid_x(P, pxt);
+        const int ng = ce_fused_ng(C);
+#define CE_REDO_L(DT, NG, SM) hipLaunchKernelGGL((k_ce_fused<DT, NG, SM, false>), dim3(gx, B), dim3(LOSS_THREADS), \
+        C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, \
+        grad_scale, grad_logits, (LossPartial*)nullptr, (int*)nullptr, computed_for, counters)
+#define CE_REDO_NG(DT, SM) do { if (ng == 3) CE_REDO_L(DT, 3, SM); else if (ng == 5) CE_REDO_L(DT, 5, SM); \
+                                else CE_REDO_L(DT, 6, SM); } while (0)
+#define CE_REDO(DT) do { if (smooth) CE_REDO_NG(DT, true); else CE_REDO_NG(DT, false); } while (0)
+        NMSA_DISPATCH_DTYPE(dtype, CE_REDO)
+#undef CE_REDO
+#undef CE_REDO_NG
+#undef CE_REDO_L
+        return check_launch();
+    }
+    if (ce_tile_supported(logits, grad_logits, dtype, C, P, label_smoothing))
+        return ce_tile_launch(false, logits, dtype, target, weights, B, C, P, label_smoothing, grad_scale,
+                              computed_for, counters, grad_logits, nullptr, nullptr, nullptr,
+                              grid_x(P, 1), stream);
     return ce_bwd_impl(logits, dtype, target, weights, B, C, H, W, label_smoothing, grad_scale,
                        nullptr, grad_logits, computed_for, counters, stream);
 }
@@ -1374,6 +1425,27 @@ extern "C" int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, i
     return check_launch();
 }
 
+extern "C" int nmsa_count_i32(const int32_t* values, int64_t n, int lo, int hi, int64_t* count,
+                              float* mean_scale, float weight, void* workspace,
+                              size_t workspace_bytes, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if ((!values && n > 0) || !count || !workspace || n < 0 || lo < 0 || lo > hi) return NMSA_ERR_ARG;
+    if (workspace_bytes < nmsa_count_workspace_bytes()) return NMSA_ERR_WORKSPACE;
+    const int vec = (((uintptr_t)values) & 15) == 0;
+    int64_t blocks = (n / 4 + LOSS_THREADS * 4 - 1) / (LOSS_THREADS * 4);
+    if (blocks < 1) blocks = 1;
+    if (blocks > COUNT_MAX_BLOCKS) blocks = COUNT_MAX_BLOCKS;
+    long long* partials = (long long*)workspace;
+    hipLaunchKernelGGL(k_count_i32, dim3((unsigned)blocks), dim3(LOSS_THREADS), 0, stream, values,
+                       (long long)n, lo, hi, vec, partials);
+    int rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_count_finalize, dim3(1), dim3(COUNT_MAX_BLOCKS), 0, stream, partials,
+                       (int)blocks, (long long*)count, mean_scale, weight);
+    return check_launch();
+}
+
 extern "C" int nmsa_loss_ce_fwd_grad_supported(int dtype, int C)
 {
     // C <= 48: register-resident column (k_ce_fused); above: two walks in one launch
@@ -1394,8 +1466,19 @@ extern "C" int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_
     if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return NMSA_ERR_ARG;
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
+    if (C > CE_FUSED_MAX_C && ce_tile_supported(logits, grad_logits, dtype, C, P, label_smoothing)) {
+        // column > registers: a pixel tile of the logits lives in LDS between the reduction over
+        // the classes and the gradient (losses_tile.hip) — one HBM read, one gradient write
+        LossPartial* partials = (LossPartial*)workspace;
+        int n_blocks = 0;
+        int rc2 = ce_tile_launch(true, logits, dtype, target, weights, B, C, P, label_smoothing,
+                                 expected_grad_scale, nullptr, nullptr, grad_logits, partials, status,
+                                 &n_blocks, grid_x(P, 1), stream);
+        if (rc2) return rc2;
+        return finalize(partials, n_blocks, loss_sum, weight_sum, n_elements, stream);
+    }
     if (C > CE_FUSED_MAX_C) {
-        // column > registers: the two-walk backward kernel also sums the loss
+        // unaligned / odd shapes: the two-walk backward kernel also sums the loss
         const int pxt = (dtype == NMSA_F32) ? 4 : 8;
         const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 15) == 0);
         const int gx = grid_x(P, pxt);
@@ -1427,7 +1510,7 @@ extern "C" int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_
     const int gx = grid_x(P, pxt);
     const bool smooth = label_smoothing != 0.0f;
     LossPartial* partials = (LossPartial*)workspace;
-    const int ng = (C <= 24) ? 3 : (C <= 40) ? 5 : 6;
+    const int ng = ce_fused_ng(C);
 #define CE_FUSED_L(DT, NG, SM) hipLaunchKernelGGL((k_ce_fused<DT, NG, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
         C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, \
         expected_grad_scale, grad_logits, partials, status)
@@ -1664,16 +1747,6 @@ int cos_chunk(int L, int D)
 }
 size_t cos_lds_bytes(int L, int DC) { return ((size_t)L * (DC + 1) + L) * sizeof(float); }
 
-// dynamic LDS above the 64 KB default is granted per kernel function, once per process (the
-// launch macros keep the result in a function-local static)
-template <typename K>
-int cos_allow_lds(K kernel, size_t bytes)
-{
-    return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
-                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) == hipSuccess
-               ? 0 : NMSA_ERR_LAUNCH;
-}
-
 }  // namespace
 
 extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t* indices,
@@ -1700,8 +1773,7 @@ extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t*
         // the per-pixel dot products are only kept on the aligned path (16-B float stores)
         const bool dots_vec = dots_out && vec && ((((uintptr_t)dots_out) & 15) == 0);
         if (dots_out && !dots_vec) return NMSA_ERR_ARG;
-#define COS_FWD(DT, PX) do { static const int denied = cos_allow_lds(k_cos_emb_lds<DT, PX, false>, COS_LDS_BUDGET + 1024); \
-        if (denied) return NMSA_ERR_LAUNCH; \
+#define COS_FWD(DT, PX) do { if (allow_dynamic_lds(k_cos_emb_lds<DT, PX, false>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
         hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, false>), dim3(gx, B), dim3(COS_THREADS), lds, \
         stream, pred, indices, lut, D, P, L, DC, ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status, \
         dots_vec ? dots_out : (float*)nullptr); } while (0)
@@ -1752,8 +1824,7 @@ extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t*
         const int gx = (P + ppb - 1) / ppb;
         const int vec = (P % pxt == 0) && ((((uintptr_t)pred | (uintptr_t)grad_pred) & 15) == 0);
         if (dots && !vec) return NMSA_ERR_ARG;
-#define COS_BWD(DT, PX) do { static const int denied = cos_allow_lds(k_cos_emb_lds<DT, PX, true>, COS_LDS_BUDGET + 1024); \
-        if (denied) return NMSA_ERR_LAUNCH; \
+#define COS_BWD(DT, PX) do { if (allow_dynamic_lds(k_cos_emb_lds<DT, PX, true>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
         hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, true>), dim3(gx, B), dim3(COS_THREADS), lds, \
         stream, pred, indices, lut, D, P, L, DC, ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr, \
         (float*)dots); } while (0)

@@ -23,6 +23,17 @@ inline int check_hip(hipError_t e)
     return NMSA_OK;
 }
 
+// Dynamic LDS above the 64 KB default is granted per kernel function AND per device: the grant
+// is cached per (kernel, device) pair (api.hip).  NMSA_OK, or NMSA_ERR_LAUNCH when the runtime
+// denies it — callers then take their smaller-LDS variant or report the error, they never
+// launch into a denied grant.
+int allow_dynamic_lds_impl(const void* kernel, size_t bytes);
+template <typename K>
+int allow_dynamic_lds(K kernel, size_t bytes)
+{
+    return allow_dynamic_lds_impl(reinterpret_cast<const void*>(kernel), bytes);
+}
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v)

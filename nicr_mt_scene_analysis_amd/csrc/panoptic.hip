@@ -902,7 +902,8 @@ constexpr int ASSIGN_THREADS = 256;
 __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(
     uint32_t* __restrict__ votes, int NC, int clear_votes, int64_t max_inst, int64_t void_label,
     int64_t* __restrict__ pan_of_inst, int32_t* __restrict__ area,
-    int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins, int32_t* __restrict__ n_ids)
+    int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins, int32_t* __restrict__ n_ids,
+    int lds_words)
 {
     extern __shared__ uint32_t s_rows[];  // rows_per_pass x NC
     __shared__ int s_vcls[256];          // classes of the valid instances, ascending id
@@ -911,7 +912,7 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(
     __shared__ int s_cls[256];
     const int b = blockIdx.x, t = threadIdx.x;
     uint32_t* tab = votes + (size_t)b * 256 * NC;
-    const int rows_per_pass = min(256, ASSIGN_LDS_WORDS / NC);
+    const int rows_per_pass = max(1, min(256, lds_words / NC));
     for (int r0 = 0; r0 < 256; r0 += rows_per_pass) {
         const int nr = min(rows_per_pass, 256 - r0);
         const int nwords = nr * NC;
@@ -1308,14 +1309,21 @@ int env_int(const char* name, int dflt)
 }
 
 // dynamic LDS of k_assign: whole rows of the vote table, at most ASSIGN_LDS_WORDS words; the
-// grant above 64 KB is requested once
-size_t assign_lds_bytes(int NC)
+// grant above 64 KB is asked for per device — when it is denied the kernel stages fewer rows per
+// pass inside the default 64 KB
+constexpr int ASSIGN_LDS_WORDS_SMALL = 12 * 1024;
+int assign_lds_words(int NC)
 {
-    static const bool granted = hipFuncSetAttribute(
-        reinterpret_cast<const void*>(k_assign), hipFuncAttributeMaxDynamicSharedMemorySize,
-        ASSIGN_LDS_WORDS * (int)sizeof(uint32_t)) == hipSuccess;
-    (void)granted;
-    const int rows = 256 < ASSIGN_LDS_WORDS / NC ? 256 : ASSIGN_LDS_WORDS / NC;
+    int words = ASSIGN_LDS_WORDS;
+    if ((size_t)256 * NC * sizeof(uint32_t) > 48 * 1024 &&
+        allow_dynamic_lds(k_assign, ASSIGN_LDS_WORDS * sizeof(uint32_t)) != NMSA_OK)
+        words = ASSIGN_LDS_WORDS_SMALL;
+    return words;
+}
+size_t assign_lds_bytes(int NC, int words)
+{
+    int rows = words / NC;
+    rows = rows > 256 ? 256 : (rows < 1 ? 1 : rows);
     return (size_t)rows * NC * sizeof(uint32_t);
 }
 
@@ -1544,9 +1552,11 @@ extern "C" int nmsa_panoptic_assign(uint32_t* votes, int B, int n_vote_classes, 
     hipStream_t stream = (hipStream_t)stream_;
     if (!votes || !pan_of_inst || !ids_pan || !ids_ins || !n_ids) return NMSA_ERR_ARG;
     if (B <= 0 || n_vote_classes <= 0 || n_vote_classes > 4096) return NMSA_ERR_ARG;
-    hipLaunchKernelGGL(k_assign, dim3(B), dim3(ASSIGN_THREADS), assign_lds_bytes(n_vote_classes), stream, votes, n_vote_classes, clear_votes,
+    const int lds_words = assign_lds_words(n_vote_classes);
+    hipLaunchKernelGGL(k_assign, dim3(B), dim3(ASSIGN_THREADS), assign_lds_bytes(n_vote_classes, lds_words),
+                       stream, votes, n_vote_classes, clear_votes,
                        max_instances_per_category, void_label, pan_of_inst, area,
-                       ids_pan, ids_ins, n_ids);
+                       ids_pan, ids_ins, n_ids, lds_words);
     return check_launch();
 }
 
@@ -1606,9 +1616,11 @@ extern "C" int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* i
                             ins_dtype, thing_seg, n_classes, P, votes);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_assign, dim3(B), dim3(ASSIGN_THREADS), assign_lds_bytes(n_classes), stream, votes, n_classes, 0,
+    const int lds_words = assign_lds_words(n_classes);
+    hipLaunchKernelGGL(k_assign, dim3(B), dim3(ASSIGN_THREADS), assign_lds_bytes(n_classes, lds_words),
+                       stream, votes, n_classes, 0,
                        max_instances_per_category, void_label, pan_of_inst, (int32_t*)nullptr,
-                       ids_pan, ids_ins, n_ids);
+                       ids_pan, ids_ins, n_ids, lds_words);
     rc = check_launch();
     if (rc) return rc;
     if (vec) hipLaunchKernelGGL(k_merge_paint<true>, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins,

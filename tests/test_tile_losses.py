@@ -1,0 +1,227 @@
+"""
+GPU tier: the one-pass forward + gradient kernels that keep a pixel tile of the prediction in
+LDS (csrc/losses_tile.hip): `k_cos_tile` (dense cosine-embedding loss, reference
+loss/cos_emb.py:21-56 + task_helper/dense_visual_embedding.py:110-171) and `k_ce_tile`
+(cross entropy at class counts beyond the register-resident kernel, loss/ce.py:40-68).
+
+Checked against torch's own ops in fp64 (the ops the reference calls), against the two-kernel
+path of this library, and for the confirm / recompute protocol of the speculative gradient:
+tile edges (pixel counts that are no multiple of the tile), every LUT-row mode (uniform lanes,
+segment boundaries inside a lane, three and more rows per lane), pixels without a target,
+row tails (D / C no multiple of the rows per step), all three dtypes.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-5
+
+
+def _gen(seed=0):
+    return torch.Generator(device='cuda').manual_seed(seed)
+
+
+def _grad_tol(dtype):
+    return {torch.float32: 2e-5, torch.bfloat16: 2 ** -7, torch.float16: 2 ** -9}[dtype]
+
+
+def _stats():
+    from nicr_mt_scene_analysis_amd.loss import speculation_stats
+    return speculation_stats()
+
+
+def _cos_reference(x, idx, lut):
+    """torch.nn.functional.cosine_embedding_loss on the gathered rows, fp64 (what the
+    reference's task helper computes), + autograd gradient of sum / n"""
+    xr = x.double().requires_grad_(True)
+    B, D, H, W = x.shape
+    valid = idx != 0
+    rows = xr.permute(0, 2, 3, 1)[valid]
+    b_idx = torch.where(valid)[0]
+    tgt = lut.double()[b_idx, (idx[valid] - 1).long()]
+    n = int(valid.sum())
+    if n == 0:
+        return 0.0, 0, torch.zeros_like(xr)
+    loss = torch.nn.functional.cosine_embedding_loss(
+        rows, tgt, torch.ones(n, device=x.device, dtype=torch.float64), reduction='sum')
+    (loss / n).backward()
+    return float(loss), n, xr.grad
+
+
+def _index_map(kind, B, H, W, L, g):
+    if kind == 'blocks':                       # 8-px aligned segments: every lane uniform
+        idx = torch.randint(0, L + 1, (B, (H + 7) // 8, (W + 7) // 8), device='cuda', generator=g,
+                            dtype=torch.int32)
+        return idx.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :H, :W].contiguous()
+    if kind == 'segments':                     # boundaries anywhere: two rows inside a lane
+        idx = torch.randint(0, L + 1, (B, (H + 4) // 5, (W + 10) // 11), device='cuda', generator=g,
+                            dtype=torch.int32)
+        return idx.repeat_interleave(5, 1).repeat_interleave(11, 2)[:, :H, :W].contiguous()
+    if kind == 'noise':                        # a different row per pixel
+        return torch.randint(0, L + 1, (B, H, W), device='cuda', generator=g, dtype=torch.int32)
+    if kind == 'empty':
+        return torch.zeros((B, H, W), device='cuda', dtype=torch.int32)
+    raise ValueError(kind)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize('kind', ['blocks', 'segments', 'noise', 'empty'])
+@pytest.mark.parametrize('shape', [(2, 64, 8, 24), (1, 100, 12, 20), (3, 512, 4, 40), (1, 770, 6, 28),
+                                   (2, 33, 16, 16)])
+def test_cos_tile_vs_torch_fp64(dtype, kind, shape):
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    B, D, H, W = shape
+    L = 7
+    g = _gen(D + H)
+    x = torch.randn((B, D, H, W), device='cuda', generator=g).to(dtype)
+    lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
+    idx = _index_map(kind, B, H, W, L, g)
+    assert F_.cos_forward_can_write_gradient(x, lut) == (D <= 768)
+    ref_loss, ref_n, ref_grad = _cos_reference(x, idx, lut)
+
+    xs = x.clone().requires_grad_(True)
+    before = _stats()
+    loss, n = CosineEmbeddingLoss().lut_sum(xs, idx, lut)          # default expectation 1 / n
+    (loss / n.clamp(min=1)).backward()
+    after = _stats()
+    assert int(n) == ref_n
+    np.testing.assert_allclose(float(loss), ref_loss, rtol=RTOL, atol=1e-6)
+    if ref_n:
+        assert (after['confirmed'] - before['confirmed'], after['recomputed'] - before['recomputed']) == (1, 0)
+    tol = _grad_tol(dtype)
+    atol = tol * float(ref_grad.abs().max()) * 0.05 + (6e-8 if dtype == torch.float16 else 1e-12)   # f16 subnormals
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol, atol=atol)
+
+    # wrong expectation: the backward launch recomputes with the real upstream gradient
+    xw = x.clone().requires_grad_(True)
+    wrong = torch.full((1,), 0.37, device='cuda')
+    loss_w, n_w = CosineEmbeddingLoss().lut_sum(xw, idx, lut, expected_scale=wrong)
+    (loss_w / n_w.clamp(min=1)).backward()
+    np.testing.assert_allclose(float(loss_w), float(loss), rtol=1e-7)
+    assert torch.equal(xw.grad, xs.grad)
+
+    # two-kernel path of the library (no expectation given, default switched off)
+    import os
+    xu = x.clone().requires_grad_(True)
+    loss_u, n_u = F_.cosine_embedding_lut_sum(xu, idx, lut, None)
+    (loss_u / n_u.clamp(min=1)).backward()
+    np.testing.assert_allclose(float(loss_u), ref_loss, rtol=RTOL, atol=1e-6)
+    np.testing.assert_allclose(xu.grad.double().cpu().numpy(), xs.grad.double().cpu().numpy(),
+                               rtol=tol, atol=atol)
+
+
+def test_cos_tile_out_of_range_index_sets_status():
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, check_loss_status
+    g = _gen(5)
+    x = torch.randn((1, 64, 8, 16), device='cuda', generator=g).requires_grad_(True)
+    lut = torch.randn((1, 3, 64), device='cuda', generator=g)
+    idx = torch.randint(0, 4, (1, 8, 16), device='cuda', generator=g, dtype=torch.int32)
+    check_loss_status()
+    idx[0, 3, 5] = 9
+    loss, n = CosineEmbeddingLoss().lut_sum(x, idx, lut)
+    with pytest.raises(IndexError):
+        check_loss_status()
+    assert int(n) == int(((idx > 0) & (idx <= 3)).sum())
+
+
+def _ce_case(B, C, H, W, dtype, seed, void_frac=0.2):
+    g = _gen(seed)
+    x = (torch.randn((B, C, H, W), device='cuda', generator=g) * 3).to(dtype)
+    t = torch.randint(1, C + 1, (B, H, W), device='cuda', generator=g)
+    t[torch.rand((B, H, W), device='cuda', generator=g) < void_frac] = 0
+    w = torch.rand(C, device='cuda', generator=g) + 0.5
+    return x, t.to(torch.uint8), w
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize('C', [49, 64, 150, 151, 255])
+@pytest.mark.parametrize('label_smoothing', [0.0, 0.1])
+@pytest.mark.parametrize('shape', [(2, 24, 36), (1, 8, 1000), (3, 5, 8)])
+def test_ce_tile_vs_torch_fp64(dtype, C, label_smoothing, shape):
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    B, H, W = shape
+    x, t, w = _ce_case(B, C, H, W, dtype, seed=C + H)
+    n = F_.count_u8(t, 1, C)
+    scale = F_.expected_scale(n)
+
+    xs = x.clone().requires_grad_(True)
+    before = _stats()
+    loss, n_el, wsum = F_.cross_entropy_sum(xs, t, w, label_smoothing, expected_scale=scale)
+    (loss / n_el).backward()
+    after = _stats()
+    assert (after['confirmed'] - before['confirmed'], after['recomputed'] - before['recomputed']) == (1, 0)
+    assert int(n_el) == int(n) == int((t != 0).sum())
+    np.testing.assert_allclose(float(wsum), float(w[(t[t != 0] - 1).long()].double().sum()), rtol=1e-6)
+
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t.long() - 1, weight=w.double(), reduction='sum',
+                                            ignore_index=-1, label_smoothing=label_smoothing)
+    (ref / int(n)).backward()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL)
+    tol = _grad_tol(dtype)
+    atol = max(tol * float(xr.grad.abs().max()) * 0.05, 4e-6 * float(w.max()) / int(n))
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(), rtol=tol, atol=atol)
+
+    # wrong expectation -> recomputed by the same single-pass kernel, identical gradient
+    xw = x.clone().requires_grad_(True)
+    loss_w, n_w, _ = F_.cross_entropy_sum(xw, t, w, label_smoothing,
+                                          expected_scale=torch.full((1,), 3.0, device='cuda'))
+    (loss_w / n_w).backward()
+    assert torch.equal(xw.grad, xs.grad)
+    np.testing.assert_allclose(float(loss_w), float(loss), rtol=1e-7)
+
+    # two-kernel path (forward + saved log-sum-exp, backward)
+    xu = x.clone().requires_grad_(True)
+    loss_u, n_u, _ = F_.cross_entropy_sum(xu, t, w, label_smoothing)
+    (loss_u / n_u).backward()
+    np.testing.assert_allclose(float(loss_u), float(ref), rtol=RTOL)
+    np.testing.assert_allclose(xu.grad.double().cpu().numpy(), xs.grad.double().cpu().numpy(),
+                               rtol=tol, atol=atol)
+
+
+def test_ce_tile_minus_infinity_logits():
+    """classes at -inf (masked logits): the waves whose rows hold only -inf must contribute
+    nothing instead of NaN"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    C = 150
+    x, t, w = _ce_case(1, C, 8, 32, torch.float32, seed=3)
+    x[:, 40:130] = -float('inf')
+    t[(t > 40) & (t <= 130)] = 0
+    n = F_.count_u8(t, 1, C)
+    xs = x.clone().requires_grad_(True)
+    loss, n_el, _ = F_.cross_entropy_sum(xs, t, w, 0.0, expected_scale=F_.expected_scale(n))
+    (loss / n_el).backward()
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t.long() - 1, weight=w.double(), reduction='sum',
+                                            ignore_index=-1)
+    (ref / int(n)).backward()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL)
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(), rtol=2e-5, atol=1e-9)
+
+
+def test_ce_c150_full_size_vs_oracle():
+    """configs[4] shape (one 768x1024 image, 150 classes, bf16): loss sum and sampled gradient
+    against the C oracle / fp64 torch"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    from oracle import oracle as orc
+    B, C, H, W = 1, 150, 768, 1024
+    x, t, w = _ce_case(B, C, H, W, torch.bfloat16, seed=150)
+    n = F_.count_u8(t, 1, C)
+    xs = x.clone().requires_grad_(True)
+    loss, n_el, wsum = F_.cross_entropy_sum(xs, t, w, 0.0, expected_scale=F_.expected_scale(n))
+    (loss / n_el).backward()
+    want, want_n, want_w, _ = orc.loss_ce(x.float().cpu().numpy(), t.cpu().numpy(), w.cpu().numpy(), 0.0)
+    assert int(n_el) == int(want_n)
+    np.testing.assert_allclose(float(loss), want, rtol=RTOL)
+    np.testing.assert_allclose(float(wsum), want_w, rtol=RTOL)
+    # gradient on a strip of rows against fp64 autograd
+    rows = slice(300, 304)
+    xr = x[:, :, rows].double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t[:, rows].long() - 1, weight=w.double(),
+                                            reduction='sum', ignore_index=-1)
+    (ref / int(n)).backward()
+    got = xs.grad[:, :, rows].double()
+    atol = max(2 ** -7 * float(xr.grad.abs().max()) * 0.05, 4e-6 * float(w.max()) / int(n))
+    np.testing.assert_allclose(got.cpu().numpy(), xr.grad.cpu().numpy(), rtol=2 ** -7, atol=atol)
