@@ -455,18 +455,17 @@ int nmsa_pq_update_with_confmat(
  *     when *grad_scale is bit-equal to *computed_for the gradient buffer is already right and
  *     the kernel returns at once (counters[0]++), otherwise it recomputes the gradient from
  *     the inputs (counters[1]++), so the result never depends on the expectation.
- *     The CE variant keeps a pixel's whole class column in registers up to C = 48; above
- *     that a pixel tile of the logits is staged once in LDS (LDS-DMA) and both the reduction
- *     over the classes and the gradient read it there: logits read once, gradient written
- *     once (H*W % 8 == 0 (4 for f32) and 16-B aligned pointers; other shapes walk the column
- *     twice through the caches).  A recomputing backward launch (*_bwd_unless on a wrong
- *     expectation) is the same single pass: it never costs more than nmsa_loss_ce_bwd.
+ *     The CE variant keeps a pixel's whole class column in registers up to C = 48; for 49..256
+ *     classes the four waves of a workgroup share the column (wave w holds a quarter of the
+ *     classes of the same pixels; maximum and sum of exponentials are exchanged through LDS):
+ *     logits read once, gradient written once.  A recomputing backward launch (*_bwd_unless on
+ *     a wrong expectation) is the same single pass: it never costs more than nmsa_loss_ce_bwd.
+ *     Beyond 256 classes the launch walks the column twice through the caches.
  *     nmsa_loss_ce_fwd_grad_supported(dtype, C): 1 for every valid dtype and C <= 4096.
  * nmsa_count_u8        *count = #{i : lo <= values[i] <= hi}  (labels 1..C, mask bytes 1..255);
  *     *mean_scale (optional) = weight / (float)count, the correctly rounded fp32 division
  *     autograd performs for `weight * loss_sum / count`;
- *     workspace: nmsa_count_workspace_bytes(); nmsa_count_i32: the same over int32 values
- *     (LUT indices 1..L of the embedding loss)
+ *     workspace: nmsa_count_workspace_bytes()
  * nmsa_loss_cos_emb_*  CosineEmbeddingLoss  loss/cos_emb.py:21-56 with the LUT gather of
  *     task_helper/dense_visual_embedding.py:110-171: pred [B,D,H,W], indices i32
  *     [B,H,W] (0 = no target), lut f32 [B,L,D];
@@ -499,9 +498,6 @@ size_t nmsa_count_workspace_bytes(void);
 int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, int64_t* count,
                   float* mean_scale, float weight,
                   void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
-int nmsa_count_i32(const int32_t* values, int64_t n, int lo, int hi, int64_t* count,
-                   float* mean_scale, float weight,
-                   void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
 int nmsa_loss_masked_fwd(const void* pred, int dtype, const float* target, const uint8_t* mask,
                          int B, int C, int H, int W, int kind,
                          double* loss_sum, int64_t* n_mask,
@@ -545,26 +541,6 @@ int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t* indices, c
                           nmsa_stream_t stream);
 /* 1 when the (L, D, H*W) combination runs the LDS-LUT kernel that can keep `dots` */
 int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
-/* Forward + gradient of the embedding loss in ONE pass over HBM (k_cos_tile): a pixel tile of
- * the prediction (all D planes of 32..256 pixels) is staged once in LDS, x.y and |x|^2 come
- * from LDS, the gradient for the EXPECTED upstream scale is written once; LUT rows are read
- * through L1 / L2.  nmsa_loss_cos_emb_bwd_unless confirms (returns at once) or recomputes with
- * the same single pass; it must be given the SAME workspace the forward call used (the |y|^2
- * table of the LUT rows lives there).  _supported: D * 128 B of LDS must fit (D <= ~1150),
- * H*W % 8 == 0 (4 for f32); pointers 16-B aligned, else NMSA_ERR_UNSUPPORTED. */
-int nmsa_loss_cos_emb_fwd_grad_supported(int dtype, int D, int H, int W, int L);
-size_t nmsa_loss_cos_emb_fwd_grad_workspace_bytes(int B, int D, int H, int W, int L);
-int nmsa_loss_cos_emb_fwd_grad(const void* pred, int dtype, const int32_t* indices,
-                               const float* lut, int B, int D, int H, int W, int L,
-                               const float* expected_grad_scale,
-                               double* loss_sum, int64_t* n_rows, void* grad_pred,
-                               int32_t* status, void* workspace, size_t workspace_bytes,
-                               nmsa_stream_t stream);
-int nmsa_loss_cos_emb_bwd_unless(const void* pred, int dtype, const int32_t* indices,
-                                 const float* lut, int B, int D, int H, int W, int L,
-                                 const float* grad_scale, void* grad_pred,
-                                 const float* computed_for, int32_t* counters,
-                                 void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
 
 #ifdef __cplusplus
 }

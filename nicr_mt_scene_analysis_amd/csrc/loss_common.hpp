@@ -1,5 +1,5 @@
-// loss_common.hpp — pieces shared by the loss kernels (losses.hip: streaming kernels,
-// losses_tile.hip: LDS-resident pixel tiles, losses_multi.hip: one launch for several losses).
+// loss_common.hpp — pieces shared by the loss kernel files (losses.hip: one kernel per loss,
+// losses_multi.hip: one launch for several losses).
 #pragma once
 #include "nmsa_common.hpp"
 
@@ -61,13 +61,5 @@ int loss_finalize(const LossPartial* partials, int n, double* sum, double* aux, 
                   hipStream_t stream);
 int loss_env_int(const char* name, int dflt);
 bool loss_bad_shape(int B, int H, int W);
-
-
-// losses_tile.hip: LDS-resident pixel tiles for class columns beyond the registers (C > 48)
-bool ce_tile_supported(const void* logits, const void* grad, int dtype, int C, int P, float ls);
-int ce_tile_launch(bool loss, const void* logits, int dtype, const uint8_t* target, const float* weights,
-                   int B, int C, int P, float ls, const float* gscale, const float* computed_for,
-                   int* counters, void* grad, LossPartial* partials, int* status, int* n_blocks,
-                   int max_blocks_per_image, hipStream_t stream);
 
 }  // namespace nmsa

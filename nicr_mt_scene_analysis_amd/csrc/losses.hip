@@ -628,6 +628,169 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
     }
 }
 
+// ---- the same for wider class columns: the column SPLIT OVER THE FOUR WAVES OF THE WORKGROUP -----
+// k_ce_fused keeps a pixel's whole column in one lane's registers (C <= 48).  Here the four waves
+// of a workgroup look at the SAME 64 x PXT pixels and wave w holds the classes [w CQ, (w + 1) CQ),
+// CQ = ceil(C / 4) <= 64, so every wave-instruction still moves one contiguous 512-byte piece of a
+// class plane (the access pattern of k_ce_fused; 128-byte row segments — a column spread over the
+// lanes of ONE wave — ran at 3.6 instead of 5.4 TB/s).  The waves exchange their per-pixel maximum
+// and sum of exp2 (and sum_c w_c x_c) through 8-12 KB of LDS, two barriers per workgroup; each
+// wave then writes the gradient of its own classes from the same registers.  Logits read once,
+// gradient written once for C <= 256.
+constexpr int CE_SPLIT_MAX_C = 256;
+
+template <int DTYPE, int NG, bool SMOOTH, bool LOSS = true>
+__global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
+    const void* __restrict__ logits, const uint8_t* __restrict__ target,
+    const float* __restrict__ weights, int C, int P, float ls, int vec,
+    const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials, int* __restrict__ status,
+    const float* __restrict__ computed_for, int* __restrict__ counters, int tiles_per_wg)
+{
+    constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
+    constexpr int NP = 8 * NG;                         // class planes per wave
+    constexpr int NWV = LOSS_THREADS / 64;             // 4
+    constexpr int TPX = 64 * PXT;                      // pixels per workgroup
+    extern __shared__ float s_w[];                     // [C] weights, then the exchange buffers
+    if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
+    float* s_m = s_w + ((C + 3) & ~3);                 // [NWV][TPX] maxima
+    float* s_s = s_m + NWV * TPX;                      // [NWV][TPX] sums of exp2
+    float* s_x = s_s + NWV * TPX;                      // [NWV][TPX] sum_c w_c x_c (label smoothing)
+    for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
+    __syncthreads();
+    float wsum = 0.f;
+    if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
+    const float g = *expected_gscale;
+    const int b = blockIdx.y;
+    const size_t img = (size_t)b * C * P;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();
+    const int CQ = (C + NWV - 1) / NWV;
+    const int c0 = w * CQ;                             // my classes: c0 .. min(c0 + CQ, C) - 1
+    const int nc = max(0, min(CQ, C - c0));            // wave-uniform
+    // a workgroup walks a RUN of consecutive pixel tiles: its C class planes are C different pages,
+    // and one 512-byte piece per page and workgroup left the address translation as the limit
+    // (4.6 TB/s with every exp removed; runs of tiles: the pages are reused tile after tile)
+    double acc = 0.0, accw = 0.0;
+    long long cnt = 0;
+    bool bad = false;
+    const int n_tiles = (P + TPX - 1) / TPX;
+    const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int p0 = (tile * 64 + l) * PXT;
+    const bool alive = p0 < P;
+    const int nvalid = alive ? min(PXT, P - p0) : 0;
+    u32x2_s r[NP];
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        r[i] = u32x2_s{0u, 0u};
+        if (i < nc && alive) r[i] = ld_plane8<DTYPE>(logits, img + (size_t)(c0 + i) * P + p0, nvalid, vec);
+    }
+    int t[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;   // ce.py:46
+    float m[PXT], s[PXT], swx[PXT], xt[PXT], k0[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) { m[j] = -INFINITY; s[j] = 0.f; swx[j] = 0.f; xt[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < nc) {
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) m[j] = fmaxf(m[j], plane_px<DTYPE>(r[i], j));
+        }
+    }
+    // ---- the column maximum over the four waves ----------------------------------------------
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) s_m[w * TPX + l * PXT + j] = m[j];
+    __syncthreads();                                   // (also: the last tile's sums have been read)
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        float mm = s_m[l * PXT + j];
+#pragma unroll
+        for (int ww = 1; ww < NWV; ++ww) mm = fmaxf(mm, s_m[ww * TPX + l * PXT + j]);
+        m[j] = mm;
+        k0[j] = -mm * LOG2E;
+    }
+    if (DTYPE != NMSA_F32) keep_packed(r);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < nc) {
+            const float wc = SMOOTH ? s_w[c0 + i] : 0.f;
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const float x = plane_px<DTYPE>(r[i], j);
+                s[j] += __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                if (SMOOTH) swx[j] = fmaf(wc, x, swx[j]);
+            }
+        }
+    }
+    // ---- the sum of exp2 (and sum_c w_c x_c) over the four waves, in wave order -------------------
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        s_s[w * TPX + l * PXT + j] = s[j];
+        if (SMOOTH) s_x[w * TPX + l * PXT + j] = swx[j];
+    }
+    __syncthreads();
+    float ag[PXT], abg[PXT];
+#pragma unroll
+    for (int j = 0; j < PXT; ++j) {
+        float ss = s_s[l * PXT + j], sx = SMOOTH ? s_x[l * PXT + j] : 0.f;
+#pragma unroll
+        for (int ww = 1; ww < NWV; ++ww) {
+            ss += s_s[ww * TPX + l * PXT + j];
+            if (SMOOTH) sx += s_x[ww * TPX + l * PXT + j];
+        }
+        s[j] = ss; swx[j] = sx;
+        k0[j] = -(fmaf(m[j], LOG2E, __log2f(ss)));                         // p = 2^(x log2e + k0)
+        const bool on = t[j] >= 0 && t[j] < C;
+        const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
+        ag[j] = g * a;
+        abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
+    }
+    if (DTYPE != NMSA_F32) keep_packed(r);
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+        if (i < nc) {
+            const int c = c0 + i;
+            float o[PXT];
+            const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const float x = plane_px<DTYPE>(r[i], j);
+                const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                float qv = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
+                const bool hit = t[j] == c;
+                qv -= hit ? ag[j] : 0.f;
+                xt[j] = hit ? x : xt[j];
+                o[j] = qv;
+            }
+            if (alive) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
+        }
+    }
+    if (LOSS) {
+        float part = 0.f, partw = 0.f;
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            if (t[j] < 0) continue;                                         // void: ignore_index
+            if (t[j] >= C) { bad = true; continue; }
+            const float lse = fmaf(__log2f(s[j]), LN2, m[j]);
+            const float wt = s_w[t[j]];
+            // the wave holding the target class adds the pixel's main term, wave 0 counts the pixel
+            if (t[j] >= c0 && t[j] < c0 + nc) part += (1.0f - ls) * wt * (lse - xt[j]);
+            if (w == 0) {
+                if (SMOOTH) part += (ls / C) * (lse * wsum - swx[j]);
+                partw += wt;
+                ++cnt;
+            }
+        }
+        acc += part; accw += partw;
+    }
+  }
+    if (LOSS) {
+        if (bad) atomicOr(status, 8);
+        block_partial(acc, accw, cnt, partials);
+    }
+}
+
 // number of bytes v with lo <= v <= hi (labels 1..C, mask bytes != 0): the element count a loss
 // is going to be divided by, known BEFORE the loss kernel runs (1 B/px).  One partial per
 // workgroup, summed by k_count_finalize (thousands of atomics on one address cost 10 ns each).
@@ -663,42 +826,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_count_u8(
     }
     for (; i < n16; i += stride) cnt += count16(__builtin_nontemporal_load((const u32x4_s*)v + i));
     for (long long k = n16 * 16 + tid; k < n; k += stride) cnt += (((unsigned)v[k] - (unsigned)lo) <= span);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long c = 0;
-        for (int k = 0; k < LOSS_THREADS / 64; ++k) c += s_cnt[k];
-        partials[blockIdx.x] = c;
-    }
-}
-
-// the same for int32 values (LUT indices of the embedding loss: 1..L are valid targets)
-__global__ __launch_bounds__(LOSS_THREADS) void k_count_i32(
-    const int32_t* __restrict__ v, long long n, int lo, int hi, int vec,
-    long long* __restrict__ partials)
-{
-    __shared__ long long s_cnt[LOSS_THREADS / 64];
-    long long cnt = 0;
-    const long long stride = (long long)gridDim.x * LOSS_THREADS;
-    const long long tid = (long long)blockIdx.x * LOSS_THREADS + threadIdx.x;
-    const long long n4 = vec ? n / 4 : 0;
-    const unsigned span = (unsigned)(hi - lo);
-    auto count4 = [&](const u32x4_s w) {
-        return (int)((w.x - (unsigned)lo) <= span) + (int)((w.y - (unsigned)lo) <= span) +
-               (int)((w.z - (unsigned)lo) <= span) + (int)((w.w - (unsigned)lo) <= span);
-    };
-    long long i = tid;
-    for (; i + 3 * stride < n4; i += 4 * stride) {
-        u32x4_s w[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load((const u32x4_s*)v + i + u * stride);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) cnt += count4(w[u]);
-    }
-    for (; i < n4; i += stride) cnt += count4(__builtin_nontemporal_load((const u32x4_s*)v + i));
-    for (long long k = n4 * 4 + tid; k < n; k += stride) cnt += (((unsigned)v[k] - (unsigned)lo) <= span);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
@@ -1265,8 +1392,8 @@ int finalize(const LossPartial* partials, int n, double* sum, double* aux, int64
 extern "C" size_t nmsa_loss_workspace_bytes(int B, int H, int W)
 {
     if (bad_shape(B, H, W)) return 0;
-    // one partial per block of the widest launch (1 px / thread for the embedding loss)
-    return (size_t)B * grid_x(H * W, 1) * sizeof(LossPartial);
+    // one partial per block of the widest launch (128 px per block: k_ce_split on f32 logits)
+    return (size_t)B * 2 * grid_x(H * W, 1) * sizeof(LossPartial);
 }
 
 #define NMSA_DISPATCH_DTYPE(dtype, CALL)          \
@@ -1358,6 +1485,47 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
 
 static int ce_fused_ng(int C) { return (C <= 24) ? 3 : (C <= 40) ? 5 : 6; }
 
+// 49 .. 256 classes: k_ce_split (column over the four lane rows); loss = false: the confirming /
+// recomputing backward launch
+static int ce_split_blocks(int P, int dtype)
+{
+    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
+    const int n_tiles = (P + 64 * pxt - 1) / (64 * pxt);
+    static const int run = loss_env_int("NMSA_CE_SPLIT_RUN", 4);
+    const int tpw = run < 1 ? 1 : run;
+    return (n_tiles + tpw - 1) / tpw;
+}
+
+static int launch_ce_split(bool loss, const void* logits, int dtype, const uint8_t* target,
+                           const float* weights, int B, int C, int P, float ls, const float* gscale,
+                           const float* computed_for, int32_t* counters, void* grad,
+                           LossPartial* partials, int32_t* status, hipStream_t stream)
+{
+    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
+    const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad) & 7) == 0);
+    const int n_tiles = (P + 64 * pxt - 1) / (64 * pxt);     // the four waves of a block share 64 x pxt pixels
+    static const int run = loss_env_int("NMSA_CE_SPLIT_RUN", 4);
+    const int tpw = run < 1 ? 1 : run;
+    const int gx = (n_tiles + tpw - 1) / tpw;
+    const bool smooth = ls != 0.0f;
+    const size_t lds = ((size_t)((C + 3) & ~3) + (size_t)(smooth ? 3 : 2) * 4 * 64 * pxt) * sizeof(float);
+    const int per_lane = (C + 3) / 4;
+    const int ng = per_lane <= 24 ? 3 : per_lane <= 32 ? 4 : per_lane <= 40 ? 5 : per_lane <= 48 ? 6 : 8;
+#define CE_SPLIT_L(DT, NG, SM, LS) hipLaunchKernelGGL((k_ce_split<DT, NG, SM, LS>), dim3(gx, B), dim3(LOSS_THREADS), \
+        lds, stream, logits, target, weights, C, P, ls, vec, gscale, grad, partials, status, \
+        computed_for, counters, tpw)
+#define CE_SPLIT_NG(DT, SM, LS) do { if (ng == 3) CE_SPLIT_L(DT, 3, SM, LS); else if (ng == 4) CE_SPLIT_L(DT, 4, SM, LS); \
+        else if (ng == 5) CE_SPLIT_L(DT, 5, SM, LS); else if (ng == 6) CE_SPLIT_L(DT, 6, SM, LS); \
+        else CE_SPLIT_L(DT, 8, SM, LS); } while (0)
+#define CE_SPLIT(DT) do { if (loss) { if (smooth) CE_SPLIT_NG(DT, true, true); else CE_SPLIT_NG(DT, false, true); } \
+                          else { if (smooth) CE_SPLIT_NG(DT, true, false); else CE_SPLIT_NG(DT, false, false); } } while (0)
+    NMSA_DISPATCH_DTYPE(dtype, CE_SPLIT)
+#undef CE_SPLIT
+#undef CE_SPLIT_NG
+#undef CE_SPLIT_L
+    return check_launch();
+}
+
 extern "C" int nmsa_loss_ce_bwd_unless(const void* logits, int dtype, const uint8_t* target,
                                        const float* weights, int B, int C, int H, int W,
                                        float label_smoothing, const float* grad_scale,
@@ -1390,10 +1558,10 @@ extern "C" int nmsa_loss_ce_bwd_unless(const void* logits, int dtype, const uint
 #undef CE_REDO_L
         return check_launch();
     }
-    if (ce_tile_supported(logits, grad_logits, dtype, C, P, label_smoothing))
-        return ce_tile_launch(false, logits, dtype, target, weights, B, C, P, label_smoothing, grad_scale,
-                              computed_for, counters, grad_logits, nullptr, nullptr, nullptr,
-                              grid_x(P, 1), stream);
+    static const int use_split = loss_env_int("NMSA_CE_SPLIT", 1);
+    if (C <= CE_SPLIT_MAX_C && use_split)
+        return launch_ce_split(false, logits, dtype, target, weights, B, C, P, label_smoothing, grad_scale,
+                               computed_for, counters, grad_logits, nullptr, nullptr, stream);
     return ce_bwd_impl(logits, dtype, target, weights, B, C, H, W, label_smoothing, grad_scale,
                        nullptr, grad_logits, computed_for, counters, stream);
 }
@@ -1425,27 +1593,6 @@ extern "C" int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, i
     return check_launch();
 }
 
-extern "C" int nmsa_count_i32(const int32_t* values, int64_t n, int lo, int hi, int64_t* count,
-                              float* mean_scale, float weight, void* workspace,
-                              size_t workspace_bytes, nmsa_stream_t stream_)
-{
-    hipStream_t stream = (hipStream_t)stream_;
-    if ((!values && n > 0) || !count || !workspace || n < 0 || lo < 0 || lo > hi) return NMSA_ERR_ARG;
-    if (workspace_bytes < nmsa_count_workspace_bytes()) return NMSA_ERR_WORKSPACE;
-    const int vec = (((uintptr_t)values) & 15) == 0;
-    int64_t blocks = (n / 4 + LOSS_THREADS * 4 - 1) / (LOSS_THREADS * 4);
-    if (blocks < 1) blocks = 1;
-    if (blocks > COUNT_MAX_BLOCKS) blocks = COUNT_MAX_BLOCKS;
-    long long* partials = (long long*)workspace;
-    hipLaunchKernelGGL(k_count_i32, dim3((unsigned)blocks), dim3(LOSS_THREADS), 0, stream, values,
-                       (long long)n, lo, hi, vec, partials);
-    int rc = check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_count_finalize, dim3(1), dim3(COUNT_MAX_BLOCKS), 0, stream, partials,
-                       (int)blocks, (long long*)count, mean_scale, weight);
-    return check_launch();
-}
-
 extern "C" int nmsa_loss_ce_fwd_grad_supported(int dtype, int C)
 {
     // C <= 48: register-resident column (k_ce_fused); above: two walks in one launch
@@ -1466,19 +1613,19 @@ extern "C" int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_
     if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return NMSA_ERR_ARG;
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
-    if (C > CE_FUSED_MAX_C && ce_tile_supported(logits, grad_logits, dtype, C, P, label_smoothing)) {
-        // column > registers: a pixel tile of the logits lives in LDS between the reduction over
-        // the classes and the gradient (losses_tile.hip) — one HBM read, one gradient write
+    static const int use_split = loss_env_int("NMSA_CE_SPLIT", 1);
+    static const int force_split = loss_env_int("NMSA_CE_FORCE_SPLIT", 0);     // experiments
+    if (((C > CE_FUSED_MAX_C && use_split) || (force_split && C >= 4)) && C <= CE_SPLIT_MAX_C) {
+        // 49 .. 256 classes: the column spread over the four lane rows of a wave (k_ce_split):
+        // logits read once, gradient written once, no LDS tile, no barrier
         LossPartial* partials = (LossPartial*)workspace;
-        int n_blocks = 0;
-        int rc2 = ce_tile_launch(true, logits, dtype, target, weights, B, C, P, label_smoothing,
-                                 expected_grad_scale, nullptr, nullptr, grad_logits, partials, status,
-                                 &n_blocks, grid_x(P, 1), stream);
+        int rc2 = launch_ce_split(true, logits, dtype, target, weights, B, C, P, label_smoothing,
+                                  expected_grad_scale, nullptr, nullptr, grad_logits, partials, status, stream);
         if (rc2) return rc2;
-        return finalize(partials, n_blocks, loss_sum, weight_sum, n_elements, stream);
+        return finalize(partials, ce_split_blocks(P, dtype) * B, loss_sum, weight_sum, n_elements, stream);
     }
     if (C > CE_FUSED_MAX_C) {
-        // unaligned / odd shapes: the two-walk backward kernel also sums the loss
+        // more than 256 classes (or NMSA_CE_SPLIT=0): the two-walk backward kernel also sums the loss
         const int pxt = (dtype == NMSA_F32) ? 4 : 8;
         const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad_logits) & 15) == 0);
         const int gx = grid_x(P, pxt);

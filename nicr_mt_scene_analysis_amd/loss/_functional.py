@@ -370,36 +370,11 @@ class VonMisesFunction(torch.autograd.Function):
         return grad, None, None, None, None
 
 
-def count_i32(values: torch.Tensor, lo: int, hi: int, with_mean_scale: bool = False):
-    """number of int32 values in [lo, hi] as an int64 0-d device tensor (LUT indices 1..L);
-    `with_mean_scale`: also 1 / count as an fp32 [1] tensor"""
-    v = L.require_device_tensor(values, 'values')
-    assert v.dtype == torch.int32
-    dev = v.device
-    out = torch.empty((1,), dtype=torch.int64, device=dev)
-    scale = torch.empty((1,), dtype=torch.float32, device=dev) if with_mean_scale else None
-    nbytes = L.lib().nmsa_count_workspace_bytes()
-    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-    L.check(L.lib().nmsa_count_i32(L.ptr(v), v.numel(), int(lo), int(hi), L.ptr(out), L.ptr(scale),
-                                   1.0, L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_count_i32')
-    return (out[0], scale) if with_mean_scale else out[0]
-
-
-def cos_forward_can_write_gradient(pred: torch.Tensor, lut: torch.Tensor) -> bool:
-    """the library has the one-pass forward + gradient kernel (prediction tile in LDS) for this
-    embedding map"""
-    if not (pred.is_cuda and pred.ndim == 4 and lut.ndim == 3):
-        return False
-    _, D, H, W = pred.shape
-    return bool(L.lib().nmsa_loss_cos_emb_fwd_grad_supported(
-        L.float_dtype_code(pred), D, H, W, lut.shape[1]))
-
-
 class CosineEmbeddingLutFunction(torch.autograd.Function):
     """sum over px with index != 0 of 1 - cos(pred[:, px], lut[b, index-1])."""
 
     @staticmethod
-    def forward(ctx, pred, indices, lut, expected=None):
+    def forward(ctx, pred, indices, lut):
         x = L.require_device_tensor(pred, 'input_')
         dev = x.device
         B, D, H, W = x.shape
@@ -408,41 +383,21 @@ class CosineEmbeddingLutFunction(torch.autograd.Function):
         Lr = lt.shape[1]
         s, n = _scalar_outputs(dev)
         status = _status_word(dev)
-        code = L.float_dtype_code(x)
-        exp = _expected(expected, dev) if ctx.needs_input_grad[0] else None
-        if exp is not None and not (L.lib().nmsa_loss_cos_emb_fwd_grad_supported(code, D, H, W, Lr)
-                                    and x.data_ptr() % 16 == 0 and idx.data_ptr() % 16 == 0):
-            exp = None
-        ctx.spec = None
-        if exp is not None:
-            # one pass: prediction tile staged in LDS, forward sum + gradient for the expected
-            # upstream scale; the workspace (|y|^2 of the LUT rows) is kept for the backward launch
-            grad = torch.empty_like(x)
-            nbytes = L.lib().nmsa_loss_cos_emb_fwd_grad_workspace_bytes(B, D, H, W, Lr)
-            ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
-            L.check(L.lib().nmsa_loss_cos_emb_fwd_grad(
-                L.ptr(x), code, L.ptr(idx), L.ptr(lt), B, D, H, W, Lr, L.ptr(exp),
-                L.ptr(s), L.ptr(n), L.ptr(grad), L.ptr(status), L.ptr(ws), nbytes,
-                L.stream_ptr(dev)), 'nmsa_loss_cos_emb_fwd_grad')
-            ctx.spec = (grad, exp, ws, nbytes)
-            ctx.save_for_backward(x, idx, lt, torch.empty(0, device=dev))
-            ctx.has_dots = False
-        else:
-            ws, nbytes = _workspace(B, H, W, dev)
-            # x.y and |x|^2 per pixel for the backward pass (8 B/px instead of a second read of
-            # the 2D B/px prediction), only when a gradient can be asked for
-            dots = None
-            if ctx.needs_input_grad[0] and x.data_ptr() % 16 == 0 and \
-                    L.lib().nmsa_loss_cos_emb_can_keep_dots(D, H, W, Lr):
-                dots = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
-            L.check(L.lib().nmsa_loss_cos_emb_fwd(
-                L.ptr(x), code, L.ptr(idx), L.ptr(lt), B, D, H, W, Lr,
-                L.ptr(s), L.ptr(n), L.ptr(dots), L.ptr(status), L.ptr(ws), nbytes,
-                L.stream_ptr(dev)), 'nmsa_loss_cos_emb_fwd')
-            ctx.save_for_backward(x, idx, lt, dots if dots is not None else torch.empty(0, device=dev))
-            ctx.has_dots = dots is not None
+        ws, nbytes = _workspace(B, H, W, dev)
+        # x.y and |x|^2 per pixel for the backward pass (8 B/px instead of a second read of the
+        # 2D B/px prediction), only when a gradient can be asked for
+        dots = None
+        if ctx.needs_input_grad[0] and x.data_ptr() % 16 == 0 and \
+                L.lib().nmsa_loss_cos_emb_can_keep_dots(D, H, W, Lr):
+            dots = torch.empty((B, 2, H, W), dtype=torch.float32, device=dev)
+        L.check(L.lib().nmsa_loss_cos_emb_fwd(
+            L.ptr(x), L.float_dtype_code(x), L.ptr(idx), L.ptr(lt), B, D, H, W, Lr,
+            L.ptr(s), L.ptr(n), L.ptr(dots), L.ptr(status), L.ptr(ws), nbytes,
+            L.stream_ptr(dev)), 'nmsa_loss_cos_emb_fwd')
         if _CHECK_EVERY_CALL:
             check_loss_status()
+        ctx.save_for_backward(x, idx, lt, dots if dots is not None else torch.empty(0, device=dev))
+        ctx.has_dots = dots is not None
         loss = s[0].to(torch.float32)
         n_el = n[0]
         ctx.mark_non_differentiable(n_el)
@@ -452,21 +407,13 @@ class CosineEmbeddingLutFunction(torch.autograd.Function):
     def backward(ctx, g_loss, g_n):
         x, idx, lt, dots = ctx.saved_tensors
         B, D, H, W = x.shape
-        gs = _grad_scale(g_loss)
-        spec, ctx.spec = ctx.spec, None
-        if spec is not None:
-            grad, exp, ws, nbytes = spec
-            L.check(L.lib().nmsa_loss_cos_emb_bwd_unless(
-                L.ptr(x), L.float_dtype_code(x), L.ptr(idx), L.ptr(lt), B, D, H, W, lt.shape[1],
-                L.ptr(gs), L.ptr(grad), L.ptr(exp), _counters_ptr(x.device), L.ptr(ws), nbytes,
-                L.stream_ptr(x.device)), 'nmsa_loss_cos_emb_bwd_unless')
-            return grad, None, None, None
         grad = torch.empty_like(x)
+        gs = _grad_scale(g_loss)
         L.check(L.lib().nmsa_loss_cos_emb_bwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(idx), L.ptr(lt), B, D, H, W, lt.shape[1],
             L.ptr(gs), L.ptr(dots) if ctx.has_dots and grad.data_ptr() % 16 == 0 else None,
             L.ptr(grad), L.stream_ptr(x.device)), 'nmsa_loss_cos_emb_bwd')
-        return grad, None, None, None
+        return grad, None, None
 
 
 def cross_entropy_sum(logits, target, weights=None, label_smoothing=0.0, expected_scale=None
@@ -498,6 +445,5 @@ def ce_forward_can_write_gradient(logits: torch.Tensor) -> bool:
         L.lib().nmsa_loss_ce_fwd_grad_supported(L.float_dtype_code(logits), logits.shape[1]))
 
 
-def cosine_embedding_lut_sum(pred, indices, lut, expected_scale=None
-                             ) -> Tuple[torch.Tensor, torch.Tensor]:
-    return CosineEmbeddingLutFunction.apply(pred, indices, lut, expected_scale)
+def cosine_embedding_lut_sum(pred, indices, lut) -> Tuple[torch.Tensor, torch.Tensor]:
+    return CosineEmbeddingLutFunction.apply(pred, indices, lut)

@@ -14,17 +14,12 @@ class CosineEmbeddingLoss(LossBase):
         assert reduction in ('sum', 'mean', 'none')
         self._reduction = reduction
 
-    def lut_sum(self, input_: torch.Tensor, indices: torch.Tensor, lut: torch.Tensor,
-                expected_scale=None) -> Tuple[torch.Tensor, torch.Tensor]:
+    def lut_sum(self, input_: torch.Tensor, indices: torch.Tensor, lut: torch.Tensor
+                ) -> Tuple[torch.Tensor, torch.Tensor]:
         """planar [B,D,H,W] prediction, int indices [B,H,W] (0 = no target) and the
         per-image LUT [B,L,D]: the gathers of task_helper/dense_visual_embedding.py:110-171
-        folded into the kernel.  -> (sum, number of valid px).
-        `expected_scale`: see LossBase.forward; default = 1 / #valid px."""
-        if expected_scale is None and input_.is_cuda and F_.mean_speculation_enabled() and \
-                F_.wants_gradient(input_) and F_.cos_forward_can_write_gradient(input_, lut):
-            indices = indices.to(input_.device, torch.int32).contiguous()
-            _, expected_scale = F_.count_i32(indices, 1, int(lut.shape[1]), with_mean_scale=True)
-        return F_.cosine_embedding_lut_sum(input_, indices, lut, expected_scale)
+        folded into the kernel.  -> (sum, number of valid px)"""
+        return F_.cosine_embedding_lut_sum(input_, indices, lut)
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor,
                       target_similarity: Optional[torch.Tensor] = None, expected_scale=None):

@@ -1,14 +1,15 @@
 """
-GPU tier: the one-pass forward + gradient kernels that keep a pixel tile of the prediction in
-LDS (csrc/losses_tile.hip): `k_cos_tile` (dense cosine-embedding loss, reference
-loss/cos_emb.py:21-56 + task_helper/dense_visual_embedding.py:110-171) and `k_ce_tile`
-(cross entropy at class counts beyond the register-resident kernel, loss/ce.py:40-68).
+GPU tier: the whole-column losses at the configs[4] shapes.
 
-Checked against torch's own ops in fp64 (the ops the reference calls), against the two-kernel
-path of this library, and for the confirm / recompute protocol of the speculative gradient:
-tile edges (pixel counts that are no multiple of the tile), every LUT-row mode (uniform lanes,
-segment boundaries inside a lane, three and more rows per lane), pixels without a target,
-row tails (D / C no multiple of the rows per step), all three dtypes.
+ * `k_ce_split` (csrc/losses.hip): cross entropy for 49..256 classes, forward + gradient in one
+   pass with the class column split over the four waves of a workgroup (reference
+   loss/ce.py:40-68) — against torch's fp64 `F.cross_entropy` (the op the reference calls), the
+   two-kernel path of this library, the confirm / recompute protocol of the speculative gradient,
+   -inf logits, a full-size 150-class image against the C oracle;
+ * the dense cosine-embedding loss (reference loss/cos_emb.py:21-56 +
+   task_helper/dense_visual_embedding.py:110-171) on index maps with aligned segments, segment
+   boundaries anywhere, per-pixel noise and no targets at all, embedding sizes around the LDS
+   chunking of `k_cos_emb_lds`, all three dtypes — against torch's fp64 op.
 """
 import numpy as np
 import pytest
@@ -69,50 +70,27 @@ def _index_map(kind, B, H, W, L, g):
 @pytest.mark.parametrize('kind', ['blocks', 'segments', 'noise', 'empty'])
 @pytest.mark.parametrize('shape', [(2, 64, 8, 24), (1, 100, 12, 20), (3, 512, 4, 40), (1, 770, 6, 28),
                                    (2, 33, 16, 16)])
-def test_cos_tile_vs_torch_fp64(dtype, kind, shape):
+def test_cos_emb_vs_torch_fp64(dtype, kind, shape):
     from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss
-    from nicr_mt_scene_analysis_amd.loss import _functional as F_
     B, D, H, W = shape
     L = 7
     g = _gen(D + H)
     x = torch.randn((B, D, H, W), device='cuda', generator=g).to(dtype)
     lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
     idx = _index_map(kind, B, H, W, L, g)
-    assert F_.cos_forward_can_write_gradient(x, lut) == (D <= 768)
     ref_loss, ref_n, ref_grad = _cos_reference(x, idx, lut)
 
     xs = x.clone().requires_grad_(True)
-    before = _stats()
-    loss, n = CosineEmbeddingLoss().lut_sum(xs, idx, lut)          # default expectation 1 / n
+    loss, n = CosineEmbeddingLoss().lut_sum(xs, idx, lut)
     (loss / n.clamp(min=1)).backward()
-    after = _stats()
     assert int(n) == ref_n
     np.testing.assert_allclose(float(loss), ref_loss, rtol=RTOL, atol=1e-6)
-    if ref_n:
-        assert (after['confirmed'] - before['confirmed'], after['recomputed'] - before['recomputed']) == (1, 0)
     tol = _grad_tol(dtype)
     atol = tol * float(ref_grad.abs().max()) * 0.05 + (6e-8 if dtype == torch.float16 else 1e-12)   # f16 subnormals
     np.testing.assert_allclose(xs.grad.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol, atol=atol)
 
-    # wrong expectation: the backward launch recomputes with the real upstream gradient
-    xw = x.clone().requires_grad_(True)
-    wrong = torch.full((1,), 0.37, device='cuda')
-    loss_w, n_w = CosineEmbeddingLoss().lut_sum(xw, idx, lut, expected_scale=wrong)
-    (loss_w / n_w.clamp(min=1)).backward()
-    np.testing.assert_allclose(float(loss_w), float(loss), rtol=1e-7)
-    assert torch.equal(xw.grad, xs.grad)
 
-    # two-kernel path of the library (no expectation given, default switched off)
-    import os
-    xu = x.clone().requires_grad_(True)
-    loss_u, n_u = F_.cosine_embedding_lut_sum(xu, idx, lut, None)
-    (loss_u / n_u.clamp(min=1)).backward()
-    np.testing.assert_allclose(float(loss_u), ref_loss, rtol=RTOL, atol=1e-6)
-    np.testing.assert_allclose(xu.grad.double().cpu().numpy(), xs.grad.double().cpu().numpy(),
-                               rtol=tol, atol=atol)
-
-
-def test_cos_tile_out_of_range_index_sets_status():
+def test_cos_emb_out_of_range_index_sets_status():
     from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, check_loss_status
     g = _gen(5)
     x = torch.randn((1, 64, 8, 16), device='cuda', generator=g).requires_grad_(True)
@@ -139,7 +117,7 @@ def _ce_case(B, C, H, W, dtype, seed, void_frac=0.2):
 @pytest.mark.parametrize('C', [49, 64, 150, 151, 255])
 @pytest.mark.parametrize('label_smoothing', [0.0, 0.1])
 @pytest.mark.parametrize('shape', [(2, 24, 36), (1, 8, 1000), (3, 5, 8)])
-def test_ce_tile_vs_torch_fp64(dtype, C, label_smoothing, shape):
+def test_ce_split_vs_torch_fp64(dtype, C, label_smoothing, shape):
     from nicr_mt_scene_analysis_amd.loss import _functional as F_
     B, H, W = shape
     x, t, w = _ce_case(B, C, H, W, dtype, seed=C + H)
@@ -161,7 +139,8 @@ def test_ce_tile_vs_torch_fp64(dtype, C, label_smoothing, shape):
     (ref / int(n)).backward()
     np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL)
     tol = _grad_tol(dtype)
-    atol = max(tol * float(xr.grad.abs().max()) * 0.05, 4e-6 * float(w.max()) / int(n))
+    atol = max(tol * float(xr.grad.abs().max()) * 0.05, 4e-6 * float(w.max()) / int(n),
+               6e-8 if dtype == torch.float16 else 0.0)                      # f16 subnormals
     np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(), rtol=tol, atol=atol)
 
     # wrong expectation -> recomputed by the same single-pass kernel, identical gradient
@@ -181,7 +160,7 @@ def test_ce_tile_vs_torch_fp64(dtype, C, label_smoothing, shape):
                                rtol=tol, atol=atol)
 
 
-def test_ce_tile_minus_infinity_logits():
+def test_ce_split_minus_infinity_logits():
     """classes at -inf (masked logits): the waves whose rows hold only -inf must contribute
     nothing instead of NaN"""
     from nicr_mt_scene_analysis_amd.loss import _functional as F_

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
-"""time nmsa_loss_cos_emb_fwd_grad / nmsa_loss_ce_fwd_grad alone (HIP events) — knobs through the
-environment (NMSA_TILE_LPR / _NW / _WGS / _ABLATE are read once per process):
-  python tools/diag_tile.py cos D [B]     |  python tools/diag_tile.py ce C [B]"""
+"""time nmsa_loss_ce_fwd_grad alone (HIP events) — knobs through the environment (NMSA_CE_SPLIT,
+NMSA_CE_SPLIT_RUN, NMSA_CE_FORCE_SPLIT are read once per process):
+  python tools/diag_tile.py ce C [B]"""
 import os
 import sys
 
@@ -26,19 +26,8 @@ wsum = torch.zeros(1, dtype=torch.float64, device=dev)
 status = torch.zeros(4, dtype=torch.int32, device=dev)
 exp = torch.full((1,), 1e-6, device=dev)
 lib = L.lib()
-if kind == 'cos':
-    Lr = 64
-    idx = torch.randint(0, Lr + 1, (B, H // 16, W // 16), device=dev, generator=g, dtype=torch.int32)
-    idx = idx.repeat_interleave(16, 1).repeat_interleave(16, 2).contiguous()
-    lut = torch.nn.functional.normalize(torch.randn((B, Lr, R), device=dev, generator=g), dim=-1)
-    nb = lib.nmsa_loss_cos_emb_fwd_grad_workspace_bytes(B, R, H, W, Lr)
-    ws = torch.empty(nb, dtype=torch.uint8, device=dev)
-
-    def run():
-        L.check(lib.nmsa_loss_cos_emb_fwd_grad(L.ptr(x), 1, L.ptr(idx), L.ptr(lut), B, R, H, W, Lr, L.ptr(exp),
-                                               L.ptr(s), L.ptr(n), L.ptr(grad), L.ptr(status), L.ptr(ws), nb,
-                                               L.stream_ptr(dev)), 'cos')
-    bytes_px = 4 * R + 4
+if kind != 'ce':
+    raise SystemExit('ce only')
 else:
     t = torch.randint(0, R + 1, (B, H, W), device=dev, generator=g).to(torch.uint8)
     w = torch.rand(R, device=dev, generator=g) + 0.5
