@@ -542,6 +542,65 @@ int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t* indices, c
 /* 1 when the (L, D, H*W) combination runs the LDS-LUT kernel that can keep `dots` */
 int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
 
+/* ---------------------------------------------------------------------------
+ * a10  the losses of a task helper in one call
+ *      InstanceTaskHelper._compute_losses  task_helper/instance.py:92-269
+ *      SemanticTaskHelper._compute_losses  task_helper/semantic.py:57-90
+ *      TaskHelperBase.accumulate_losses    task_helper/base.py:161-182
+ * Every (loss, supervision scale) pair is an ITEM; the items whose sums the caller adds and
+ * divides by their summed element counts (accumulate_losses) form a TOTAL.  One call
+ *   counts the labels / mask bytes of all items                          (launch 1, 1 B/px)
+ *   forms per total the divisor n and the EXPECTED upstream gradient w / n of its loss sums
+ *     (launch 2; w lives in the total's spec record and is learned from the backward passes:
+ *     loss weights, AMP scale, ... need no hint from the caller)
+ *   computes all forward sums and writes all gradients for that expectation (launch 3: block
+ *     ranges per item; cross entropies above 48 classes run k_ce_split as launches of their own)
+ *   reduces the block partials per item in a fixed order                  (launch 4)
+ * nmsa_multitask_loss_bwd_unless compares the real upstream gradients with the expectation on
+ * the device (launch 1: one thread per total, also updates w) and recomputes only the items
+ * that differ (launch 2: every other workgroup returns at once).
+ *   items        HOST array; pointers inside are device pointers.  kind NMSA_LOSS_*; CE: pred =
+ *                logits [B,C,H,W], mask = labels u8 [B,H,W] (0 = void), weights f32 [C] or NULL,
+ *                param = label smoothing; MSE / L1 / FOCAL: pred [B,C,H,W] (C = 1 for [B,H,W]),
+ *                target f32, mask u8 [B,H,W] or NULL; VONMISES: pred / target [B,2,H,W], mask,
+ *                param = kappa.  grad = gradient buffer shaped like pred, or NULL (forward only).
+ *                clamp_count: the item's count enters its total as max(count, 1)
+ *                (task_helper/instance.py:206-211)
+ *   spec         i32 [n_totals][8] device, persistent, owned by the caller (zero it, then store
+ *                the fp32 bits of the initial upstream weight, usually 1.0f, at [t][2]):
+ *                [0] backward passes that found their gradient written [1] ... that recomputed
+ *   expect       f32 [n_totals][2] device, out: expected upstream gradient (NaN: none) and the
+ *                divisor as float; must be handed to nmsa_multitask_loss_bwd_unless unchanged
+ *   loss_sums    f64 [n_items], counts i64 [n_items], aux f64 [n_items] or NULL (CE: sum of the
+ *                label weights, ce.py:57-68) — device
+ *   counters     i32 [2] device or NULL: per total and backward pass, [0] += 1 when the expectation
+ *                held, [1] += 1 when it did not (a tally over all callers; the spec records keep
+ *                their own)
+ * ------------------------------------------------------------------------- */
+enum { NMSA_LOSS_CE = 0, NMSA_LOSS_MSE = 1, NMSA_LOSS_L1 = 2, NMSA_LOSS_FOCAL = 3, NMSA_LOSS_VONMISES = 4 };
+#define NMSA_MULTI_MAX_ITEMS 16
+#define NMSA_MULTI_MAX_TOTALS 8
+typedef struct nmsa_loss_item {
+    int32_t kind, dtype, B, C, H, W;
+    int32_t total;        /* index of the total this item belongs to */
+    int32_t clamp_count;  /* 1: max(count, 1) enters the total */
+    float param;          /* label smoothing | kappa */
+    int32_t reserved;
+    const void* pred;
+    const void* target;
+    const void* mask;     /* labels (CE) or mask bytes; NULL = every pixel */
+    const float* weights;
+    void* grad;
+} nmsa_loss_item;
+size_t nmsa_multitask_loss_workspace_bytes(const nmsa_loss_item* items_host, int n_items);
+int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items_host, int n_items, int n_totals,
+                                 int32_t* spec, float* expect, double* loss_sums, int64_t* counts,
+                                 double* aux, int32_t* status, void* workspace,
+                                 size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items_host, int n_items, int n_totals,
+                                   const float* grad_scales, const float* expect, int32_t* spec,
+                                   int32_t* counters, nmsa_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -75,8 +75,8 @@ __device__ __forceinline__ void ld_mask4(const uint8_t* m, size_t off, int nvali
 }
 
 // block reduction -> one LossPartial per block (fixed order: lane tree, then wave order)
-__device__ __forceinline__ void block_partial(double sum, double aux, long long count,
-                                              LossPartial* __restrict__ partials)
+__device__ __forceinline__ void block_partial_at(double sum, double aux, long long count,
+                                                 LossPartial* __restrict__ slot)
 {
     __shared__ double s_sum[LOSS_THREADS / 64], s_aux[LOSS_THREADS / 64];
     __shared__ long long s_cnt[LOSS_THREADS / 64];
@@ -91,8 +91,14 @@ __device__ __forceinline__ void block_partial(double sum, double aux, long long 
         double a = 0, b = 0; long long c = 0;
         for (int k = 0; k < LOSS_THREADS / 64; ++k) { a += s_sum[k]; b += s_aux[k]; c += s_cnt[k]; }
         LossPartial p; p.sum = a; p.aux = b; p.count = c; p.pad = 0;
-        partials[blockIdx.y * gridDim.x + blockIdx.x] = p;
+        *slot = p;
     }
+}
+
+__device__ __forceinline__ void block_partial(double sum, double aux, long long count,
+                                              LossPartial* __restrict__ partials)
+{
+    block_partial_at(sum, aux, count, partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x);
 }
 
 // one workgroup sums the block partials in a FIXED order (thread t takes partials t, t + 1024,
@@ -522,29 +528,27 @@ __device__ __forceinline__ void keep_packed(u32x2_s (&r)[NP])
 // the forward launch was computed for the real upstream scale, otherwise recomputes it with the
 // same single pass (a miss costs one read of the logits + one gradient write, no more than the
 // backward of the two-kernel path)
-template <int DTYPE, int NG, bool SMOOTH, bool LOSS = true>
-__global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
+// body of workgroup (bx, b): shared by k_ce_fused and the multi-loss launch (k_multi_loss).
+// g = upstream scale the gradient is written for; a NaN g (no expectation) writes no gradient.
+template <int DTYPE, int NG, bool SMOOTH, bool LOSS>
+__device__ __forceinline__ void ce_fused_body(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
-    const float* __restrict__ weights, int C, int P, float ls, int vec,
-    const float* __restrict__ expected_gscale, void* __restrict__ grad,
-    LossPartial* __restrict__ partials, int* __restrict__ status,
-    const float* __restrict__ computed_for = nullptr, int* __restrict__ counters = nullptr)
+    const float* __restrict__ weights, int C, int P, float ls, int vec, float g,
+    void* __restrict__ grad, LossPartial* __restrict__ slot, int* __restrict__ status,
+    float* s_w, int bx, int b)
 {
     constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
     constexpr int NP = 8 * NG;
-    extern __shared__ float s_w[];
-    if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
     float wsum = 0.f;
     if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    const float g = *expected_gscale;
-    const int b = blockIdx.y;
+    const bool write_grad = g == g;
     const size_t img = (size_t)b * C * P;
     double acc = 0.0, accw = 0.0;
     long long cnt = 0;
     bool bad = false;
-    const int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * PXT;
+    const int p0 = (bx * LOSS_THREADS + threadIdx.x) * PXT;
     if (p0 < P) {
         const int nvalid = min(PXT, P - p0);
         u32x2_s r[NP];
@@ -604,7 +608,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
                     xt[j] = hit ? x : xt[j];
                     o[j] = q;
                 }
-                st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
+                if (write_grad) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
             }
         }
         float part = 0.f, partw = 0.f;
@@ -624,8 +628,23 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
     }
     if (LOSS) {
         if (bad) atomicOr(status, 8);
-        block_partial(acc, accw, cnt, partials);
+        block_partial_at(acc, accw, cnt, slot);
     }
+}
+
+template <int DTYPE, int NG, bool SMOOTH, bool LOSS = true>
+__global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
+    const void* __restrict__ logits, const uint8_t* __restrict__ target,
+    const float* __restrict__ weights, int C, int P, float ls, int vec,
+    const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials, int* __restrict__ status,
+    const float* __restrict__ computed_for = nullptr, int* __restrict__ counters = nullptr)
+{
+    extern __shared__ float s_w[];
+    if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
+    ce_fused_body<DTYPE, NG, SMOOTH, LOSS>(logits, target, weights, C, P, ls, vec, *expected_gscale, grad,
+                                           partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, status,
+                                           s_w, blockIdx.x, blockIdx.y);
 }
 
 // ---- the same for wider class columns: the column SPLIT OVER THE FOUR WAVES OF THE WORKGROUP -----
@@ -948,17 +967,19 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_bwd(
 }
 
 // forward + gradient for the expected upstream scale (see k_ce_fused)
-template <int DTYPE, int KIND>
-__global__ __launch_bounds__(LOSS_THREADS) void k_elem_fused(
+// body of workgroup bx (of nbx) of image b; gs = upstream scale (NaN: no gradient is written);
+// LOSS = false: gradient only (the recomputing backward launch of k_multi_loss)
+template <int DTYPE, int KIND, bool LOSS>
+__device__ __forceinline__ void elem_fused_body(
     const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
-    int C, int P, int vec, const float* __restrict__ expected_gscale, void* __restrict__ grad,
-    LossPartial* __restrict__ partials)
+    int C, int P, int vec, float gs, void* __restrict__ grad, LossPartial* __restrict__ slot,
+    int bx, int nbx, int b)
 {
-    const int b = blockIdx.y;
     double acc = 0.0; long long cnt = 0;
     const float invC = 1.0f / C;
-    const float g = *expected_gscale / C;
-    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * LOSS_THREADS * 4) {
+    const float g = gs / C;
+    const bool write_grad = gs == gs;
+    for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
         const int nvalid = min(4, P - p0);
         bool mk[4];
         ld_mask4(mask, (size_t)b * P + p0, nvalid, vec, mk);
@@ -982,12 +1003,23 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_fused(
                 }
                 part += (KIND == 0) ? d * d : fabsf(d);
             }
-            st4<DTYPE>(grad, off, nvalid, vec, o);
+            if (write_grad) st4<DTYPE>(grad, off, nvalid, vec, o);
         }
         acc += part * invC;
         if (KIND != 2) for (int j = 0; j < 4; ++j) cnt += (j < nvalid) && mk[j];
     }
-    block_partial(acc, 0.0, cnt, partials);
+    if (LOSS) block_partial_at(acc, 0.0, cnt, slot);
+}
+
+template <int DTYPE, int KIND>
+__global__ __launch_bounds__(LOSS_THREADS) void k_elem_fused(
+    const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
+    int C, int P, int vec, const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials)
+{
+    elem_fused_body<DTYPE, KIND, true>(pred, target, mask, C, P, vec, *expected_gscale, grad,
+                                       partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x,
+                                       blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // =================================================================================
@@ -1054,16 +1086,15 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_vm_bwd(
 }
 
 // forward + gradient for the expected upstream scale (see k_ce_fused)
-template <int DTYPE>
-__global__ __launch_bounds__(LOSS_THREADS) void k_vm_fused(
+template <int DTYPE, bool LOSS>
+__device__ __forceinline__ void vm_fused_body(
     const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
-    int P, float kappa, int vec, const float* __restrict__ expected_gscale, void* __restrict__ grad,
-    LossPartial* __restrict__ partials)
+    int P, float kappa, int vec, float g, void* __restrict__ grad, LossPartial* __restrict__ slot,
+    int bx, int nbx, int b)
 {
-    const int b = blockIdx.y;
-    const float g = *expected_gscale;
+    const bool write_grad = g == g;
     double acc = 0.0; long long cnt = 0;
-    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += gridDim.x * LOSS_THREADS * 4) {
+    for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
         const int nvalid = min(4, P - p0);
         bool mk[4];
         ld_mask4(mask, (size_t)b * P + p0, nvalid, vec, mk);
@@ -1083,10 +1114,23 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_vm_fused(
             if (mk[j]) { part += 1.0f - ex; ++cnt; }
         }
         acc += part;
-        st4<DTYPE>(grad, o0, nvalid, vec, g0);
-        st4<DTYPE>(grad, o1, nvalid, vec, g1);
+        if (write_grad) {
+            st4<DTYPE>(grad, o0, nvalid, vec, g0);
+            st4<DTYPE>(grad, o1, nvalid, vec, g1);
+        }
     }
-    block_partial(acc, 0.0, cnt, partials);
+    if (LOSS) block_partial_at(acc, 0.0, cnt, slot);
+}
+
+template <int DTYPE>
+__global__ __launch_bounds__(LOSS_THREADS) void k_vm_fused(
+    const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
+    int P, float kappa, int vec, const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials)
+{
+    vm_fused_body<DTYPE, true>(pred, target, mask, P, kappa, vec, *expected_gscale, grad,
+                               partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x,
+                               blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // =================================================================================
@@ -1342,6 +1386,246 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
     }
 }
 
+
+// =================================================================================
+// a10: the losses of a task helper in ONE forward launch (task_helper/instance.py:92-269,
+// task_helper/semantic.py:57-90, task_helper/base.py:161-182): every (loss, scale) pair is an
+// ITEM, items whose sums the caller adds before dividing by the summed counts form a TOTAL.
+//   k_multi_count    counts the labels / mask bytes of every item                 (1 B/px)
+//   k_multi_expect   counts per item, divisor per total, and the EXPECTED upstream gradient of
+//                    the total's loss sums: w / n with w from the total's spec record
+//   k_multi_loss     all items in one launch (block ranges): forward sums + gradients
+//   k_multi_finalize block partials -> sums / counts per item, fixed order
+// backward: k_multi_spec (one thread per total) compares the real upstream gradient with the
+// expectation and keeps the record's `w` up to date; k_multi_loss<..., LOSS = false> recomputes
+// only the items whose upstream gradient differs bit-wise from the expectation.
+//
+// Spec record (int32[8], device): [0] confirmed [1] recomputed [2] w (fp32 bits): the factor the
+// caller multiplies the total with before backward (loss weights, AMP scale: learned, see
+// k_multi_spec) [3] last upstream gradient [4] last divisor [5] flags (bit 0: expectation
+// switched off) [6] misses in a row [7] agreeing estimates in a row while switched off.
+// =================================================================================
+constexpr int MULTI_MAX_ITEMS = NMSA_MULTI_MAX_ITEMS;
+constexpr int MULTI_MAX_TOTALS = NMSA_MULTI_MAX_TOTALS;
+constexpr int MULTI_COUNT_MAX_BLOCKS = 64;             // per item
+
+struct MultiItem {
+    const void* pred; const void* target; const uint8_t* mask; const float* weights; void* grad;
+    int kind, dtype, B, C, P, vec, total, clamp;
+    float param;
+    int block0, nbx;                                   // first block of the item, blocks per image
+    int cblock0, cnblocks;                             // count pass: first block, blocks
+    int count_mode;                                    // 0: B * P, 1: bytes of `mask` in [lo, hi], 2: none
+    int lo, hi;
+    int in_launch;                                     // 1: part of k_multi_loss, 0: own kernel (wide CE)
+    int first_of_total;
+};
+struct MultiArgs { MultiItem it[MULTI_MAX_ITEMS]; int n_items, n_totals, n_blocks; };
+
+__global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long long* __restrict__ partials)
+{
+    __shared__ long long s_cnt[LOSS_THREADS / 64];
+    int i = 0;
+    while (i + 1 < a.n_items && (int)blockIdx.x >= a.it[i].cblock0 + a.it[i].cnblocks) ++i;
+    const MultiItem& it = a.it[i];
+    if (it.count_mode != 1 || (int)blockIdx.x < it.cblock0) { if (threadIdx.x == 0) partials[blockIdx.x] = 0; return; }
+    const int bi = blockIdx.x - it.cblock0;
+    const long long n = (long long)it.B * it.P;
+    const long long per = ((n + it.cnblocks - 1) / it.cnblocks + 15) / 16 * 16;
+    const long long begin = min(n, per * bi), end = min(n, begin + per);
+    const uint8_t* v = it.mask;
+    const unsigned lo = (unsigned)it.lo, span = (unsigned)(it.hi - it.lo);
+    const bool vec = (((uintptr_t)v) & 15) == 0;
+    long long cnt = 0;
+    long long k = begin + (long long)threadIdx.x * 16;
+    if (vec) {
+        for (; k + 16 <= end; k += LOSS_THREADS * 16) {
+            const u32x4_s w = __builtin_nontemporal_load((const u32x4_s*)(v + k));
+            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+            int c = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) c += ((((ww[q] >> (8 * j)) & 0xFF) - lo) <= span);
+            cnt += c;
+        }
+    }
+    for (; k < end; k += LOSS_THREADS * 16)
+        for (long long j = k; j < min(end, k + 16); ++j) cnt += (((unsigned)v[j] - lo) <= span);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        long long c = 0;
+        for (int q = 0; q < LOSS_THREADS / 64; ++q) c += s_cnt[q];
+        partials[blockIdx.x] = c;
+    }
+}
+
+__global__ __launch_bounds__(LOSS_THREADS) void k_multi_expect(MultiArgs a, const long long* __restrict__ partials,
+                                                               const int32_t* __restrict__ spec,
+                                                               float* __restrict__ expect)
+{
+    __shared__ long long s_count[MULTI_MAX_ITEMS];
+    const int w = threadIdx.x >> 6, l = lane_id();
+    for (int i = w; i < a.n_items; i += LOSS_THREADS / 64) {
+        const MultiItem& it = a.it[i];
+        long long c = 0;
+        if (it.count_mode == 1) { for (int k = l; k < it.cnblocks; k += 64) c += partials[it.cblock0 + k]; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+        if (l == 0) s_count[i] = it.count_mode == 1 ? c : (long long)it.B * it.P;
+    }
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_totals) {
+        const int t = threadIdx.x;
+        long long n = 0;
+        bool known = true;
+        for (int i = 0; i < a.n_items; ++i) {
+            if (a.it[i].total != t) continue;
+            if (a.it[i].count_mode == 2) known = false;                 // the divisor is not a count of the targets
+            n += a.it[i].clamp ? max(s_count[i], 1LL) : s_count[i];
+        }
+        // accumulate_losses: loss_sum / max(count, 1) as float32
+        const float nf = (float)max(n, 1LL);
+        const float wv = __int_as_float(spec[8 * t + 2]);
+        const bool off = (spec[8 * t + 5] & 1) || !known;
+        expect[2 * t] = off ? __int_as_float(0x7fc00000) : wv / nf;     // NaN: the forward writes no gradient
+        expect[2 * t + 1] = nf;
+    }
+}
+
+// upstream weight behind an observed gradient g = fl(w / n): candidates around fl(g n) that
+// reproduce g, preferring one that also explains the previous observation, then the "roundest"
+__device__ inline float spec_estimate_w(float g, float n, float g_prev, float n_prev)
+{
+    const float c0 = g * n;
+    float best = c0;
+    int best_score = -1;
+    for (int k = -4; k <= 4; ++k) {
+        const float c = __int_as_float(__float_as_int(c0) + k);
+        if (!(c / n == g)) continue;
+        int score = 1 + __builtin_ctz((unsigned)__float_as_int(c) | 0x800000u);     // trailing zero bits of the significand
+        if (n_prev > 0.f && c / n_prev == g_prev) score += 64;
+        if (score > best_score) { best_score = score; best = c; }
+    }
+    return best;
+}
+
+__global__ void k_multi_spec(MultiArgs a, const float* __restrict__ gs, const float* __restrict__ expect,
+                             int32_t* __restrict__ spec, int32_t* __restrict__ counters)
+{
+    const int t = threadIdx.x;
+    if (t >= a.n_totals) return;
+    int first = -1;
+    for (int i = 0; i < a.n_items; ++i) if (a.it[i].total == t && a.it[i].grad && first < 0) first = i;
+    if (first < 0) return;
+    int32_t* r = spec + 8 * t;
+    const float g = gs[first], e = expect[2 * t], n = expect[2 * t + 1];
+    const float g_prev = __int_as_float(r[3]), n_prev = __int_as_float(r[4]);
+    const bool same = __float_as_int(g) == __float_as_int(e);
+    if (counters) atomicAdd(&counters[same ? 0 : 1], 1);       // per-device tally (statistics only)
+    if (same) { r[0] += 1; r[6] = 0; }
+    else {
+        r[1] += 1;
+        const float w_old = __int_as_float(r[2]);
+        const float w_new = (g == g && g != 0.f) ? spec_estimate_w(g, n, g_prev, n_prev) : w_old;
+        if (r[5] & 1) {
+            // switched off: back on once the estimate has been stable for a few steps
+            r[7] = (__float_as_int(w_new) == __float_as_int(w_old)) ? r[7] + 1 : 0;
+            if (r[7] >= 3) { r[5] &= ~1; r[6] = 0; r[7] = 0; }
+        } else {
+            r[6] += 1;
+            if (r[6] >= 8) { r[5] |= 1; r[7] = 0; }     // the caller's factor keeps changing: stop guessing
+        }
+        r[2] = __float_as_int(w_new);
+    }
+    r[3] = __float_as_int(g);
+    r[4] = __float_as_int(n);
+}
+
+// all items of one call: block ranges [block0, block0 + nbx * B) per item.  CE_* select the ONE
+// cross-entropy variant compiled into this instantiation (CE_NG = 0: no CE item in the launch);
+// the element-wise and von Mises bodies are selected at run time (they are small).
+template <int CE_DT, int CE_NG, bool CE_SM, bool LOSS>
+__global__ __launch_bounds__(LOSS_THREADS) void k_multi_loss(
+    MultiArgs a, const float* __restrict__ expect, const float* __restrict__ gs,
+    LossPartial* __restrict__ partials, int* __restrict__ status)
+{
+    extern __shared__ float s_w[];
+    int i = 0;
+    while (i + 1 < a.n_items && (!a.it[i].in_launch || (int)blockIdx.x >= a.it[i].block0 + a.it[i].nbx * a.it[i].B)) ++i;
+    const MultiItem& it = a.it[i];
+    const int local = blockIdx.x - it.block0;
+    if (!it.in_launch || local < 0) return;
+    const int bx = local % it.nbx, b = local / it.nbx;
+    float g = expect[2 * it.total];
+    if (!it.grad) g = __int_as_float(0x7fc00000);
+    if (!LOSS) {
+        if (!it.grad) return;
+        const float gr = gs[i];
+        if (__float_as_int(gr) == __float_as_int(g)) return;           // the forward's gradient stands
+        g = gr;
+    }
+    LossPartial* slot = partials ? partials + blockIdx.x : nullptr;
+#define MULTI_DT(CALL) switch (it.dtype) { case NMSA_F32: CALL(NMSA_F32); break; case NMSA_BF16: CALL(NMSA_BF16); break; \
+                                            default: CALL(NMSA_F16); break; }
+    switch (it.kind) {
+        case NMSA_LOSS_CE:
+            if constexpr (CE_NG != 0)
+                ce_fused_body<CE_DT, CE_NG, CE_SM, LOSS>(it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P,
+                                                         it.param, it.vec, g, it.grad, slot, status, s_w, bx, b);
+            break;
+        case NMSA_LOSS_MSE:
+#define CALL(DT) elem_fused_body<DT, 0, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
+            MULTI_DT(CALL)
+#undef CALL
+            break;
+        case NMSA_LOSS_L1:
+#define CALL(DT) elem_fused_body<DT, 1, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
+            MULTI_DT(CALL)
+#undef CALL
+            break;
+        case NMSA_LOSS_FOCAL:
+#define CALL(DT) elem_fused_body<DT, 2, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
+            MULTI_DT(CALL)
+#undef CALL
+            break;
+        default:
+#define CALL(DT) vm_fused_body<DT, LOSS>(it.pred, (const float*)it.target, it.mask, it.P, it.param, it.vec, g, it.grad, slot, bx, it.nbx, b)
+            MULTI_DT(CALL)
+#undef CALL
+            break;
+    }
+#undef MULTI_DT
+}
+
+// one workgroup per item: its block partials in a fixed order
+__global__ __launch_bounds__(FIN_THREADS) void k_multi_finalize(
+    MultiArgs a, const LossPartial* __restrict__ partials, double* __restrict__ sums,
+    long long* __restrict__ counts, double* __restrict__ aux)
+{
+    __shared__ double s_sum[FIN_THREADS], s_aux[FIN_THREADS];
+    __shared__ long long s_cnt[FIN_THREADS];
+    const MultiItem& it = a.it[blockIdx.x];
+    const LossPartial* p = partials + it.block0;
+    const int n = it.nbx * it.B;
+    double x = 0, y = 0; long long c = 0;
+    for (int k = threadIdx.x; k < n; k += FIN_THREADS) { x += p[k].sum; y += p[k].aux; c += p[k].count; }
+    s_sum[threadIdx.x] = x; s_aux[threadIdx.x] = y; s_cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = FIN_THREADS / 2; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) {
+            s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
+            s_aux[threadIdx.x] += s_aux[threadIdx.x + o];
+            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { sums[blockIdx.x] = s_sum[0]; counts[blockIdx.x] = s_cnt[0]; if (aux) aux[blockIdx.x] = s_aux[0]; }
+}
+
 }  // namespace nmsa
 
 using namespace nmsa;
@@ -1590,6 +1874,29 @@ extern "C" int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, i
     if (rc) return rc;
     hipLaunchKernelGGL(k_count_finalize, dim3(1), dim3(COUNT_MAX_BLOCKS), 0, stream, partials,
                        (int)blocks, (long long*)count, mean_scale, weight);
+    return check_launch();
+}
+
+// k_ce_fused forward + gradient into a caller-owned partial region, no finalize (used by the
+// multi-loss call for a cross entropy whose variant differs from the one in its joint launch)
+static int nmsa_loss_ce_fwd_grad_partials(const void* logits, int dtype, const uint8_t* target,
+                                          const float* weights, int B, int C, int P, float ls,
+                                          const float* expected, void* grad, LossPartial* partials,
+                                          int32_t* status, hipStream_t stream)
+{
+    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
+    const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad) & 7) == 0);
+    const int gx = grid_x(P, pxt);
+    const bool smooth = ls != 0.0f;
+    const int ng = ce_fused_ng(C);
+#define CE_P_L(DT, NG, SM) hipLaunchKernelGGL((k_ce_fused<DT, NG, SM>), dim3(gx, B), dim3(LOSS_THREADS), \
+        C * sizeof(float), stream, logits, target, weights, C, P, ls, vec, expected, grad, partials, status)
+#define CE_P_NG(DT, SM) do { if (ng == 3) CE_P_L(DT, 3, SM); else if (ng == 5) CE_P_L(DT, 5, SM); else CE_P_L(DT, 6, SM); } while (0)
+#define CE_P(DT) do { if (smooth) CE_P_NG(DT, true); else CE_P_NG(DT, false); } while (0)
+    NMSA_DISPATCH_DTYPE(dtype, CE_P)
+#undef CE_P
+#undef CE_P_NG
+#undef CE_P_L
     return check_launch();
 }
 
@@ -1991,4 +2298,198 @@ extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t*
     NMSA_DISPATCH_DTYPE(dtype, CALL)
 #undef CALL
     return check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------
+// a10: all losses of a task helper in one call (see k_multi_loss)
+namespace {
+
+struct MultiPlan {
+    MultiArgs args;
+    int n_count_blocks;
+    int ce_dt, ce_ng, ce_sm;                           // the cross-entropy variant inside the launch (ng 0: none)
+    int max_c;
+    size_t lds;
+};
+
+int multi_plan(const nmsa_loss_item* items, int n_items, int n_totals, MultiPlan& pl)
+{
+    if (!items || n_items <= 0 || n_items > MULTI_MAX_ITEMS || n_totals <= 0 || n_totals > MULTI_MAX_TOTALS)
+        return NMSA_ERR_ARG;
+    MultiArgs& a = pl.args;
+    a.n_items = n_items; a.n_totals = n_totals; a.n_blocks = 0;
+    pl.ce_ng = 0; pl.ce_dt = NMSA_F32; pl.ce_sm = 0; pl.max_c = 0;
+    int block = 0, cblock = 0;
+    bool seen_total[MULTI_MAX_TOTALS] = {false};
+    for (int pass = 0; pass < 2; ++pass) {             // pass 0: the items of the joint launch, pass 1: the others
+        for (int i = 0; i < n_items; ++i) {
+            const nmsa_loss_item& s = items[i];
+            MultiItem& it = a.it[i];
+            if (pass == 0) {
+                if (!s.pred || s.total < 0 || s.total >= n_totals || bad_shape(s.B, s.H, s.W) || s.C <= 0)
+                    return NMSA_ERR_ARG;
+                if (s.dtype != NMSA_F32 && s.dtype != NMSA_BF16 && s.dtype != NMSA_F16) return NMSA_ERR_ARG;
+                if (s.kind < NMSA_LOSS_CE || s.kind > NMSA_LOSS_VONMISES) return NMSA_ERR_ARG;
+                if (s.kind != NMSA_LOSS_CE && !s.target) return NMSA_ERR_ARG;
+                if (s.kind == NMSA_LOSS_CE && !s.mask) return NMSA_ERR_ARG;
+                if (s.kind == NMSA_LOSS_VONMISES && s.C != 2) return NMSA_ERR_ARG;
+                it.pred = s.pred; it.target = s.target; it.mask = (const uint8_t*)s.mask; it.weights = s.weights;
+                it.grad = s.grad;
+                it.kind = s.kind; it.dtype = s.dtype; it.B = s.B; it.C = s.C; it.P = s.H * s.W;
+                it.total = s.total; it.clamp = s.clamp_count != 0; it.param = s.param;
+                it.first_of_total = !seen_total[s.total];
+                seen_total[s.total] = true;
+                const uintptr_t al = (uintptr_t)s.pred | (uintptr_t)s.grad | (uintptr_t)s.target;
+                it.in_launch = 1;
+                if (s.kind == NMSA_LOSS_CE) {
+                    if (s.C > CE_SPLIT_MAX_C) return NMSA_ERR_UNSUPPORTED;
+                    const int pxt = (s.dtype == NMSA_F32) ? 2 : 4;
+                    it.vec = (it.P % pxt == 0) && ((((uintptr_t)s.pred | (uintptr_t)s.grad) & 7) == 0);
+                    it.count_mode = 1; it.lo = 1; it.hi = s.C < 255 ? s.C : 255;
+                    if (s.C > CE_FUSED_MAX_C) {
+                        it.in_launch = 0;
+                        it.nbx = ce_split_blocks(it.P, s.dtype);
+                    } else {
+                        const int ng = ce_fused_ng(s.C), sm = s.param != 0.0f;
+                        if (pl.ce_ng == 0) { pl.ce_ng = ng; pl.ce_dt = s.dtype; pl.ce_sm = sm; }
+                        if (ng != pl.ce_ng || s.dtype != pl.ce_dt || sm != pl.ce_sm) it.in_launch = 0;
+                        it.nbx = grid_x(it.P, pxt);
+                        if (it.in_launch && s.C > pl.max_c) pl.max_c = s.C;
+                    }
+                } else {
+                    it.vec = (it.P % 4 == 0) && (((al | (uintptr_t)s.mask) & 15) == 0);
+                    it.nbx = grid_x(it.P, 8);
+                    it.count_mode = s.kind == NMSA_LOSS_FOCAL ? 2 : (s.mask ? 1 : 0);
+                    it.lo = 1; it.hi = 255;
+                }
+                if (it.count_mode == 1) {
+                    const long long n = (long long)it.B * it.P;
+                    long long cb = (n / 16 + LOSS_THREADS * 4 - 1) / (LOSS_THREADS * 4);
+                    it.cnblocks = (int)(cb < 1 ? 1 : cb > MULTI_COUNT_MAX_BLOCKS ? MULTI_COUNT_MAX_BLOCKS : cb);
+                } else {
+                    it.cnblocks = 1;
+                }
+                it.cblock0 = cblock;
+                cblock += it.cnblocks;
+            }
+            if ((pass == 0) == (it.in_launch != 0)) {
+                it.block0 = block;
+                block += it.nbx * it.B;
+                if (pass == 0) a.n_blocks = block;      // blocks of the joint launch
+            }
+            if (block < 0 || block > (1 << 28)) return NMSA_ERR_ARG;
+        }
+    }
+    pl.n_count_blocks = cblock;
+    pl.lds = (size_t)(pl.max_c > 0 ? pl.max_c : 1) * sizeof(float);
+    return NMSA_OK;
+}
+
+size_t multi_partial_blocks(const MultiPlan& pl)
+{
+    size_t n = 0;
+    for (int i = 0; i < pl.args.n_items; ++i) n += (size_t)pl.args.it[i].nbx * pl.args.it[i].B;
+    return n;
+}
+
+template <bool LOSS>
+int multi_launch_joint(const MultiPlan& pl, const float* expect, const float* gs, LossPartial* partials,
+                       int* status, hipStream_t stream)
+{
+    const MultiArgs& a = pl.args;
+    if (a.n_blocks <= 0) return NMSA_OK;
+#define ML(DT, NG, SM) hipLaunchKernelGGL((k_multi_loss<DT, NG, SM, LOSS>), dim3(a.n_blocks), dim3(LOSS_THREADS), \
+        pl.lds, stream, a, expect, gs, partials, status)
+#define ML_NG(DT, SM) do { if (pl.ce_ng == 3) ML(DT, 3, SM); else if (pl.ce_ng == 5) ML(DT, 5, SM); else ML(DT, 6, SM); } while (0)
+#define ML_DT(DT) do { if (pl.ce_sm) ML_NG(DT, true); else ML_NG(DT, false); } while (0)
+    if (pl.ce_ng == 0) ML(NMSA_F32, 0, false);
+    else switch (pl.ce_dt) {
+        case NMSA_F32: ML_DT(NMSA_F32); break;
+        case NMSA_BF16: ML_DT(NMSA_BF16); break;
+        default: ML_DT(NMSA_F16); break;
+    }
+#undef ML_DT
+#undef ML_NG
+#undef ML
+    return check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t nmsa_multitask_loss_workspace_bytes(const nmsa_loss_item* items, int n_items)
+{
+    MultiPlan pl;
+    int nt = 1;
+    if (!items) return 0;
+    for (int i = 0; i < n_items && i < MULTI_MAX_ITEMS; ++i) if (items[i].total + 1 > nt) nt = items[i].total + 1;
+    if (nt > MULTI_MAX_TOTALS || multi_plan(items, n_items, nt, pl)) return 0;
+    return multi_partial_blocks(pl) * sizeof(LossPartial) + (size_t)pl.n_count_blocks * sizeof(long long) + 64;
+}
+
+extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_items, int n_totals,
+                                            int32_t* spec, float* expect, double* loss_sums,
+                                            int64_t* counts, double* aux, int32_t* status,
+                                            void* workspace, size_t workspace_bytes, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!spec || !expect || !loss_sums || !counts || !status || !workspace) return NMSA_ERR_ARG;
+    MultiPlan pl;
+    int rc = multi_plan(items, n_items, n_totals, pl);
+    if (rc) return rc;
+    const size_t nb = multi_partial_blocks(pl);
+    if (workspace_bytes < nb * sizeof(LossPartial) + (size_t)pl.n_count_blocks * sizeof(long long)) return NMSA_ERR_WORKSPACE;
+    LossPartial* partials = (LossPartial*)workspace;
+    long long* cpart = (long long*)(partials + nb);
+    const MultiArgs& a = pl.args;
+    hipLaunchKernelGGL(k_multi_count, dim3(pl.n_count_blocks), dim3(LOSS_THREADS), 0, stream, a, cpart);
+    rc = check_launch();
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_multi_expect, dim3(1), dim3(LOSS_THREADS), 0, stream, a, cpart, spec, expect);
+    rc = check_launch();
+    if (rc) return rc;
+    rc = multi_launch_joint<true>(pl, expect, nullptr, partials, status, stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_items; ++i) {                 // cross entropies outside the joint launch
+        const MultiItem& it = a.it[i];
+        if (it.in_launch) continue;
+        if (it.C > CE_FUSED_MAX_C) {
+            rc = launch_ce_split(true, it.pred, it.dtype, it.mask, it.weights, it.B, it.C, it.P, it.param,
+                                 expect + 2 * it.total, nullptr, nullptr, it.grad, partials + it.block0, status,
+                                 stream);
+        } else {
+            // a second register-resident variant in one call: its own forward + gradient launch
+            rc = nmsa_loss_ce_fwd_grad_partials(it.pred, it.dtype, it.mask, it.weights, it.B, it.C, it.P,
+                                                it.param, expect + 2 * it.total, it.grad, partials + it.block0,
+                                                status, stream);
+        }
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_multi_finalize, dim3(n_items), dim3(FIN_THREADS), 0, stream, a, partials, loss_sums,
+                       (long long*)counts, aux);
+    return check_launch();
+}
+
+extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n_items, int n_totals,
+                                              const float* grad_scales, const float* expect,
+                                              int32_t* spec, int32_t* counters, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!grad_scales || !expect || !spec) return NMSA_ERR_ARG;
+    MultiPlan pl;
+    int rc = multi_plan(items, n_items, n_totals, pl);
+    if (rc) return rc;
+    const MultiArgs& a = pl.args;
+    hipLaunchKernelGGL(k_multi_spec, dim3(1), dim3(64), 0, stream, a, grad_scales, expect, spec, counters);
+    rc = check_launch();
+    if (rc) return rc;
+    rc = multi_launch_joint<false>(pl, expect, grad_scales, nullptr, nullptr, stream);
+    if (rc) return rc;
+    for (int i = 0; i < n_items; ++i) {
+        const MultiItem& it = a.it[i];
+        if (it.in_launch || !it.grad) continue;
+        rc = nmsa_loss_ce_bwd_unless(it.pred, it.dtype, it.mask, it.weights, it.B, it.C, 1, it.P, it.param,
+                                     grad_scales + i, it.grad, expect + 2 * it.total, nullptr, stream_);
+        if (rc) return rc;
+    }
+    return NMSA_OK;
 }

@@ -33,10 +33,10 @@ class _ElementwiseLoss(LossBase):
         """(sum_px mean_c f(input_*mask - target), sum(mask)) — the masking of
         task_helper/instance.py:129-139,154-167 without materialising input_*mask.
         `expected_scale`: see LossBase.forward; default = 1 / sum(mask)."""
-        if expected_scale is None and mask is not None and self._kind != 'focal' and \
-                input_.is_cuda and F_.mean_speculation_enabled() and F_.wants_gradient(input_):
-            mask = F_._u8(mask.to(input_.device))
-            _, expected_scale = F_.count_u8(mask, with_mean_scale=True)
+        if expected_scale is None and self._can_speculate(input_) and input_.ndim in (3, 4) and \
+                not target.requires_grad:
+            loss, n, _ = self._speculative_single(self._kind, input_, target, mask=mask)
+            return loss, n
         return F_.masked_elementwise_sum(input_, target, mask, self._kind, expected_scale)
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor, expected_scale=None):
@@ -44,9 +44,11 @@ class _ElementwiseLoss(LossBase):
         kernel_ok = input_.ndim in (3, 4) and input_.numel() > 0 and not target.requires_grad
         if self._reduction in ('sum', 'mean') and kernel_ok:
             n_px = input_.numel() // (input_.shape[1] if input_.ndim == 4 else 1)
-            if expected_scale is None and self._kind != 'focal' and \
-                    F_.mean_speculation_enabled() and F_.wants_gradient(input_):
-                expected_scale = F_.expected_scale(n_px, device=input_.device)   # loss / n_px
+            if expected_scale is None and self._kind != 'focal' and self._can_speculate(input_):
+                loss, _, _ = self._speculative_single(self._kind, input_, target)
+                if self._reduction == 'mean':
+                    return loss / n_px, 1
+                return loss, n_px
             loss, _ = F_.masked_elementwise_sum(input_, target, None, self._kind, expected_scale)
             if self._reduction == 'mean':
                 return loss / n_px, 1           # mean over all elements == sum_px mean_c / n_px

@@ -16,7 +16,6 @@ recomputes only when they differ bit-wise, so results never depend on the expect
 right.  `speculation_stats()` counts both outcomes.  NMSA_SPECULATIVE_GRAD=0 turns it off.
 """
 import os
-import warnings
 from typing import Dict, Optional, Tuple
 
 import ctypes as C
@@ -53,8 +52,6 @@ def _scalar_outputs(dev):
 _STATUS: Dict[torch.device, torch.Tensor] = {}      # int32 [status, confirmed, recomputed, -]
 _CHECK_EVERY_CALL = bool(int(os.environ.get('NMSA_CHECK_STATUS', '0') or 0))
 _SPECULATE = bool(int(os.environ.get('NMSA_SPECULATIVE_GRAD', '1') or 0))
-_SPEC_TOTALS = {'confirmed': 0, 'recomputed': 0}
-_MEAN_SPECULATION = {'on': True, 'warned': False}
 
 
 def _status_word(dev: torch.device) -> torch.Tensor:
@@ -68,56 +65,38 @@ def _counters_ptr(dev: torch.device):
     return C.c_void_p(_status_word(dev).data_ptr() + 4)
 
 
-def _drain_status():
-    """read and clear the per-device words (host sync) -> {device: status bits}"""
-    bits = {}
-    for dev, st in _STATUS.items():
-        status, confirmed, recomputed, _ = (int(v) for v in st.tolist())
-        st.zero_()
-        bits[dev] = status
-        _SPEC_TOTALS['confirmed'] += confirmed
-        _SPEC_TOTALS['recomputed'] += recomputed
-    if _MEAN_SPECULATION['on'] and _SPEC_TOTALS['recomputed'] >= 8 and \
-            _SPEC_TOTALS['recomputed'] > _SPEC_TOTALS['confirmed']:
-        # the default expectation (`loss_sum / n` of the same call) keeps missing: stop paying
-        # for gradients that get recomputed.  Explicit `expected_scale=` arguments stay honoured.
-        _MEAN_SPECULATION['on'] = False
-        if not _MEAN_SPECULATION['warned']:
-            _MEAN_SPECULATION['warned'] = True
-            warnings.warn('loss gradients written for `loss_sum / n` were recomputed in most '
-                          'backward passes; default speculation is off from here on (pass '
-                          'expected_scale= or set backward_scale on the task helper).')
-    return bits
-
-
 def check_loss_status() -> None:
     """raise IndexError if any loss kernel since the last check saw a label >= C + 1 or a LUT
     index outside [0, L] (host sync)"""
-    for dev, v in _drain_status().items():
+    for dev, st in _STATUS.items():
+        v = int(st[0].item())
         if v:
+            st[0] = 0
             raise IndexError(f'loss kernels on {dev}: target label / LUT index out of range '
                              '(PyTorch raises a device-side assert for these)')
 
 
 def speculation_stats() -> Dict[str, int]:
     """backward passes that found their gradient already written by the forward kernel
-    ('confirmed') / had to recompute it ('recomputed') since the process started (host sync;
-    pending status bits are kept for check_loss_status)"""
-    pending = {dev: int(st[0].item()) for dev, st in _STATUS.items()}
-    _drain_status()
-    for dev, v in pending.items():
-        if v:
-            _STATUS[dev][0] = v
-    return dict(_SPEC_TOTALS)
+    ('confirmed') / had to recompute it ('recomputed') since the process started or the last
+    reset: a per-device tally next to the status word that every backward launch adds to (explicit
+    `expected_scale=` calls count per loss, the learned expectations of loss instances and task
+    helpers — loss/_multi.py — per total).  Statistics only: no policy reads them.  Host sync."""
+    out = {'confirmed': 0, 'recomputed': 0}
+    for st in _STATUS.values():
+        _, confirmed, recomputed, _ = (int(v) for v in st.tolist())
+        out['confirmed'] += confirmed
+        out['recomputed'] += recomputed
+    return out
 
 
 def reset_speculation_state() -> None:
-    """forget the confirmed / recomputed history (host sync) and switch the default expectation
-    of the loss classes back on — a new training run, a test, a benchmark leg"""
-    speculation_stats()                     # drains the counters, keeps pending status bits
-    _SPEC_TOTALS['confirmed'] = _SPEC_TOTALS['recomputed'] = 0
-    _MEAN_SPECULATION['on'] = True
-    _MEAN_SPECULATION['warned'] = False
+    """forget the confirmed / recomputed history and the learned upstream factors of every live
+    loss instance / task helper (host sync) — a new training run, a test, a benchmark leg"""
+    from . import _multi
+    _multi.reset_all()
+    for st in _STATUS.values():
+        st[1:3] = 0
 
 
 def speculation_enabled() -> bool:
@@ -125,9 +104,9 @@ def speculation_enabled() -> bool:
 
 
 def mean_speculation_enabled() -> bool:
-    """default expectation of the loss classes: the caller divides this call's sum by this
-    call's count"""
-    return _SPECULATE and _MEAN_SPECULATION['on']
+    """kept for callers of round 2: the default expectation of the loss classes is a learned,
+    per-instance state now (loss/_multi.py); this only says whether speculation is compiled in"""
+    return _SPECULATE
 
 
 def count_u8(values: torch.Tensor, lo: int = 1, hi: int = 255, with_mean_scale: bool = False):

@@ -1,0 +1,202 @@
+"""All losses of a task helper in ONE call of the C ABI (`nmsa_multitask_loss_fwd_grad`,
+csrc/losses.hip k_multi_*; reference task_helper/instance.py:92-269, semantic.py:57-90,
+base.py:161-182).
+
+Every (loss, supervision scale) pair is an ITEM, the items whose sums the caller adds and divides
+by their summed element counts form a TOTAL.  The forward call counts the labels / mask bytes,
+forms per total the divisor and the EXPECTED upstream gradient `w / n` of its loss sums, computes
+all sums and writes all gradients for that expectation (4 launches whatever the number of items);
+backward compares the real upstream gradients with the expectation ON THE DEVICE and recomputes
+only what differs (2 launches).  `w` — the factor the trainer multiplies the total with before
+`backward()`: loss weights (reference loss_weighting/fixed.py:28-37), an AMP scale — lives in a
+`SpecState` owned by the caller (a task helper, a loss instance) and is LEARNED on the device from
+the upstream gradients it sees: constant factors are confirmed from the second step on without any
+hint, factors that keep changing switch the expectation of that total off (the forward pass then
+writes no gradient and backward recomputes, as without speculation).  There is no process-global
+policy state.
+"""
+import ctypes as C
+import weakref
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from .. import _lib as L
+
+KIND = {'ce': 0, 'mse': 1, 'l1': 2, 'focal': 3, 'vonmises': 4}
+MAX_ITEMS, MAX_TOTALS = 16, 8
+
+
+class _Item(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('dtype', C.c_int32), ('B', C.c_int32), ('C', C.c_int32),
+                ('H', C.c_int32), ('W', C.c_int32), ('total', C.c_int32), ('clamp_count', C.c_int32),
+                ('param', C.c_float), ('reserved', C.c_int32),
+                ('pred', C.c_void_p), ('target', C.c_void_p), ('mask', C.c_void_p),
+                ('weights', C.c_void_p), ('grad', C.c_void_p)]
+
+
+_STATES: 'weakref.WeakSet[SpecState]' = weakref.WeakSet()
+
+
+class SpecState:
+    """device-resident spec records of the totals of one caller: int32 [n_totals, 8]
+    ([0] confirmed, [1] recomputed, [2] w as fp32 bits, [5] flags; see csrc/losses.hip)"""
+
+    def __init__(self, n_totals: int, initial_weight=1.0) -> None:
+        assert 1 <= n_totals <= MAX_TOTALS
+        self.n_totals = n_totals
+        self._w0 = [float(initial_weight)] * n_totals if not isinstance(initial_weight, (list, tuple)) \
+            else [float(v) for v in initial_weight]
+        self._rec: Dict[torch.device, torch.Tensor] = {}
+        _STATES.add(self)
+
+    def records(self, dev) -> torch.Tensor:
+        dev = torch.device(dev)
+        if dev.type == 'cuda' and dev.index is None:
+            dev = torch.device('cuda', torch.cuda.current_device())
+        r = self._rec.get(dev)
+        if r is None:
+            host = torch.zeros((self.n_totals, 8), dtype=torch.int32)
+            host.view(torch.float32)[:, 2] = torch.tensor(self._w0, dtype=torch.float32)
+            r = self._rec[dev] = host.to(dev)
+        return r
+
+    def reset(self) -> None:
+        for dev in list(self._rec):
+            del self._rec[dev]
+
+    def stats(self) -> Dict[str, int]:
+        """host sync"""
+        out = {'confirmed': 0, 'recomputed': 0}
+        for r in self._rec.values():
+            v = r[:, :2].sum(dim=0).tolist()
+            out['confirmed'] += int(v[0])
+            out['recomputed'] += int(v[1])
+        return out
+
+    def weights(self, dev) -> List[float]:
+        """the learned upstream factors (host sync; tests, diagnostics)"""
+        return self.records(dev).view(torch.float32)[:, 2].tolist()
+
+
+def reset_all() -> None:
+    """forget what every live SpecState has learned (new records on next use)"""
+    for st in list(_STATES):
+        st.reset()
+
+
+def supported(items: Sequence[dict]) -> bool:
+    """every item can go through the multi-loss call (device tensors, C <= 256 for CE)"""
+    if not 1 <= len(items) <= MAX_ITEMS:
+        return False
+    for it in items:
+        p = it['pred']
+        if not (isinstance(p, torch.Tensor) and p.is_cuda and p.dtype in
+                (torch.float32, torch.bfloat16, torch.float16) and p.numel() > 0):
+            return False
+        if it['kind'] == 'ce' and p.shape[1] > 255:
+            return False
+    return True
+
+
+def _u8(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    t = t.to(dev)
+    if t.dtype == torch.bool:
+        return t.contiguous().view(torch.uint8)
+    if t.dtype == torch.uint8:
+        return t.contiguous()
+    return (t != 0).contiguous().view(torch.uint8)
+
+
+class MultiLossFunction(torch.autograd.Function):
+    """apply(desc, *preds) -> (sum_0, ..., sum_{n-1}) as fp32 0-d tensors; counts / aux on `desc`"""
+
+    @staticmethod
+    def forward(ctx, desc, *preds):
+        items, n_totals, spec = desc['items'], desc['n_totals'], desc['spec']
+        dev = preds[0].device
+        n = len(items)
+        arr = (_Item * n)()
+        keep = []
+        grads: List[Optional[torch.Tensor]] = []
+        for i, (it, x) in enumerate(zip(items, preds)):
+            x = L.require_device_tensor(x, 'input_')
+            kind = it['kind']
+            if x.ndim == 3:
+                B, H, W = x.shape
+                Cc = 1
+            else:
+                B, Cc, H, W = x.shape
+            a = arr[i]
+            a.kind, a.dtype = KIND[kind], L.float_dtype_code(x)
+            a.B, a.C, a.H, a.W = B, Cc, H, W
+            a.total, a.clamp_count = int(it['total']), int(bool(it.get('clamp', False)))
+            a.param = float(it.get('param', 0.0))
+            tgt, msk, wts = it.get('target'), it.get('mask'), it.get('weights')
+            if kind == 'ce':
+                from ._functional import labels_u8
+                msk = labels_u8(msk, dev)
+                tgt = None
+                wts = None if wts is None else wts.to(dev, torch.float32).contiguous()
+            else:
+                tgt = tgt.to(dev, torch.float32).contiguous()
+                msk = _u8(msk, dev)
+            # (grad mode is off inside forward(): needs_input_grad is what says whether autograd
+            # is going to ask for this gradient)
+            g = torch.empty_like(x) if ctx.needs_input_grad[i + 1] else None
+            a.pred, a.target = x.data_ptr(), (tgt.data_ptr() if tgt is not None else None)
+            a.mask = msk.data_ptr() if msk is not None else None
+            a.weights = wts.data_ptr() if wts is not None else None
+            a.grad = g.data_ptr() if g is not None else None
+            keep.append((x, tgt, msk, wts))
+            grads.append(g)
+        rec = spec.records(dev)
+        expect = torch.empty((n_totals, 2), dtype=torch.float32, device=dev)
+        sums = torch.empty((n,), dtype=torch.float64, device=dev)
+        counts = torch.empty((n,), dtype=torch.int64, device=dev)
+        aux = torch.empty((n,), dtype=torch.float64, device=dev)
+        from ._functional import _status_word
+        status = _status_word(dev)
+        lib = L.lib()
+        nbytes = lib.nmsa_multitask_loss_workspace_bytes(arr, n)
+        if nbytes == 0:
+            raise L.NmsaError('nmsa_multitask_loss_workspace_bytes: invalid items')
+        ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+        L.check(lib.nmsa_multitask_loss_fwd_grad(arr, n, n_totals, L.ptr(rec), L.ptr(expect), L.ptr(sums),
+                                                 L.ptr(counts), L.ptr(aux), L.ptr(status), L.ptr(ws),
+                                                 nbytes, L.stream_ptr(dev)), 'nmsa_multitask_loss_fwd_grad')
+        ctx.arr, ctx.keep, ctx.grads = arr, keep, grads
+        ctx.n_totals, ctx.rec, ctx.expect = n_totals, rec, expect
+        desc['counts'], desc['aux'], desc['divisors'] = counts, aux, expect[:, 1]
+        return tuple(sums.to(torch.float32).unbind(0))
+
+    @staticmethod
+    def backward(ctx, *g):
+        dev = ctx.expect.device
+        n = len(ctx.grads)
+        zero = None
+        parts = []
+        for gi in g:
+            if gi is None:
+                if zero is None:
+                    zero = torch.zeros((), dtype=torch.float32, device=dev)
+                gi = zero
+            parts.append(gi.detach().to(torch.float32).reshape(()))
+        gs = torch.stack(parts).contiguous()
+        from ._functional import _counters_ptr
+        L.check(L.lib().nmsa_multitask_loss_bwd_unless(ctx.arr, n, ctx.n_totals, L.ptr(gs), L.ptr(ctx.expect),
+                                                       L.ptr(ctx.rec), _counters_ptr(dev), L.stream_ptr(dev)),
+                'nmsa_multitask_loss_bwd_unless')
+        return (None, *ctx.grads)
+
+
+def multi_loss(items: Sequence[dict], n_totals: int, spec: SpecState
+               ) -> Tuple[Tuple[torch.Tensor, ...], torch.Tensor, torch.Tensor, torch.Tensor]:
+    """items: dicts with kind ('ce' | 'mse' | 'l1' | 'focal' | 'vonmises'), pred, target (not CE),
+    mask (labels for CE), weights (CE), param (label smoothing | kappa), total, clamp.
+    -> (loss sums as fp32 0-d tensors, counts int64 [n], aux float64 [n], divisors float32 [n_totals])"""
+    desc = {'items': list(items), 'n_totals': n_totals, 'spec': spec}
+    sums = MultiLossFunction.apply(desc, *[it['pred'] for it in items])
+    return sums, desc['counts'], desc['aux'], desc['divisors']

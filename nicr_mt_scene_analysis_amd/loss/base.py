@@ -5,6 +5,23 @@ import torch
 
 
 class LossBase(torch.nn.Module):
+    def _speculative_single(self, kind, input_, target, mask=None, weights=None, param=0.0):
+        """one item through the multi-loss call with THIS instance's learned expectation of the
+        upstream gradient (loss/_multi.py): forward sum + gradient in one pass, confirmed or
+        recomputed in backward -> (loss sum, element count, aux)"""
+        from . import _multi
+        spec = self.__dict__.get('_spec')
+        if spec is None:
+            spec = self.__dict__['_spec'] = _multi.SpecState(1)
+        item = {'kind': kind, 'pred': input_, 'target': target, 'mask': mask, 'weights': weights,
+                'param': param, 'total': 0}
+        sums, counts, aux, _ = _multi.multi_loss([item], 1, spec)
+        return sums[0], counts[0], aux[0]
+
+    def _can_speculate(self, input_) -> bool:
+        from . import _functional as F_
+        return input_.is_cuda and input_.numel() > 0 and F_.speculation_enabled() and F_.wants_gradient(input_)
+
     def _compute_loss(self, input_, target):
         """one scale -> (loss, number of loss elements)"""
         raise NotImplementedError(f'{type(self).__name__} must define _compute_loss')

@@ -26,6 +26,8 @@ class CenterFocalLoss(LossBase):
                    mask: Optional[torch.Tensor], expected_scale=None
                    ) -> Tuple[torch.Tensor, torch.Tensor]:
         """(loss sum over the masked pixels, max(#positive masked pixels, 1))"""
+        # the divisor (number of heat-map peaks) is no count of mask bytes: no expectation, the
+        # two-kernel path (forward, then backward) — also inside the multi-loss call
         loss, n_pos = F_.masked_elementwise_sum(input_, target, mask, 'focal', expected_scale)
         return loss, n_pos.clamp(min=1)
 

@@ -22,10 +22,9 @@ class VonMisesLossBiternion(LossBase):
         """planar [B,2,H,W] prediction/target + [B,H,W] mask: the permute + boolean
         gather of task_helper/instance.py:186-216 folded into the kernel.
         `expected_scale`: see LossBase.forward; default = 1 / sum(mask)."""
-        if expected_scale is None and mask is not None and input_.is_cuda and \
-                F_.mean_speculation_enabled() and F_.wants_gradient(input_):
-            mask = F_._u8(mask.to(input_.device))
-            _, expected_scale = F_.count_u8(mask, with_mean_scale=True)
+        if expected_scale is None and self._can_speculate(input_) and not target.requires_grad:
+            loss, n, _ = self._speculative_single('vonmises', input_, target, mask=mask, param=self._kappa)
+            return loss, n
         return F_.vonmises_sum(input_, target, mask, self._kappa, expected_scale)
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor, expected_scale=None):
@@ -44,7 +43,8 @@ class VonMisesLossBiternion(LossBase):
         # rows (n, 2) -> planar (1, 2, n, 1) for the kernel (autograd carries the transpose)
         x = input_.t().contiguous().view(1, 2, n, 1)
         y = target.t().contiguous().view(1, 2, n, 1)
-        if expected_scale is None and F_.mean_speculation_enabled() and F_.wants_gradient(input_):
-            expected_scale = F_.expected_scale(n, device=input_.device)             # loss / n
+        if expected_scale is None and self._can_speculate(x):
+            loss, _, _ = self._speculative_single('vonmises', x, y, param=self._kappa)
+            return loss, n
         loss, _ = F_.vonmises_sum(x, y, None, self._kappa, expected_scale)
         return loss, n

@@ -68,32 +68,48 @@ def _last_dim(output):
 
 class TaskHelperBase(torch.nn.Module):
     # Extension: the factor the trainer multiplies this task's total loss with before calling
-    # backward.  The HIP losses write their gradient in the forward pass for
-    # `backward_scale / sum_scales(n)` — what autograd sends back through accumulate_losses —
-    # and re-do it in backward only when the real upstream gradient differs, so a wrong value
-    # costs time, never correctness (loss/_functional.py).  A dict gives one factor per total
-    # ('instance_center', 'instance_offset', 'instance_orientation', 'semantic'; default 1).
+    # backward — only the STARTING value of what the helper learns on the device from the upstream
+    # gradients it sees (loss/_multi.py): the HIP losses write their gradient in the forward pass
+    # for `w / sum_scales(n)` and re-do it in backward only when the real upstream gradient
+    # differs, so a wrong value costs one recomputation, never correctness.  A dict gives one
+    # factor per total ('instance_center', 'instance_offset', 'instance_orientation', 'semantic').
     backward_scale = 1.0
 
     def initialize(self, device):
         """create losses / metrics on `device`"""
 
-    def expected_scale_for_total(self, counts, predictions, name=None):
-        """the gradient `backward_scale * accumulate_losses(sums, counts)` hands to each loss
-        sum of the total `name`, or None when no gradient is going to be asked for"""
-        from ..loss import _functional as F_
-        if not F_.speculation_enabled() or not torch.is_grad_enabled():
-            return None
-        if not any(isinstance(p, torch.Tensor) and p.requires_grad for p in predictions):
-            return None
-        count = sum(counts)
-        if not isinstance(count, torch.Tensor):
-            return None
-        # accumulate_losses: loss_sum / count.clamp(min=1).to(float32)
-        weight = self.backward_scale
-        if isinstance(weight, dict):
-            weight = weight.get(name, 1.0)
-        return F_.expected_scale(count.clamp(min=1).to(torch.float32), float(weight))
+    def spec_state(self, names):
+        """the learned upstream factors of this helper's totals (loss/_multi.py `SpecState`),
+        one per name, starting from `backward_scale`"""
+        from ..loss import _multi
+        st = self.__dict__.get('_spec_states')
+        if st is None:
+            st = self.__dict__['_spec_states'] = {}
+        key = tuple(names)
+        if key not in st:
+            w = self.backward_scale
+            init = [float(w.get(n, 1.0)) if isinstance(w, dict) else float(w) for n in names]
+            st[key] = _multi.SpecState(len(names), init)
+        return st[key]
+
+    def multi_losses(self, items, total_names):
+        """`items` (loss/_multi.py) through ONE forward call -> (per item loss / count as a
+        tuple of 0-d tensors, {total name: sum_scales loss / sum_scales count})  — the
+        reductions of reference base.py:161-182 as two vector ops instead of one op per scale"""
+        from ..loss import _multi
+        sums, counts, _, divisors = _multi.multi_loss(items, len(total_names), self.spec_state(total_names))
+        dev = counts.device
+        idx = self.__dict__.setdefault('_total_index', {})
+        key = (tuple(it['total'] for it in items), dev)
+        if key not in idx:
+            idx[key] = torch.tensor(key[0], dtype=torch.long, device=dev)
+        clamp = torch.tensor([1 if it.get('clamp') else 0 for it in items], device=dev) \
+            if any(it.get('clamp') for it in items) else None
+        s = torch.stack(sums)
+        n = counts if clamp is None else torch.maximum(counts, clamp)
+        per_item = (s / n.to(s.dtype)).unbind(0)
+        totals = torch.zeros((len(total_names),), dtype=s.dtype, device=dev).index_add_(0, idx[key], s) / divisors
+        return per_item, dict(zip(total_names, totals.unbind(0))), counts
 
     # ---- pairing predictions and targets over the supervision scales ---------------------
     def collect_predictions_for_loss(self, predictions_post, predictions_post_key,

@@ -71,52 +71,49 @@ class InstanceTaskHelper(TaskHelperBase):
         def targets(key):
             return self.collect_targets_for_loss(batch, batch_key=key, downscales=downscales)
 
-        def expected(name, preds_, masks, clamp=False):
-            """per scale: the gradient the total over the scales sends back (None: not asked)"""
-            if not (torch.is_grad_enabled() and F_.speculation_enabled()) or \
-                    not any(p.requires_grad for p in preds_):
-                return [None] * len(preds_), masks
-            masks = [F_._u8(m.to(p.device)) for m, p in zip(masks, preds_)]
-            counts = [F_.count_u8(m) for m in masks]
-            if clamp:
-                counts = [c.clamp(min=1) for c in counts]
-            return [self.expected_scale_for_total(counts, preds_, name)] * len(preds_), masks
-
+        center_kind = self._loss_name_instance_center
+        items, names = [], []
         # center: pred*mask vs target, n = sum(mask)            (instance.py:115-139)
-        center_focal = self._loss_name_instance_center == 'focal'     # n = #positives: no count
-        exp, masks = ([None] * len(preds_center), targets('instance_center_mask')) if center_focal \
-            else expected('instance_center', preds_center, targets('instance_center_mask'))
-        out_center = [self._loss_center.masked_sum(p.contiguous(), t, m, expected_scale=e)
-                      for p, t, m, e in zip(preds_center, targets('instance_center'), masks, exp)]
+        for k, p, t, m in zip(keys, preds_center, targets('instance_center'), targets('instance_center_mask')):
+            items.append({'kind': center_kind, 'pred': p.contiguous(), 'target': t, 'mask': m, 'total': 0})
+            names.append(f'instance_center_loss_{k}')
         # offset: pred*foreground vs target, n = sum(foreground)  (instance.py:141-167)
-        exp, masks = expected('instance_offset', preds_offset, targets('instance_foreground'))
-        out_offset = [self._loss_offset.masked_sum(p.contiguous(), t, m, expected_scale=e)
-                      for p, t, m, e in zip(preds_offset, targets('instance_offset'), masks, exp)]
-        loss_dict = {}
-        loss_dict.update({f'instance_center_loss_{k}': l / n
-                          for k, (l, n) in zip(keys, out_center)})
-        loss_dict.update({f'instance_offset_loss_{k}': l / n
-                          for k, (l, n) in zip(keys, out_offset)})
-        total = {
-            'instance_center': self.accumulate_losses([l for l, _ in out_center],
-                                                      [n for _, n in out_center]),
-            'instance_offset': self.accumulate_losses([l for l, _ in out_offset],
-                                                      [n for _, n in out_offset]),
-        }
+        for k, p, t, m in zip(keys, preds_offset, targets('instance_offset'), targets('instance_foreground')):
+            items.append({'kind': 'l1', 'pred': p.contiguous(), 'target': t, 'mask': m, 'total': 1})
+            names.append(f'instance_offset_loss_{k}')
+        total_names = ['instance_center', 'instance_offset']
         if self._with_orientation:
             # masked rows, n = max(sum(mask), 1)                 (instance.py:170-216)
-            out_ori = []
-            exp, masks = expected('instance_orientation', preds_orientation,
-                                  targets('orientation_foreground'), clamp=True)
-            for p, t, m, e in zip(preds_orientation, targets('orientation'), masks, exp):
-                l, n = self._loss_orientation.masked_sum(p.contiguous(), t, m, expected_scale=e)
-                out_ori.append((l, n.clamp(min=1)))
-            loss_dict.update({f'instance_orientation_loss_{k}': l / n
-                              for k, (l, n) in zip(keys, out_ori)})
-            total['instance_orientation'] = self.accumulate_losses(
-                [l for l, _ in out_ori], [n for _, n in out_ori])
-        for k, v in total.items():
-            loss_dict[self.mark_as_total(k)] = v
+            for k, p, t, m in zip(keys, preds_orientation, targets('orientation'),
+                                  targets('orientation_foreground')):
+                items.append({'kind': 'vonmises', 'pred': p.contiguous(), 'target': t, 'mask': m,
+                              'param': self._loss_orientation._kappa, 'total': 2, 'clamp': True})
+                names.append(f'instance_orientation_loss_{k}')
+            total_names.append('instance_orientation')
+        from ..loss import _multi
+        if center_kind != 'focal' and F_.speculation_enabled() and _multi.supported(items):
+            # every loss of every scale in ONE forward call
+            per_item, totals, _ = self.multi_losses(items, tuple(total_names))
+            loss_dict = dict(zip(names, per_item))
+            for k in total_names:
+                loss_dict[self.mark_as_total(k)] = totals[k]
+            return loss_dict
+        # the focal extension (its divisor is no count of mask bytes), host tensors, > 16 items:
+        # loss by loss
+        out = []
+        for it in items:
+            if it['kind'] == 'vonmises':
+                l, n = self._loss_orientation.masked_sum(it['pred'], it['target'], it['mask'])
+                n = n.clamp(min=1)
+            elif it['total'] == 0:
+                l, n = self._loss_center.masked_sum(it['pred'], it['target'], it['mask'])
+            else:
+                l, n = self._loss_offset.masked_sum(it['pred'], it['target'], it['mask'])
+            out.append((l, n))
+        loss_dict = {name: l / n for name, (l, n) in zip(names, out)}
+        for ti, k in enumerate(total_names):
+            sel = [o for it, o in zip(items, out) if it['total'] == ti]
+            loss_dict[self.mark_as_total(k)] = self.accumulate_losses([l for l, _ in sel], [n for _, n in sel])
         return loss_dict
 
     @append_profile_to_logs('instance_step_time')

@@ -48,17 +48,17 @@ class SemanticTaskHelper(TaskHelperBase):
         predictions, targets, scale_names = self.collect_predictions_and_targets_for_loss(
             batch=batch, batch_key=_TASK, predictions_post=predictions_post,
             predictions_post_key=f'{_TASK}_output', side_outputs_key=side_key)
-        expected = None
-        if torch.is_grad_enabled() and F_.speculation_enabled() and \
-                any(p.requires_grad and F_.ce_forward_can_write_gradient(p) for p in predictions):
-            # non-void pixels per scale first (1 B/px): the total's divisor, hence the gradient
-            # of every scale's sum, is known before the loss kernels run
-            targets = [F_.labels_u8(t, p.device) for t, p in zip(targets, predictions)]
-            counts = [F_.count_u8(t, 1, min(self._n_classes, 255)) for t in targets]
-            scale = self.expected_scale_for_total(counts, predictions, _TASK)
-            expected = [scale] * len(predictions)
-        per_scale = self._loss(input_tensors=predictions, target_tensors=targets,
-                               expected_scales=expected)
+        from ..loss import _multi
+        items = [{'kind': 'ce', 'pred': p, 'mask': t, 'weights': self._class_weights,
+                  'param': self._label_smoothing, 'total': 0} for p, t in zip(predictions, targets)]
+        if F_.speculation_enabled() and _multi.supported(items) and \
+                all(p.ndim == 4 for p in predictions):
+            # all scales in ONE forward call (count, expectation, forward + gradient, finalize)
+            per_scale, totals, _ = self.multi_losses(items, (_TASK,))
+            losses = {f'{_TASK}_loss_{name}': v for name, v in zip(scale_names, per_scale)}
+            losses[self.mark_as_total(_TASK)] = totals[_TASK]
+            return losses
+        per_scale = self._loss(input_tensors=predictions, target_tensors=targets)
         sums = [loss_sum for loss_sum, _ in per_scale]
         counts = [count for _, count in per_scale]
         losses = {f'{_TASK}_loss_{name}': s / n for name, s, n in zip(scale_names, sums, counts)}

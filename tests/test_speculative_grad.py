@@ -290,37 +290,75 @@ def test_no_gradient_is_written_without_autograd():
     assert _delta(before) == (0, 0)
 
 
-def test_default_expectation_switches_itself_off_after_misses():
-    """a caller whose reduction is not `loss / n` (here: backward on the bare sum) makes every
-    default expectation miss; after 8 misses in the majority the loss classes stop writing
-    gradients nobody confirms (one warning), explicit expectations stay honoured"""
-    from nicr_mt_scene_analysis_amd.loss import L1Loss, check_loss_status
-    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+def test_expectation_is_learned_per_instance_and_switches_off_when_unstable():
+    """no process-global policy: every loss instance (and task helper) owns the upstream factor it
+    expects and learns it ON THE DEVICE.  (1) A constant factor the caller never told anybody
+    about (`3 * loss / n`) misses once and is confirmed from then on; (2) an instance whose
+    upstream gradient is no `w / n` at all (backward on the bare sum, with a varying count)
+    switches ITS expectation off after 8 misses in a row — other instances are unaffected — and
+    gradients stay right throughout"""
+    from nicr_mt_scene_analysis_amd.loss import L1Loss
     g = _gen(9)
     p = torch.randn((1, 2, 16, 20), device='cuda', generator=g)
     y = torch.randn((1, 2, 16, 20), device='cuda', generator=g)
-    m = torch.rand((1, 16, 20), device='cuda', generator=g) > 0.5
-    loss = L1Loss()
-    assert F_.mean_speculation_enabled()
-    for _ in range(9):
-        ps = p.clone().requires_grad_(True)
-        loss.masked_sum(ps, y, m)[0].backward()
-    with pytest.warns(UserWarning, match='recomputed'):
-        check_loss_status()
-    assert not F_.mean_speculation_enabled()
+
+    def reference(m, scale):
+        pr = p.double().requires_grad_(True)
+        ((pr * m.unsqueeze(1) - y.double()).abs().mean(dim=1).sum() * scale).backward()
+        return pr.grad
+
+    steady, erratic = L1Loss(), L1Loss()
     before = _stats()
-    ps = p.clone().requires_grad_(True)
-    l, n = loss.masked_sum(ps, y, m)
-    (l / n).backward()
-    assert _delta(before) == (0, 0)                      # plain two-kernel path now
-    ps = p.clone().requires_grad_(True)
-    l, n = loss.masked_sum(ps, y, m, expected_scale=F_.expected_scale(F_.count_u8(m)))
-    (l / n).backward()
-    assert _delta(before) == (1, 0)
-    pr = p.double().requires_grad_(True)
-    ((pr * m.unsqueeze(1) - y.double()).abs().mean(dim=1).sum() / int(m.sum())).backward()
-    np.testing.assert_allclose(ps.grad.double().cpu().numpy(), pr.grad.cpu().numpy(),
-                               rtol=2e-5, atol=1e-9)
+    for step in range(12):
+        m = torch.rand((1, 16, 20), device='cuda', generator=g) > 0.5       # a new count every step
+        ps = p.clone().requires_grad_(True)
+        l, n = steady.masked_sum(ps, y, m)
+        (3.0 * (l / n)).backward()                                          # weight x normalised loss
+        np.testing.assert_allclose(ps.grad.double().cpu().numpy(), reference(m, 3.0 / int(m.sum())).cpu().numpy(),
+                                   rtol=2e-5, atol=1e-9)
+        ps = p.clone().requires_grad_(True)
+        erratic.masked_sum(ps, y, m)[0].backward()                          # upstream gradient 1.0, not w / n
+        np.testing.assert_allclose(ps.grad.double().cpu().numpy(), reference(m, 1.0).cpu().numpy(),
+                                   rtol=2e-5, atol=1e-9)
+    s = steady._spec.stats()
+    assert s['recomputed'] == 1 and s['confirmed'] == 11, s                 # one miss, then learned
+    assert steady._spec.weights('cuda')[0] == 3.0
+    e = erratic._spec.records('cuda').tolist()[0]
+    assert e[0] == 0 and e[1] == 12 and (e[5] & 1) == 1, e                   # never confirmed: switched off
+    assert _delta(before) == (11, 13)
+
+
+def test_constant_loss_weights_confirm_without_backward_scale():
+    """the reference's FixedLossWeighting (loss_weighting/fixed.py:28-37) multiplies the task
+    totals with constant weights; nobody sets `backward_scale`: the helpers learn the factors from
+    the first backward pass and >= 90 % of the totals' backward passes are confirmed"""
+    from test_task_helpers import make_loss_batch
+    from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper, SemanticTaskHelper
+    weights = {'semantic': 2.0, 'instance_center': 0.5, 'instance_offset': 0.1,
+               'instance_orientation': 3.0}
+    batch, preds, t = make_loss_batch()
+    sem = SemanticTaskHelper(n_classes=9, class_weights=t['class_weights'].cpu().numpy())
+    ins = InstanceTaskHelper(semantic_n_classes=10, semantic_classes_is_thing=(False,) * 5 + (True,) * 5)
+    sem.initialize(torch.device('cuda'))
+    ins.initialize(torch.device('cuda'))
+    leaves = [preds['semantic_output'], *preds['instance_output']]
+    before = _stats()
+    steps = 12
+    for _ in range(steps):
+        for x in leaves:
+            x.grad = None
+        losses = {}
+        for helper in (sem, ins):
+            losses.update(helper.training_step(batch, 0, preds)[0])
+        sum(w * losses[f'{k}_total_loss'] for k, w in weights.items()).backward()
+    confirmed, recomputed = _delta(before)
+    assert confirmed + recomputed == 4 * steps
+    assert recomputed == 4 and confirmed >= 0.9 * 4 * steps, (confirmed, recomputed)
+    learned = dict(zip(('semantic',), sem.spec_state(('semantic',)).weights('cuda')))
+    learned.update(zip(('instance_center', 'instance_offset', 'instance_orientation'),
+                       ins.spec_state(('instance_center', 'instance_offset', 'instance_orientation')).weights('cuda')))
+    for k, w in weights.items():
+        assert learned[k] == np.float32(w), (k, learned[k])
 
 
 def test_count_u8_ranges_sizes_and_alignments():
@@ -347,8 +385,8 @@ def test_count_u8_ranges_sizes_and_alignments():
 
 
 def test_nothing_selected_gives_zero_gradients():
-    """all labels void / all mask bytes 0: n = 0, the expected scale is 1 / 0 = inf — the same inf
-    autograd sends back for `loss / n` — and the written gradient is all zeros, not NaN"""
+    """all labels void / all mask bytes 0: n = 0, `loss / n` sends inf back — and the gradient is
+    all zeros, not NaN"""
     from nicr_mt_scene_analysis_amd.loss import CrossEntropyLossSemantic, L1Loss, VonMisesLossBiternion
     g = _gen(5)
     x = torch.randn((2, 7, 12, 20), device='cuda', generator=g).requires_grad_(True)
@@ -357,7 +395,8 @@ def test_nothing_selected_gives_zero_gradients():
     (l, n), = CrossEntropyLossSemantic()([x], [t])
     assert int(n) == 0 and float(l) == 0.0
     (l / n).backward()
-    assert _delta(before) == (1, 0)
+    # (the expectation divides by max(n, 1) as the task helpers do; `l / 0` sends inf: recomputed)
+    assert sum(_delta(before)) == 1
     assert torch.count_nonzero(x.grad) == 0
     p = torch.randn((2, 2, 12, 20), device='cuda', generator=g).requires_grad_(True)
     y = torch.randn((2, 2, 12, 20), device='cuda', generator=g)
@@ -372,7 +411,7 @@ def test_nothing_selected_gives_zero_gradients():
     from nicr_mt_scene_analysis_amd.task_helper.base import TaskHelperBase
     helper = TaskHelperBase()
     p.grad = None
-    l, n = L1Loss().masked_sum(p, y, m, expected_scale=helper.expected_scale_for_total([n], [p]))
+    l, n = L1Loss().masked_sum(p, y, m)
     total = helper.accumulate_losses([l], [n])
     assert float(total) == float(l)          # masked-out pixels still count |0 - target| (instance.py:129-139)
     total.backward()

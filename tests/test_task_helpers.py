@@ -111,9 +111,9 @@ def test_instance_task_helper_losses():
 
 
 def test_task_helper_totals_confirm_forward_written_gradients(monkeypatch):
-    """the helpers tell the loss kernels what `weight * total` is going to send back (sum over
-    the scales of the counts): every backward launch confirms, and the gradients are those of
-    the two-kernel path"""
+    """with `backward_scale` as the starting value of the learned upstream factors every total's
+    backward pass confirms from the first step (one forward call per helper for all scales), and
+    the gradients are those of the two-kernel path"""
     from nicr_mt_scene_analysis_amd.loss import _functional as F_
     from nicr_mt_scene_analysis_amd.loss import reset_speculation_state, speculation_stats
     from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper, SemanticTaskHelper
@@ -147,7 +147,7 @@ def test_task_helper_totals_confirm_forward_written_gradients(monkeypatch):
     total, grads = run()
     after = speculation_stats()
     assert after['recomputed'] == before['recomputed']
-    assert after['confirmed'] - before['confirmed'] == 3 + 3 * 3       # scales x (CE + 3 instance)
+    assert after['confirmed'] - before['confirmed'] == 1 + 3           # one per total: CE + 3 instance
     monkeypatch.setattr(F_, '_SPECULATE', False)
     total_plain, grads_plain = run()
     assert speculation_stats() == after
