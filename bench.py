@@ -87,6 +87,10 @@ def host_cores():
     return {'nproc': nproc, 'affinity': affinity, 'cgroup_quota': quota, 'usable': usable}
 
 
+def host_threads_per_rank(n_ranks):
+    return max(1, host_cores()['usable'] // max(n_ranks, 1))
+
+
 def cpu_baseline(inp_dev, n_images, C, H, W, metrics=None, reps=3):
     """The C oracle ("port" of the reference's CPU path) timed on the host, single
     thread, on the first `n_images` images of the very batch the GPU processes."""
@@ -145,6 +149,9 @@ def cpu_baseline(inp_dev, n_images, C, H, W, metrics=None, reps=3):
             'nproc': cores['nproc'], 'affinity': cores['affinity'],
             'cgroup_cpu_quota': cores['cgroup_quota'],
             'kind': 'port', 'value_1core': round(one_core, 3),
+            # stated context, not measured here: the reference's own Python / torch-CPU path on the
+            # build container (8 vCPU; /root/reference does not exist on this box)
+            'reference_python_mpix_s': 0.33, 'reference_python_cores': 8,
             'sample': f'{max(1, reps)} passes over {n} images {W}x{H}x{C} of the bench batch, C oracle '
                       f'({what}): {dt:.2f} s on 1 core, {dt_mt:.2f} s with {threads} threads '
                       '(one image per task)'}, (idx, inst, pan)
@@ -159,6 +166,9 @@ def launch_ranks(args) -> int:
         port = sock.getsockname()[1]
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    # the ranks share the job's CPU quota (16 cores for the whole GPU box): bound every rank's host
+    # thread pools, or 8 ranks x (intra-op pool + RCCL proxy + HSA threads) oversubscribe it
+    env.setdefault('OMP_NUM_THREADS', str(host_threads_per_rank(args.gpus)))
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
            f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
            '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
@@ -279,12 +289,25 @@ def secondary_losses(dev, B=64, C=40, H=480, W=640):
     center_t_peaks = torch.where(torch.rand((B, H, W), device=dev, generator=g) < 1e-3,
                                  torch.ones((), device=dev), center_t * 0.98)
 
+    from nicr_mt_scene_analysis_amd.loss import _multi
+    spec4 = _multi.SpecState(4)
+
     def fwd(center_loss=mse, center_target=center_t):
-        (lc, n), = ce([logits], [labels])
-        a = center_loss.masked_sum(center, center_target, m1)
-        b = l1.masked_sum(offset, offset_t, m2)
-        c = vm.masked_sum(ori, ori_t, m3)
-        return lc / n + a[0] / a[1] + b[0] / b[1] + c[0] / c[1]
+        if center_loss is not mse:
+            # the focal extension: its divisor is no count of mask bytes -> loss by loss
+            (lc, n), = ce([logits], [labels])
+            a = center_loss.masked_sum(center, center_target, m1)
+            b = l1.masked_sum(offset, offset_t, m2)
+            c = vm.masked_sum(ori, ori_t, m3)
+            return lc / n + a[0] / a[1] + b[0] / b[1] + c[0] / c[1]
+        # configs[2] as ONE call (what the task helpers issue): count, expectation, one launch for
+        # the four forward sums + gradients, finalize
+        items = [{'kind': 'ce', 'pred': logits, 'mask': labels, 'weights': w, 'total': 0},
+                 {'kind': 'mse', 'pred': center, 'target': center_target, 'mask': m1, 'total': 1},
+                 {'kind': 'l1', 'pred': offset, 'target': offset_t, 'mask': m2, 'total': 2},
+                 {'kind': 'vonmises', 'pred': ori, 'target': ori_t, 'mask': m3, 'param': 1.0, 'total': 3,
+                  'clamp': True}]
+        return _multi.multi_loss(items, 4, spec4).total_losses.sum()
 
     def fwd_bwd(center_loss=mse, center_target=center_t):
         for t in (logits, center, offset, ori):
@@ -303,8 +326,9 @@ def secondary_losses(dev, B=64, C=40, H=480, W=640):
         # forward kernels that also write the gradient: per loss the element count
         # (labels / mask, 1 B/px) + inputs once + gradient once; backward launches only confirm
         moved = (1 + 2 * C + 1 + 2 * C) + (1 + 7 + 2) + 2 * (1 + 13 + 4)
-        how = ('forward kernels write the gradient for the expected upstream scale 1/n (count '
-               'pass 1 B/px per loss); the backward launches confirm it on the device')
+        how = ('ONE multi-loss call: count of labels / masks (1 B/px per loss), expectation, one '
+               'launch for the four forward sums + gradients, finalize; backward compares on the '
+               'device and recomputes nothing when the expectation held')
     else:
         # two-kernel path: forward inputs (2C+34) + log-sum-exp write 4; CE backward logits 2C +
         # label 1 + lse 4 + gradient 2C; element-wise backward pred + target + mask + gradient
@@ -450,6 +474,153 @@ def secondary_next_rows(ops, syn, dev, B=32, C=40, H=480, W=640):
     return out
 
 
+def secondary_api(syn, dev):
+    """the reference-shaped API on the driver's clock: wall time per call incl.
+    the host, and the host's own share (`host_issue_ms`: time until the last launch of a call has
+    been queued).  postprocess: PanopticPostprocessing.postprocess B=32 (eager = one device->host
+    copy per call; deferred = none); validation_step: postprocess + PanopticTaskHelper +
+    SemanticTaskHelper validation steps; training_step: SemanticTaskHelper + InstanceTaskHelper
+    training_step + backward, B=64 bf16, main + two side outputs (1/2, 1/4)."""
+    from nicr_mt_scene_analysis_amd.data.preprocessing import APPLIED_PREPROCESSING_KEY
+    from nicr_mt_scene_analysis_amd.model.postprocessing import get_postprocessing_class
+    from nicr_mt_scene_analysis_amd.task_helper import (InstanceTaskHelper, PanopticTaskHelper,
+                                                        SemanticTaskHelper)
+    from nicr_mt_scene_analysis_amd.task_helper.base import get_total_loss_key
+    from nicr_mt_scene_analysis_amd.loss import reset_speculation_state, speculation_stats
+    out = {}
+
+    def timed(fn, n, warm):
+        for i in range(warm):
+            fn(i)
+        torch.cuda.synchronize()
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            t1 = time.perf_counter()
+            torch.cuda.synchronize()
+            t2 = time.perf_counter()
+            if best is None or t2 - t0 < best[0]:
+                best = (t2 - t0, t1 - t0)
+        return best[0] / n * 1e3, best[1] / n * 1e3
+
+    B, C, H, W = 32, 40, 480, 640
+    inp = syn.make_panoptic_inputs_torch(B, C, H, W, device=dev, seed=1)
+    is_thing = tuple(bool(x) for x in inp['semantic_classes_is_thing'].cpu().tolist())
+    g = torch.Generator(device=dev).manual_seed(3)
+    batch = {'rgb_fullres': torch.zeros((B, 3, H, W)),
+             'semantic': torch.randint(0, C + 1, (B, H, W), device=dev, generator=g).to(torch.uint8),
+             'semantic_fullres': torch.randint(0, C + 1, (B, H, W), device=dev, generator=g).to(torch.uint8),
+             'panoptic_ids_to_instance_dict': [{} for _ in range(B)],
+             APPLIED_PREPROCESSING_KEY: [[{'type': 'Resize', 'valid_region_slice_y': slice(0, H),
+                                           'valid_region_slice_x': slice(0, W)}]] * B}
+    data = ((inp['semantic_logits'], (inp['instance_center'], inp['instance_offset'])), (None, None))
+
+    def make_post(defer):
+        return get_postprocessing_class('panoptic')(
+            semantic_postprocessing=get_postprocessing_class('semantic')(),
+            instance_postprocessing=get_postprocessing_class('instance')(),
+            semantic_classes_is_thing=is_thing, semantic_class_has_orientation=is_thing,
+            defer_host_sync=defer)
+    pan = make_post(False).postprocess(data, batch, is_training=False)['panoptic_segmentation_deeplab_fullres']
+    tgt = torch.roll(pan, shifts=(3, 3), dims=(1, 2)).contiguous()
+    tgt[:, :3] = 0
+    batch['panoptic_fullres'] = tgt
+    n_px = B * H * W
+    for defer in (False, True):
+        post = make_post(defer)
+        ms, host = timed(lambda i: post.postprocess(data, batch, is_training=False), 40, 5)
+        out['postprocess_deferred' if defer else 'postprocess'] = _leg(
+            ms, n_px, 4 * C + 21, host_issue_ms=round(host, 4),
+            what='PanopticPostprocessing.postprocess, B=32 640x480 C=40 f32'
+                 + (' (defer_host_sync=True)' if defer else ''))
+        ph = PanopticTaskHelper(C + 1, (False,) + is_thing)
+        sh = SemanticTaskHelper(n_classes=C, disable_multiscale_supervision=True)
+        ph.initialize(dev)
+        sh.initialize(dev)
+
+        def vstep(i):
+            r = post.postprocess(data, batch, is_training=False)
+            ph.validation_step(batch, i, r)
+            sh.validation_step(batch, i, r)
+        ms, host = timed(vstep, 30, 5)
+        out['validation_step_deferred' if defer else 'validation_step'] = _leg(
+            ms, n_px, 4 * C + 21 + 17 + 4 * C + 1 + 2, host_issue_ms=round(host, 4),
+            what='postprocess + PanopticTaskHelper.validation_step (PQ + mIoU) + '
+                 'SemanticTaskHelper.validation_step (CE + mIoU)')
+        ph.validation_epoch_end()
+        sh.validation_epoch_end()
+    del inp, data, batch, pan, tgt
+    torch.cuda.empty_cache()
+
+    # ---- training step through the task helpers, B=64 bf16, three supervision scales -------------
+    B = 64
+    dt = torch.bfloat16
+
+    def rnd(*shape, dtype=torch.float32):
+        return torch.randn(shape, device=dev, generator=g).to(dtype)
+    batch = {
+        'semantic': torch.randint(0, C + 1, (B, H, W), device=dev, generator=g).to(torch.uint8),
+        'instance_center': torch.rand((B, H, W), device=dev, generator=g),
+        'instance_center_mask': torch.rand((B, H, W), device=dev, generator=g) < 0.7,
+        'instance_offset': rnd(B, 2, H, W) * 0.1,
+        'instance_foreground': torch.rand((B, H, W), device=dev, generator=g) < 0.5,
+        'orientation': torch.nn.functional.normalize(rnd(B, 2, H, W), dim=1),
+        'orientation_foreground': torch.rand((B, H, W), device=dev, generator=g) < 0.3,
+    }
+    for sc in (2, 4):
+        batch[f'_down_{sc}'] = {k: v[..., ::sc, ::sc].contiguous() for k, v in batch.items()
+                               if isinstance(v, torch.Tensor)}
+    sem_main = rnd(B, C, H, W, dtype=dt).requires_grad_(True)
+    sem_side = tuple(rnd(B, C, H // sc, W // sc, dtype=dt).requires_grad_(True) for sc in (2, 4))
+
+    def inst(sc):
+        return tuple(t.requires_grad_(True) for t in (
+            rnd(B, 1, H // sc, W // sc, dtype=dt), rnd(B, 2, H // sc, W // sc, dtype=dt),
+            torch.nn.functional.normalize(rnd(B, 2, H // sc, W // sc), dim=1).to(dt)))
+    preds = {'semantic_output': sem_main, 'semantic_side_outputs': sem_side,
+             'instance_output': inst(1), 'instance_side_outputs': (inst(2), inst(4))}
+    sem = SemanticTaskHelper(n_classes=C, class_weights=torch.rand(C) + 0.5)
+    ins = InstanceTaskHelper(semantic_n_classes=C + 1, semantic_classes_is_thing=(False,) + is_thing)
+    sem.initialize(dev)
+    ins.initialize(dev)
+    leaves = [sem_main, *sem_side, *preds['instance_output'],
+              *(t for side in preds['instance_side_outputs'] for t in side)]
+    loss_weights = {'semantic': 1.0, 'instance_center': 2.0, 'instance_offset': 0.5,
+                    'instance_orientation': 1.0}                  # FixedLossWeighting-style constants
+
+    def tstep(i):
+        for t in leaves:
+            t.grad = None
+        ls, _ = sem.training_step(batch, i, preds)
+        li, _ = ins.training_step(batch, i, preds)
+        total = sum(wt * (ls if k == 'semantic' else li)[get_total_loss_key(k)]
+                    for k, wt in loss_weights.items())
+        total.backward()
+    reset_speculation_state()
+    s0 = speculation_stats()
+    ms, host = timed(tstep, 20, 4)
+    s1 = speculation_stats()
+    if os.environ.get('NMSA_BENCH_API_PROFILE'):                   # where the host's share goes (stderr)
+        import cProfile
+        import pstats
+        pr = cProfile.Profile()
+        pr.enable()
+        for i in range(10):
+            tstep(i)
+        pr.disable()
+        torch.cuda.synchronize()
+        pstats.Stats(pr, stream=sys.stderr).sort_stats('cumulative').print_stats(45)
+    scale_px = int(B * H * W * (1 + 1 / 4 + 1 / 16))
+    out['training_step'] = _leg(
+        ms, scale_px, 2 * C + 34 + 2 * C + 2 + 4 + 4, host_issue_ms=round(host, 4),
+        what='SemanticTaskHelper + InstanceTaskHelper training_step + backward, B=64 bf16, main + two '
+             'side outputs, loss weights (1, 2, 0.5, 1) never announced (no backward_scale)',
+        backward_totals={k: s1[k] - s0[k] for k in s1})
+    return out
+
+
 def secondary(ops, syn, dev):
     out = {}
     legs = (
@@ -462,12 +633,14 @@ def secondary(ops, syn, dev):
         ('cfg5_cos_emb_D512', lambda: secondary_cos_emb(dev, B=16, D=512)),
         ('cfg5_cos_emb_D768', lambda: secondary_cos_emb(dev, B=16, D=768)),
         ('next_rows', lambda: secondary_next_rows(ops, syn, dev)),
+        ('api', lambda: secondary_api(syn, dev)),
     )
     for name, fn in legs:
         try:
             out[name] = fn()
-        except Exception as e:                      # a failed leg must not lose the headline
+        except Exception as e:                      # a failed leg must not lose the headline ...
             out[name] = {'error': f'{type(e).__name__}: {e}'[:300]}
+            out['failed_legs'] = out.get('failed_legs', []) + [name]      # ... but it must show
         torch.cuda.empty_cache()
     return out
 
@@ -486,6 +659,8 @@ def main():
     from nicr_mt_scene_analysis_amd import ops
     from nicr_mt_scene_analysis_amd.testing import synthetic as syn
 
+    host_threads = host_threads_per_rank(world)
+    torch.set_num_threads(host_threads)          # intra-op pool of this rank (see launch_ranks)
     n_dev = torch.cuda.device_count()
     dev_index = local_rank % max(n_dev, 1)       # rehearsal: several ranks may share one GPU
     torch.cuda.set_device(dev_index)
@@ -632,6 +807,7 @@ def main():
         'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(ms_per_step, 4),
         # host time to queue one step (this rank): below ms_per_step = the GPU sets the pace
         'host_issue_ms_per_step': round(host_issue / args.steps * 1e3, 4),
+        'host_threads_per_rank': host_threads,
         'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': {torch.float32: 'f32', torch.bfloat16: 'bf16', torch.float16: 'f16'}[logits.dtype],
         'data': 'synthetic',
@@ -666,11 +842,16 @@ def main():
         torch.cuda.empty_cache()
         out['secondary'] = secondary(ops, syn, dev)
 
+    failed = bool(out.get('secondary', {}).get('failed_legs'))
+    if failed:
+        out['secondary_failed'] = out['secondary']['failed_legs']
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if failed:
+        sys.exit(3)                                 # the line above is complete; a leg raised
 
 
 if __name__ == '__main__':

@@ -555,16 +555,21 @@ int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
  *     loss weights, AMP scale, ... need no hint from the caller)
  *   computes all forward sums and writes all gradients for that expectation (launch 3: block
  *     ranges per item; cross entropies above 48 classes run k_ce_split as launches of their own)
- *   reduces the block partials per item in a fixed order                  (launch 4)
- * nmsa_multitask_loss_bwd_unless compares the real upstream gradients with the expectation on
- * the device (launch 1: one thread per total, also updates w) and recomputes only the items
- * that differ (launch 2: every other workgroup returns at once).
+ *   reduces the block partials per item in a fixed order and forms per item loss_sum / count
+ *     and per total sum(loss sums) / divisor (launch 4; the reductions of accumulate_losses, in
+ *     item order, float32)
+ * A call without any gradient buffer (validation) skips the count and takes the divisors from
+ * the finalized counts (3 launches).
+ * nmsa_multitask_loss_bwd_unless turns the upstream gradients of the three outputs into one
+ * upstream scale per item, compares it with the expectation on the device (launch 1: also
+ * updates w) and recomputes only the items that differ (launch 2: a small grid that walks the
+ * block list and is gone at once when every gradient stands).
  *   items        HOST array; pointers inside are device pointers.  kind NMSA_LOSS_*; CE: pred =
  *                logits [B,C,H,W], mask = labels u8 [B,H,W] (0 = void), weights f32 [C] or NULL,
  *                param = label smoothing; MSE / L1 / FOCAL: pred [B,C,H,W] (C = 1 for [B,H,W]),
  *                target f32, mask u8 [B,H,W] or NULL; VONMISES: pred / target [B,2,H,W], mask,
  *                param = kappa.  grad = gradient buffer shaped like pred, or NULL (forward only).
- *                clamp_count: the item's count enters its total as max(count, 1)
+ *                clamp_count: the item's count enters its loss and its total as max(count, 1)
  *                (task_helper/instance.py:206-211)
  *   spec         i32 [n_totals][8] device, persistent, owned by the caller (zero it, then store
  *                the fp32 bits of the initial upstream weight, usually 1.0f, at [t][2]):
@@ -573,6 +578,14 @@ int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
  *                divisor as float; must be handed to nmsa_multitask_loss_bwd_unless unchanged
  *   loss_sums    f64 [n_items], counts i64 [n_items], aux f64 [n_items] or NULL (CE: sum of the
  *                label weights, ce.py:57-68) — device
+ *   out_f32      f32 [2 n_items + n_totals] device or NULL: the loss sums as float32, then
+ *                item_loss[i] = float32(sum_i) / float32(count_i), then total_loss[t] =
+ *                (sum of the float32 sums of its items, in item order) / divisor_t
+ *   grad_sums / grad_item_losses / grad_total_losses   f32 [n_items] / [n_items] / [n_totals]
+ *                device or NULL: upstream gradients of the three parts of out_f32; item i's
+ *                upstream scale is grad_sums[i] + grad_item_losses[i] / count_i +
+ *                grad_total_losses[total_i] / divisor_t
+ *   grad_scales  f32 [n_items] device, scratch: receives those upstream scales
  *   counters     i32 [2] device or NULL: per total and backward pass, [0] += 1 when the expectation
  *                held, [1] += 1 when it did not (a tally over all callers; the spec records keep
  *                their own)
@@ -595,10 +608,12 @@ typedef struct nmsa_loss_item {
 size_t nmsa_multitask_loss_workspace_bytes(const nmsa_loss_item* items_host, int n_items);
 int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items_host, int n_items, int n_totals,
                                  int32_t* spec, float* expect, double* loss_sums, int64_t* counts,
-                                 double* aux, int32_t* status, void* workspace,
+                                 double* aux, float* out_f32, int32_t* status, void* workspace,
                                  size_t workspace_bytes, nmsa_stream_t stream);
 int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items_host, int n_items, int n_totals,
-                                   const float* grad_scales, const float* expect, int32_t* spec,
+                                   const float* grad_sums, const float* grad_item_losses,
+                                   const float* grad_total_losses, const int64_t* counts,
+                                   const float* expect, int32_t* spec, float* grad_scales,
                                    int32_t* counters, nmsa_stream_t stream);
 
 #ifdef __cplusplus

@@ -543,7 +543,7 @@ __device__ __forceinline__ void ce_fused_body(
     __syncthreads();
     float wsum = 0.f;
     if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    const bool write_grad = g == g;
+    const bool write_grad = g == g && grad != nullptr;
     const size_t img = (size_t)b * C * P;
     double acc = 0.0, accw = 0.0;
     long long cnt = 0;
@@ -593,22 +593,33 @@ __device__ __forceinline__ void ce_fused_body(
             abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
         }
         if (DTYPE != NMSA_F32) keep_packed(r);
+        if (write_grad) {
 #pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            if (c < C) {
-                float o[PXT];
-                const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
+            for (int c = 0; c < NP; ++c) {
+                if (c < C) {
+                    float o[PXT];
+                    const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
 #pragma unroll
-                for (int j = 0; j < PXT; ++j) {
-                    const float x = plane_px<DTYPE>(r[c], j);
-                    const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
-                    float q = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
-                    const bool hit = t[j] == c;
-                    q -= hit ? ag[j] : 0.f;
-                    xt[j] = hit ? x : xt[j];
-                    o[j] = q;
+                    for (int j = 0; j < PXT; ++j) {
+                        const float x = plane_px<DTYPE>(r[c], j);
+                        const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                        float q = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
+                        const bool hit = t[j] == c;
+                        q -= hit ? ag[j] : 0.f;
+                        xt[j] = hit ? x : xt[j];
+                        o[j] = q;
+                    }
+                    st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
                 }
-                if (write_grad) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
+            }
+        } else if (LOSS) {
+            // forward only (no expectation / no gradient wanted): just the target logit
+#pragma unroll
+            for (int c = 0; c < NP; ++c) {
+                if (c < C) {
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) xt[j] = (t[j] == c) ? plane_px<DTYPE>(r[c], j) : xt[j];
+                }
             }
         }
         float part = 0.f, partw = 0.f;
@@ -642,7 +653,8 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
 {
     extern __shared__ float s_w[];
     if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
-    ce_fused_body<DTYPE, NG, SMOOTH, LOSS>(logits, target, weights, C, P, ls, vec, *expected_gscale, grad,
+    ce_fused_body<DTYPE, NG, SMOOTH, LOSS>(logits, target, weights, C, P, ls, vec,
+                                           grad ? *expected_gscale : __int_as_float(0x7fc00000), grad,
                                            partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, status,
                                            s_w, blockIdx.x, blockIdx.y);
 }
@@ -679,7 +691,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
     __syncthreads();
     float wsum = 0.f;
     if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    const float g = *expected_gscale;
+    // (no gradient buffer: forward only; a NaN expectation writes no gradient either)
+    const float g = grad ? *expected_gscale : __int_as_float(0x7fc00000);
+    const bool write_grad = g == g && grad != nullptr;
     const int b = blockIdx.y;
     const size_t img = (size_t)b * C * P;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();
@@ -766,23 +780,34 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
         abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
     }
     if (DTYPE != NMSA_F32) keep_packed(r);
+    if (write_grad) {
 #pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        if (i < nc) {
-            const int c = c0 + i;
-            float o[PXT];
-            const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
+        for (int i = 0; i < NP; ++i) {
+            if (i < nc) {
+                const int c = c0 + i;
+                float o[PXT];
+                const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
 #pragma unroll
-            for (int j = 0; j < PXT; ++j) {
-                const float x = plane_px<DTYPE>(r[i], j);
-                const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
-                float qv = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
-                const bool hit = t[j] == c;
-                qv -= hit ? ag[j] : 0.f;
-                xt[j] = hit ? x : xt[j];
-                o[j] = qv;
+                for (int j = 0; j < PXT; ++j) {
+                    const float x = plane_px<DTYPE>(r[i], j);
+                    const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                    float qv = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
+                    const bool hit = t[j] == c;
+                    qv -= hit ? ag[j] : 0.f;
+                    xt[j] = hit ? x : xt[j];
+                    o[j] = qv;
+                }
+                if (alive) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
             }
-            if (alive) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
+        }
+    } else if (LOSS) {
+        // forward only (no expectation / no gradient wanted): just the target logit
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            if (i < nc) {
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) xt[j] = (t[j] == c0 + i) ? plane_px<DTYPE>(r[i], j) : xt[j];
+            }
         }
     }
     if (LOSS) {
@@ -978,7 +1003,7 @@ __device__ __forceinline__ void elem_fused_body(
     double acc = 0.0; long long cnt = 0;
     const float invC = 1.0f / C;
     const float g = gs / C;
-    const bool write_grad = gs == gs;
+    const bool write_grad = gs == gs && grad != nullptr;
     for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
         const int nvalid = min(4, P - p0);
         bool mk[4];
@@ -1092,7 +1117,7 @@ __device__ __forceinline__ void vm_fused_body(
     int P, float kappa, int vec, float g, void* __restrict__ grad, LossPartial* __restrict__ slot,
     int bx, int nbx, int b)
 {
-    const bool write_grad = g == g;
+    const bool write_grad = g == g && grad != nullptr;
     double acc = 0.0; long long cnt = 0;
     for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
         const int nvalid = min(4, P - p0);
@@ -1407,7 +1432,7 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
 // =================================================================================
 constexpr int MULTI_MAX_ITEMS = NMSA_MULTI_MAX_ITEMS;
 constexpr int MULTI_MAX_TOTALS = NMSA_MULTI_MAX_TOTALS;
-constexpr int MULTI_COUNT_MAX_BLOCKS = 64;             // per item
+constexpr int MULTI_COUNT_MAX_BLOCKS = 256;            // per item
 
 struct MultiItem {
     const void* pred; const void* target; const uint8_t* mask; const float* weights; void* grad;
@@ -1438,17 +1463,25 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long 
     const bool vec = (((uintptr_t)v) & 15) == 0;
     long long cnt = 0;
     long long k = begin + (long long)threadIdx.x * 16;
+    auto count16 = [&](const u32x4_s w) {
+        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
+        int c = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) c += ((((ww[q] >> (8 * j)) & 0xFF) - lo) <= span);
+        return c;
+    };
     if (vec) {
-        for (; k + 16 <= end; k += LOSS_THREADS * 16) {
-            const u32x4_s w = __builtin_nontemporal_load((const u32x4_s*)(v + k));
-            const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-            int c = 0;
+        constexpr long long STEP = LOSS_THREADS * 16;
+        for (; k + 3 * STEP + 16 <= end; k += 4 * STEP) {          // 4 x 16 B in flight per lane
+            u32x4_s w[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
+            for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load((const u32x4_s*)(v + k + u * STEP));
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c += ((((ww[q] >> (8 * j)) & 0xFF) - lo) <= span);
-            cnt += c;
+            for (int u = 0; u < 4; ++u) cnt += count16(w[u]);
         }
+        for (; k + 16 <= end; k += STEP) cnt += count16(__builtin_nontemporal_load((const u32x4_s*)(v + k)));
     }
     for (; k < end; k += LOSS_THREADS * 16)
         for (long long j = k; j < min(end, k + 16); ++j) cnt += (((unsigned)v[j] - lo) <= span);
@@ -1463,16 +1496,32 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long 
     }
 }
 
+// divisor of total t from per-item counts (accumulate_losses: max(sum of counts, 1) as float32;
+// an item with clamp enters as max(count, 1), task_helper/instance.py:206-211)
+__device__ inline float multi_divisor(const MultiArgs& a, const long long* counts, int t)
+{
+    long long n = 0;
+    for (int i = 0; i < a.n_items; ++i)
+        if (a.it[i].total == t) n += a.it[i].clamp ? max(counts[i], 1LL) : counts[i];
+    return (float)max(n, 1LL);
+}
+
+// always the first launch of a call.  With count partials: divisor + expected upstream gradient
+// per total.  Without (forward-only call, nobody needs them before the sums): no expectation,
+// the divisors are filled in by k_multi_finalize from the finalized counts.  Also zeroes the
+// ticket k_multi_finalize's workgroups draw to find out which of them is the last.
 __global__ __launch_bounds__(LOSS_THREADS) void k_multi_expect(MultiArgs a, const long long* __restrict__ partials,
                                                                const int32_t* __restrict__ spec,
-                                                               float* __restrict__ expect)
+                                                               float* __restrict__ expect,
+                                                               unsigned int* __restrict__ ticket)
 {
     __shared__ long long s_count[MULTI_MAX_ITEMS];
+    if (threadIdx.x == 0) *ticket = 0u;
     const int w = threadIdx.x >> 6, l = lane_id();
     for (int i = w; i < a.n_items; i += LOSS_THREADS / 64) {
         const MultiItem& it = a.it[i];
         long long c = 0;
-        if (it.count_mode == 1) { for (int k = l; k < it.cnblocks; k += 64) c += partials[it.cblock0 + k]; }
+        if (it.count_mode == 1 && partials) { for (int k = l; k < it.cnblocks; k += 64) c += partials[it.cblock0 + k]; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
         if (l == 0) s_count[i] = it.count_mode == 1 ? c : (long long)it.B * it.P;
@@ -1480,19 +1529,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_expect(MultiArgs a, cons
     __syncthreads();
     if ((int)threadIdx.x < a.n_totals) {
         const int t = threadIdx.x;
-        long long n = 0;
-        bool known = true;
-        for (int i = 0; i < a.n_items; ++i) {
-            if (a.it[i].total != t) continue;
-            if (a.it[i].count_mode == 2) known = false;                 // the divisor is not a count of the targets
-            n += a.it[i].clamp ? max(s_count[i], 1LL) : s_count[i];
-        }
-        // accumulate_losses: loss_sum / max(count, 1) as float32
-        const float nf = (float)max(n, 1LL);
+        bool known = partials != nullptr;
+        for (int i = 0; i < a.n_items; ++i)
+            if (a.it[i].total == t && a.it[i].count_mode == 2) known = false;   // the divisor is no count of mask bytes
+        const float nf = multi_divisor(a, s_count, t);
         const float wv = __int_as_float(spec[8 * t + 2]);
         const bool off = (spec[8 * t + 5] & 1) || !known;
         expect[2 * t] = off ? __int_as_float(0x7fc00000) : wv / nf;     // NaN: the forward writes no gradient
-        expect[2 * t + 1] = nf;
+        expect[2 * t + 1] = nf;                                         // (!known: k_multi_finalize corrects it)
     }
 }
 
@@ -1513,16 +1557,31 @@ __device__ inline float spec_estimate_w(float g, float n, float g_prev, float n_
     return best;
 }
 
-__global__ void k_multi_spec(MultiArgs a, const float* __restrict__ gs, const float* __restrict__ expect,
-                             int32_t* __restrict__ spec, int32_t* __restrict__ counters)
+__global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, const float* __restrict__ grad_items,
+                             const float* __restrict__ grad_totals, const long long* __restrict__ counts,
+                             const float* __restrict__ expect, int32_t* __restrict__ spec,
+                             float* __restrict__ gs, int32_t* __restrict__ counters)
 {
+    // upstream scale of item i's raw loss sum from the gradients of the three outputs (what
+    // autograd's division backward gives: grad / divisor, float32)
+    const int n = a.n_items;
+    if ((int)threadIdx.x < n) {
+        const int i = threadIdx.x;
+        const MultiItem& it = a.it[i];
+        float g = grad_sums ? grad_sums[i] : 0.f;
+        const float gi = grad_items ? grad_items[i] : 0.f, gt = grad_totals ? grad_totals[it.total] : 0.f;
+        if (gi != 0.f) g += gi / (float)(it.clamp ? max(counts[i], 1LL) : counts[i]);
+        if (gt != 0.f) g += gt / expect[2 * it.total + 1];
+        gs[i] = g;
+    }
+    __syncthreads();
     const int t = threadIdx.x;
     if (t >= a.n_totals) return;
     int first = -1;
     for (int i = 0; i < a.n_items; ++i) if (a.it[i].total == t && a.it[i].grad && first < 0) first = i;
     if (first < 0) return;
     int32_t* r = spec + 8 * t;
-    const float g = gs[first], e = expect[2 * t], n = expect[2 * t + 1];
+    const float g = gs[first], e = expect[2 * t], nf = expect[2 * t + 1];
     const float g_prev = __int_as_float(r[3]), n_prev = __int_as_float(r[4]);
     const bool same = __float_as_int(g) == __float_as_int(e);
     if (counters) atomicAdd(&counters[same ? 0 : 1], 1);       // per-device tally (statistics only)
@@ -1530,7 +1589,7 @@ __global__ void k_multi_spec(MultiArgs a, const float* __restrict__ gs, const fl
     else {
         r[1] += 1;
         const float w_old = __int_as_float(r[2]);
-        const float w_new = (g == g && g != 0.f) ? spec_estimate_w(g, n, g_prev, n_prev) : w_old;
+        const float w_new = (g == g && g != 0.f) ? spec_estimate_w(g, nf, g_prev, n_prev) : w_old;
         if (r[5] & 1) {
             // switched off: back on once the estimate has been stable for a few steps
             r[7] = (__float_as_int(w_new) == __float_as_int(w_old)) ? r[7] + 1 : 0;
@@ -1542,7 +1601,7 @@ __global__ void k_multi_spec(MultiArgs a, const float* __restrict__ gs, const fl
         r[2] = __float_as_int(w_new);
     }
     r[3] = __float_as_int(g);
-    r[4] = __float_as_int(n);
+    r[4] = __float_as_int(nf);
 }
 
 // all items of one call: block ranges [block0, block0 + nbx * B) per item.  CE_* select the ONE
@@ -1554,68 +1613,97 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_loss(
     LossPartial* __restrict__ partials, int* __restrict__ status)
 {
     extern __shared__ float s_w[];
-    int i = 0;
-    while (i + 1 < a.n_items && (!a.it[i].in_launch || (int)blockIdx.x >= a.it[i].block0 + a.it[i].nbx * a.it[i].B)) ++i;
-    const MultiItem& it = a.it[i];
-    const int local = blockIdx.x - it.block0;
-    if (!it.in_launch || local < 0) return;
-    const int bx = local % it.nbx, b = local / it.nbx;
-    float g = expect[2 * it.total];
-    if (!it.grad) g = __int_as_float(0x7fc00000);
     if (!LOSS) {
-        if (!it.grad) return;
-        const float gr = gs[i];
-        if (__float_as_int(gr) == __float_as_int(g)) return;           // the forward's gradient stands
-        g = gr;
+        // the recomputing launch is a small grid walking the block list: when every item's
+        // gradient stands (the usual case) its workgroups are gone after this check
+        bool any = false;
+        for (int i = 0; i < a.n_items; ++i) {
+            const MultiItem& it = a.it[i];
+            any = any || (it.in_launch && it.grad &&
+                          __float_as_int(gs[i]) != __float_as_int(expect[2 * it.total]));
+        }
+        if (!any) return;
     }
-    LossPartial* slot = partials ? partials + blockIdx.x : nullptr;
+    for (int blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {     // LOSS: exactly one pass
+        int i = 0;
+        while (i + 1 < a.n_items && (!a.it[i].in_launch || blk >= a.it[i].block0 + a.it[i].nbx * a.it[i].B)) ++i;
+        const MultiItem& it = a.it[i];
+        const int local = blk - it.block0;
+        if (!it.in_launch || local < 0) continue;
+        const int bx = local % it.nbx, b = local / it.nbx;
+        float g = __int_as_float(0x7fc00000);              // NaN: no gradient wanted / no expectation
+        if (it.grad && expect) g = expect[2 * it.total];
+        if (!LOSS) {
+            if (!it.grad) continue;
+            const float gr = gs[i];
+            if (__float_as_int(gr) == __float_as_int(g)) continue;         // the forward's gradient stands
+            g = gr;
+        }
+        LossPartial* slot = partials ? partials + blk : nullptr;
 #define MULTI_DT(CALL) switch (it.dtype) { case NMSA_F32: CALL(NMSA_F32); break; case NMSA_BF16: CALL(NMSA_BF16); break; \
                                             default: CALL(NMSA_F16); break; }
-    switch (it.kind) {
-        case NMSA_LOSS_CE:
-            if constexpr (CE_NG != 0)
-                ce_fused_body<CE_DT, CE_NG, CE_SM, LOSS>(it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P,
-                                                         it.param, it.vec, g, it.grad, slot, status, s_w, bx, b);
-            break;
-        case NMSA_LOSS_MSE:
+        switch (it.kind) {
+            case NMSA_LOSS_CE:
+                if constexpr (CE_NG != 0)
+                    ce_fused_body<CE_DT, CE_NG, CE_SM, LOSS>(it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P,
+                                                             it.param, it.vec, g, it.grad, slot, status, s_w, bx, b);
+                break;
+            case NMSA_LOSS_MSE:
 #define CALL(DT) elem_fused_body<DT, 0, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
-            MULTI_DT(CALL)
+                MULTI_DT(CALL)
 #undef CALL
-            break;
-        case NMSA_LOSS_L1:
+                break;
+            case NMSA_LOSS_L1:
 #define CALL(DT) elem_fused_body<DT, 1, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
-            MULTI_DT(CALL)
+                MULTI_DT(CALL)
 #undef CALL
-            break;
-        case NMSA_LOSS_FOCAL:
+                break;
+            case NMSA_LOSS_FOCAL:
 #define CALL(DT) elem_fused_body<DT, 2, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
-            MULTI_DT(CALL)
+                MULTI_DT(CALL)
 #undef CALL
-            break;
-        default:
+                break;
+            default:
 #define CALL(DT) vm_fused_body<DT, LOSS>(it.pred, (const float*)it.target, it.mask, it.P, it.param, it.vec, g, it.grad, slot, bx, it.nbx, b)
-            MULTI_DT(CALL)
+                MULTI_DT(CALL)
 #undef CALL
-            break;
-    }
+                break;
+        }
 #undef MULTI_DT
+        if (!LOSS) __syncthreads();                        // s_w is rewritten by the next block of the walk
+    }
 }
 
-// one workgroup per item: its block partials in a fixed order
-__global__ __launch_bounds__(FIN_THREADS) void k_multi_finalize(
-    MultiArgs a, const LossPartial* __restrict__ partials, double* __restrict__ sums,
-    long long* __restrict__ counts, double* __restrict__ aux)
+// MULTI_FIN_SPLIT workgroups per item reduce slices of its block partials (fixed order); the LAST
+// workgroup of the launch to finish (ticket) adds the slices per item, again in a fixed order, and
+// forms the outputs: sums / counts / aux per item; divisors of totals k_multi_expect could not
+// know (forward-only calls, focal items: counts that only the loss kernels produce); and
+// out[0 .. n): the sums as float32, [n .. 2n): sum / count per item, [2n .. 2n + T): per total the
+// float32 sums of its items added in item order, divided by the total's divisor
+// (accumulate_losses, task_helper/base.py:161-182)
+constexpr int MULTI_FIN_SPLIT = 8;
+constexpr int MULTI_FIN_THREADS = 256;
+
+__global__ __launch_bounds__(MULTI_FIN_THREADS) void k_multi_finalize(
+    MultiArgs a, const LossPartial* __restrict__ partials, LossPartial* __restrict__ slices,
+    unsigned int* __restrict__ ticket, int late_divisors, double* __restrict__ sums,
+    long long* __restrict__ counts, double* __restrict__ aux, float* __restrict__ expect,
+    float* __restrict__ out)
 {
-    __shared__ double s_sum[FIN_THREADS], s_aux[FIN_THREADS];
-    __shared__ long long s_cnt[FIN_THREADS];
-    const MultiItem& it = a.it[blockIdx.x];
+    __shared__ double s_sum[MULTI_FIN_THREADS], s_aux[MULTI_FIN_THREADS];
+    __shared__ long long s_cnt[MULTI_FIN_THREADS];
+    __shared__ bool s_last;
+    const int item = blockIdx.x / MULTI_FIN_SPLIT, sl = blockIdx.x % MULTI_FIN_SPLIT;
+    const MultiItem& it = a.it[item];
     const LossPartial* p = partials + it.block0;
     const int n = it.nbx * it.B;
+    const int per = (n + MULTI_FIN_SPLIT - 1) / MULTI_FIN_SPLIT;
+    const int begin = min(n, sl * per), end = min(n, begin + per);
     double x = 0, y = 0; long long c = 0;
-    for (int k = threadIdx.x; k < n; k += FIN_THREADS) { x += p[k].sum; y += p[k].aux; c += p[k].count; }
+    for (int k = begin + threadIdx.x; k < end; k += MULTI_FIN_THREADS) { x += p[k].sum; y += p[k].aux; c += p[k].count; }
     s_sum[threadIdx.x] = x; s_aux[threadIdx.x] = y; s_cnt[threadIdx.x] = c;
     __syncthreads();
-    for (int o = FIN_THREADS / 2; o > 0; o >>= 1) {
+    for (int o = MULTI_FIN_THREADS / 2; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) {
             s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
             s_aux[threadIdx.x] += s_aux[threadIdx.x + o];
@@ -1623,7 +1711,46 @@ __global__ __launch_bounds__(FIN_THREADS) void k_multi_finalize(
         }
         __syncthreads();
     }
-    if (threadIdx.x == 0) { sums[blockIdx.x] = s_sum[0]; counts[blockIdx.x] = s_cnt[0]; if (aux) aux[blockIdx.x] = s_aux[0]; }
+    if (threadIdx.x == 0) {
+        LossPartial r; r.sum = s_sum[0]; r.aux = s_aux[0]; r.count = s_cnt[0]; r.pad = 0;
+        slices[blockIdx.x] = r;
+        __threadfence();                                   // the slice before the ticket
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+    }
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();                                       // the other workgroups' slices after the ticket
+    __shared__ long long s_count[MULTI_MAX_ITEMS];
+    __shared__ float s_f[MULTI_MAX_ITEMS];
+    const int ni = a.n_items, t = threadIdx.x;
+    if (t < ni) {
+        double sx = 0, sy = 0; long long sc = 0;
+        for (int k = 0; k < MULTI_FIN_SPLIT; ++k) {
+            const volatile LossPartial* q = slices + t * MULTI_FIN_SPLIT + k;
+            sx += q->sum; sy += q->aux; sc += q->count;
+        }
+        sums[t] = sx; counts[t] = sc;
+        if (aux) aux[t] = sy;
+        s_count[t] = sc;
+        s_f[t] = (float)sx;
+        if (out) {
+            const long long cc = a.it[t].clamp ? max(sc, 1LL) : sc;
+            out[t] = (float)sx;
+            out[ni + t] = (float)sx / (float)cc;
+        }
+    }
+    __syncthreads();
+    if (t < a.n_totals) {
+        bool known = !late_divisors;
+        for (int i = 0; i < ni; ++i) if (a.it[i].total == t && a.it[i].count_mode == 2) known = false;
+        float nf = expect[2 * t + 1];
+        if (!known) { nf = multi_divisor(a, s_count, t); expect[2 * t + 1] = nf; }
+        if (out) {
+            float acc = 0.f;
+            for (int i = 0; i < ni; ++i) if (a.it[i].total == t) acc += s_f[i];
+            out[2 * ni + t] = acc / nf;
+        }
+    }
 }
 
 }  // namespace nmsa
@@ -2398,7 +2525,9 @@ int multi_launch_joint(const MultiPlan& pl, const float* expect, const float* gs
 {
     const MultiArgs& a = pl.args;
     if (a.n_blocks <= 0) return NMSA_OK;
-#define ML(DT, NG, SM) hipLaunchKernelGGL((k_multi_loss<DT, NG, SM, LOSS>), dim3(a.n_blocks), dim3(LOSS_THREADS), \
+    // (the recomputing launch: a small grid that walks the block list, see k_multi_loss)
+    const int grid = LOSS ? a.n_blocks : (a.n_blocks < 4096 ? a.n_blocks : 4096);
+#define ML(DT, NG, SM) hipLaunchKernelGGL((k_multi_loss<DT, NG, SM, LOSS>), dim3(grid), dim3(LOSS_THREADS), \
         pl.lds, stream, a, expect, gs, partials, status)
 #define ML_NG(DT, SM) do { if (pl.ce_ng == 3) ML(DT, 3, SM); else if (pl.ce_ng == 5) ML(DT, 5, SM); else ML(DT, 6, SM); } while (0)
 #define ML_DT(DT) do { if (pl.ce_sm) ML_NG(DT, true); else ML_NG(DT, false); } while (0)
@@ -2416,6 +2545,14 @@ int multi_launch_joint(const MultiPlan& pl, const float* expect, const float* gs
 
 }  // namespace
 
+namespace {
+size_t multi_workspace_bytes(const MultiPlan& pl)
+{
+    return (multi_partial_blocks(pl) + (size_t)MULTI_MAX_ITEMS * MULTI_FIN_SPLIT) * sizeof(LossPartial) +
+           (size_t)pl.n_count_blocks * sizeof(long long) + 64;
+}
+}  // namespace
+
 extern "C" size_t nmsa_multitask_loss_workspace_bytes(const nmsa_loss_item* items, int n_items)
 {
     MultiPlan pl;
@@ -2423,12 +2560,12 @@ extern "C" size_t nmsa_multitask_loss_workspace_bytes(const nmsa_loss_item* item
     if (!items) return 0;
     for (int i = 0; i < n_items && i < MULTI_MAX_ITEMS; ++i) if (items[i].total + 1 > nt) nt = items[i].total + 1;
     if (nt > MULTI_MAX_TOTALS || multi_plan(items, n_items, nt, pl)) return 0;
-    return multi_partial_blocks(pl) * sizeof(LossPartial) + (size_t)pl.n_count_blocks * sizeof(long long) + 64;
+    return multi_workspace_bytes(pl);
 }
 
 extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_items, int n_totals,
                                             int32_t* spec, float* expect, double* loss_sums,
-                                            int64_t* counts, double* aux, int32_t* status,
+                                            int64_t* counts, double* aux, float* out_f32, int32_t* status,
                                             void* workspace, size_t workspace_bytes, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
@@ -2437,14 +2574,23 @@ extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_i
     int rc = multi_plan(items, n_items, n_totals, pl);
     if (rc) return rc;
     const size_t nb = multi_partial_blocks(pl);
-    if (workspace_bytes < nb * sizeof(LossPartial) + (size_t)pl.n_count_blocks * sizeof(long long)) return NMSA_ERR_WORKSPACE;
+    if (workspace_bytes < multi_workspace_bytes(pl)) return NMSA_ERR_WORKSPACE;
     LossPartial* partials = (LossPartial*)workspace;
-    long long* cpart = (long long*)(partials + nb);
+    LossPartial* slices = partials + nb;
+    long long* cpart = (long long*)(slices + (size_t)MULTI_MAX_ITEMS * MULTI_FIN_SPLIT);
+    unsigned int* ticket = (unsigned int*)(cpart + pl.n_count_blocks);
     const MultiArgs& a = pl.args;
-    hipLaunchKernelGGL(k_multi_count, dim3(pl.n_count_blocks), dim3(LOSS_THREADS), 0, stream, a, cpart);
-    rc = check_launch();
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_multi_expect, dim3(1), dim3(LOSS_THREADS), 0, stream, a, cpart, spec, expect);
+    bool any_grad = false;
+    for (int i = 0; i < n_items; ++i) any_grad = any_grad || a.it[i].grad != nullptr;
+    // (forward only: nobody needs a count before the sums; k_multi_expect then only marks "no
+    // expectation" and the divisors come out of the finalized counts)
+    if (any_grad) {
+        hipLaunchKernelGGL(k_multi_count, dim3(pl.n_count_blocks), dim3(LOSS_THREADS), 0, stream, a, cpart);
+        rc = check_launch();
+        if (rc) return rc;
+    }
+    hipLaunchKernelGGL(k_multi_expect, dim3(1), dim3(LOSS_THREADS), 0, stream, a,
+                       any_grad ? (const long long*)cpart : (const long long*)nullptr, spec, expect, ticket);
     rc = check_launch();
     if (rc) return rc;
     rc = multi_launch_joint<true>(pl, expect, nullptr, partials, status, stream);
@@ -2464,22 +2610,26 @@ extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_i
         }
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_multi_finalize, dim3(n_items), dim3(FIN_THREADS), 0, stream, a, partials, loss_sums,
-                       (long long*)counts, aux);
+    hipLaunchKernelGGL(k_multi_finalize, dim3(n_items * MULTI_FIN_SPLIT), dim3(MULTI_FIN_THREADS), 0, stream, a,
+                       partials, slices, ticket, any_grad ? 0 : 1, loss_sums, (long long*)counts, aux, expect,
+                       out_f32);
     return check_launch();
 }
 
 extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n_items, int n_totals,
-                                              const float* grad_scales, const float* expect,
-                                              int32_t* spec, int32_t* counters, nmsa_stream_t stream_)
+                                              const float* grad_sums, const float* grad_item_losses,
+                                              const float* grad_total_losses, const int64_t* counts,
+                                              const float* expect, int32_t* spec, float* grad_scales,
+                                              int32_t* counters, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!grad_scales || !expect || !spec) return NMSA_ERR_ARG;
+    if (!counts || !grad_scales || !expect || !spec) return NMSA_ERR_ARG;
     MultiPlan pl;
     int rc = multi_plan(items, n_items, n_totals, pl);
     if (rc) return rc;
     const MultiArgs& a = pl.args;
-    hipLaunchKernelGGL(k_multi_spec, dim3(1), dim3(64), 0, stream, a, grad_scales, expect, spec, counters);
+    hipLaunchKernelGGL(k_multi_spec, dim3(1), dim3(64), 0, stream, a, grad_sums, grad_item_losses,
+                       grad_total_losses, (const long long*)counts, expect, spec, grad_scales, counters);
     rc = check_launch();
     if (rc) return rc;
     rc = multi_launch_joint<false>(pl, expect, grad_scales, nullptr, nullptr, stream);

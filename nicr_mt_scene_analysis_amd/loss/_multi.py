@@ -111,16 +111,20 @@ def _u8(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
 
 
 class MultiLossFunction(torch.autograd.Function):
-    """apply(desc, *preds) -> (sum_0, ..., sum_{n-1}) as fp32 0-d tensors; counts / aux on `desc`"""
+    """apply(desc, *preds) -> (sums [n], item_losses [n], total_losses [T]) float32: the loss sums,
+    sum / count per item and sum(sums) / divisor per total (csrc k_multi_finalize), three views
+    of one vector; counts / aux / divisors are left on `desc`"""
 
     @staticmethod
     def forward(ctx, desc, *preds):
         items, n_totals, spec = desc['items'], desc['n_totals'], desc['spec']
         dev = preds[0].device
         n = len(items)
+        want_grad = desc.get('grad_enabled', True)
         arr = (_Item * n)()
         keep = []
         grads: List[Optional[torch.Tensor]] = []
+        from ._functional import _status_word, labels_u8
         for i, (it, x) in enumerate(zip(items, preds)):
             x = L.require_device_tensor(x, 'input_')
             kind = it['kind']
@@ -136,16 +140,15 @@ class MultiLossFunction(torch.autograd.Function):
             a.param = float(it.get('param', 0.0))
             tgt, msk, wts = it.get('target'), it.get('mask'), it.get('weights')
             if kind == 'ce':
-                from ._functional import labels_u8
                 msk = labels_u8(msk, dev)
                 tgt = None
                 wts = None if wts is None else wts.to(dev, torch.float32).contiguous()
             else:
                 tgt = tgt.to(dev, torch.float32).contiguous()
                 msk = _u8(msk, dev)
-            # (grad mode is off inside forward(): needs_input_grad is what says whether autograd
-            # is going to ask for this gradient)
-            g = torch.empty_like(x) if ctx.needs_input_grad[i + 1] else None
+            # (grad mode is always off inside forward(): desc['grad_enabled'] is the caller's grad
+            # mode, needs_input_grad says which inputs autograd is going to ask a gradient for)
+            g = torch.empty_like(x) if want_grad and ctx.needs_input_grad[i + 1] else None
             a.pred, a.target = x.data_ptr(), (tgt.data_ptr() if tgt is not None else None)
             a.mask = msk.data_ptr() if msk is not None else None
             a.weights = wts.data_ptr() if wts is not None else None
@@ -153,11 +156,11 @@ class MultiLossFunction(torch.autograd.Function):
             keep.append((x, tgt, msk, wts))
             grads.append(g)
         rec = spec.records(dev)
+        # one allocation for the small outputs: sums f64 [n] | aux f64 [n] | counts i64 [n]
+        small = torch.empty((3 * n,), dtype=torch.float64, device=dev)
+        sums, aux, counts = small[:n], small[n:2 * n], small[2 * n:].view(torch.int64)
         expect = torch.empty((n_totals, 2), dtype=torch.float32, device=dev)
-        sums = torch.empty((n,), dtype=torch.float64, device=dev)
-        counts = torch.empty((n,), dtype=torch.int64, device=dev)
-        aux = torch.empty((n,), dtype=torch.float64, device=dev)
-        from ._functional import _status_word
+        out = torch.empty((2 * n + n_totals,), dtype=torch.float32, device=dev)
         status = _status_word(dev)
         lib = L.lib()
         nbytes = lib.nmsa_multitask_loss_workspace_bytes(arr, n)
@@ -165,38 +168,50 @@ class MultiLossFunction(torch.autograd.Function):
             raise L.NmsaError('nmsa_multitask_loss_workspace_bytes: invalid items')
         ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
         L.check(lib.nmsa_multitask_loss_fwd_grad(arr, n, n_totals, L.ptr(rec), L.ptr(expect), L.ptr(sums),
-                                                 L.ptr(counts), L.ptr(aux), L.ptr(status), L.ptr(ws),
-                                                 nbytes, L.stream_ptr(dev)), 'nmsa_multitask_loss_fwd_grad')
+                                                 L.ptr(counts), L.ptr(aux), L.ptr(out), L.ptr(status),
+                                                 L.ptr(ws), nbytes, L.stream_ptr(dev)),
+                'nmsa_multitask_loss_fwd_grad')
         ctx.arr, ctx.keep, ctx.grads = arr, keep, grads
-        ctx.n_totals, ctx.rec, ctx.expect = n_totals, rec, expect
-        desc['counts'], desc['aux'], desc['divisors'] = counts, aux, expect[:, 1]
-        return tuple(sums.to(torch.float32).unbind(0))
+        ctx.n_totals, ctx.rec, ctx.expect, ctx.counts = n_totals, rec, expect, counts
+        desc['counts'], desc['aux'], desc['divisors'], desc['packed'] = counts, aux, expect[:, 1], out
+        return out[:n], out[n:2 * n], out[2 * n:]
 
     @staticmethod
-    def backward(ctx, *g):
+    def backward(ctx, g_sums, g_items, g_totals):
         dev = ctx.expect.device
-        n = len(ctx.grads)
-        zero = None
-        parts = []
-        for gi in g:
-            if gi is None:
-                if zero is None:
-                    zero = torch.zeros((), dtype=torch.float32, device=dev)
-                gi = zero
-            parts.append(gi.detach().to(torch.float32).reshape(()))
-        gs = torch.stack(parts).contiguous()
+        # (dropping the context's reference lets autograd take the buffers as .grad instead of
+        # cloning them: a logits-sized copy per prediction otherwise)
+        grads, ctx.grads = ctx.grads, None
+        if grads is None:
+            raise RuntimeError('the multi-loss graph was already used for a backward pass')
+        n = len(grads)
+        up = [None if g is None else g.detach().to(torch.float32).contiguous()
+              for g in (g_sums, g_items, g_totals)]
+        gs = torch.empty((n,), dtype=torch.float32, device=dev)
         from ._functional import _counters_ptr
-        L.check(L.lib().nmsa_multitask_loss_bwd_unless(ctx.arr, n, ctx.n_totals, L.ptr(gs), L.ptr(ctx.expect),
-                                                       L.ptr(ctx.rec), _counters_ptr(dev), L.stream_ptr(dev)),
-                'nmsa_multitask_loss_bwd_unless')
-        return (None, *ctx.grads)
+        L.check(L.lib().nmsa_multitask_loss_bwd_unless(
+            ctx.arr, n, ctx.n_totals, *(None if g is None else L.ptr(g) for g in up), L.ptr(ctx.counts),
+            L.ptr(ctx.expect), L.ptr(ctx.rec), L.ptr(gs), _counters_ptr(dev), L.stream_ptr(dev)),
+            'nmsa_multitask_loss_bwd_unless')
+        return (None, *grads)
 
 
-def multi_loss(items: Sequence[dict], n_totals: int, spec: SpecState
-               ) -> Tuple[Tuple[torch.Tensor, ...], torch.Tensor, torch.Tensor, torch.Tensor]:
+class MultiLossResult:
+    """what one call returns: `sums` [n] float32 loss sums, `item_losses` [n] = sum / count,
+    `total_losses` [T] = sum over the total's items / divisor (all three differentiable),
+    `counts` int64 [n], `aux` float64 [n], `divisors` float32 [T], `packed`: the detached
+    [2 n + T] vector the three are views of"""
+    __slots__ = ('sums', 'item_losses', 'total_losses', 'counts', 'aux', 'divisors', 'packed')
+
+    def __init__(self, outs, desc):
+        self.sums, self.item_losses, self.total_losses = outs
+        self.counts, self.aux, self.divisors = desc['counts'], desc['aux'], desc['divisors']
+        self.packed = desc['packed']
+
+
+def multi_loss(items: Sequence[dict], n_totals: int, spec: SpecState) -> MultiLossResult:
     """items: dicts with kind ('ce' | 'mse' | 'l1' | 'focal' | 'vonmises'), pred, target (not CE),
-    mask (labels for CE), weights (CE), param (label smoothing | kappa), total, clamp.
-    -> (loss sums as fp32 0-d tensors, counts int64 [n], aux float64 [n], divisors float32 [n_totals])"""
-    desc = {'items': list(items), 'n_totals': n_totals, 'spec': spec}
-    sums = MultiLossFunction.apply(desc, *[it['pred'] for it in items])
-    return sums, desc['counts'], desc['aux'], desc['divisors']
+    mask (labels for CE), weights (CE), param (label smoothing | kappa), total, clamp."""
+    desc = {'items': list(items), 'n_totals': n_totals, 'spec': spec, 'grad_enabled': torch.is_grad_enabled()}
+    outs = MultiLossFunction.apply(desc, *[it['pred'] for it in items])
+    return MultiLossResult(outs, desc)

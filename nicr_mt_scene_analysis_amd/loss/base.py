@@ -15,8 +15,8 @@ class LossBase(torch.nn.Module):
             spec = self.__dict__['_spec'] = _multi.SpecState(1)
         item = {'kind': kind, 'pred': input_, 'target': target, 'mask': mask, 'weights': weights,
                 'param': param, 'total': 0}
-        sums, counts, aux, _ = _multi.multi_loss([item], 1, spec)
-        return sums[0], counts[0], aux[0]
+        res = _multi.multi_loss([item], 1, spec)
+        return res.sums[0], res.counts[0], res.aux[0]
 
     def _can_speculate(self, input_) -> bool:
         from . import _functional as F_

@@ -36,13 +36,27 @@ def _around_step(after):
     return decorate
 
 
+class PackedLosses(dict):
+    """loss dict whose values are elements of ONE device vector (the output of the multi-loss
+    call): `packed` is that vector, `index[name]` the element — lets the log copy be one clone"""
+    packed = None
+    index = None
+
+
 def append_detached_losses_to_logs(disabled=False):
     """(losses, logs) steps: copy every loss, detached, into the logs"""
     def after(result, _seconds):
         losses, logs = result
-        if not disabled:
-            for name, value in losses.items():
-                logs[name] = value.detach().clone()
+        if disabled:
+            return
+        if isinstance(losses, PackedLosses) and losses.packed is not None and \
+                losses.keys() == losses.index.keys():
+            copy = losses.packed.detach().clone().unbind(0)
+            for name, i in losses.index.items():
+                logs[name] = copy[i]
+            return
+        for name, value in losses.items():
+            logs[name] = value.detach().clone()
     return _around_step(after)
 
 
@@ -92,24 +106,24 @@ class TaskHelperBase(torch.nn.Module):
             st[key] = _multi.SpecState(len(names), init)
         return st[key]
 
-    def multi_losses(self, items, total_names):
-        """`items` (loss/_multi.py) through ONE forward call -> (per item loss / count as a
-        tuple of 0-d tensors, {total name: sum_scales loss / sum_scales count})  — the
-        reductions of reference base.py:161-182 as two vector ops instead of one op per scale"""
+    def multi_losses(self, items, item_names, total_names):
+        """`items` (loss/_multi.py) through ONE forward call -> PackedLosses {item name: loss sum /
+        count, total key: sum_scales loss sum / sum_scales count} — the reductions of reference
+        base.py:161-182 done by the call itself (csrc k_multi_totals), no tensor op per scale"""
         from ..loss import _multi
-        sums, counts, _, divisors = _multi.multi_loss(items, len(total_names), self.spec_state(total_names))
-        dev = counts.device
-        idx = self.__dict__.setdefault('_total_index', {})
-        key = (tuple(it['total'] for it in items), dev)
-        if key not in idx:
-            idx[key] = torch.tensor(key[0], dtype=torch.long, device=dev)
-        clamp = torch.tensor([1 if it.get('clamp') else 0 for it in items], device=dev) \
-            if any(it.get('clamp') for it in items) else None
-        s = torch.stack(sums)
-        n = counts if clamp is None else torch.maximum(counts, clamp)
-        per_item = (s / n.to(s.dtype)).unbind(0)
-        totals = torch.zeros((len(total_names),), dtype=s.dtype, device=dev).index_add_(0, idx[key], s) / divisors
-        return per_item, dict(zip(total_names, totals.unbind(0))), counts
+        res = _multi.multi_loss(items, len(total_names), self.spec_state(total_names))
+        n = len(items)
+        per_item, totals = res.item_losses.unbind(0), res.total_losses.unbind(0)
+        out = PackedLosses()
+        out.packed, out.index = res.packed, {}
+        for i, name in enumerate(item_names):
+            out[name] = per_item[i]
+            out.index[name] = n + i
+        for t, name in enumerate(total_names):
+            key = self.mark_as_total(name)
+            out[key] = totals[t]
+            out.index[key] = 2 * n + t
+        return out
 
     # ---- pairing predictions and targets over the supervision scales ---------------------
     def collect_predictions_for_loss(self, predictions_post, predictions_post_key,

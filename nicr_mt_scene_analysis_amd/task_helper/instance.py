@@ -93,11 +93,7 @@ class InstanceTaskHelper(TaskHelperBase):
         from ..loss import _multi
         if center_kind != 'focal' and F_.speculation_enabled() and _multi.supported(items):
             # every loss of every scale in ONE forward call
-            per_item, totals, _ = self.multi_losses(items, tuple(total_names))
-            loss_dict = dict(zip(names, per_item))
-            for k in total_names:
-                loss_dict[self.mark_as_total(k)] = totals[k]
-            return loss_dict
+            return self.multi_losses(items, names, tuple(total_names))
         # the focal extension (its divisor is no count of mask bytes), host tensors, > 16 items:
         # loss by loss
         out = []

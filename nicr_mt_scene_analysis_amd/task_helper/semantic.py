@@ -54,10 +54,7 @@ class SemanticTaskHelper(TaskHelperBase):
         if F_.speculation_enabled() and _multi.supported(items) and \
                 all(p.ndim == 4 for p in predictions):
             # all scales in ONE forward call (count, expectation, forward + gradient, finalize)
-            per_scale, totals, _ = self.multi_losses(items, (_TASK,))
-            losses = {f'{_TASK}_loss_{name}': v for name, v in zip(scale_names, per_scale)}
-            losses[self.mark_as_total(_TASK)] = totals[_TASK]
-            return losses
+            return self.multi_losses(items, [f'{_TASK}_loss_{name}' for name in scale_names], (_TASK,))
         per_scale = self._loss(input_tensors=predictions, target_tensors=targets)
         sums = [loss_sum for loss_sum, _ in per_scale]
         counts = [count for _, count in per_scale]

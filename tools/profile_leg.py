@@ -5,7 +5,8 @@
 
 legs: cfg2_f32 cfg2_bf16 cfg5_f32 cfg5_bf16 (pipeline + metric updates), cfg3_losses,
 ce150 (cross entropy at 150 classes), cos512, cos768, next_rows (f2 full resolution, f3 scores,
-f4 targets)"""
+f4 targets), api (postprocess / validation / training step through the reference-shaped API;
+NMSA_BENCH_API_PROFILE=1 adds a cProfile of the training step on stderr)"""
 import os
 import sys
 
@@ -28,6 +29,8 @@ elif leg == 'cfg3_losses':
     out = bench.secondary_losses(dev)
 elif leg == 'next_rows':
     out = bench.secondary_next_rows(ops, syn, dev)
+elif leg == 'api':
+    out = bench.secondary_api(syn, dev)
 elif leg == 'ce150':
     out = bench.secondary_ce(dev)
 elif leg in ('cos512', 'cos768'):
