@@ -426,6 +426,77 @@ def secondary_cos_emb(dev, B=8, D=512, H=768, W=1024, L=64):
                             note='the backward re-reads the prediction: 3x2D+8 B/px moved')}
 
 
+def secondary_cfg5_full(ops, syn, dev, B=16, C=150, H=768, W=1024, K=48, D=512, L=64):
+    """BASELINE configs[4] as ONE figure ("full pipeline incl. losses"): per step of a
+    B=16 1024x768 batch with 150 classes, bf16 predictions — the panoptic pipeline (center NMS,
+    grouping, merge) + the mIoU / PQ accumulator updates + forward and backward of the multi-task
+    losses (CE at 150 classes, center MSE, offset L1, von Mises orientation: one multi-loss call)
+    + forward and backward of the dense visual-embedding cosine loss (D=512, 64-row LUTs).
+    Mpix/s = B H W / wall time of the step on one stream; the algorithmic bytes are the sums of
+    the legs' SURVEY §8d figures."""
+    from tools import bench_support
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi, reset_speculation_state
+    reset_speculation_state()
+    dt = torch.bfloat16
+    inp = syn.make_panoptic_inputs_torch(B, C, H, W, n_centers=K, seed=4321, device=dev, logits_dtype=dt)
+    a = (inp['semantic_logits'], inp['instance_center'], inp['instance_offset'],
+         inp['semantic_classes_is_thing'])
+    metrics = bench_support.MetricAccumulators(C + 1, dev, inp, 0, side_stream=False)
+    g = torch.Generator(device=dev).manual_seed(17)
+
+    def rnd(*shape):
+        return torch.randn(shape, device=dev, generator=g)
+    logits = a[0].detach().clone().requires_grad_(True)          # the loss sees the same logits
+    labels = torch.randint(0, C + 1, (B, H, W), device=dev, generator=g).to(torch.uint8)
+    w = torch.rand(C, device=dev, generator=g) + 0.5
+    center = torch.rand((B, H, W), device=dev, generator=g).to(dt).requires_grad_(True)
+    center_t = torch.rand((B, H, W), device=dev, generator=g)
+    offset = rnd(B, 2, H, W).to(dt).requires_grad_(True)
+    offset_t = rnd(B, 2, H, W)
+    ori = rnd(B, 2, H, W).to(dt).requires_grad_(True)
+    ori_t = torch.nn.functional.normalize(rnd(B, 2, H, W), dim=1)
+    m1 = torch.rand((B, H, W), device=dev, generator=g) < 0.7
+    m2 = torch.rand((B, H, W), device=dev, generator=g) < 0.5
+    m3 = torch.rand((B, H, W), device=dev, generator=g) < 0.3
+    emb = torch.empty((B, D, H, W), device=dev, dtype=dt)
+    for b in range(B):                                  # per image: bounds the f32 temporary
+        emb[b] = torch.randn((D, H, W), device=dev, generator=g).to(dt)
+    emb.requires_grad_(True)
+    idx = torch.randint(0, L + 1, (B, H // 16, W // 16), device=dev, generator=g, dtype=torch.int32)
+    idx = idx.repeat_interleave(16, 1).repeat_interleave(16, 2).contiguous()
+    lut = torch.nn.functional.normalize(torch.randn((B, L, D), device=dev, generator=g), dim=-1)
+    cos = CosineEmbeddingLoss()
+    spec = _multi.SpecState(4)
+    items = [{'kind': 'ce', 'pred': logits, 'mask': labels, 'weights': w, 'total': 0},
+             {'kind': 'mse', 'pred': center, 'target': center_t, 'mask': m1, 'total': 1},
+             {'kind': 'l1', 'pred': offset, 'target': offset_t, 'mask': m2, 'total': 2},
+             {'kind': 'vonmises', 'pred': ori, 'target': ori_t, 'mask': m3, 'param': 1.0, 'total': 3,
+              'clamp': True}]
+    leaves = (logits, center, offset, ori, emb)
+
+    def step():
+        r = ops.panoptic_pipeline(*a)
+        metrics.update_and_reduce(r['panoptic'])
+        for t in leaves:
+            t.grad = None
+        total = _multi.multi_loss(items, 4, spec).total_losses.sum()
+        l, n = cos.lut_sum(emb, idx, lut)
+        (total + l / n).backward()
+    ms = hip_timed(step, reps=6, warm=3)
+    metrics.pq._check_status()
+    metrics.miou._check_status()
+    n_px = B * H * W
+    parts = {'pipeline': 2 * C + 21, 'metrics': 17, 'multitask_losses_fwd_bwd': (2 * C + 34) + (2 * C + 10),
+             'cos_emb_fwd_bwd': 2 * D + 4 + 2 * D}
+    out = _leg(ms, n_px, sum(parts.values()), algorithmic_bytes_per_px_by_part=parts,
+               shape=f'B={B} C={C} {W}x{H} D={D} L={L}', pred_dtype='bfloat16',
+               what='panoptic pipeline + mIoU/PQ updates + multi-task losses fwd+bwd + cosine-embedding '
+                    'loss fwd+bwd, one stream, HIP events around the whole step')
+    del inp, a, emb, logits
+    torch.cuda.empty_cache()
+    return out
+
+
 def secondary_next_rows(ops, syn, dev, B=32, C=40, H=480, W=640):
     """SURVEY §8(f) rows that sit either side of the headline path, each as one HIP-event-timed
     call on B=32 640x480 inputs: f2 the full-resolution step (crop + bilinear resize + softmax
@@ -632,6 +703,7 @@ def secondary(ops, syn, dev):
         ('cfg5_ce_C150', lambda: secondary_ce(dev)),
         ('cfg5_cos_emb_D512', lambda: secondary_cos_emb(dev, B=16, D=512)),
         ('cfg5_cos_emb_D768', lambda: secondary_cos_emb(dev, B=16, D=768)),
+        ('cfg5_full', lambda: secondary_cfg5_full(ops, syn, dev)),
         ('next_rows', lambda: secondary_next_rows(ops, syn, dev)),
         ('api', lambda: secondary_api(syn, dev)),
     )

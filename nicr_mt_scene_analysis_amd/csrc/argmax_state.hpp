@@ -65,7 +65,8 @@ __device__ __forceinline__ float tie_band_magnitude()
 template <int DTYPE>
 __device__ __forceinline__ bool may_tie_in_probability(float m)
 {
-    return fabsf(m) < tie_band_magnitude<DTYPE>();
+    // (<=: a maximum of exactly 0.5 has its lower neighbour 2^-25 away)
+    return fabsf(m) <= tie_band_magnitude<DTYPE>();
 }
 
 }  // namespace nmsa

@@ -530,7 +530,9 @@ __device__ __forceinline__ void keep_packed(u32x2_s (&r)[NP])
 // backward of the two-kernel path)
 // body of workgroup (bx, b): shared by k_ce_fused and the multi-loss launch (k_multi_loss).
 // g = upstream scale the gradient is written for; a NaN g (no expectation) writes no gradient.
-template <int DTYPE, int NG, bool SMOOTH, bool LOSS>
+// MODE 0: loss + gradient (a NaN g: loss only, at the price of the gradient arithmetic), 1: loss
+// only (forward-only calls: no third walk over the registers), 2: gradient only
+template <int DTYPE, int NG, bool SMOOTH, int MODE>
 __device__ __forceinline__ void ce_fused_body(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec, float g,
@@ -539,11 +541,12 @@ __device__ __forceinline__ void ce_fused_body(
 {
     constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
     constexpr int NP = 8 * NG;
+    constexpr bool LOSS = MODE != 2;
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
     float wsum = 0.f;
     if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    const bool write_grad = g == g && grad != nullptr;
+    const bool write_grad = MODE != 1 && g == g && grad != nullptr;
     const size_t img = (size_t)b * C * P;
     double acc = 0.0, accw = 0.0;
     long long cnt = 0;
@@ -580,6 +583,7 @@ __device__ __forceinline__ void ce_fused_body(
                     const float x = plane_px<DTYPE>(r[c], j);
                     s[j] += __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
                     if (SMOOTH) swx[j] = fmaf(s_w[c], x, swx[j]);
+                    if (MODE == 1) xt[j] = (t[j] == c) ? x : xt[j];             // forward only: no third walk
                 }
             }
         }
@@ -593,7 +597,7 @@ __device__ __forceinline__ void ce_fused_body(
             abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
         }
         if (DTYPE != NMSA_F32) keep_packed(r);
-        if (write_grad) {
+        if (MODE != 1) {
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
                 if (c < C) {
@@ -609,16 +613,7 @@ __device__ __forceinline__ void ce_fused_body(
                         xt[j] = hit ? x : xt[j];
                         o[j] = q;
                     }
-                    st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
-                }
-            }
-        } else if (LOSS) {
-            // forward only (no expectation / no gradient wanted): just the target logit
-#pragma unroll
-            for (int c = 0; c < NP; ++c) {
-                if (c < C) {
-#pragma unroll
-                    for (int j = 0; j < PXT; ++j) xt[j] = (t[j] == c) ? plane_px<DTYPE>(r[c], j) : xt[j];
+                    if (write_grad) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
                 }
             }
         }
@@ -653,7 +648,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
 {
     extern __shared__ float s_w[];
     if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
-    ce_fused_body<DTYPE, NG, SMOOTH, LOSS>(logits, target, weights, C, P, ls, vec,
+    ce_fused_body<DTYPE, NG, SMOOTH, LOSS ? 0 : 2>(logits, target, weights, C, P, ls, vec,
                                            grad ? *expected_gscale : __int_as_float(0x7fc00000), grad,
                                            partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, status,
                                            s_w, blockIdx.x, blockIdx.y);
@@ -670,7 +665,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
 // gradient written once for C <= 256.
 constexpr int CE_SPLIT_MAX_C = 256;
 
-template <int DTYPE, int NG, bool SMOOTH, bool LOSS = true>
+template <int DTYPE, int NG, bool SMOOTH, int MODE>           // MODE as in ce_fused_body
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
@@ -681,6 +676,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
     constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
     constexpr int NP = 8 * NG;                         // class planes per wave
     constexpr int NWV = LOSS_THREADS / 64;             // 4
+    constexpr bool LOSS = MODE != 2;
     constexpr int TPX = 64 * PXT;                      // pixels per workgroup
     extern __shared__ float s_w[];                     // [C] weights, then the exchange buffers
     if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
@@ -753,6 +749,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
                 const float x = plane_px<DTYPE>(r[i], j);
                 s[j] += __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
                 if (SMOOTH) swx[j] = fmaf(wc, x, swx[j]);
+                if (MODE == 1) xt[j] = (t[j] == c0 + i) ? x : xt[j];            // forward only: no third walk
             }
         }
     }
@@ -780,7 +777,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
         abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
     }
     if (DTYPE != NMSA_F32) keep_packed(r);
-    if (write_grad) {
+    if (MODE != 1) {
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             if (i < nc) {
@@ -797,16 +794,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
                     xt[j] = hit ? x : xt[j];
                     o[j] = qv;
                 }
-                if (alive) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
-            }
-        }
-    } else if (LOSS) {
-        // forward only (no expectation / no gradient wanted): just the target logit
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            if (i < nc) {
-#pragma unroll
-                for (int j = 0; j < PXT; ++j) xt[j] = (t[j] == c0 + i) ? plane_px<DTYPE>(r[i], j) : xt[j];
+                if (alive && write_grad) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
             }
         }
     }
@@ -994,16 +982,17 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_bwd(
 // forward + gradient for the expected upstream scale (see k_ce_fused)
 // body of workgroup bx (of nbx) of image b; gs = upstream scale (NaN: no gradient is written);
 // LOSS = false: gradient only (the recomputing backward launch of k_multi_loss)
-template <int DTYPE, int KIND, bool LOSS>
-__device__ __forceinline__ void elem_fused_body(
+template <int DTYPE, int KIND, int MODE>                   // MODE as in ce_fused_body
+__device__ __attribute__((noinline)) void elem_fused_body(
     const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
     int C, int P, int vec, float gs, void* __restrict__ grad, LossPartial* __restrict__ slot,
     int bx, int nbx, int b)
 {
+    constexpr bool LOSS = MODE != 2;
     double acc = 0.0; long long cnt = 0;
     const float invC = 1.0f / C;
     const float g = gs / C;
-    const bool write_grad = gs == gs && grad != nullptr;
+    const bool write_grad = MODE != 1 && gs == gs && grad != nullptr;
     for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
         const int nvalid = min(4, P - p0);
         bool mk[4];
@@ -1042,7 +1031,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_fused(
     int C, int P, int vec, const float* __restrict__ expected_gscale, void* __restrict__ grad,
     LossPartial* __restrict__ partials)
 {
-    elem_fused_body<DTYPE, KIND, true>(pred, target, mask, C, P, vec, *expected_gscale, grad,
+    elem_fused_body<DTYPE, KIND, 0>(pred, target, mask, C, P, vec, *expected_gscale, grad,
                                        partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x,
                                        blockIdx.x, gridDim.x, blockIdx.y);
 }
@@ -1111,13 +1100,14 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_vm_bwd(
 }
 
 // forward + gradient for the expected upstream scale (see k_ce_fused)
-template <int DTYPE, bool LOSS>
-__device__ __forceinline__ void vm_fused_body(
+template <int DTYPE, int MODE>                             // MODE as in ce_fused_body
+__device__ __attribute__((noinline)) void vm_fused_body(
     const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
     int P, float kappa, int vec, float g, void* __restrict__ grad, LossPartial* __restrict__ slot,
     int bx, int nbx, int b)
 {
-    const bool write_grad = g == g && grad != nullptr;
+    constexpr bool LOSS = MODE != 2;
+    const bool write_grad = MODE != 1 && g == g && grad != nullptr;
     double acc = 0.0; long long cnt = 0;
     for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
         const int nvalid = min(4, P - p0);
@@ -1153,7 +1143,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_vm_fused(
     int P, float kappa, int vec, const float* __restrict__ expected_gscale, void* __restrict__ grad,
     LossPartial* __restrict__ partials)
 {
-    vm_fused_body<DTYPE, true>(pred, target, mask, P, kappa, vec, *expected_gscale, grad,
+    vm_fused_body<DTYPE, 0>(pred, target, mask, P, kappa, vec, *expected_gscale, grad,
                                partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x,
                                blockIdx.x, gridDim.x, blockIdx.y);
 }
@@ -1607,12 +1597,16 @@ __global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, c
 // all items of one call: block ranges [block0, block0 + nbx * B) per item.  CE_* select the ONE
 // cross-entropy variant compiled into this instantiation (CE_NG = 0: no CE item in the launch);
 // the element-wise and von Mises bodies are selected at run time (they are small).
-template <int CE_DT, int CE_NG, bool CE_SM, bool LOSS>
-__global__ __launch_bounds__(LOSS_THREADS) void k_multi_loss(
+// (up to 40 class planes in registers: 4 waves per SIMD as in k_ce_fused — the calls of the small
+// bodies cost the allocator 16 registers otherwise and one wave per SIMD with them)
+template <int CE_DT, int CE_NG, bool CE_SM, int MODE>        // MODE as in ce_fused_body
+__global__ __launch_bounds__(LOSS_THREADS)
+__attribute__((amdgpu_waves_per_eu((CE_NG <= 5) ? 4 : 3, (CE_NG <= 5) ? 8 : 3))) void k_multi_loss(
     MultiArgs a, const float* __restrict__ expect, const float* __restrict__ gs,
     LossPartial* __restrict__ partials, int* __restrict__ status)
 {
     extern __shared__ float s_w[];
+    constexpr bool LOSS = MODE != 2;
     if (!LOSS) {
         // the recomputing launch is a small grid walking the block list: when every item's
         // gradient stands (the usual case) its workgroups are gone after this check
@@ -1632,7 +1626,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_loss(
         if (!it.in_launch || local < 0) continue;
         const int bx = local % it.nbx, b = local / it.nbx;
         float g = __int_as_float(0x7fc00000);              // NaN: no gradient wanted / no expectation
-        if (it.grad && expect) g = expect[2 * it.total];
+        if (MODE != 1 && it.grad && expect) g = expect[2 * it.total];
         if (!LOSS) {
             if (!it.grad) continue;
             const float gr = gs[i];
@@ -1645,26 +1639,26 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_loss(
         switch (it.kind) {
             case NMSA_LOSS_CE:
                 if constexpr (CE_NG != 0)
-                    ce_fused_body<CE_DT, CE_NG, CE_SM, LOSS>(it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P,
+                    ce_fused_body<CE_DT, CE_NG, CE_SM, MODE>(it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P,
                                                              it.param, it.vec, g, it.grad, slot, status, s_w, bx, b);
                 break;
             case NMSA_LOSS_MSE:
-#define CALL(DT) elem_fused_body<DT, 0, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
+#define CALL(DT) elem_fused_body<DT, 0, MODE>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
                 MULTI_DT(CALL)
 #undef CALL
                 break;
             case NMSA_LOSS_L1:
-#define CALL(DT) elem_fused_body<DT, 1, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
+#define CALL(DT) elem_fused_body<DT, 1, MODE>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
                 MULTI_DT(CALL)
 #undef CALL
                 break;
             case NMSA_LOSS_FOCAL:
-#define CALL(DT) elem_fused_body<DT, 2, LOSS>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
+#define CALL(DT) elem_fused_body<DT, 2, MODE>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
                 MULTI_DT(CALL)
 #undef CALL
                 break;
             default:
-#define CALL(DT) vm_fused_body<DT, LOSS>(it.pred, (const float*)it.target, it.mask, it.P, it.param, it.vec, g, it.grad, slot, bx, it.nbx, b)
+#define CALL(DT) vm_fused_body<DT, MODE>(it.pred, (const float*)it.target, it.mask, it.P, it.param, it.vec, g, it.grad, slot, bx, it.nbx, b)
                 MULTI_DT(CALL)
 #undef CALL
                 break;
@@ -1681,8 +1675,9 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_loss(
 // out[0 .. n): the sums as float32, [n .. 2n): sum / count per item, [2n .. 2n + T): per total the
 // float32 sums of its items added in item order, divided by the total's divisor
 // (accumulate_losses, task_helper/base.py:161-182)
-constexpr int MULTI_FIN_SPLIT = 8;
+constexpr int MULTI_FIN_SPLIT = 16;
 constexpr int MULTI_FIN_THREADS = 256;
+static_assert(MULTI_MAX_ITEMS * MULTI_FIN_SPLIT <= MULTI_FIN_THREADS, "one thread per slice in the last workgroup");
 
 __global__ __launch_bounds__(MULTI_FIN_THREADS) void k_multi_finalize(
     MultiArgs a, const LossPartial* __restrict__ partials, LossPartial* __restrict__ slices,
@@ -1700,7 +1695,15 @@ __global__ __launch_bounds__(MULTI_FIN_THREADS) void k_multi_finalize(
     const int per = (n + MULTI_FIN_SPLIT - 1) / MULTI_FIN_SPLIT;
     const int begin = min(n, sl * per), end = min(n, begin + per);
     double x = 0, y = 0; long long c = 0;
-    for (int k = begin + threadIdx.x; k < end; k += MULTI_FIN_THREADS) { x += p[k].sum; y += p[k].aux; c += p[k].count; }
+    int k = begin + threadIdx.x;
+    for (; k + 3 * MULTI_FIN_THREADS < end; k += 4 * MULTI_FIN_THREADS) {       // 4 independent loads per round
+        LossPartial q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) q[u] = p[k + u * MULTI_FIN_THREADS];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { x += q[u].sum; y += q[u].aux; c += q[u].count; }
+    }
+    for (; k < end; k += MULTI_FIN_THREADS) { x += p[k].sum; y += p[k].aux; c += p[k].count; }
     s_sum[threadIdx.x] = x; s_aux[threadIdx.x] = y; s_cnt[threadIdx.x] = c;
     __syncthreads();
     for (int o = MULTI_FIN_THREADS / 2; o > 0; o >>= 1) {
@@ -1723,11 +1726,15 @@ __global__ __launch_bounds__(MULTI_FIN_THREADS) void k_multi_finalize(
     __shared__ long long s_count[MULTI_MAX_ITEMS];
     __shared__ float s_f[MULTI_MAX_ITEMS];
     const int ni = a.n_items, t = threadIdx.x;
+    if (t < ni * MULTI_FIN_SPLIT) {                        // every slice by its own thread, then item by item
+        const volatile LossPartial* q = slices + t;
+        s_sum[t] = q->sum; s_aux[t] = q->aux; s_cnt[t] = q->count;
+    }
+    __syncthreads();
     if (t < ni) {
         double sx = 0, sy = 0; long long sc = 0;
         for (int k = 0; k < MULTI_FIN_SPLIT; ++k) {
-            const volatile LossPartial* q = slices + t * MULTI_FIN_SPLIT + k;
-            sx += q->sum; sy += q->aux; sc += q->count;
+            sx += s_sum[t * MULTI_FIN_SPLIT + k]; sy += s_aux[t * MULTI_FIN_SPLIT + k]; sc += s_cnt[t * MULTI_FIN_SPLIT + k];
         }
         sums[t] = sx; counts[t] = sc;
         if (aux) aux[t] = sy;
@@ -1928,10 +1935,12 @@ static int launch_ce_split(bool loss, const void* logits, int dtype, const uint8
 #define CE_SPLIT_NG(DT, SM, LS) do { if (ng == 3) CE_SPLIT_L(DT, 3, SM, LS); else if (ng == 4) CE_SPLIT_L(DT, 4, SM, LS); \
         else if (ng == 5) CE_SPLIT_L(DT, 5, SM, LS); else if (ng == 6) CE_SPLIT_L(DT, 6, SM, LS); \
         else CE_SPLIT_L(DT, 8, SM, LS); } while (0)
-#define CE_SPLIT(DT) do { if (loss) { if (smooth) CE_SPLIT_NG(DT, true, true); else CE_SPLIT_NG(DT, false, true); } \
-                          else { if (smooth) CE_SPLIT_NG(DT, true, false); else CE_SPLIT_NG(DT, false, false); } } while (0)
+    // MODE 0: loss + gradient, 1: loss only (no gradient buffer), 2: gradient only
+#define CE_SPLIT_M(DT, LS) do { if (smooth) CE_SPLIT_NG(DT, true, LS); else CE_SPLIT_NG(DT, false, LS); } while (0)
+#define CE_SPLIT(DT) do { if (!loss) CE_SPLIT_M(DT, 2); else if (grad) CE_SPLIT_M(DT, 0); else CE_SPLIT_M(DT, 1); } while (0)
     NMSA_DISPATCH_DTYPE(dtype, CE_SPLIT)
 #undef CE_SPLIT
+#undef CE_SPLIT_M
 #undef CE_SPLIT_NG
 #undef CE_SPLIT_L
     return check_launch();
@@ -2519,15 +2528,15 @@ size_t multi_partial_blocks(const MultiPlan& pl)
     return n;
 }
 
-template <bool LOSS>
+template <int MODE>
 int multi_launch_joint(const MultiPlan& pl, const float* expect, const float* gs, LossPartial* partials,
                        int* status, hipStream_t stream)
 {
     const MultiArgs& a = pl.args;
     if (a.n_blocks <= 0) return NMSA_OK;
     // (the recomputing launch: a small grid that walks the block list, see k_multi_loss)
-    const int grid = LOSS ? a.n_blocks : (a.n_blocks < 4096 ? a.n_blocks : 4096);
-#define ML(DT, NG, SM) hipLaunchKernelGGL((k_multi_loss<DT, NG, SM, LOSS>), dim3(grid), dim3(LOSS_THREADS), \
+    const int grid = MODE != 2 ? a.n_blocks : (a.n_blocks < 4096 ? a.n_blocks : 4096);
+#define ML(DT, NG, SM) hipLaunchKernelGGL((k_multi_loss<DT, NG, SM, MODE>), dim3(grid), dim3(LOSS_THREADS), \
         pl.lds, stream, a, expect, gs, partials, status)
 #define ML_NG(DT, SM) do { if (pl.ce_ng == 3) ML(DT, 3, SM); else if (pl.ce_ng == 5) ML(DT, 5, SM); else ML(DT, 6, SM); } while (0)
 #define ML_DT(DT) do { if (pl.ce_sm) ML_NG(DT, true); else ML_NG(DT, false); } while (0)
@@ -2593,7 +2602,8 @@ extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_i
                        any_grad ? (const long long*)cpart : (const long long*)nullptr, spec, expect, ticket);
     rc = check_launch();
     if (rc) return rc;
-    rc = multi_launch_joint<true>(pl, expect, nullptr, partials, status, stream);
+    rc = any_grad ? multi_launch_joint<0>(pl, expect, nullptr, partials, status, stream)
+                  : multi_launch_joint<1>(pl, expect, nullptr, partials, status, stream);
     if (rc) return rc;
     for (int i = 0; i < n_items; ++i) {                 // cross entropies outside the joint launch
         const MultiItem& it = a.it[i];
@@ -2632,7 +2642,7 @@ extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n
                        grad_total_losses, (const long long*)counts, expect, spec, grad_scales, counters);
     rc = check_launch();
     if (rc) return rc;
-    rc = multi_launch_joint<false>(pl, expect, grad_scales, nullptr, nullptr, stream);
+    rc = multi_launch_joint<2>(pl, expect, grad_scales, nullptr, nullptr, stream);
     if (rc) return rc;
     for (int i = 0; i < n_items; ++i) {
         const MultiItem& it = a.it[i];

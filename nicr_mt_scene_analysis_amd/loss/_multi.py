@@ -120,6 +120,7 @@ class MultiLossFunction(torch.autograd.Function):
         items, n_totals, spec = desc['items'], desc['n_totals'], desc['spec']
         dev = preds[0].device
         n = len(items)
+        ctx.set_materialize_grads(False)       # unused outputs come back as None, not as zero tensors
         want_grad = desc.get('grad_enabled', True)
         arr = (_Item * n)()
         keep = []

@@ -22,13 +22,15 @@ leg = sys.argv[1] if len(sys.argv) > 1 else 'cfg5_bf16'
 dev = torch.device('cuda', 0)
 torch.cuda.set_device(dev)
 shapes = {'cfg2': (32, 40, 480, 640, 24), 'cfg5': (16, 150, 768, 1024, 48)}
-if leg[:4] in shapes:
+if leg[:4] in shapes and leg[5:] in ('f32', 'bf16', 'f16'):
     dt = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[leg[5:]]
     out = bench.secondary_pipeline(ops, syn, dev, *shapes[leg[:4]], dt, overlap=False)
 elif leg == 'cfg3_losses':
     out = bench.secondary_losses(dev)
 elif leg == 'next_rows':
     out = bench.secondary_next_rows(ops, syn, dev)
+elif leg == 'cfg5_full':
+    out = bench.secondary_cfg5_full(ops, syn, dev)
 elif leg == 'api':
     out = bench.secondary_api(syn, dev)
 elif leg == 'ce150':
