@@ -9,7 +9,7 @@
 # profiles/<tag>_<leg>_*, and one plain bench.py run whose JSON line is kept next to them.
 set -e -o pipefail
 TAG=${1:-r02x}
-LEGS=${2:-"cfg2_bf16 cfg3_losses cfg5_bf16 ce150 cos512 cos768 next_rows"}
+LEGS=${2:-"cfg2_bf16 cfg3_losses cfg5_bf16 ce150 cos512 cos768 next_rows api cfg5_full"}
 ROOT=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$ROOT/gpurun_out/prof_$TAG
 rm -rf "$OUT"; mkdir -p "$OUT"
