@@ -12,6 +12,8 @@ The metric kernels are enqueued on a side HIP stream: they only depend on the pa
 map of their own step, so the latency-bound per-image kernels (matching, accumulation,
 all-reduce) overlap with the next step's streaming kernels.
 """
+import os
+
 import torch
 
 from nicr_mt_scene_analysis_amd import ops
@@ -51,7 +53,10 @@ class MetricAccumulators:
                                    device=device) if world_size > 1 else None
         self._finalized = False
         self._n_conf = n_conf
-        self.stream = torch.cuda.Stream(device=device) if side_stream else None
+        # NMSA_BENCH_METRIC_PRIORITY=-1: a high-priority side stream (the metric chain of a batch
+        # then does not queue behind the next batch's streaming kernels)
+        prio = int(os.environ.get('NMSA_BENCH_METRIC_PRIORITY', '0'))
+        self.stream = torch.cuda.Stream(device=device, priority=prio) if side_stream else None
         self._ready = torch.cuda.Event()
         # synthetic ground truth: the prediction shifted by 3 px with a
         # void band, and uniformly random semantic labels
