@@ -416,3 +416,161 @@ def test_nothing_selected_gives_zero_gradients():
     assert float(total) == float(l)          # masked-out pixels still count |0 - target| (instance.py:129-139)
     total.backward()
     assert torch.count_nonzero(p.grad) == 0
+
+
+# ---- the multi-loss call itself (loss/_multi.py, csrc k_multi_*) -----------------------------------
+def _multi_case(seed=21, B=2, H=24, W=40, dtype=torch.bfloat16):
+    g = _gen(seed)
+
+    def rnd(*s):
+        return torch.randn(s, device='cuda', generator=g)
+    case = {
+        'ce40': ((rnd(B, 40, H, W) * 3).to(dtype), torch.randint(0, 41, (B, H, W), device='cuda', generator=g).to(torch.uint8),
+                 torch.rand(40, device='cuda', generator=g) + 0.5),
+        'ce19': ((rnd(B, 19, H // 2, W // 2) * 3).to(dtype),
+                 torch.randint(0, 20, (B, H // 2, W // 2), device='cuda', generator=g).to(torch.uint8), None),
+        'ce150': ((rnd(B, 150, H // 2, W // 2) * 3).to(dtype),
+                  torch.randint(0, 151, (B, H // 2, W // 2), device='cuda', generator=g).to(torch.uint8),
+                  torch.rand(150, device='cuda', generator=g) + 0.5),
+        'mse': (torch.rand((B, H, W), device='cuda', generator=g).to(dtype), torch.rand((B, H, W), device='cuda', generator=g),
+                torch.rand((B, H, W), device='cuda', generator=g) < 0.7),
+        'l1': (rnd(B, 2, H, W).to(dtype), rnd(B, 2, H, W), torch.rand((B, H, W), device='cuda', generator=g) < 0.5),
+        'vm': (rnd(B, 2, H, W).to(dtype), torch.nn.functional.normalize(rnd(B, 2, H, W), dim=1),
+               torch.zeros((B, H, W), dtype=torch.bool, device='cuda')),      # empty mask: clamp
+    }
+    peaks = torch.rand((B, H, W), device='cuda', generator=g)
+    peaks = torch.where(peaks > 0.97, torch.ones((), device='cuda'), peaks * 0.9)
+    case['focal'] = (torch.rand((B, H, W), device='cuda', generator=g).clamp(0.02, 0.98).to(dtype), peaks,
+                     torch.rand((B, H, W), device='cuda', generator=g) < 0.8)
+    return case
+
+
+def _torch_sums(case):
+    """fp64 torch restatement of the item sums / counts (the loss definitions of loss/*.py)"""
+    out = {}
+    for k in ('ce40', 'ce19', 'ce150'):
+        x, t, w = case[k]
+        tl = t.long() - 1
+        out[k] = (torch.nn.functional.cross_entropy(x.double(), tl, weight=None if w is None else w.double(),
+                                                    ignore_index=-1, reduction='sum'), int((t != 0).sum()))
+    x, y, m = case['mse']
+    out['mse'] = (((x.double() * m - y.double()) ** 2).sum(), int(m.sum()))
+    x, y, m = case['l1']
+    out['l1'] = ((x.double() * m.unsqueeze(1) - y.double()).abs().mean(dim=1).sum(), int(m.sum()))
+    x, y, m = case['vm']
+    out['vm'] = ((1 - torch.exp(1.0 * ((x.double() * y.double()).sum(dim=1) - 1)))[m].sum(), int(m.sum()))
+    return out
+
+
+@pytest.mark.parametrize('with_grad', [True, False])
+def test_multi_loss_mixed_items_one_call(with_grad):
+    """one call with everything the dispatcher has: two register-resident CE variants (40 and 19
+    classes: the second runs as a launch of its own), a 150-class CE (k_ce_split), MSE, L1 and a
+    von Mises item whose mask is EMPTY (its count enters as max(0, 1)); with gradients and
+    forward only (no count pass, divisors from the finalized counts) — sums, counts, per-item
+    losses, totals and gradients against torch in fp64"""
+    from nicr_mt_scene_analysis_amd.loss import _multi
+    case = _multi_case()
+    leaves = {k: v[0].clone().requires_grad_(with_grad) for k, v in case.items()}
+    items = [{'kind': 'ce', 'pred': leaves['ce40'], 'mask': case['ce40'][1], 'weights': case['ce40'][2], 'total': 0},
+             {'kind': 'ce', 'pred': leaves['ce19'], 'mask': case['ce19'][1], 'total': 0},
+             {'kind': 'ce', 'pred': leaves['ce150'], 'mask': case['ce150'][1], 'weights': case['ce150'][2], 'total': 1},
+             {'kind': 'mse', 'pred': leaves['mse'], 'target': case['mse'][1], 'mask': case['mse'][2], 'total': 2},
+             {'kind': 'l1', 'pred': leaves['l1'], 'target': case['l1'][1], 'mask': case['l1'][2], 'total': 3},
+             {'kind': 'vonmises', 'pred': leaves['vm'], 'target': case['vm'][1], 'mask': case['vm'][2], 'param': 1.0,
+              'total': 3, 'clamp': True}]
+    names = ['ce40', 'ce19', 'ce150', 'mse', 'l1', 'vm']
+    ref = _torch_sums(case)
+    spec = _multi.SpecState(4)
+    for step in range(2):                                     # second step: the expectation (w = 1) is confirmed
+        for v in leaves.values():
+            v.grad = None
+        if with_grad:
+            res = _multi.multi_loss(items, 4, spec)
+        else:
+            with torch.no_grad():
+                res = _multi.multi_loss(items, 4, spec)
+        counts = res.counts.tolist()
+        for i, k in enumerate(names):
+            assert counts[i] == ref[k][1], (k, counts[i], ref[k][1])
+            np.testing.assert_allclose(float(res.sums[i]), float(ref[k][0]), rtol=RTOL, atol=1e-6)
+            np.testing.assert_allclose(float(res.item_losses[i]), float(ref[k][0]) / max(ref[k][1], 1),
+                                       rtol=RTOL, atol=1e-6)
+        div = [ref['ce40'][1] + ref['ce19'][1], ref['ce150'][1], ref['mse'][1], ref['l1'][1] + max(ref['vm'][1], 1)]
+        tot = [float(ref['ce40'][0] + ref['ce19'][0]), float(ref['ce150'][0]), float(ref['mse'][0]),
+               float(ref['l1'][0] + ref['vm'][0])]
+        assert res.divisors.tolist() == [float(max(d, 1)) for d in div]
+        np.testing.assert_allclose(res.total_losses.tolist(), [t / max(d, 1) for t, d in zip(tot, div)], rtol=RTOL)
+        if not with_grad:
+            continue
+        (res.total_losses * torch.tensor([1.0, 1.0, 1.0, 1.0], device='cuda')).sum().backward()
+        # torch fp64 gradients of the same totals
+        dbl = {k: case[k][0].double().requires_grad_(True) for k in names}
+        c2 = {k: (dbl[k],) + tuple(case[k][1:]) for k in names}
+        r2 = _torch_sums(c2)
+        ((r2['ce40'][0] + r2['ce19'][0]) / div[0] + r2['ce150'][0] / div[1] + r2['mse'][0] / div[2]
+         + (r2['l1'][0] + r2['vm'][0]) / div[3]).backward()
+        for k in names:
+            gd = dbl[k].grad if dbl[k].grad is not None else torch.zeros_like(dbl[k])
+            got = leaves[k].grad.double()
+            tol = _grad_tol(torch.bfloat16)
+            err = (got - gd).abs() - tol * gd.abs()
+            assert float(err.max()) <= 1e-7, (k, step, float(err.max()))
+    if with_grad:
+        assert spec.stats() == {'confirmed': 8, 'recomputed': 0}
+
+
+def test_multi_loss_focal_total_takes_its_divisor_from_the_loss_kernel():
+    """the center-focal extension divides by the number of heat-map PEAKS, which only the loss
+    kernel counts: such a total gets no expectation (backward recomputes) and its divisor is
+    filled in by the finalize step — with and without gradients"""
+    from nicr_mt_scene_analysis_amd.loss import CenterFocalLoss, _multi
+    case = _multi_case(seed=5, dtype=torch.float32)
+    x0, peaks, m = case['focal']
+    focal = CenterFocalLoss()
+    xs = x0.clone().requires_grad_(True)
+    ls, n = focal.masked_sum(xs, peaks, m)                     # the loss-by-loss path
+    (ls / n).backward()
+    spec = _multi.SpecState(1)
+    xm = x0.clone().requires_grad_(True)
+    res = _multi.multi_loss([{'kind': 'focal', 'pred': xm, 'target': peaks, 'mask': m, 'total': 0}], 1, spec)
+    assert int(res.counts[0]) == int(n) == int(((peaks == 1) & m).sum())
+    assert float(res.divisors[0]) == float(max(int(n), 1))
+    np.testing.assert_allclose(float(res.total_losses[0]), float(ls / n), rtol=1e-6)
+    res.total_losses[0].backward()
+    np.testing.assert_allclose(xm.grad.cpu().numpy(), xs.grad.cpu().numpy(), rtol=2e-5, atol=1e-9)
+    assert spec.stats() == {'confirmed': 0, 'recomputed': 1}
+    with torch.no_grad():
+        res = _multi.multi_loss([{'kind': 'focal', 'pred': xm, 'target': peaks, 'mask': m, 'total': 0}], 1, spec)
+    np.testing.assert_allclose(float(res.total_losses[0]), float(ls / n), rtol=1e-6)
+
+
+def test_multi_loss_sixteen_items_and_recompute_walk():
+    """the largest call (16 items, 8 totals) with upstream factors that are NOT the expected ones:
+    the recomputing launch walks all block ranges with its small grid; gradients equal the ones
+    of sixteen single calls"""
+    from nicr_mt_scene_analysis_amd.loss import L1Loss, _multi
+    g = _gen(31)
+    preds, tgts, masks = [], [], []
+    for i in range(16):
+        H, W = 8 + 4 * (i % 5), 20 + 4 * (i % 3)
+        preds.append(torch.randn((2, 2, H, W), device='cuda', generator=g))
+        tgts.append(torch.randn((2, 2, H, W), device='cuda', generator=g))
+        masks.append(torch.rand((2, H, W), device='cuda', generator=g) < 0.6)
+    factors = torch.tensor([0.3, 1.7, 2.0, 0.5, 1.0, 4.0, 0.25, 3.0], device='cuda')
+    leaves = [p.clone().requires_grad_(True) for p in preds]
+    items = [{'kind': 'l1', 'pred': leaves[i], 'target': tgts[i], 'mask': masks[i], 'total': i // 2}
+             for i in range(16)]
+    spec = _multi.SpecState(8)
+    res = _multi.multi_loss(items, 8, spec)
+    (res.total_losses * factors).sum().backward()
+    assert spec.stats() == {'confirmed': 1, 'recomputed': 7}            # only the factor 1.0 was expected
+    single = L1Loss()
+    for i in range(16):
+        p = preds[i].clone().requires_grad_(True)
+        j = i ^ 1
+        l, n = single.masked_sum(p, tgts[i], masks[i])
+        n_total = n + masks[j].sum()
+        (factors[i // 2] * l / n_total).backward()
+        np.testing.assert_allclose(leaves[i].grad.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-5, atol=1e-9)
+    assert not _multi.supported(items + [items[0]])                       # 17 items: loss by loss
