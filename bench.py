@@ -923,7 +923,11 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if failed:
-        sys.exit(3)                                 # the line above is complete; a leg raised
+        # the line above is complete and says so at top level (`secondary_failed`); the headline
+        # measurement stands, so the exit code stays 0 unless NMSA_BENCH_STRICT=1 asks otherwise
+        print(f'bench.py: secondary legs raised: {out["secondary_failed"]}', file=sys.stderr, flush=True)
+        if os.environ.get('NMSA_BENCH_STRICT') == '1':
+            sys.exit(3)
 
 
 if __name__ == '__main__':
