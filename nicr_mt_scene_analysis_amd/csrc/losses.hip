@@ -262,24 +262,24 @@ __device__ __forceinline__ void ce_scan(const void* logits, size_t img, int P, i
     }
 }
 
+// body of workgroup bx (of nbx per image) of image b: shared by k_ce_fwd and the forward-only
+// cross-entropy items of the multi-loss launch (k_multi_loss, MODE 1)
 template <int DTYPE, int PXT, bool SMOOTH, int U>
-__global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
+__device__ __forceinline__ void ce_fwd_body(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
-    LossPartial* __restrict__ partials, int* __restrict__ status, float* __restrict__ lse2_out)
+    LossPartial* __restrict__ slot, int* __restrict__ status, float* __restrict__ lse2_out,
+    float* s_w, int bx, int nbx, int b)
 {
-    extern __shared__ float s_w[];
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
     float wsum = 0.f;
     if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    const int b = blockIdx.y;
     const size_t img = (size_t)b * C * P;
     double acc = 0.0, accw = 0.0;
     long long cnt = 0;
     bool bad = false;
-    for (int p0 = (blockIdx.x * LOSS_THREADS + threadIdx.x) * PXT; p0 < P;
-         p0 += gridDim.x * LOSS_THREADS * PXT) {
+    for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * PXT; p0 < P; p0 += nbx * LOSS_THREADS * PXT) {
         const int nvalid = min(PXT, P - p0);
         float m[PXT], s[PXT], swx[PXT], xts[PXT];
         int tt[PXT];
@@ -321,7 +321,19 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
         acc += part; accw += partw;
     }
     if (bad) atomicOr(status, 8);
-    block_partial(acc, accw, cnt, partials);
+    block_partial_at(acc, accw, cnt, slot);
+}
+
+template <int DTYPE, int PXT, bool SMOOTH, int U>
+__global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
+    const void* __restrict__ logits, const uint8_t* __restrict__ target,
+    const float* __restrict__ weights, int C, int P, float ls, int vec,
+    LossPartial* __restrict__ partials, int* __restrict__ status, float* __restrict__ lse2_out)
+{
+    extern __shared__ float s_w[];
+    ce_fwd_body<DTYPE, PXT, SMOOTH, U>(logits, target, weights, C, P, ls, vec,
+                                       partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, status,
+                                       lse2_out, s_w, blockIdx.x, gridDim.x, blockIdx.y);
 }
 
 // d loss_sum / d logits, times the upstream gradient *gscale  (ce.py via autograd)
@@ -1638,9 +1650,18 @@ __attribute__((amdgpu_waves_per_eu((CE_NG <= 5) ? 4 : 3, (CE_NG <= 5) ? 8 : 3)))
                                             default: CALL(NMSA_F16); break; }
         switch (it.kind) {
             case NMSA_LOSS_CE:
-                if constexpr (CE_NG != 0)
+                if constexpr (CE_NG != 0 && MODE == 1) {
+                    // forward only: the streaming walk of k_ce_fwd (16-byte loads, 4 planes in
+                    // flight, few registers) is faster than the register-resident column
+                    constexpr int FPX = (CE_DT == NMSA_F32) ? 4 : 8;
+                    const int vec16 = (it.P % FPX == 0) && ((((uintptr_t)it.pred) & 15) == 0);
+                    ce_fwd_body<CE_DT, FPX, CE_SM, (CE_DT == NMSA_F32) ? 8 : 4>(
+                        it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P, it.param, vec16, slot, status,
+                        nullptr, s_w, bx, it.nbx, b);
+                } else if constexpr (CE_NG != 0) {
                     ce_fused_body<CE_DT, CE_NG, CE_SM, MODE>(it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P,
                                                              it.param, it.vec, g, it.grad, slot, status, s_w, bx, b);
+                }
                 break;
             case NMSA_LOSS_MSE:
 #define CALL(DT) elem_fused_body<DT, 0, MODE>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
