@@ -173,6 +173,7 @@ class MultiLossFunction(torch.autograd.Function):
                                                  L.ptr(ws), nbytes, L.stream_ptr(dev)),
                 'nmsa_multitask_loss_fwd_grad')
         ctx.arr, ctx.keep, ctx.grads = arr, keep, grads
+        ctx.has_grad = [g is not None for g in grads]
         ctx.n_totals, ctx.rec, ctx.expect, ctx.counts = n_totals, rec, expect, counts
         desc['counts'], desc['aux'], desc['divisors'], desc['packed'] = counts, aux, expect[:, 1], out
         return out[:n], out[n:2 * n], out[2 * n:]
@@ -183,8 +184,15 @@ class MultiLossFunction(torch.autograd.Function):
         # (dropping the context's reference lets autograd take the buffers as .grad instead of
         # cloning them: a logits-sized copy per prediction otherwise)
         grads, ctx.grads = ctx.grads, None
+        expect = ctx.expect
         if grads is None:
-            raise RuntimeError('the multi-loss graph was already used for a backward pass')
+            # a second backward pass through the same graph (retain_graph=True): the buffers of
+            # the first one belong to autograd now -> fresh ones, and no expectation to confirm
+            grads = [torch.empty_like(k[0]) if has else None for k, has in zip(ctx.keep, ctx.has_grad)]
+            for a, gbuf in zip(ctx.arr, grads):
+                a.grad = gbuf.data_ptr() if gbuf is not None else None
+            expect = ctx.expect.clone()
+            expect[:, 0] = float('nan')
         n = len(grads)
         up = [None if g is None else g.detach().to(torch.float32).contiguous()
               for g in (g_sums, g_items, g_totals)]
@@ -192,7 +200,7 @@ class MultiLossFunction(torch.autograd.Function):
         from ._functional import _counters_ptr
         L.check(L.lib().nmsa_multitask_loss_bwd_unless(
             ctx.arr, n, ctx.n_totals, *(None if g is None else L.ptr(g) for g in up), L.ptr(ctx.counts),
-            L.ptr(ctx.expect), L.ptr(ctx.rec), L.ptr(gs), _counters_ptr(dev), L.stream_ptr(dev)),
+            L.ptr(expect), L.ptr(ctx.rec), L.ptr(gs), _counters_ptr(dev), L.stream_ptr(dev)),
             'nmsa_multitask_loss_bwd_unless')
         return (None, *grads)
 

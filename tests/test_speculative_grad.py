@@ -574,3 +574,22 @@ def test_multi_loss_sixteen_items_and_recompute_walk():
         (factors[i // 2] * l / n_total).backward()
         np.testing.assert_allclose(leaves[i].grad.cpu().numpy(), p.grad.cpu().numpy(), rtol=2e-5, atol=1e-9)
     assert not _multi.supported(items + [items[0]])                       # 17 items: loss by loss
+
+
+def test_multi_loss_second_backward_through_a_retained_graph():
+    """backward twice through one graph (retain_graph=True, e.g. per-task gradient norms): the
+    second pass recomputes into fresh buffers and accumulates like autograd does"""
+    from nicr_mt_scene_analysis_amd.loss import L1Loss
+    g = _gen(3)
+    p = torch.randn((2, 2, 12, 20), device='cuda', generator=g).requires_grad_(True)
+    y = torch.randn((2, 2, 12, 20), device='cuda', generator=g)
+    m = torch.rand((2, 12, 20), device='cuda', generator=g) > 0.4
+    l, n = L1Loss().masked_sum(p, y, m)
+    loss = l / n
+    loss.backward(retain_graph=True)
+    g1 = p.grad.clone()
+    (2.0 * loss).backward()
+    np.testing.assert_allclose(p.grad.cpu().numpy(), (3.0 * g1).cpu().numpy(), rtol=1e-6, atol=1e-9)
+    pr = p.detach().double().requires_grad_(True)
+    ((pr * m.unsqueeze(1) - y.double()).abs().mean(dim=1).sum() / int(m.sum())).backward()
+    np.testing.assert_allclose(g1.double().cpu().numpy(), pr.grad.cpu().numpy(), rtol=2e-5, atol=1e-9)
