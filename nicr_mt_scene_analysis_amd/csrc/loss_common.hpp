@@ -1,7 +1,16 @@
 // loss_common.hpp — pieces shared by the loss kernel files (losses.hip: one kernel per loss,
-// losses_multi.hip: one launch for several losses).
+// losses_split.hip: wide-column cross entropy, losses_multi.hip: one launch for several losses).
 #pragma once
 #include "nmsa_common.hpp"
+
+// run CALL(<dtype constant>) for the runtime dtype code (host side)
+#define NMSA_DISPATCH_DTYPE(dtype, CALL)          \
+    switch (dtype) {                              \
+        case NMSA_F32: CALL(NMSA_F32); break;     \
+        case NMSA_BF16: CALL(NMSA_BF16); break;   \
+        case NMSA_F16: CALL(NMSA_F16); break;     \
+        default: return NMSA_ERR_ARG;             \
+    }
 
 namespace nmsa {
 
@@ -57,6 +66,16 @@ __device__ __forceinline__ bool grad_already_computed(const float* __restrict__ 
 }
 
 // host side, defined in losses.hip
+int loss_ce_fwd_grad_partials(const void* logits, int dtype, const uint8_t* target, const float* weights,
+                              int B, int C, int P, float ls, const float* expected_gscale, void* grad,
+                              LossPartial* partials, int32_t* status, hipStream_t stream);
+// losses_split.hip: cross entropy for 49..256 classes (k_ce_split)
+constexpr int CE_SPLIT_MAX_C = 256;
+int ce_split_blocks(int P, int dtype);
+int launch_ce_split(bool loss, const void* logits, int dtype, const uint8_t* target,
+                    const float* weights, int B, int C, int P, float ls, const float* gscale,
+                    const float* computed_for, int32_t* counters, void* grad,
+                    LossPartial* partials, int32_t* status, hipStream_t stream);
 int loss_finalize(const LossPartial* partials, int n, double* sum, double* aux, int64_t* count,
                   hipStream_t stream);
 int loss_env_int(const char* name, int dflt);

@@ -17,89 +17,9 @@
 // are run-to-run deterministic.  Backward kernels recompute from the inputs and
 // scale by the upstream gradient read from a device scalar (no host sync).
 #include <stdlib.h>
-#include "loss_common.hpp"
+#include "loss_bodies.hpp"
 
 namespace nmsa {
-
-// ---- typed 4-px helpers --------------------------------------------------------------
-template <int DTYPE>
-__device__ __forceinline__ float4 ld4(const void* base, size_t off, int nvalid, bool vec)
-{
-    float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (DTYPE == NMSA_F32) {
-        const float* p = (const float*)base + off;
-        if (vec) return *(const float4*)p;
-        if (nvalid > 0) r.x = p[0];
-        if (nvalid > 1) r.y = p[1];
-        if (nvalid > 2) r.z = p[2];
-        if (nvalid > 3) r.w = p[3];
-    } else {
-        const uint16_t* p = (const uint16_t*)base + off;
-        uint16_t h[4] = {0, 0, 0, 0};
-        if (vec) { const ushort4 u = *(const ushort4*)p; h[0] = u.x; h[1] = u.y; h[2] = u.z; h[3] = u.w; }
-        else for (int j = 0; j < 4; ++j) if (j < nvalid) h[j] = p[j];
-        if (DTYPE == NMSA_BF16) {
-            r.x = bf16_to_f32(h[0]); r.y = bf16_to_f32(h[1]); r.z = bf16_to_f32(h[2]); r.w = bf16_to_f32(h[3]);
-        } else {
-            r.x = f16_to_f32(h[0]); r.y = f16_to_f32(h[1]); r.z = f16_to_f32(h[2]); r.w = f16_to_f32(h[3]);
-        }
-    }
-    return r;
-}
-
-template <int DTYPE>
-__device__ __forceinline__ void st4(void* base, size_t off, int nvalid, bool vec, const float v[4])
-{
-    if (DTYPE == NMSA_F32) {
-        float* p = (float*)base + off;
-        if (vec) *(float4*)p = make_float4(v[0], v[1], v[2], v[3]);
-        else for (int j = 0; j < nvalid; ++j) p[j] = v[j];
-    } else {
-        uint16_t* p = (uint16_t*)base + off;
-        uint16_t h[4];
-        for (int j = 0; j < 4; ++j) h[j] = (DTYPE == NMSA_BF16) ? f32_to_bf16(v[j]) : f32_to_f16(v[j]);
-        if (vec) *(ushort4*)p = make_ushort4(h[0], h[1], h[2], h[3]);
-        else for (int j = 0; j < nvalid; ++j) p[j] = h[j];
-    }
-}
-
-__device__ __forceinline__ void ld_mask4(const uint8_t* m, size_t off, int nvalid, bool vec, bool out[4])
-{
-    if (!m) { for (int j = 0; j < 4; ++j) out[j] = j < nvalid; return; }
-    if (vec) {
-        const uchar4 u = *(const uchar4*)(m + off);
-        out[0] = u.x != 0; out[1] = u.y != 0; out[2] = u.z != 0; out[3] = u.w != 0;
-    } else {
-        for (int j = 0; j < 4; ++j) out[j] = (j < nvalid) && (m[off + j] != 0);
-    }
-}
-
-// block reduction -> one LossPartial per block (fixed order: lane tree, then wave order)
-__device__ __forceinline__ void block_partial_at(double sum, double aux, long long count,
-                                                 LossPartial* __restrict__ slot)
-{
-    __shared__ double s_sum[LOSS_THREADS / 64], s_aux[LOSS_THREADS / 64];
-    __shared__ long long s_cnt[LOSS_THREADS / 64];
-    sum = wave_reduce_sum(sum);
-    aux = wave_reduce_sum(aux);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) count += __shfl_down(count, o);
-    const int w = threadIdx.x >> 6;
-    if (lane_id() == 0) { s_sum[w] = sum; s_aux[w] = aux; s_cnt[w] = count; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double a = 0, b = 0; long long c = 0;
-        for (int k = 0; k < LOSS_THREADS / 64; ++k) { a += s_sum[k]; b += s_aux[k]; c += s_cnt[k]; }
-        LossPartial p; p.sum = a; p.aux = b; p.count = c; p.pad = 0;
-        *slot = p;
-    }
-}
-
-__device__ __forceinline__ void block_partial(double sum, double aux, long long count,
-                                              LossPartial* __restrict__ partials)
-{
-    block_partial_at(sum, aux, count, partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x);
-}
 
 // one workgroup sums the block partials in a FIXED order (thread t takes partials t, t + 1024,
 // ...; then a tree over the threads): deterministic.  1024 threads with 4 loads in flight each —
@@ -136,192 +56,6 @@ __global__ __launch_bounds__(FIN_THREADS) void k_loss_finalize(
         if (out_aux) *out_aux = s_aux[0];
         if (out_count) *out_count = s_cnt[0];
     }
-}
-
-// =================================================================================
-// a6: cross entropy (weights, ignore void, label smoothing)
-//   per px (t = label-1 >= 0):  (1-ls)*w_t*(lse - x_t) + (ls/C)*(lse*W - sum_c w_c x_c)
-//   outputs: sum, n = #non-void px, aux = sum_px w_t  (divisor of the ESANet
-//   "weighted_reduction", ce.py:57-68)
-//
-// PXT pixels per lane: 4 for f32, 8 for bf16 / f16 — always 16-B loads.  The class loop
-// works in groups of U planes: group maximum with v_max3, ONE rescale of the running sum
-// per group, then 3 VALU per element (fma into the base-2 domain, v_exp_f32, add).  The
-// target logit x_t is fetched with one gather per pixel after the loop (the tile was just
-// streamed, the gather hits L2) instead of a compare/select per class.
-// =================================================================================
-#ifndef NMSA_GRAD_NT
-#define NMSA_GRAD_NT 1
-#endif
-constexpr bool GRAD_NT = NMSA_GRAD_NT != 0;     // gradient planes are written once: streaming stores
-
-template <int DTYPE, int PXT, bool NT = true>
-__device__ __forceinline__ void ldpx(const void* base, size_t off, int nvalid, bool vec, float out[PXT])
-{
-    if (DTYPE == NMSA_F32) {
-        const float* p = (const float*)base + off;
-        if (vec) {
-            const f32x4_s v = NT ? __builtin_nontemporal_load((const f32x4_s*)p) : *(const f32x4_s*)p;
-            out[0] = v.x; out[1] = v.y; out[2] = v.z; out[3] = v.w;
-        } else {
-            for (int j = 0; j < PXT; ++j) out[j] = (j < nvalid) ? p[j] : 0.f;
-        }
-    } else {
-        const uint16_t* p = (const uint16_t*)base + off;
-        uint16_t h[PXT];
-        if (vec) {
-            const u32x4_s v = NT ? __builtin_nontemporal_load((const u32x4_s*)p) : *(const u32x4_s*)p;
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) { h[2 * j] = (uint16_t)(w[j] & 0xFFFF); h[2 * j + 1] = (uint16_t)(w[j] >> 16); }
-        } else {
-            for (int j = 0; j < PXT; ++j) h[j] = (j < nvalid) ? p[j] : 0;
-        }
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) out[j] = (DTYPE == NMSA_BF16) ? bf16_to_f32(h[j]) : f16_to_f32(h[j]);
-    }
-}
-
-template <int DTYPE, int PXT, bool NT = false>
-__device__ __forceinline__ void stpx(void* base, size_t off, int nvalid, bool vec, const float v[PXT])
-{
-    if (DTYPE == NMSA_F32) {
-        float* p = (float*)base + off;
-        if (vec) {
-            const f32x4_s w = {v[0], v[1], v[2], v[3]};
-            if (NT) __builtin_nontemporal_store(w, (f32x4_s*)p); else *(f32x4_s*)p = w;
-        }
-        else for (int j = 0; j < nvalid; ++j) p[j] = v[j];
-    } else {
-        uint16_t* p = (uint16_t*)base + off;
-        uint16_t h[PXT];
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) h[j] = (DTYPE == NMSA_BF16) ? f32_to_bf16(v[j]) : f32_to_f16(v[j]);
-        if (vec) {
-            u32x4_s w;
-            w.x = h[0] | ((uint32_t)h[1] << 16); w.y = h[2] | ((uint32_t)h[3] << 16);
-            w.z = h[4] | ((uint32_t)h[5] << 16); w.w = h[6] | ((uint32_t)h[7] << 16);
-            if (NT) __builtin_nontemporal_store(w, (u32x4_s*)p); else *(u32x4_s*)p = w;
-        } else {
-            for (int j = 0; j < nvalid; ++j) p[j] = h[j];
-        }
-    }
-}
-
-template <int DTYPE>
-__device__ __forceinline__ float ld_scalar(const void* base, size_t off)
-{
-    if (DTYPE == NMSA_F32) return ((const float*)base)[off];
-    const uint16_t h = ((const uint16_t*)base)[off];
-    return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
-}
-
-// streaming max / sum-of-exp2 over the classes for PXT pixels; SMOOTH adds sum_c w_c x_c
-template <int DTYPE, int PXT, int U, bool SMOOTH, bool TRACK_T, bool NT>
-__device__ __forceinline__ void ce_scan(const void* logits, size_t img, int P, int p0, int nvalid,
-                                        bool vec, int C, const float* s_w, const int t[PXT],
-                                        float m[PXT], float s[PXT], float swx[PXT], float xt[PXT])
-{
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) { m[j] = -INFINITY; s[j] = 0.f; swx[j] = 0.f; xt[j] = 0.f; }
-    int c = 0;
-    for (; c + U <= C; c += U) {
-        float v[U][PXT];
-#pragma unroll
-        for (int u = 0; u < U; ++u) ldpx<DTYPE, PXT, NT>(logits, img + (size_t)(c + u) * P + p0, nvalid, vec, v[u]);
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) {
-            const int tj = TRACK_T ? t[j] - c : 0;
-            float g = v[0][j];
-#pragma unroll
-            for (int u = 1; u < U; ++u) g = fmaxf(g, v[u][j]);
-            const float mn = fmaxf(m[j], g);
-            const float k = -mn * LOG2E;
-            float acc = s[j] * __builtin_amdgcn_exp2f(fmaf(m[j], LOG2E, k));        // rescale once per group
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                acc += __builtin_amdgcn_exp2f(fmaf(v[u][j], LOG2E, k));
-                if (SMOOTH) swx[j] = fmaf(s_w[c + u], v[u][j], swx[j]);
-                if (TRACK_T) xt[j] = (tj == u) ? v[u][j] : xt[j];
-            }
-            s[j] = acc; m[j] = mn;
-        }
-    }
-    for (; c < C; ++c) {
-        float v[PXT];
-        ldpx<DTYPE, PXT, NT>(logits, img + (size_t)c * P + p0, nvalid, vec, v);
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) {
-            const float mn = fmaxf(m[j], v[j]);
-            const float k = -mn * LOG2E;
-            s[j] = s[j] * __builtin_amdgcn_exp2f(fmaf(m[j], LOG2E, k)) + __builtin_amdgcn_exp2f(fmaf(v[j], LOG2E, k));
-            m[j] = mn;
-            if (SMOOTH) swx[j] = fmaf(s_w[c], v[j], swx[j]);
-            if (TRACK_T) xt[j] = (t[j] == c) ? v[j] : xt[j];
-        }
-    }
-}
-
-// body of workgroup bx (of nbx per image) of image b: shared by k_ce_fwd and the forward-only
-// cross-entropy items of the multi-loss launch (k_multi_loss, MODE 1)
-template <int DTYPE, int PXT, bool SMOOTH, int U>
-__device__ __forceinline__ void ce_fwd_body(
-    const void* __restrict__ logits, const uint8_t* __restrict__ target,
-    const float* __restrict__ weights, int C, int P, float ls, int vec,
-    LossPartial* __restrict__ slot, int* __restrict__ status, float* __restrict__ lse2_out,
-    float* s_w, int bx, int nbx, int b)
-{
-    for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
-    __syncthreads();
-    float wsum = 0.f;
-    if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    const size_t img = (size_t)b * C * P;
-    double acc = 0.0, accw = 0.0;
-    long long cnt = 0;
-    bool bad = false;
-    for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * PXT; p0 < P; p0 += nbx * LOSS_THREADS * PXT) {
-        const int nvalid = min(PXT, P - p0);
-        float m[PXT], s[PXT], swx[PXT], xts[PXT];
-        int tt[PXT];
-#pragma unroll
-        for (int j = 0; j < PXT; ++j)
-            tt[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;       // ce.py:46
-        ce_scan<DTYPE, PXT, U, SMOOTH, true, true>(logits, img, P, p0, nvalid, vec, C, s_w, tt,
-                                                   m, s, swx, xts);
-        if (lse2_out) {
-            // log2-domain log-sum-exp per pixel, kept for the backward pass (one read of the
-            // logits there instead of two)
-            float k0[PXT];
-#pragma unroll
-            for (int j = 0; j < PXT; ++j) k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));
-            float* q = lse2_out + (size_t)b * P + p0;
-            if (vec && nvalid == PXT) {
-#pragma unroll
-                for (int j = 0; j < PXT; j += 4)
-                    *(float4*)(q + j) = make_float4(k0[j], k0[j + 1], k0[j + 2], k0[j + 3]);
-            } else {
-                for (int j = 0; j < nvalid; ++j) q[j] = k0[j];
-            }
-        }
-        float part = 0.f, partw = 0.f;
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) {
-            const int t = tt[j];
-            if (t < 0) continue;                                            // void: ignore_index
-            if (t >= C) { bad = true; continue; }
-            const float xt = xts[j];
-            const float lse = fmaf(__log2f(s[j]), LN2, m[j]);
-            const float wt = s_w[t];
-            float l = (1.0f - ls) * wt * (lse - xt);
-            if (SMOOTH) l += (ls / C) * (lse * wsum - swx[j]);
-            part += l;
-            partw += wt;
-            ++cnt;
-        }
-        acc += part; accw += partw;
-    }
-    if (bad) atomicOr(status, 8);
-    block_partial_at(acc, accw, cnt, slot);
 }
 
 template <int DTYPE, int PXT, bool SMOOTH, int U>
@@ -453,203 +187,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     }
 }
 
-// ---- forward + gradient in ONE pass over the logits ------------------------------------------
-// The gradient of the summed loss needs the upstream scale g, which autograd hands over only
-// in backward.  The callers know what it is going to be (1 / n for a mean, w / sum_scales n in
-// the task helpers; n comes from a 1 B/px count over the labels, k_count_u8), so the forward
-// kernel writes g_expected * d loss / d logits right away and the backward launch only confirms
-// it (grad_already_computed).  Per px: logits 2C|4C read once + gradient written once instead
-// of forward read + log-sum-exp write + backward read + log-sum-exp read + gradient write.
-//
-// A lane keeps its pixels' WHOLE class column in registers (8 B per plane and lane: 4 px of a
-// 16-bit dtype, 2 px of f32; 8*NG planes -> 16*NG VGPRs), so the maximum, the sum of
-// exponentials and the softmax each walk registers, not memory.  C <= 48 (NG <= 6); larger C
-// falls back to the two-kernel path.
-
-template <int DTYPE>
-__device__ __forceinline__ u32x2_s ld_plane8(const void* base, size_t off, int nvalid, bool vec)
-{
-    if (DTYPE == NMSA_F32) {
-        const float* p = (const float*)base + off;
-        if (vec) return __builtin_nontemporal_load((const u32x2_s*)p);
-        u32x2_s r = {0u, 0u};
-        if (nvalid > 0) r.x = __float_as_uint(p[0]);
-        if (nvalid > 1) r.y = __float_as_uint(p[1]);
-        return r;
-    }
-    const uint16_t* p = (const uint16_t*)base + off;
-    if (vec) return __builtin_nontemporal_load((const u32x2_s*)p);
-    uint16_t h[4] = {0, 0, 0, 0};
-    for (int j = 0; j < 4; ++j) if (j < nvalid) h[j] = p[j];
-    u32x2_s r = {h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16)};
-    return r;
-}
-
-template <int DTYPE>
-__device__ __forceinline__ float plane_px(const u32x2_s r, int j)
-{
-    if (DTYPE == NMSA_F32) return __uint_as_float(j == 0 ? r.x : r.y);
-    const uint32_t w = (j < 2) ? r.x : r.y;
-    if (DTYPE == NMSA_BF16) return __uint_as_float((j & 1) ? (w & 0xFFFF0000u) : (w << 16));
-    return f16_to_f32((uint16_t)((j & 1) ? (w >> 16) : (w & 0xFFFFu)));
-}
-
-template <int DTYPE>
-__device__ __forceinline__ void st_plane8(void* base, size_t off, int nvalid, bool vec, const float* v)
-{
-    if (DTYPE == NMSA_F32) {
-        float* p = (float*)base + off;
-        if (vec) {
-            const u32x2_s w = {__float_as_uint(v[0]), __float_as_uint(v[1])};
-            if (GRAD_NT) __builtin_nontemporal_store(w, (u32x2_s*)p); else *(u32x2_s*)p = w;
-        } else {
-            for (int j = 0; j < nvalid; ++j) p[j] = v[j];
-        }
-        return;
-    }
-    uint16_t* p = (uint16_t*)base + off;
-    uint16_t h[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) h[j] = (DTYPE == NMSA_BF16) ? f32_to_bf16(v[j]) : f32_to_f16(v[j]);
-    if (vec) {
-        const u32x2_s w = {h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16)};
-        if (GRAD_NT) __builtin_nontemporal_store(w, (u32x2_s*)p); else *(u32x2_s*)p = w;
-    } else {
-        for (int j = 0; j < nvalid; ++j) p[j] = h[j];
-    }
-}
-
-constexpr int CE_FUSED_MAX_C = 48;
-#ifndef NMSA_CE_FUSED_KEEP_PACKED
-#define NMSA_CE_FUSED_KEEP_PACKED 1
-#endif
-
-// Between the three walks over the register tile the compiler would rather keep the UNPACKED
-// fp32 values of a 16-bit tile (4 px x 40 planes = 160 more VGPRs, 1-2 waves per SIMD) than
-// unpack again (one shift / and per element); this makes the tile opaque so it stays packed.
-template <int NP>
-__device__ __forceinline__ void keep_packed(u32x2_s (&r)[NP])
-{
-#if NMSA_CE_FUSED_KEEP_PACKED
-#pragma unroll
-    for (int c = 0; c < NP; ++c) { asm volatile("" : "+v"(r[c].x), "+v"(r[c].y)); }
-#endif
-}
-
-// LOSS = false: the confirming backward launch — returns at once when the gradient written by
-// the forward launch was computed for the real upstream scale, otherwise recomputes it with the
-// same single pass (a miss costs one read of the logits + one gradient write, no more than the
-// backward of the two-kernel path)
-// body of workgroup (bx, b): shared by k_ce_fused and the multi-loss launch (k_multi_loss).
-// g = upstream scale the gradient is written for; a NaN g (no expectation) writes no gradient.
-// MODE 0: loss + gradient (a NaN g: loss only, at the price of the gradient arithmetic), 1: loss
-// only (forward-only calls: no third walk over the registers), 2: gradient only
-template <int DTYPE, int NG, bool SMOOTH, int MODE>
-__device__ __forceinline__ void ce_fused_body(
-    const void* __restrict__ logits, const uint8_t* __restrict__ target,
-    const float* __restrict__ weights, int C, int P, float ls, int vec, float g,
-    void* __restrict__ grad, LossPartial* __restrict__ slot, int* __restrict__ status,
-    float* s_w, int bx, int b)
-{
-    constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
-    constexpr int NP = 8 * NG;
-    constexpr bool LOSS = MODE != 2;
-    for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
-    __syncthreads();
-    float wsum = 0.f;
-    if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    const bool write_grad = MODE != 1 && g == g && grad != nullptr;
-    const size_t img = (size_t)b * C * P;
-    double acc = 0.0, accw = 0.0;
-    long long cnt = 0;
-    bool bad = false;
-    const int p0 = (bx * LOSS_THREADS + threadIdx.x) * PXT;
-    if (p0 < P) {
-        const int nvalid = min(PXT, P - p0);
-        u32x2_s r[NP];
-#pragma unroll
-        for (int c = 0; c < NP; ++c)
-            if (c < C) r[c] = ld_plane8<DTYPE>(logits, img + (size_t)c * P + p0, nvalid, vec);
-        int t[PXT];
-#pragma unroll
-        for (int j = 0; j < PXT; ++j)
-            t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;       // ce.py:46
-        float m[PXT], s[PXT], swx[PXT], xt[PXT], k0[PXT];
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) { m[j] = -INFINITY; s[j] = 0.f; swx[j] = 0.f; xt[j] = 0.f; }
-#pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            if (c < C) {
-#pragma unroll
-                for (int j = 0; j < PXT; ++j) m[j] = fmaxf(m[j], plane_px<DTYPE>(r[c], j));
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) k0[j] = -m[j] * LOG2E;
-        if (DTYPE != NMSA_F32) keep_packed(r);
-#pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            if (c < C) {
-#pragma unroll
-                for (int j = 0; j < PXT; ++j) {
-                    const float x = plane_px<DTYPE>(r[c], j);
-                    s[j] += __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
-                    if (SMOOTH) swx[j] = fmaf(s_w[c], x, swx[j]);
-                    if (MODE == 1) xt[j] = (t[j] == c) ? x : xt[j];             // forward only: no third walk
-                }
-            }
-        }
-        float ag[PXT], abg[PXT];
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) {
-            k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));                   // p = 2^(x log2e + k0)
-            const bool on = t[j] >= 0 && t[j] < C;
-            const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
-            ag[j] = g * a;
-            abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
-        }
-        if (DTYPE != NMSA_F32) keep_packed(r);
-        if (MODE != 1) {
-#pragma unroll
-            for (int c = 0; c < NP; ++c) {
-                if (c < C) {
-                    float o[PXT];
-                    const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
-#pragma unroll
-                    for (int j = 0; j < PXT; ++j) {
-                        const float x = plane_px<DTYPE>(r[c], j);
-                        const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
-                        float q = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
-                        const bool hit = t[j] == c;
-                        q -= hit ? ag[j] : 0.f;
-                        xt[j] = hit ? x : xt[j];
-                        o[j] = q;
-                    }
-                    if (write_grad) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
-                }
-            }
-        }
-        float part = 0.f, partw = 0.f;
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) {
-            if (t[j] < 0) continue;                                         // void: ignore_index
-            if (t[j] >= C) { bad = true; continue; }
-            const float lse = fmaf(__log2f(s[j]), LN2, m[j]);
-            const float wt = s_w[t[j]];
-            float l = (1.0f - ls) * wt * (lse - xt[j]);
-            if (SMOOTH) l += (ls / C) * (lse * wsum - swx[j]);
-            part += l;
-            partw += wt;
-            ++cnt;
-        }
-        acc = part; accw = partw;
-    }
-    if (LOSS) {
-        if (bad) atomicOr(status, 8);
-        block_partial_at(acc, accw, cnt, slot);
-    }
-}
-
 template <int DTYPE, int NG, bool SMOOTH, bool LOSS = true>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
@@ -664,175 +201,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fused(
                                            grad ? *expected_gscale : __int_as_float(0x7fc00000), grad,
                                            partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, status,
                                            s_w, blockIdx.x, blockIdx.y);
-}
-
-// ---- the same for wider class columns: the column SPLIT OVER THE FOUR WAVES OF THE WORKGROUP -----
-// k_ce_fused keeps a pixel's whole column in one lane's registers (C <= 48).  Here the four waves
-// of a workgroup look at the SAME 64 x PXT pixels and wave w holds the classes [w CQ, (w + 1) CQ),
-// CQ = ceil(C / 4) <= 64, so every wave-instruction still moves one contiguous 512-byte piece of a
-// class plane (the access pattern of k_ce_fused; 128-byte row segments — a column spread over the
-// lanes of ONE wave — ran at 3.6 instead of 5.4 TB/s).  The waves exchange their per-pixel maximum
-// and sum of exp2 (and sum_c w_c x_c) through 8-12 KB of LDS, two barriers per workgroup; each
-// wave then writes the gradient of its own classes from the same registers.  Logits read once,
-// gradient written once for C <= 256.
-constexpr int CE_SPLIT_MAX_C = 256;
-
-template <int DTYPE, int NG, bool SMOOTH, int MODE>           // MODE as in ce_fused_body
-__global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
-    const void* __restrict__ logits, const uint8_t* __restrict__ target,
-    const float* __restrict__ weights, int C, int P, float ls, int vec,
-    const float* __restrict__ expected_gscale, void* __restrict__ grad,
-    LossPartial* __restrict__ partials, int* __restrict__ status,
-    const float* __restrict__ computed_for, int* __restrict__ counters, int tiles_per_wg)
-{
-    constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
-    constexpr int NP = 8 * NG;                         // class planes per wave
-    constexpr int NWV = LOSS_THREADS / 64;             // 4
-    constexpr bool LOSS = MODE != 2;
-    constexpr int TPX = 64 * PXT;                      // pixels per workgroup
-    extern __shared__ float s_w[];                     // [C] weights, then the exchange buffers
-    if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
-    float* s_m = s_w + ((C + 3) & ~3);                 // [NWV][TPX] maxima
-    float* s_s = s_m + NWV * TPX;                      // [NWV][TPX] sums of exp2
-    float* s_x = s_s + NWV * TPX;                      // [NWV][TPX] sum_c w_c x_c (label smoothing)
-    for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
-    __syncthreads();
-    float wsum = 0.f;
-    if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    // (no gradient buffer: forward only; a NaN expectation writes no gradient either)
-    const float g = grad ? *expected_gscale : __int_as_float(0x7fc00000);
-    const bool write_grad = g == g && grad != nullptr;
-    const int b = blockIdx.y;
-    const size_t img = (size_t)b * C * P;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();
-    const int CQ = (C + NWV - 1) / NWV;
-    const int c0 = w * CQ;                             // my classes: c0 .. min(c0 + CQ, C) - 1
-    const int nc = max(0, min(CQ, C - c0));            // wave-uniform
-    // a workgroup walks a RUN of consecutive pixel tiles: its C class planes are C different pages,
-    // and one 512-byte piece per page and workgroup left the address translation as the limit
-    // (4.6 TB/s with every exp removed; runs of tiles: the pages are reused tile after tile)
-    double acc = 0.0, accw = 0.0;
-    long long cnt = 0;
-    bool bad = false;
-    const int n_tiles = (P + TPX - 1) / TPX;
-    const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
-  for (int tile = t_begin; tile < t_end; ++tile) {
-    const int p0 = (tile * 64 + l) * PXT;
-    const bool alive = p0 < P;
-    const int nvalid = alive ? min(PXT, P - p0) : 0;
-    u32x2_s r[NP];
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        r[i] = u32x2_s{0u, 0u};
-        if (i < nc && alive) r[i] = ld_plane8<DTYPE>(logits, img + (size_t)(c0 + i) * P + p0, nvalid, vec);
-    }
-    int t[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;   // ce.py:46
-    float m[PXT], s[PXT], swx[PXT], xt[PXT], k0[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) { m[j] = -INFINITY; s[j] = 0.f; swx[j] = 0.f; xt[j] = 0.f; }
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        if (i < nc) {
-#pragma unroll
-            for (int j = 0; j < PXT; ++j) m[j] = fmaxf(m[j], plane_px<DTYPE>(r[i], j));
-        }
-    }
-    // ---- the column maximum over the four waves ----------------------------------------------
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) s_m[w * TPX + l * PXT + j] = m[j];
-    __syncthreads();                                   // (also: the last tile's sums have been read)
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) {
-        float mm = s_m[l * PXT + j];
-#pragma unroll
-        for (int ww = 1; ww < NWV; ++ww) mm = fmaxf(mm, s_m[ww * TPX + l * PXT + j]);
-        m[j] = mm;
-        k0[j] = -mm * LOG2E;
-    }
-    if (DTYPE != NMSA_F32) keep_packed(r);
-#pragma unroll
-    for (int i = 0; i < NP; ++i) {
-        if (i < nc) {
-            const float wc = SMOOTH ? s_w[c0 + i] : 0.f;
-#pragma unroll
-            for (int j = 0; j < PXT; ++j) {
-                const float x = plane_px<DTYPE>(r[i], j);
-                s[j] += __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
-                if (SMOOTH) swx[j] = fmaf(wc, x, swx[j]);
-                if (MODE == 1) xt[j] = (t[j] == c0 + i) ? x : xt[j];            // forward only: no third walk
-            }
-        }
-    }
-    // ---- the sum of exp2 (and sum_c w_c x_c) over the four waves, in wave order -------------------
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) {
-        s_s[w * TPX + l * PXT + j] = s[j];
-        if (SMOOTH) s_x[w * TPX + l * PXT + j] = swx[j];
-    }
-    __syncthreads();
-    float ag[PXT], abg[PXT];
-#pragma unroll
-    for (int j = 0; j < PXT; ++j) {
-        float ss = s_s[l * PXT + j], sx = SMOOTH ? s_x[l * PXT + j] : 0.f;
-#pragma unroll
-        for (int ww = 1; ww < NWV; ++ww) {
-            ss += s_s[ww * TPX + l * PXT + j];
-            if (SMOOTH) sx += s_x[ww * TPX + l * PXT + j];
-        }
-        s[j] = ss; swx[j] = sx;
-        k0[j] = -(fmaf(m[j], LOG2E, __log2f(ss)));                         // p = 2^(x log2e + k0)
-        const bool on = t[j] >= 0 && t[j] < C;
-        const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
-        ag[j] = g * a;
-        abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
-    }
-    if (DTYPE != NMSA_F32) keep_packed(r);
-    if (MODE != 1) {
-#pragma unroll
-        for (int i = 0; i < NP; ++i) {
-            if (i < nc) {
-                const int c = c0 + i;
-                float o[PXT];
-                const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
-#pragma unroll
-                for (int j = 0; j < PXT; ++j) {
-                    const float x = plane_px<DTYPE>(r[i], j);
-                    const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
-                    float qv = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
-                    const bool hit = t[j] == c;
-                    qv -= hit ? ag[j] : 0.f;
-                    xt[j] = hit ? x : xt[j];
-                    o[j] = qv;
-                }
-                if (alive && write_grad) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
-            }
-        }
-    }
-    if (LOSS) {
-        float part = 0.f, partw = 0.f;
-#pragma unroll
-        for (int j = 0; j < PXT; ++j) {
-            if (t[j] < 0) continue;                                         // void: ignore_index
-            if (t[j] >= C) { bad = true; continue; }
-            const float lse = fmaf(__log2f(s[j]), LN2, m[j]);
-            const float wt = s_w[t[j]];
-            // the wave holding the target class adds the pixel's main term, wave 0 counts the pixel
-            if (t[j] >= c0 && t[j] < c0 + nc) part += (1.0f - ls) * wt * (lse - xt[j]);
-            if (w == 0) {
-                if (SMOOTH) part += (ls / C) * (lse * wsum - swx[j]);
-                partw += wt;
-                ++cnt;
-            }
-        }
-        acc += part; accw += partw;
-    }
-  }
-    if (LOSS) {
-        if (bad) atomicOr(status, 8);
-        block_partial(acc, accw, cnt, partials);
-    }
 }
 
 // number of bytes v with lo <= v <= hi (labels 1..C, mask bytes != 0): the element count a loss
@@ -901,30 +269,6 @@ __global__ __launch_bounds__(COUNT_MAX_BLOCKS) void k_count_finalize(
     }
 }
 
-// =================================================================================
-// a7: masked MSE / L1 with channel mean (C = 1: center, C = 2: offset)
-//   loss = sum_px mean_c f(pred*mask - target);  n = sum(mask)
-// =================================================================================
-// KIND 2 — center focal loss (EXTENSION: the reference has only MSE / L1 for the center heat-map;
-// the penalty-reduced focal loss of CenterNet, alpha = 2, beta = 4, on p = clamp(pred, 1e-4,
-// 1 - 1e-4)):  -(1-p)^2 log p where target == 1,  -(1-target)^4 p^2 log(1-p) elsewhere; masked-out
-// pixels contribute nothing and the count is the number of positive (target == 1) masked pixels.
-__device__ __forceinline__ float focal_value(float x, float y)
-{
-    const float p = fminf(fmaxf(x, 1e-4f), 1.0f - 1e-4f);
-    if (y == 1.0f) return -(1.0f - p) * (1.0f - p) * __logf(p);
-    const float w = (1.0f - y) * (1.0f - y);
-    return -w * w * p * p * __logf(1.0f - p);
-}
-__device__ __forceinline__ float focal_grad(float x, float y)
-{
-    if (!(x > 1e-4f && x < 1.0f - 1e-4f)) return 0.f;     // clamped: no gradient
-    const float q = 1.0f - x;
-    if (y == 1.0f) return 2.0f * q * __logf(x) - q * q / x;
-    const float w = (1.0f - y) * (1.0f - y);
-    return -w * w * (2.0f * x * __logf(q) - x * x / q);
-}
-
 template <int DTYPE, int KIND /* 0 mse, 1 l1, 2 center focal */>
 __global__ __launch_bounds__(LOSS_THREADS) void k_elem_fwd(
     const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
@@ -989,52 +333,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_elem_bwd(
             st4<DTYPE>(grad, off, nvalid, vec, o);
         }
     }
-}
-
-// forward + gradient for the expected upstream scale (see k_ce_fused)
-// body of workgroup bx (of nbx) of image b; gs = upstream scale (NaN: no gradient is written);
-// LOSS = false: gradient only (the recomputing backward launch of k_multi_loss)
-template <int DTYPE, int KIND, int MODE>                   // MODE as in ce_fused_body
-__device__ __attribute__((noinline)) void elem_fused_body(
-    const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
-    int C, int P, int vec, float gs, void* __restrict__ grad, LossPartial* __restrict__ slot,
-    int bx, int nbx, int b)
-{
-    constexpr bool LOSS = MODE != 2;
-    double acc = 0.0; long long cnt = 0;
-    const float invC = 1.0f / C;
-    const float g = gs / C;
-    const bool write_grad = MODE != 1 && gs == gs && grad != nullptr;
-    for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
-        const int nvalid = min(4, P - p0);
-        bool mk[4];
-        ld_mask4(mask, (size_t)b * P + p0, nvalid, vec, mk);
-        float part = 0.f;
-        for (int c = 0; c < C; ++c) {
-            const size_t off = ((size_t)b * C + c) * P + p0;
-            const float4 x = ld4<DTYPE>(pred, off, nvalid, vec);
-            const float4 y = ld4<NMSA_F32>(target, off, nvalid, vec);
-            const float xv[4] = {x.x, x.y, x.z, x.w}, yv[4] = {y.x, y.y, y.z, y.w};
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float d = (mk[j] ? xv[j] : 0.f) - yv[j];       // pred*mask - target
-                const float dd = (KIND == 2) ? focal_grad(xv[j], yv[j])
-                               : (KIND == 0) ? 2.0f * d : (float)((d > 0.f) - (d < 0.f));
-                o[j] = mk[j] ? g * dd : 0.f;
-                if (j >= nvalid) continue;
-                if (KIND == 2) {
-                    if (mk[j]) { part += focal_value(xv[j], yv[j]); cnt += (yv[j] == 1.0f); }
-                    continue;
-                }
-                part += (KIND == 0) ? d * d : fabsf(d);
-            }
-            if (write_grad) st4<DTYPE>(grad, off, nvalid, vec, o);
-        }
-        acc += part * invC;
-        if (KIND != 2) for (int j = 0; j < 4; ++j) cnt += (j < nvalid) && mk[j];
-    }
-    if (LOSS) block_partial_at(acc, 0.0, cnt, slot);
 }
 
 template <int DTYPE, int KIND>
@@ -1109,44 +407,6 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_vm_bwd(
         st4<DTYPE>(grad, o0, nvalid, vec, g0);
         st4<DTYPE>(grad, o1, nvalid, vec, g1);
     }
-}
-
-// forward + gradient for the expected upstream scale (see k_ce_fused)
-template <int DTYPE, int MODE>                             // MODE as in ce_fused_body
-__device__ __attribute__((noinline)) void vm_fused_body(
-    const void* __restrict__ pred, const float* __restrict__ target, const uint8_t* __restrict__ mask,
-    int P, float kappa, int vec, float g, void* __restrict__ grad, LossPartial* __restrict__ slot,
-    int bx, int nbx, int b)
-{
-    constexpr bool LOSS = MODE != 2;
-    const bool write_grad = MODE != 1 && g == g && grad != nullptr;
-    double acc = 0.0; long long cnt = 0;
-    for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
-        const int nvalid = min(4, P - p0);
-        bool mk[4];
-        ld_mask4(mask, (size_t)b * P + p0, nvalid, vec, mk);
-        const size_t o0 = ((size_t)b * 2) * P + p0, o1 = o0 + P;
-        const float4 x0 = ld4<DTYPE>(pred, o0, nvalid, vec), x1 = ld4<DTYPE>(pred, o1, nvalid, vec);
-        const float4 y0 = ld4<NMSA_F32>(target, o0, nvalid, vec), y1 = ld4<NMSA_F32>(target, o1, nvalid, vec);
-        const float a0[4] = {x0.x, x0.y, x0.z, x0.w}, a1[4] = {x1.x, x1.y, x1.z, x1.w};
-        const float b0[4] = {y0.x, y0.y, y0.z, y0.w}, b1[4] = {y1.x, y1.y, y1.z, y1.w};
-        float g0[4], g1[4];
-        float part = 0.f;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float dot = fmaf(a1[j], b1[j], a0[j] * b0[j]);
-            const float ex = __expf(kappa * (dot - 1.0f));
-            const float e = mk[j] ? -g * kappa * ex : 0.f;
-            g0[j] = e * b0[j]; g1[j] = e * b1[j];
-            if (mk[j]) { part += 1.0f - ex; ++cnt; }
-        }
-        acc += part;
-        if (write_grad) {
-            st4<DTYPE>(grad, o0, nvalid, vec, g0);
-            st4<DTYPE>(grad, o1, nvalid, vec, g1);
-        }
-    }
-    if (LOSS) block_partial_at(acc, 0.0, cnt, slot);
 }
 
 template <int DTYPE>
@@ -1414,373 +674,6 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
 }
 
 
-// =================================================================================
-// a10: the losses of a task helper in ONE forward launch (task_helper/instance.py:92-269,
-// task_helper/semantic.py:57-90, task_helper/base.py:161-182): every (loss, scale) pair is an
-// ITEM, items whose sums the caller adds before dividing by the summed counts form a TOTAL.
-//   k_multi_count    counts the labels / mask bytes of every item                 (1 B/px)
-//   k_multi_expect   counts per item, divisor per total, and the EXPECTED upstream gradient of
-//                    the total's loss sums: w / n with w from the total's spec record
-//   k_multi_loss     all items in one launch (block ranges): forward sums + gradients
-//   k_multi_finalize block partials -> sums / counts per item, fixed order
-// backward: k_multi_spec (one thread per total) compares the real upstream gradient with the
-// expectation and keeps the record's `w` up to date; k_multi_loss<..., LOSS = false> recomputes
-// only the items whose upstream gradient differs bit-wise from the expectation.
-//
-// Spec record (int32[8], device): [0] confirmed [1] recomputed [2] w (fp32 bits): the factor the
-// caller multiplies the total with before backward (loss weights, AMP scale: learned, see
-// k_multi_spec) [3] last upstream gradient [4] last divisor [5] flags (bit 0: expectation
-// switched off) [6] misses in a row [7] agreeing estimates in a row while switched off.
-// =================================================================================
-constexpr int MULTI_MAX_ITEMS = NMSA_MULTI_MAX_ITEMS;
-constexpr int MULTI_MAX_TOTALS = NMSA_MULTI_MAX_TOTALS;
-constexpr int MULTI_COUNT_MAX_BLOCKS = 256;            // per item
-
-struct MultiItem {
-    const void* pred; const void* target; const uint8_t* mask; const float* weights; void* grad;
-    int kind, dtype, B, C, P, vec, total, clamp;
-    float param;
-    int block0, nbx;                                   // first block of the item, blocks per image
-    int cblock0, cnblocks;                             // count pass: first block, blocks
-    int count_mode;                                    // 0: B * P, 1: bytes of `mask` in [lo, hi], 2: none
-    int lo, hi;
-    int in_launch;                                     // 1: part of k_multi_loss, 0: own kernel (wide CE)
-    int first_of_total;
-};
-struct MultiArgs { MultiItem it[MULTI_MAX_ITEMS]; int n_items, n_totals, n_blocks; };
-
-__global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long long* __restrict__ partials)
-{
-    __shared__ long long s_cnt[LOSS_THREADS / 64];
-    int i = 0;
-    while (i + 1 < a.n_items && (int)blockIdx.x >= a.it[i].cblock0 + a.it[i].cnblocks) ++i;
-    const MultiItem& it = a.it[i];
-    if (it.count_mode != 1 || (int)blockIdx.x < it.cblock0) { if (threadIdx.x == 0) partials[blockIdx.x] = 0; return; }
-    const int bi = blockIdx.x - it.cblock0;
-    const long long n = (long long)it.B * it.P;
-    const long long per = ((n + it.cnblocks - 1) / it.cnblocks + 15) / 16 * 16;
-    const long long begin = min(n, per * bi), end = min(n, begin + per);
-    const uint8_t* v = it.mask;
-    const unsigned lo = (unsigned)it.lo, span = (unsigned)(it.hi - it.lo);
-    const bool vec = (((uintptr_t)v) & 15) == 0;
-    long long cnt = 0;
-    long long k = begin + (long long)threadIdx.x * 16;
-    auto count16 = [&](const u32x4_s w) {
-        const uint32_t ww[4] = {w.x, w.y, w.z, w.w};
-        int c = 0;
-#pragma unroll
-        for (int q = 0; q < 4; ++q)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) c += ((((ww[q] >> (8 * j)) & 0xFF) - lo) <= span);
-        return c;
-    };
-    if (vec) {
-        constexpr long long STEP = LOSS_THREADS * 16;
-        for (; k + 3 * STEP + 16 <= end; k += 4 * STEP) {          // 4 x 16 B in flight per lane
-            u32x4_s w[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) w[u] = __builtin_nontemporal_load((const u32x4_s*)(v + k + u * STEP));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) cnt += count16(w[u]);
-        }
-        for (; k + 16 <= end; k += STEP) cnt += count16(__builtin_nontemporal_load((const u32x4_s*)(v + k)));
-    }
-    for (; k < end; k += LOSS_THREADS * 16)
-        for (long long j = k; j < min(end, k + 16); ++j) cnt += (((unsigned)v[j] - lo) <= span);
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-    if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        long long c = 0;
-        for (int q = 0; q < LOSS_THREADS / 64; ++q) c += s_cnt[q];
-        partials[blockIdx.x] = c;
-    }
-}
-
-// divisor of total t from per-item counts (accumulate_losses: max(sum of counts, 1) as float32;
-// an item with clamp enters as max(count, 1), task_helper/instance.py:206-211)
-__device__ inline float multi_divisor(const MultiArgs& a, const long long* counts, int t)
-{
-    long long n = 0;
-    for (int i = 0; i < a.n_items; ++i)
-        if (a.it[i].total == t) n += a.it[i].clamp ? max(counts[i], 1LL) : counts[i];
-    return (float)max(n, 1LL);
-}
-
-// always the first launch of a call.  With count partials: divisor + expected upstream gradient
-// per total.  Without (forward-only call, nobody needs them before the sums): no expectation,
-// the divisors are filled in by k_multi_finalize from the finalized counts.  Also zeroes the
-// ticket k_multi_finalize's workgroups draw to find out which of them is the last.
-__global__ __launch_bounds__(LOSS_THREADS) void k_multi_expect(MultiArgs a, const long long* __restrict__ partials,
-                                                               const int32_t* __restrict__ spec,
-                                                               float* __restrict__ expect,
-                                                               unsigned int* __restrict__ ticket)
-{
-    __shared__ long long s_count[MULTI_MAX_ITEMS];
-    if (threadIdx.x == 0) *ticket = 0u;
-    const int w = threadIdx.x >> 6, l = lane_id();
-    for (int i = w; i < a.n_items; i += LOSS_THREADS / 64) {
-        const MultiItem& it = a.it[i];
-        long long c = 0;
-        if (it.count_mode == 1 && partials) { for (int k = l; k < it.cnblocks; k += 64) c += partials[it.cblock0 + k]; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-        if (l == 0) s_count[i] = it.count_mode == 1 ? c : (long long)it.B * it.P;
-    }
-    __syncthreads();
-    if ((int)threadIdx.x < a.n_totals) {
-        const int t = threadIdx.x;
-        bool known = partials != nullptr;
-        for (int i = 0; i < a.n_items; ++i)
-            if (a.it[i].total == t && a.it[i].count_mode == 2) known = false;   // the divisor is no count of mask bytes
-        const float nf = multi_divisor(a, s_count, t);
-        const float wv = __int_as_float(spec[8 * t + 2]);
-        const bool off = (spec[8 * t + 5] & 1) || !known;
-        expect[2 * t] = off ? __int_as_float(0x7fc00000) : wv / nf;     // NaN: the forward writes no gradient
-        expect[2 * t + 1] = nf;                                         // (!known: k_multi_finalize corrects it)
-    }
-}
-
-// upstream weight behind an observed gradient g = fl(w / n): candidates around fl(g n) that
-// reproduce g, preferring one that also explains the previous observation, then the "roundest"
-__device__ inline float spec_estimate_w(float g, float n, float g_prev, float n_prev)
-{
-    const float c0 = g * n;
-    float best = c0;
-    int best_score = -1;
-    for (int k = -4; k <= 4; ++k) {
-        const float c = __int_as_float(__float_as_int(c0) + k);
-        if (!(c / n == g)) continue;
-        int score = 1 + __builtin_ctz((unsigned)__float_as_int(c) | 0x800000u);     // trailing zero bits of the significand
-        if (n_prev > 0.f && c / n_prev == g_prev) score += 64;
-        if (score > best_score) { best_score = score; best = c; }
-    }
-    return best;
-}
-
-__global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, const float* __restrict__ grad_items,
-                             const float* __restrict__ grad_totals, const long long* __restrict__ counts,
-                             const float* __restrict__ expect, int32_t* __restrict__ spec,
-                             float* __restrict__ gs, int32_t* __restrict__ counters)
-{
-    // upstream scale of item i's raw loss sum from the gradients of the three outputs (what
-    // autograd's division backward gives: grad / divisor, float32)
-    const int n = a.n_items;
-    if ((int)threadIdx.x < n) {
-        const int i = threadIdx.x;
-        const MultiItem& it = a.it[i];
-        float g = grad_sums ? grad_sums[i] : 0.f;
-        const float gi = grad_items ? grad_items[i] : 0.f, gt = grad_totals ? grad_totals[it.total] : 0.f;
-        if (gi != 0.f) g += gi / (float)(it.clamp ? max(counts[i], 1LL) : counts[i]);
-        if (gt != 0.f) g += gt / expect[2 * it.total + 1];
-        gs[i] = g;
-    }
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t >= a.n_totals) return;
-    int first = -1;
-    for (int i = 0; i < a.n_items; ++i) if (a.it[i].total == t && a.it[i].grad && first < 0) first = i;
-    if (first < 0) return;
-    int32_t* r = spec + 8 * t;
-    const float g = gs[first], e = expect[2 * t], nf = expect[2 * t + 1];
-    const float g_prev = __int_as_float(r[3]), n_prev = __int_as_float(r[4]);
-    const bool same = __float_as_int(g) == __float_as_int(e);
-    if (counters) atomicAdd(&counters[same ? 0 : 1], 1);       // per-device tally (statistics only)
-    if (same) { r[0] += 1; r[6] = 0; }
-    else {
-        r[1] += 1;
-        const float w_old = __int_as_float(r[2]);
-        const float w_new = (g == g && g != 0.f) ? spec_estimate_w(g, nf, g_prev, n_prev) : w_old;
-        if (r[5] & 1) {
-            // switched off: back on once the estimate has been stable for a few steps
-            r[7] = (__float_as_int(w_new) == __float_as_int(w_old)) ? r[7] + 1 : 0;
-            if (r[7] >= 3) { r[5] &= ~1; r[6] = 0; r[7] = 0; }
-        } else {
-            r[6] += 1;
-            if (r[6] >= 8) { r[5] |= 1; r[7] = 0; }     // the caller's factor keeps changing: stop guessing
-        }
-        r[2] = __float_as_int(w_new);
-    }
-    r[3] = __float_as_int(g);
-    r[4] = __float_as_int(nf);
-}
-
-// all items of one call: block ranges [block0, block0 + nbx * B) per item.  CE_* select the ONE
-// cross-entropy variant compiled into this instantiation (CE_NG = 0: no CE item in the launch);
-// the element-wise and von Mises bodies are selected at run time (they are small).
-// (up to 40 class planes in registers: 4 waves per SIMD as in k_ce_fused — the calls of the small
-// bodies cost the allocator 16 registers otherwise and one wave per SIMD with them)
-template <int CE_DT, int CE_NG, bool CE_SM, int MODE>        // MODE as in ce_fused_body
-__global__ __launch_bounds__(LOSS_THREADS)
-__attribute__((amdgpu_waves_per_eu((CE_NG <= 5) ? 4 : 3, (CE_NG <= 5) ? 8 : 3))) void k_multi_loss(
-    MultiArgs a, const float* __restrict__ expect, const float* __restrict__ gs,
-    LossPartial* __restrict__ partials, int* __restrict__ status)
-{
-    extern __shared__ float s_w[];
-    constexpr bool LOSS = MODE != 2;
-    if (!LOSS) {
-        // the recomputing launch is a small grid walking the block list: when every item's
-        // gradient stands (the usual case) its workgroups are gone after this check
-        bool any = false;
-        for (int i = 0; i < a.n_items; ++i) {
-            const MultiItem& it = a.it[i];
-            any = any || (it.in_launch && it.grad &&
-                          __float_as_int(gs[i]) != __float_as_int(expect[2 * it.total]));
-        }
-        if (!any) return;
-    }
-    for (int blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {     // LOSS: exactly one pass
-        int i = 0;
-        while (i + 1 < a.n_items && (!a.it[i].in_launch || blk >= a.it[i].block0 + a.it[i].nbx * a.it[i].B)) ++i;
-        const MultiItem& it = a.it[i];
-        const int local = blk - it.block0;
-        if (!it.in_launch || local < 0) continue;
-        const int bx = local % it.nbx, b = local / it.nbx;
-        float g = __int_as_float(0x7fc00000);              // NaN: no gradient wanted / no expectation
-        if (MODE != 1 && it.grad && expect) g = expect[2 * it.total];
-        if (!LOSS) {
-            if (!it.grad) continue;
-            const float gr = gs[i];
-            if (__float_as_int(gr) == __float_as_int(g)) continue;         // the forward's gradient stands
-            g = gr;
-        }
-        LossPartial* slot = partials ? partials + blk : nullptr;
-#define MULTI_DT(CALL) switch (it.dtype) { case NMSA_F32: CALL(NMSA_F32); break; case NMSA_BF16: CALL(NMSA_BF16); break; \
-                                            default: CALL(NMSA_F16); break; }
-        switch (it.kind) {
-            case NMSA_LOSS_CE:
-                if constexpr (CE_NG != 0 && MODE == 1) {
-                    // forward only: the streaming walk of k_ce_fwd (16-byte loads, 4 planes in
-                    // flight, few registers) is faster than the register-resident column
-                    constexpr int FPX = (CE_DT == NMSA_F32) ? 4 : 8;
-                    const int vec16 = (it.P % FPX == 0) && ((((uintptr_t)it.pred) & 15) == 0);
-                    ce_fwd_body<CE_DT, FPX, CE_SM, (CE_DT == NMSA_F32) ? 8 : 4>(
-                        it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P, it.param, vec16, slot, status,
-                        nullptr, s_w, bx, it.nbx, b);
-                } else if constexpr (CE_NG != 0) {
-                    ce_fused_body<CE_DT, CE_NG, CE_SM, MODE>(it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P,
-                                                             it.param, it.vec, g, it.grad, slot, status, s_w, bx, b);
-                }
-                break;
-            case NMSA_LOSS_MSE:
-#define CALL(DT) elem_fused_body<DT, 0, MODE>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
-                MULTI_DT(CALL)
-#undef CALL
-                break;
-            case NMSA_LOSS_L1:
-#define CALL(DT) elem_fused_body<DT, 1, MODE>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
-                MULTI_DT(CALL)
-#undef CALL
-                break;
-            case NMSA_LOSS_FOCAL:
-#define CALL(DT) elem_fused_body<DT, 2, MODE>(it.pred, (const float*)it.target, it.mask, it.C, it.P, it.vec, g, it.grad, slot, bx, it.nbx, b)
-                MULTI_DT(CALL)
-#undef CALL
-                break;
-            default:
-#define CALL(DT) vm_fused_body<DT, MODE>(it.pred, (const float*)it.target, it.mask, it.P, it.param, it.vec, g, it.grad, slot, bx, it.nbx, b)
-                MULTI_DT(CALL)
-#undef CALL
-                break;
-        }
-#undef MULTI_DT
-        if (!LOSS) __syncthreads();                        // s_w is rewritten by the next block of the walk
-    }
-}
-
-// MULTI_FIN_SPLIT workgroups per item reduce slices of its block partials (fixed order); the LAST
-// workgroup of the launch to finish (ticket) adds the slices per item, again in a fixed order, and
-// forms the outputs: sums / counts / aux per item; divisors of totals k_multi_expect could not
-// know (forward-only calls, focal items: counts that only the loss kernels produce); and
-// out[0 .. n): the sums as float32, [n .. 2n): sum / count per item, [2n .. 2n + T): per total the
-// float32 sums of its items added in item order, divided by the total's divisor
-// (accumulate_losses, task_helper/base.py:161-182)
-constexpr int MULTI_FIN_SPLIT = 16;
-constexpr int MULTI_FIN_THREADS = 256;
-static_assert(MULTI_MAX_ITEMS * MULTI_FIN_SPLIT <= MULTI_FIN_THREADS, "one thread per slice in the last workgroup");
-
-__global__ __launch_bounds__(MULTI_FIN_THREADS) void k_multi_finalize(
-    MultiArgs a, const LossPartial* __restrict__ partials, LossPartial* __restrict__ slices,
-    unsigned int* __restrict__ ticket, int late_divisors, double* __restrict__ sums,
-    long long* __restrict__ counts, double* __restrict__ aux, float* __restrict__ expect,
-    float* __restrict__ out)
-{
-    __shared__ double s_sum[MULTI_FIN_THREADS], s_aux[MULTI_FIN_THREADS];
-    __shared__ long long s_cnt[MULTI_FIN_THREADS];
-    __shared__ bool s_last;
-    const int item = blockIdx.x / MULTI_FIN_SPLIT, sl = blockIdx.x % MULTI_FIN_SPLIT;
-    const MultiItem& it = a.it[item];
-    const LossPartial* p = partials + it.block0;
-    const int n = it.nbx * it.B;
-    const int per = (n + MULTI_FIN_SPLIT - 1) / MULTI_FIN_SPLIT;
-    const int begin = min(n, sl * per), end = min(n, begin + per);
-    double x = 0, y = 0; long long c = 0;
-    int k = begin + threadIdx.x;
-    for (; k + 3 * MULTI_FIN_THREADS < end; k += 4 * MULTI_FIN_THREADS) {       // 4 independent loads per round
-        LossPartial q[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) q[u] = p[k + u * MULTI_FIN_THREADS];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) { x += q[u].sum; y += q[u].aux; c += q[u].count; }
-    }
-    for (; k < end; k += MULTI_FIN_THREADS) { x += p[k].sum; y += p[k].aux; c += p[k].count; }
-    s_sum[threadIdx.x] = x; s_aux[threadIdx.x] = y; s_cnt[threadIdx.x] = c;
-    __syncthreads();
-    for (int o = MULTI_FIN_THREADS / 2; o > 0; o >>= 1) {
-        if ((int)threadIdx.x < o) {
-            s_sum[threadIdx.x] += s_sum[threadIdx.x + o];
-            s_aux[threadIdx.x] += s_aux[threadIdx.x + o];
-            s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) {
-        LossPartial r; r.sum = s_sum[0]; r.aux = s_aux[0]; r.count = s_cnt[0]; r.pad = 0;
-        slices[blockIdx.x] = r;
-        __threadfence();                                   // the slice before the ticket
-        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
-    }
-    __syncthreads();
-    if (!s_last) return;
-    __threadfence();                                       // the other workgroups' slices after the ticket
-    __shared__ long long s_count[MULTI_MAX_ITEMS];
-    __shared__ float s_f[MULTI_MAX_ITEMS];
-    const int ni = a.n_items, t = threadIdx.x;
-    if (t < ni * MULTI_FIN_SPLIT) {                        // every slice by its own thread, then item by item
-        const volatile LossPartial* q = slices + t;
-        s_sum[t] = q->sum; s_aux[t] = q->aux; s_cnt[t] = q->count;
-    }
-    __syncthreads();
-    if (t < ni) {
-        double sx = 0, sy = 0; long long sc = 0;
-        for (int k = 0; k < MULTI_FIN_SPLIT; ++k) {
-            sx += s_sum[t * MULTI_FIN_SPLIT + k]; sy += s_aux[t * MULTI_FIN_SPLIT + k]; sc += s_cnt[t * MULTI_FIN_SPLIT + k];
-        }
-        sums[t] = sx; counts[t] = sc;
-        if (aux) aux[t] = sy;
-        s_count[t] = sc;
-        s_f[t] = (float)sx;
-        if (out) {
-            const long long cc = a.it[t].clamp ? max(sc, 1LL) : sc;
-            out[t] = (float)sx;
-            out[ni + t] = (float)sx / (float)cc;
-        }
-    }
-    __syncthreads();
-    if (t < a.n_totals) {
-        bool known = !late_divisors;
-        for (int i = 0; i < ni; ++i) if (a.it[i].total == t && a.it[i].count_mode == 2) known = false;
-        float nf = expect[2 * t + 1];
-        if (!known) { nf = multi_divisor(a, s_count, t); expect[2 * t + 1] = nf; }
-        if (out) {
-            float acc = 0.f;
-            for (int i = 0; i < ni; ++i) if (a.it[i].total == t) acc += s_f[i];
-            out[2 * ni + t] = acc / nf;
-        }
-    }
-}
-
 }  // namespace nmsa
 
 using namespace nmsa;
@@ -1810,13 +703,7 @@ int loss_finalize(const LossPartial* partials, int n, double* sum, double* aux, 
 
 namespace {
 
-int grid_x(int P, int px_per_thread)
-{
-    const int64_t per_block = (int64_t)LOSS_THREADS * px_per_thread;
-    int64_t g = (P + per_block - 1) / per_block;
-    if (g < 1) g = 1;
-    return (int)g;
-}
+int grid_x(int P, int px_per_thread) { return loss_grid_x(P, px_per_thread); }
 
 bool bad_shape(int B, int H, int W) { return loss_bad_shape(B, H, W); }
 
@@ -1835,13 +722,6 @@ extern "C" size_t nmsa_loss_workspace_bytes(int B, int H, int W)
     return (size_t)B * 2 * grid_x(H * W, 1) * sizeof(LossPartial);
 }
 
-#define NMSA_DISPATCH_DTYPE(dtype, CALL)          \
-    switch (dtype) {                              \
-        case NMSA_F32: CALL(NMSA_F32); break;     \
-        case NMSA_BF16: CALL(NMSA_BF16); break;   \
-        case NMSA_F16: CALL(NMSA_F16); break;     \
-        default: return NMSA_ERR_ARG;             \
-    }
 
 extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* target,
                                 const float* weights, int B, int C, int H, int W,
@@ -1922,51 +802,9 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
                        grad_logits, nullptr, nullptr, stream);
 }
 
-static int ce_fused_ng(int C) { return (C <= 24) ? 3 : (C <= 40) ? 5 : 6; }
 
 // 49 .. 256 classes: k_ce_split (column over the four lane rows); loss = false: the confirming /
 // recomputing backward launch
-static int ce_split_blocks(int P, int dtype)
-{
-    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
-    const int n_tiles = (P + 64 * pxt - 1) / (64 * pxt);
-    static const int run = loss_env_int("NMSA_CE_SPLIT_RUN", 4);
-    const int tpw = run < 1 ? 1 : run;
-    return (n_tiles + tpw - 1) / tpw;
-}
-
-static int launch_ce_split(bool loss, const void* logits, int dtype, const uint8_t* target,
-                           const float* weights, int B, int C, int P, float ls, const float* gscale,
-                           const float* computed_for, int32_t* counters, void* grad,
-                           LossPartial* partials, int32_t* status, hipStream_t stream)
-{
-    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
-    const int vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad) & 7) == 0);
-    const int n_tiles = (P + 64 * pxt - 1) / (64 * pxt);     // the four waves of a block share 64 x pxt pixels
-    static const int run = loss_env_int("NMSA_CE_SPLIT_RUN", 4);
-    const int tpw = run < 1 ? 1 : run;
-    const int gx = (n_tiles + tpw - 1) / tpw;
-    const bool smooth = ls != 0.0f;
-    const size_t lds = ((size_t)((C + 3) & ~3) + (size_t)(smooth ? 3 : 2) * 4 * 64 * pxt) * sizeof(float);
-    const int per_lane = (C + 3) / 4;
-    const int ng = per_lane <= 24 ? 3 : per_lane <= 32 ? 4 : per_lane <= 40 ? 5 : per_lane <= 48 ? 6 : 8;
-#define CE_SPLIT_L(DT, NG, SM, LS) hipLaunchKernelGGL((k_ce_split<DT, NG, SM, LS>), dim3(gx, B), dim3(LOSS_THREADS), \
-        lds, stream, logits, target, weights, C, P, ls, vec, gscale, grad, partials, status, \
-        computed_for, counters, tpw)
-#define CE_SPLIT_NG(DT, SM, LS) do { if (ng == 3) CE_SPLIT_L(DT, 3, SM, LS); else if (ng == 4) CE_SPLIT_L(DT, 4, SM, LS); \
-        else if (ng == 5) CE_SPLIT_L(DT, 5, SM, LS); else if (ng == 6) CE_SPLIT_L(DT, 6, SM, LS); \
-        else CE_SPLIT_L(DT, 8, SM, LS); } while (0)
-    // MODE 0: loss + gradient, 1: loss only (no gradient buffer), 2: gradient only
-#define CE_SPLIT_M(DT, LS) do { if (smooth) CE_SPLIT_NG(DT, true, LS); else CE_SPLIT_NG(DT, false, LS); } while (0)
-#define CE_SPLIT(DT) do { if (!loss) CE_SPLIT_M(DT, 2); else if (grad) CE_SPLIT_M(DT, 0); else CE_SPLIT_M(DT, 1); } while (0)
-    NMSA_DISPATCH_DTYPE(dtype, CE_SPLIT)
-#undef CE_SPLIT
-#undef CE_SPLIT_M
-#undef CE_SPLIT_NG
-#undef CE_SPLIT_L
-    return check_launch();
-}
-
 extern "C" int nmsa_loss_ce_bwd_unless(const void* logits, int dtype, const uint8_t* target,
                                        const float* weights, int B, int C, int H, int W,
                                        float label_smoothing, const float* grad_scale,
@@ -2036,7 +874,7 @@ extern "C" int nmsa_count_u8(const uint8_t* values, int64_t n, int lo, int hi, i
 
 // k_ce_fused forward + gradient into a caller-owned partial region, no finalize (used by the
 // multi-loss call for a cross entropy whose variant differs from the one in its joint launch)
-static int nmsa_loss_ce_fwd_grad_partials(const void* logits, int dtype, const uint8_t* target,
+int nmsa::loss_ce_fwd_grad_partials(const void* logits, int dtype, const uint8_t* target,
                                           const float* weights, int B, int C, int P, float ls,
                                           const float* expected, void* grad, LossPartial* partials,
                                           int32_t* status, hipStream_t stream)
@@ -2457,220 +1295,3 @@ extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t*
     return check_launch();
 }
 
-// ---------------------------------------------------------------------------------------------
-// a10: all losses of a task helper in one call (see k_multi_loss)
-namespace {
-
-struct MultiPlan {
-    MultiArgs args;
-    int n_count_blocks;
-    int ce_dt, ce_ng, ce_sm;                           // the cross-entropy variant inside the launch (ng 0: none)
-    int max_c;
-    size_t lds;
-};
-
-int multi_plan(const nmsa_loss_item* items, int n_items, int n_totals, MultiPlan& pl)
-{
-    if (!items || n_items <= 0 || n_items > MULTI_MAX_ITEMS || n_totals <= 0 || n_totals > MULTI_MAX_TOTALS)
-        return NMSA_ERR_ARG;
-    MultiArgs& a = pl.args;
-    a.n_items = n_items; a.n_totals = n_totals; a.n_blocks = 0;
-    pl.ce_ng = 0; pl.ce_dt = NMSA_F32; pl.ce_sm = 0; pl.max_c = 0;
-    int block = 0, cblock = 0;
-    bool seen_total[MULTI_MAX_TOTALS] = {false};
-    for (int pass = 0; pass < 2; ++pass) {             // pass 0: the items of the joint launch, pass 1: the others
-        for (int i = 0; i < n_items; ++i) {
-            const nmsa_loss_item& s = items[i];
-            MultiItem& it = a.it[i];
-            if (pass == 0) {
-                if (!s.pred || s.total < 0 || s.total >= n_totals || bad_shape(s.B, s.H, s.W) || s.C <= 0)
-                    return NMSA_ERR_ARG;
-                if (s.dtype != NMSA_F32 && s.dtype != NMSA_BF16 && s.dtype != NMSA_F16) return NMSA_ERR_ARG;
-                if (s.kind < NMSA_LOSS_CE || s.kind > NMSA_LOSS_VONMISES) return NMSA_ERR_ARG;
-                if (s.kind != NMSA_LOSS_CE && !s.target) return NMSA_ERR_ARG;
-                if (s.kind == NMSA_LOSS_CE && !s.mask) return NMSA_ERR_ARG;
-                if (s.kind == NMSA_LOSS_VONMISES && s.C != 2) return NMSA_ERR_ARG;
-                it.pred = s.pred; it.target = s.target; it.mask = (const uint8_t*)s.mask; it.weights = s.weights;
-                it.grad = s.grad;
-                it.kind = s.kind; it.dtype = s.dtype; it.B = s.B; it.C = s.C; it.P = s.H * s.W;
-                it.total = s.total; it.clamp = s.clamp_count != 0; it.param = s.param;
-                it.first_of_total = !seen_total[s.total];
-                seen_total[s.total] = true;
-                const uintptr_t al = (uintptr_t)s.pred | (uintptr_t)s.grad | (uintptr_t)s.target;
-                it.in_launch = 1;
-                if (s.kind == NMSA_LOSS_CE) {
-                    if (s.C > CE_SPLIT_MAX_C) return NMSA_ERR_UNSUPPORTED;
-                    const int pxt = (s.dtype == NMSA_F32) ? 2 : 4;
-                    it.vec = (it.P % pxt == 0) && ((((uintptr_t)s.pred | (uintptr_t)s.grad) & 7) == 0);
-                    it.count_mode = 1; it.lo = 1; it.hi = s.C < 255 ? s.C : 255;
-                    if (s.C > CE_FUSED_MAX_C) {
-                        it.in_launch = 0;
-                        it.nbx = ce_split_blocks(it.P, s.dtype);
-                    } else {
-                        const int ng = ce_fused_ng(s.C), sm = s.param != 0.0f;
-                        if (pl.ce_ng == 0) { pl.ce_ng = ng; pl.ce_dt = s.dtype; pl.ce_sm = sm; }
-                        if (ng != pl.ce_ng || s.dtype != pl.ce_dt || sm != pl.ce_sm) it.in_launch = 0;
-                        it.nbx = grid_x(it.P, pxt);
-                        if (it.in_launch && s.C > pl.max_c) pl.max_c = s.C;
-                    }
-                } else {
-                    it.vec = (it.P % 4 == 0) && (((al | (uintptr_t)s.mask) & 15) == 0);
-                    it.nbx = grid_x(it.P, 8);
-                    it.count_mode = s.kind == NMSA_LOSS_FOCAL ? 2 : (s.mask ? 1 : 0);
-                    it.lo = 1; it.hi = 255;
-                }
-                if (it.count_mode == 1) {
-                    const long long n = (long long)it.B * it.P;
-                    long long cb = (n / 16 + LOSS_THREADS * 4 - 1) / (LOSS_THREADS * 4);
-                    it.cnblocks = (int)(cb < 1 ? 1 : cb > MULTI_COUNT_MAX_BLOCKS ? MULTI_COUNT_MAX_BLOCKS : cb);
-                } else {
-                    it.cnblocks = 1;
-                }
-                it.cblock0 = cblock;
-                cblock += it.cnblocks;
-            }
-            if ((pass == 0) == (it.in_launch != 0)) {
-                it.block0 = block;
-                block += it.nbx * it.B;
-                if (pass == 0) a.n_blocks = block;      // blocks of the joint launch
-            }
-            if (block < 0 || block > (1 << 28)) return NMSA_ERR_ARG;
-        }
-    }
-    pl.n_count_blocks = cblock;
-    pl.lds = (size_t)(pl.max_c > 0 ? pl.max_c : 1) * sizeof(float);
-    return NMSA_OK;
-}
-
-size_t multi_partial_blocks(const MultiPlan& pl)
-{
-    size_t n = 0;
-    for (int i = 0; i < pl.args.n_items; ++i) n += (size_t)pl.args.it[i].nbx * pl.args.it[i].B;
-    return n;
-}
-
-template <int MODE>
-int multi_launch_joint(const MultiPlan& pl, const float* expect, const float* gs, LossPartial* partials,
-                       int* status, hipStream_t stream)
-{
-    const MultiArgs& a = pl.args;
-    if (a.n_blocks <= 0) return NMSA_OK;
-    // (the recomputing launch: a small grid that walks the block list, see k_multi_loss)
-    const int grid = MODE != 2 ? a.n_blocks : (a.n_blocks < 4096 ? a.n_blocks : 4096);
-#define ML(DT, NG, SM) hipLaunchKernelGGL((k_multi_loss<DT, NG, SM, MODE>), dim3(grid), dim3(LOSS_THREADS), \
-        pl.lds, stream, a, expect, gs, partials, status)
-#define ML_NG(DT, SM) do { if (pl.ce_ng == 3) ML(DT, 3, SM); else if (pl.ce_ng == 5) ML(DT, 5, SM); else ML(DT, 6, SM); } while (0)
-#define ML_DT(DT) do { if (pl.ce_sm) ML_NG(DT, true); else ML_NG(DT, false); } while (0)
-    if (pl.ce_ng == 0) ML(NMSA_F32, 0, false);
-    else switch (pl.ce_dt) {
-        case NMSA_F32: ML_DT(NMSA_F32); break;
-        case NMSA_BF16: ML_DT(NMSA_BF16); break;
-        default: ML_DT(NMSA_F16); break;
-    }
-#undef ML_DT
-#undef ML_NG
-#undef ML
-    return check_launch();
-}
-
-}  // namespace
-
-namespace {
-size_t multi_workspace_bytes(const MultiPlan& pl)
-{
-    return (multi_partial_blocks(pl) + (size_t)MULTI_MAX_ITEMS * MULTI_FIN_SPLIT) * sizeof(LossPartial) +
-           (size_t)pl.n_count_blocks * sizeof(long long) + 64;
-}
-}  // namespace
-
-extern "C" size_t nmsa_multitask_loss_workspace_bytes(const nmsa_loss_item* items, int n_items)
-{
-    MultiPlan pl;
-    int nt = 1;
-    if (!items) return 0;
-    for (int i = 0; i < n_items && i < MULTI_MAX_ITEMS; ++i) if (items[i].total + 1 > nt) nt = items[i].total + 1;
-    if (nt > MULTI_MAX_TOTALS || multi_plan(items, n_items, nt, pl)) return 0;
-    return multi_workspace_bytes(pl);
-}
-
-extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_items, int n_totals,
-                                            int32_t* spec, float* expect, double* loss_sums,
-                                            int64_t* counts, double* aux, float* out_f32, int32_t* status,
-                                            void* workspace, size_t workspace_bytes, nmsa_stream_t stream_)
-{
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!spec || !expect || !loss_sums || !counts || !status || !workspace) return NMSA_ERR_ARG;
-    MultiPlan pl;
-    int rc = multi_plan(items, n_items, n_totals, pl);
-    if (rc) return rc;
-    const size_t nb = multi_partial_blocks(pl);
-    if (workspace_bytes < multi_workspace_bytes(pl)) return NMSA_ERR_WORKSPACE;
-    LossPartial* partials = (LossPartial*)workspace;
-    LossPartial* slices = partials + nb;
-    long long* cpart = (long long*)(slices + (size_t)MULTI_MAX_ITEMS * MULTI_FIN_SPLIT);
-    unsigned int* ticket = (unsigned int*)(cpart + pl.n_count_blocks);
-    const MultiArgs& a = pl.args;
-    bool any_grad = false;
-    for (int i = 0; i < n_items; ++i) any_grad = any_grad || a.it[i].grad != nullptr;
-    // (forward only: nobody needs a count before the sums; k_multi_expect then only marks "no
-    // expectation" and the divisors come out of the finalized counts)
-    if (any_grad) {
-        hipLaunchKernelGGL(k_multi_count, dim3(pl.n_count_blocks), dim3(LOSS_THREADS), 0, stream, a, cpart);
-        rc = check_launch();
-        if (rc) return rc;
-    }
-    hipLaunchKernelGGL(k_multi_expect, dim3(1), dim3(LOSS_THREADS), 0, stream, a,
-                       any_grad ? (const long long*)cpart : (const long long*)nullptr, spec, expect, ticket);
-    rc = check_launch();
-    if (rc) return rc;
-    rc = any_grad ? multi_launch_joint<0>(pl, expect, nullptr, partials, status, stream)
-                  : multi_launch_joint<1>(pl, expect, nullptr, partials, status, stream);
-    if (rc) return rc;
-    for (int i = 0; i < n_items; ++i) {                 // cross entropies outside the joint launch
-        const MultiItem& it = a.it[i];
-        if (it.in_launch) continue;
-        if (it.C > CE_FUSED_MAX_C) {
-            rc = launch_ce_split(true, it.pred, it.dtype, it.mask, it.weights, it.B, it.C, it.P, it.param,
-                                 expect + 2 * it.total, nullptr, nullptr, it.grad, partials + it.block0, status,
-                                 stream);
-        } else {
-            // a second register-resident variant in one call: its own forward + gradient launch
-            rc = nmsa_loss_ce_fwd_grad_partials(it.pred, it.dtype, it.mask, it.weights, it.B, it.C, it.P,
-                                                it.param, expect + 2 * it.total, it.grad, partials + it.block0,
-                                                status, stream);
-        }
-        if (rc) return rc;
-    }
-    hipLaunchKernelGGL(k_multi_finalize, dim3(n_items * MULTI_FIN_SPLIT), dim3(MULTI_FIN_THREADS), 0, stream, a,
-                       partials, slices, ticket, any_grad ? 0 : 1, loss_sums, (long long*)counts, aux, expect,
-                       out_f32);
-    return check_launch();
-}
-
-extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n_items, int n_totals,
-                                              const float* grad_sums, const float* grad_item_losses,
-                                              const float* grad_total_losses, const int64_t* counts,
-                                              const float* expect, int32_t* spec, float* grad_scales,
-                                              int32_t* counters, nmsa_stream_t stream_)
-{
-    hipStream_t stream = (hipStream_t)stream_;
-    if (!counts || !grad_scales || !expect || !spec) return NMSA_ERR_ARG;
-    MultiPlan pl;
-    int rc = multi_plan(items, n_items, n_totals, pl);
-    if (rc) return rc;
-    const MultiArgs& a = pl.args;
-    hipLaunchKernelGGL(k_multi_spec, dim3(1), dim3(64), 0, stream, a, grad_sums, grad_item_losses,
-                       grad_total_losses, (const long long*)counts, expect, spec, grad_scales, counters);
-    rc = check_launch();
-    if (rc) return rc;
-    rc = multi_launch_joint<2>(pl, expect, grad_scales, nullptr, nullptr, stream);
-    if (rc) return rc;
-    for (int i = 0; i < n_items; ++i) {
-        const MultiItem& it = a.it[i];
-        if (it.in_launch || !it.grad) continue;
-        rc = nmsa_loss_ce_bwd_unless(it.pred, it.dtype, it.mask, it.weights, it.B, it.C, 1, it.P, it.param,
-                                     grad_scales + i, it.grad, expect + 2 * it.total, nullptr, stream_);
-        if (rc) return rc;
-    }
-    return NMSA_OK;
-}
