@@ -198,3 +198,62 @@ def test_forward_written_gradient_entry_points_return_codes(env):
     assert lib.nmsa_loss_vonmises_bwd_unless(p(pred), 0, p(tgt), p(t['fg']), B, H, W, 1.0, p(one),
                                              p(gp), None, None, st) == ERR_ARG
     torch.cuda.synchronize()
+
+
+def test_multitask_loss_bad_arguments(env):
+    """nmsa_multitask_loss_*: item lists the dispatcher cannot take answer a code, a valid call
+    in between still works"""
+    L, lib, dev, (B, C, H, W), t = env
+    from nicr_mt_scene_analysis_amd.loss._multi import _Item
+    p, st = L.ptr, L.stream_ptr(dev)
+    labels = torch.randint(0, C + 1, (B, H, W), device=dev).to(torch.uint8)
+    grad = torch.empty_like(t['logits'])
+    spec = torch.zeros((2, 8), dtype=torch.int32, device=dev)
+    spec.view(torch.float32)[:, 2] = 1.0
+    expect = torch.empty((2, 2), dtype=torch.float32, device=dev)
+    small = torch.empty((6,), dtype=torch.float64, device=dev)
+    out = torch.empty((5,), dtype=torch.float32, device=dev)
+
+    def items(n=1, **over):
+        arr = (_Item * n)()
+        for a in arr:
+            a.kind, a.dtype, a.B, a.C, a.H, a.W, a.total = 0, 0, B, C, H, W, 0
+            a.pred, a.mask, a.grad = t['logits'].data_ptr(), labels.data_ptr(), grad.data_ptr()
+            for k, v in over.items():
+                setattr(a, k, v)
+        return arr
+
+    def fwd(arr, n=1, n_totals=1, ws_bytes=None, spec_=spec):
+        need = lib.nmsa_multitask_loss_workspace_bytes(arr, n)
+        return lib.nmsa_multitask_loss_fwd_grad(arr, n, n_totals, p(spec_), p(expect), p(small[:2]),
+                                                p(small[4:].view(torch.int64)), p(small[2:4]), p(out),
+                                                p(t['status']), p(t['ws']),
+                                                need if ws_bytes is None else ws_bytes, st)
+    good = items()
+    assert fwd(good) == 0
+    assert fwd(good, spec_=None) == ERR_ARG
+    assert fwd(good, ws_bytes=16) == ERR_WORKSPACE
+    assert fwd(good, n=0) == ERR_ARG
+    assert fwd(items(17), n=17) == ERR_ARG                          # NMSA_MULTI_MAX_ITEMS = 16
+    assert lib.nmsa_multitask_loss_workspace_bytes(items(17), 17) == 0
+    assert fwd(items(total=1)) == ERR_ARG                           # total index outside n_totals
+    assert fwd(items(total=-1)) == ERR_ARG
+    assert fwd(items(dtype=7)) == ERR_ARG
+    assert fwd(items(kind=9)) == ERR_ARG
+    assert fwd(items(mask=None)) == ERR_ARG                         # a cross entropy needs its labels
+    assert fwd(items(kind=1)) == ERR_ARG                            # MSE without a target
+    assert fwd(items(kind=4, target=t['logits'].data_ptr())) == ERR_ARG     # von Mises needs 2 channels
+    assert fwd(items(C=300)) != 0                                   # beyond the 256-class column split
+    assert fwd(items(B=0)) == ERR_ARG
+    gs = torch.empty((1,), dtype=torch.float32, device=dev)
+    g_tot = torch.ones((1,), dtype=torch.float32, device=dev)
+    counts = small[4:].view(torch.int64)
+
+    def bwd(arr, counts_=counts, gs_=gs):
+        return lib.nmsa_multitask_loss_bwd_unless(arr, 1, 1, None, None, p(g_tot), p(counts_), p(expect),
+                                                  p(spec), p(gs_), None, st)
+    assert fwd(good) == 0 and bwd(good) == 0
+    assert bwd(good, counts_=None) == ERR_ARG
+    assert bwd(good, gs_=None) == ERR_ARG
+    torch.cuda.synchronize()
+    assert int(spec[0, 0]) + int(spec[0, 1]) == 1                   # exactly one backward pass was judged
