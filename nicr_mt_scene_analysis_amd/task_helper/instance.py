@@ -75,7 +75,8 @@ class InstanceTaskHelper(TaskHelperBase):
         items, names = [], []
         # center: pred*mask vs target, n = sum(mask)            (instance.py:115-139)
         for k, p, t, m in zip(keys, preds_center, targets('instance_center'), targets('instance_center_mask')):
-            items.append({'kind': center_kind, 'pred': p.contiguous(), 'target': t, 'mask': m, 'total': 0})
+            items.append({'kind': center_kind, 'pred': p.contiguous(), 'target': t, 'mask': m, 'total': 0,
+                          'clamp': center_kind == 'focal'})      # focal: n = max(#peaks, 1) per scale
             names.append(f'instance_center_loss_{k}')
         # offset: pred*foreground vs target, n = sum(foreground)  (instance.py:141-167)
         for k, p, t, m in zip(keys, preds_offset, targets('instance_offset'), targets('instance_foreground')):
@@ -91,11 +92,10 @@ class InstanceTaskHelper(TaskHelperBase):
                 names.append(f'instance_orientation_loss_{k}')
             total_names.append('instance_orientation')
         from ..loss import _multi
-        if center_kind != 'focal' and F_.speculation_enabled() and _multi.supported(items):
+        if F_.speculation_enabled() and _multi.supported(items):
             # every loss of every scale in ONE forward call
             return self.multi_losses(items, names, tuple(total_names))
-        # the focal extension (its divisor is no count of mask bytes), host tensors, > 16 items:
-        # loss by loss
+        # host tensors, > 16 items: loss by loss
         out = []
         for it in items:
             if it['kind'] == 'vonmises':
