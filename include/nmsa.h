@@ -539,6 +539,21 @@ int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t* indices, c
                           int B, int D, int H, int W, int L,
                           const float* grad_scale, const float* dots, void* grad_pred,
                           nmsa_stream_t stream);
+/* forward + gradient in ONE pass over the prediction (k_cos_split: the D-column of a pixel
+ * stays in the registers of the D / 64 waves of a workgroup, the image's LUT in LDS): D % 64 == 0,
+ * D <= 512, LUT + exchange buffers within the CU's LDS, H*W a multiple of 4 (2 for f32), 8-byte
+ * aligned planes.  The gradient is written for *expected_gscale; nmsa_loss_cos_emb_bwd_unless
+ * confirms it (bit-equal *grad_scale) or recomputes. */
+int nmsa_loss_cos_emb_fwd_grad_supported(int dtype, int D, int H, int W, int L);
+size_t nmsa_loss_cos_emb_fwd_grad_workspace_bytes(int B, int D, int H, int W, int L);
+int nmsa_loss_cos_emb_fwd_grad(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                               int B, int D, int H, int W, int L, const float* expected_gscale,
+                               double* loss_sum, int64_t* n_rows, void* grad_pred, int32_t* status,
+                               void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
+int nmsa_loss_cos_emb_bwd_unless(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                                 int B, int D, int H, int W, int L, const float* grad_scale,
+                                 void* grad_pred, const float* computed_for, int32_t* counters,
+                                 nmsa_stream_t stream);
 /* 1 when the (L, D, H*W) combination runs the LDS-LUT kernel that can keep `dots` */
 int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
 
@@ -568,7 +583,11 @@ int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
  *                logits [B,C,H,W], mask = labels u8 [B,H,W] (0 = void), weights f32 [C] or NULL,
  *                param = label smoothing; MSE / L1 / FOCAL: pred [B,C,H,W] (C = 1 for [B,H,W]),
  *                target f32, mask u8 [B,H,W] or NULL; VONMISES: pred / target [B,2,H,W], mask,
- *                param = kappa.  grad = gradient buffer shaped like pred, or NULL (forward only).
+ *                param = kappa; COS_EMB (loss/cos_emb.py:21-56 with the LUT gather of
+ *                task_helper/dense_visual_embedding.py:110-171): pred [B,D,H,W] with C = D, target =
+ *                LUT f32 [B,L,D] with L in `reserved`, mask = indices i32 [B,H,W] (0 = no target) —
+ *                shapes nmsa_loss_cos_emb_fwd_grad_supported accepts, else NMSA_ERR_UNSUPPORTED.
+ *                grad = gradient buffer shaped like pred, or NULL (forward only).
  *                clamp_count: the item's count enters its loss and its total as max(count, 1)
  *                (task_helper/instance.py:206-211)
  *   spec         i32 [n_totals][8] device, persistent, owned by the caller (zero it, then store
@@ -590,15 +609,16 @@ int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
  *                held, [1] += 1 when it did not (a tally over all callers; the spec records keep
  *                their own)
  * ------------------------------------------------------------------------- */
-enum { NMSA_LOSS_CE = 0, NMSA_LOSS_MSE = 1, NMSA_LOSS_L1 = 2, NMSA_LOSS_FOCAL = 3, NMSA_LOSS_VONMISES = 4 };
+enum { NMSA_LOSS_CE = 0, NMSA_LOSS_MSE = 1, NMSA_LOSS_L1 = 2, NMSA_LOSS_FOCAL = 3, NMSA_LOSS_VONMISES = 4,
+       NMSA_LOSS_COS_EMB = 5 };
 #define NMSA_MULTI_MAX_ITEMS 16
 #define NMSA_MULTI_MAX_TOTALS 8
 typedef struct nmsa_loss_item {
     int32_t kind, dtype, B, C, H, W;
     int32_t total;        /* index of the total this item belongs to */
-    int32_t clamp_count;  /* 1: max(count, 1) enters the total */
+    int32_t clamp_count;  /* 1: max(count, 1) is the item's divisor and enters the total; 2: the item's divisor only */
     float param;          /* label smoothing | kappa */
-    int32_t reserved;
+    int32_t reserved;     /* COS_EMB: L, the LUT rows per image; otherwise 0 */
     const void* pred;
     const void* target;
     const void* mask;     /* labels (CE) or mask bytes; NULL = every pixel */

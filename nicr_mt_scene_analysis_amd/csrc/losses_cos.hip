@@ -1,0 +1,332 @@
+// losses_cos.hip — cosine-embedding loss, forward + gradient in ONE pass over the prediction.
+//   CosineEmbeddingLoss._compute_loss   loss/cos_emb.py:21-56 (+ the LUT gather of
+//                                       task_helper/dense_visual_embedding.py:110-171)
+//   per valid px (index != 0):  1 - x.y / sqrt((|x|^2 + eps)(|y|^2 + eps)), eps = 1e-12,
+//   y = lut[b][index - 1];   d/dx = -y / den + (x.y) x / ((|x|^2 + eps) den)
+//
+// The gradient needs x.y and |x|^2 over the pixel's whole D-column (1 KB at D = 512) before its
+// first element can be written; the two-kernel path reads the prediction twice (1.5x the
+// algorithmic bytes).  Here the column stays in REGISTERS between the reduction and the gradient,
+// in the layout that made the wide cross entropy byte-exact (k_ce_split): the NW = D / 64 waves
+// of a workgroup look at the SAME 64 x PXT pixels, wave w keeps the planes [64 w, 64 w + 64), so
+// every wave-instruction moves one contiguous 512-byte piece of a plane.  The waves exchange
+// their partial x.y and |x|^2 through LDS (two barriers per tile, back to back), each wave then
+// writes the gradient of its own planes from its registers — and, as a register is consumed,
+// requests the same plane of the NEXT tile into it, so the memory pipe stays busy through the
+// arithmetic although the CU holds a single workgroup (the fp32 LUT of the image, 128 KB at
+// D = 512 / L = 64, fills its LDS).  Indices are piecewise constant: when the PXT pixels of every
+// lane share one LUT row, one LDS read per plane serves them all.
+#include <stdlib.h>
+#include "loss_bodies.hpp"
+
+namespace nmsa {
+
+constexpr int COSS_NP = 64;                            // planes per wave
+constexpr int COSS_MAX_WAVES = 8;                      // D <= 512: 8 waves = 2 per SIMD, 256 VGPRs each
+
+// (loss, count) of the workgroup -> its partial slot; any number of waves up to COSS_MAX_WAVES
+__device__ __forceinline__ void block_partial_wide(double acc, long long cnt, LossPartial* __restrict__ partials)
+{
+    __shared__ double r_sum[COSS_MAX_WAVES];
+    __shared__ long long r_cnt[COSS_MAX_WAVES];
+    acc = wave_reduce_sum(acc);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+    if (lane_id() == 0) { r_sum[threadIdx.x >> 6] = acc; r_cnt[threadIdx.x >> 6] = cnt; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double a = 0; long long c = 0;
+        for (int k = 0; k < (int)(blockDim.x >> 6); ++k) { a += r_sum[k]; c += r_cnt[k]; }
+        LossPartial pr; pr.sum = a; pr.aux = 0; pr.count = c; pr.pad = 0;
+        partials[(size_t)blockIdx.y * gridDim.x + blockIdx.x] = pr;
+    }
+}
+
+template <int DTYPE, int MODE>                         // MODE 0: loss + gradient, 2: gradient only
+__global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
+    const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
+    int D, int P, int L, int vec, int tiles_per_wg,
+    const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials, int* __restrict__ status,
+    const float* __restrict__ computed_for, int* __restrict__ counters)
+{
+    constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
+    constexpr int NP = COSS_NP;
+    constexpr int TPX = 64 * PXT;                      // pixels per tile
+    constexpr bool LOSS = MODE != 2;
+    extern __shared__ float s_mem[];                   // [L][D + 1] LUT | yy[L] | xy[NW][TPX] | xx[NW][TPX]
+    if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
+    const int NW = blockDim.x >> 6;
+    const int ld = D + 1;
+    float* s_lut = s_mem;
+    float* s_yy = s_lut + (size_t)L * ld;
+    float* s_xy = s_yy + ((L + 3) & ~3);
+    float* s_xx = s_xy + NW * TPX;
+    const int b = blockIdx.y;
+    const float* lut_b = lut + (size_t)b * L * D;
+    for (int i = threadIdx.x; i < L * D; i += blockDim.x) {
+        const int r = i / D, d = i - r * D;
+        s_lut[r * ld + d] = lut_b[i];
+    }
+    __syncthreads();
+    for (int r = threadIdx.x >> 6; r < L; r += NW) {   // |y|^2 per row: one wave per row
+        float yy = 0.f;
+        for (int d = lane_id(); d < D; d += 64) { const float v = s_lut[r * ld + d]; yy = fmaf(v, v, yy); }
+        yy = wave_reduce_sum(yy);
+        if (lane_id() == 0) s_yy[r] = yy;
+    }
+    __syncthreads();
+
+    const float EPS = 1e-12f;
+    const float g = grad ? *expected_gscale : __int_as_float(0x7fc00000);
+    const bool write_grad = g == g;
+    const size_t img = (size_t)b * D * P;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();
+    const int c0 = w * NP;
+    constexpr int nc = NP;                             // D % NP == 0 (the host checks): no per-plane branches
+    double acc = 0.0;
+    long long cnt = 0;
+    bool bad = false;
+    const int n_tiles = (P + TPX - 1) / TPX;
+    const int t_begin = blockIdx.x * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+    if (t_begin >= t_end) { if (LOSS) block_partial_wide(0.0, 0, partials); return; }
+
+    // `vec` layouts only (P % PXT == 0, 8-byte aligned planes: the host checks): every plane access
+    // is ONE 8-byte load / store at a wave-uniform plane base + a 32-bit lane offset shared by all
+    // planes — no per-plane 64-bit address registers, no edge branches inside the walks.  Lanes
+    // past the end of the image (last tile) read the image's first pixels and store nothing.
+    constexpr int ESIZE = (DTYPE == NMSA_F32) ? 4 : 2;
+    const char* pred_b = (const char*)pred + img * ESIZE;
+    char* grad_b = (char*)grad + img * ESIZE;
+    u32x2_s r[NP];
+    auto lane_offset = [&](int tile) -> uint32_t {
+        const int p0 = (tile * 64 + l) * PXT;
+        return (uint32_t)((p0 < P ? p0 : 0) * ESIZE);
+    };
+    auto request_plane = [&](int i, uint32_t off) {
+        const char* pb = pred_b + (size_t)(c0 + i) * P * ESIZE;          // wave-uniform
+        r[i] = __builtin_nontemporal_load((const u32x2_s*)(pb + off));
+    };
+    auto store_plane = [&](int i, uint32_t off, const float o[PXT]) {
+        char* gb = grad_b + (size_t)(c0 + i) * P * ESIZE;               // wave-uniform
+        u32x2_s v;
+        if (DTYPE == NMSA_F32) { v.x = __float_as_uint(o[0]); v.y = __float_as_uint(o[1]); }
+        else { v.x = pack16<DTYPE>(o[0], o[1]); v.y = pack16<DTYPE>(o[2], o[3]); }
+        __builtin_nontemporal_store(v, (u32x2_s*)(gb + off));
+    };
+    auto request = [&](int tile) {                     // all planes of `tile` into r[]
+        const uint32_t off = lane_offset(tile);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            r[i] = u32x2_s{0u, 0u};
+            if (i < nc) request_plane(i, off);
+        }
+    };
+#ifndef COSS_PREFETCH
+#define COSS_PREFETCH 1
+#endif
+    if (COSS_PREFETCH) request(t_begin);
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        if (!COSS_PREFETCH) request(tile);
+        const int p0 = (tile * 64 + l) * PXT;
+        const bool alive = p0 < P;
+        const int nvalid = alive ? min(PXT, P - p0) : 0;
+        int row[PXT], ridx[PXT];
+        bool on[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const int ix = (j < nvalid) ? indices[(size_t)b * P + p0 + j] : 0;
+            if (ix < 0 || ix > L) bad = true;
+            on[j] = ix > 0 && ix <= L;
+            ridx[j] = on[j] ? ix - 1 : 0;
+            row[j] = ridx[j] * ld;
+        }
+        // ---- pass 1: partial x.y and |x|^2 over my planes --------------------------------------
+        // (one LDS read per pixel and plane: lanes that share a row are a broadcast, different
+        // rows sit in different banks — row stride D + 1; one code path for segment interiors and
+        // boundaries keeps the walks straight-line)
+        float xy[PXT], xx[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) { xy[j] = 0.f; xx[j] = 0.f; row[j] += c0; }
+        if (DTYPE != NMSA_F32) keep_packed(r);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const float x = plane_px<DTYPE>(r[i], j);
+                xy[j] = fmaf(x, s_lut[row[j] + i], xy[j]);
+                xx[j] = fmaf(x, x, xx[j]);
+            }
+        }
+        // ---- the sums over the waves, in wave order (the second barrier follows the first by a few
+        // LDS reads: the LUT leaves no room for a second set of exchange buffers) --------------------
+        float* bxy = s_xy;
+        float* bxx = s_xx;
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) { bxy[w * TPX + l * PXT + j] = xy[j]; bxx[w * TPX + l * PXT + j] = xx[j]; }
+        __syncthreads();
+        float k1[PXT], k2[PXT];
+        float part = 0.f;
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            float sxy = bxy[l * PXT + j], sxx = bxx[l * PXT + j];
+            for (int ww = 1; ww < NW; ++ww) { sxy += bxy[ww * TPX + l * PXT + j]; sxx += bxx[ww * TPX + l * PXT + j]; }
+            const float den = sqrtf((sxx + EPS) * (s_yy[ridx[j]] + EPS));
+            k1[j] = on[j] ? -g / den : 0.f;
+            k2[j] = on[j] ? g * sxy / ((sxx + EPS) * den) : 0.f;
+            if (LOSS && w == 0 && on[j]) { part += 1.0f - sxy / den; ++cnt; }
+        }
+        acc += part;
+        __syncthreads();                                // every wave has read the sums: the buffers are free
+        // ---- pass 2: the gradient of my planes; each register then takes the next tile's plane ----
+        const bool more = COSS_PREFETCH && tile + 1 < t_end;        // wave-uniform
+        const uint32_t off = lane_offset(tile), qoff = lane_offset(more ? tile + 1 : tile);
+        const bool store = alive && write_grad;
+        if (DTYPE != NMSA_F32) keep_packed(r);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) {
+            float o[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j)
+                o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
+            if (store) store_plane(i, off, o);
+            if (COSS_PREFETCH) request_plane(i, qoff);         // (the last tile re-reads itself: no branch in the walk)
+        }
+    }
+    if (LOSS) {
+        if (bad) atomicOr(status, 8);
+        block_partial_wide(acc, cnt, partials);
+    }
+}
+
+}  // namespace nmsa
+
+using namespace nmsa;
+
+namespace {
+
+size_t coss_lds_bytes(int D, int L, int nw, int pxt)
+{
+    return ((size_t)L * (D + 1) + ((L + 3) & ~3) + (size_t)2 * nw * 64 * pxt) * sizeof(float);
+}
+
+}  // namespace
+
+// 1 when the one-pass kernel takes this shape: the image's fp32 LUT and the exchange buffers fit
+// the LDS of a CU, the column fits the waves of one workgroup
+extern "C" int nmsa_loss_cos_emb_fwd_grad_supported(int dtype, int D, int H, int W, int L)
+{
+    if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return 0;
+    if (D <= 0 || L <= 0 || H <= 0 || W <= 0) return 0;
+    if (D % COSS_NP != 0) return 0;                     // whole groups of 64 planes per wave
+    const int nw = D / COSS_NP;
+    if (nw > COSS_MAX_WAVES) return 0;
+    static const int on = loss_env_int("NMSA_COS_SPLIT", 1);
+    if (!on) return 0;
+    return coss_lds_bytes(D, L, nw, dtype == NMSA_F32 ? 2 : 4) <= (size_t)158 * 1024;
+}
+
+extern "C" size_t nmsa_loss_cos_emb_fwd_grad_workspace_bytes(int B, int D, int H, int W, int L)
+{
+    (void)D; (void)L;
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    const int nb = cos_split_blocks(B, H * W, NMSA_F32) > cos_split_blocks(B, H * W, NMSA_BF16)
+                       ? cos_split_blocks(B, H * W, NMSA_F32) : cos_split_blocks(B, H * W, NMSA_BF16);
+    return (size_t)B * nb * sizeof(LossPartial) + 64;
+}
+
+namespace {
+
+// workgroups per image and tiles per workgroup: one workgroup per CU is resident (the LUT fills
+// the LDS), a few workgroups per CU over the whole batch, each walking a run of consecutive
+// tiles of one image
+void coss_geometry(int B, int P, int dtype, int* gx, int* tpw)
+{
+    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
+    const int n_tiles = (P + 64 * pxt - 1) / (64 * pxt);
+    static const int per_cu = loss_env_int("NMSA_COS_SPLIT_WGS_PER_CU", 2);
+    int per_img = (256 * (per_cu < 1 ? 1 : per_cu) + B - 1) / B;
+    if (per_img > n_tiles) per_img = n_tiles;
+    if (per_img > 4096) per_img = 4096;
+    if (per_img < 1) per_img = 1;
+    *tpw = (n_tiles + per_img - 1) / per_img;
+    *gx = (n_tiles + *tpw - 1) / *tpw;
+}
+
+template <int MODE>
+int coss_launch(const void* pred, int dtype, const int32_t* indices, const float* lut, int B, int D, int P,
+                int L, const float* gscale, void* grad, LossPartial* partials, int32_t* status,
+                const float* computed_for, int32_t* counters, hipStream_t stream)
+{
+    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
+    const int nw = D / COSS_NP;
+    // the kernel only has the 8-byte plane accesses: whole groups of PXT pixels, aligned planes
+    if (P % pxt != 0 || ((((uintptr_t)pred | (uintptr_t)grad) & 7) != 0)) return NMSA_ERR_UNSUPPORTED;
+    int gx, tpw;
+    coss_geometry(B, P, dtype, &gx, &tpw);
+    const size_t lds = coss_lds_bytes(D, L, nw, pxt);
+#define COSS(DT) do { int rc_ = allow_dynamic_lds(k_cos_split<DT, MODE>, lds); if (rc_) return rc_;              \
+        hipLaunchKernelGGL((k_cos_split<DT, MODE>), dim3(gx, B), dim3(64 * nw), lds, stream, pred, indices, lut, \
+                           D, P, L, 1, tpw, gscale, grad, partials, status, computed_for, counters); } while (0)
+    NMSA_DISPATCH_DTYPE(dtype, COSS)
+#undef COSS
+    return check_launch();
+}
+
+}  // namespace
+
+namespace nmsa {
+
+int cos_split_blocks(int B, int P, int dtype)
+{
+    int gx, tpw;
+    coss_geometry(B, P, dtype, &gx, &tpw);
+    return gx;
+}
+
+int launch_cos_split(bool loss, const void* pred, int dtype, const int32_t* indices, const float* lut,
+                     int B, int D, int P, int L, const float* gscale, const float* computed_for,
+                     int32_t* counters, void* grad, LossPartial* partials, int32_t* status, hipStream_t stream)
+{
+    return loss ? coss_launch<0>(pred, dtype, indices, lut, B, D, P, L, gscale, grad, partials, status,
+                                 computed_for, counters, stream)
+                : coss_launch<2>(pred, dtype, indices, lut, B, D, P, L, gscale, grad, partials, status,
+                                 computed_for, counters, stream);
+}
+
+}  // namespace nmsa
+
+// forward sum + n_rows + the gradient for the EXPECTED upstream scale *expected_gscale (a NaN:
+// no gradient is written), one pass over the prediction
+extern "C" int nmsa_loss_cos_emb_fwd_grad(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                                          int B, int D, int H, int W, int L, const float* expected_gscale,
+                                          double* loss_sum, int64_t* n_rows, void* grad_pred, int32_t* status,
+                                          void* workspace, size_t workspace_bytes, nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!pred || !indices || !lut || !expected_gscale || !loss_sum || !n_rows || !status || !workspace)
+        return NMSA_ERR_ARG;
+    if (loss_bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
+    if (!nmsa_loss_cos_emb_fwd_grad_supported(dtype, D, H, W, L)) return NMSA_ERR_UNSUPPORTED;
+    if (workspace_bytes < nmsa_loss_cos_emb_fwd_grad_workspace_bytes(B, D, H, W, L)) return NMSA_ERR_WORKSPACE;
+    LossPartial* partials = (LossPartial*)workspace;
+    int rc = coss_launch<0>(pred, dtype, indices, lut, B, D, H * W, L, expected_gscale, grad_pred, partials,
+                            status, nullptr, nullptr, stream);
+    if (rc) return rc;
+    return loss_finalize(partials, cos_split_blocks(B, H * W, dtype) * B, loss_sum, nullptr, n_rows, stream);
+}
+
+// confirms the gradient nmsa_loss_cos_emb_fwd_grad wrote (returns at once when *grad_scale is
+// bit-equal to *computed_for) or recomputes it
+extern "C" int nmsa_loss_cos_emb_bwd_unless(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                                            int B, int D, int H, int W, int L, const float* grad_scale,
+                                            void* grad_pred, const float* computed_for, int32_t* counters,
+                                            nmsa_stream_t stream_)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!pred || !indices || !lut || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
+    if (loss_bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
+    if (!nmsa_loss_cos_emb_fwd_grad_supported(dtype, D, H, W, L)) return NMSA_ERR_UNSUPPORTED;
+    return coss_launch<2>(pred, dtype, indices, lut, B, D, H * W, L, grad_scale, grad_pred, nullptr, nullptr,
+                          computed_for, counters, stream);
+}

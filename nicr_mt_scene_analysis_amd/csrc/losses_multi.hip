@@ -32,10 +32,11 @@ struct MultiItem {
     float param;
     int block0, nbx;                                   // first block of the item, blocks per image
     int cblock0, cnblocks;                             // count pass: first block, blocks
-    int count_mode;                                    // 0: B * P, 1: bytes of `mask` in [lo, hi], 2: none
+    int count_mode;                                    // 0: B * P, 1: bytes of `mask` in [lo, hi], 2: none, 3: int32 words of `mask` in [lo, hi]
     int lo, hi;
     int in_launch;                                     // 1: part of k_multi_loss, 0: own kernel (wide CE)
     int first_of_total;
+    int L;                                             // cosine embedding: LUT rows per image
 };
 struct MultiArgs { MultiItem it[MULTI_MAX_ITEMS]; int n_items, n_totals, n_blocks; };
 
@@ -45,9 +46,39 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long 
     int i = 0;
     while (i + 1 < a.n_items && (int)blockIdx.x >= a.it[i].cblock0 + a.it[i].cnblocks) ++i;
     const MultiItem& it = a.it[i];
-    if (it.count_mode != 1 || (int)blockIdx.x < it.cblock0) { if (threadIdx.x == 0) partials[blockIdx.x] = 0; return; }
+    if ((it.count_mode != 1 && it.count_mode != 3) || (int)blockIdx.x < it.cblock0) {
+        if (threadIdx.x == 0) partials[blockIdx.x] = 0;
+        return;
+    }
     const int bi = blockIdx.x - it.cblock0;
     const long long n = (long long)it.B * it.P;
+    if (it.count_mode == 3) {
+        // int32 indices (cosine embedding: 0 = no target): 4 words per 16-byte load
+        const int32_t* v32 = (const int32_t*)it.mask;
+        const long long per4 = ((n + it.cnblocks - 1) / it.cnblocks + 3) / 4 * 4;
+        const long long b4 = min(n, per4 * bi), e4 = min(n, b4 + per4);
+        const unsigned lo3 = (unsigned)it.lo, span3 = (unsigned)(it.hi - it.lo);
+        long long c3 = 0;
+        long long q = b4 + (long long)threadIdx.x * 4;
+        if ((((uintptr_t)v32) & 15) == 0) {
+            for (; q + 4 <= e4; q += LOSS_THREADS * 4) {
+                const u32x4_s w = __builtin_nontemporal_load((const u32x4_s*)(v32 + q));
+                c3 += ((w.x - lo3) <= span3) + ((w.y - lo3) <= span3) + ((w.z - lo3) <= span3) + ((w.w - lo3) <= span3);
+            }
+        }
+        for (; q < e4; q += LOSS_THREADS * 4)
+            for (long long j = q; j < min(e4, q + 4); ++j) c3 += (((unsigned)v32[j] - lo3) <= span3);
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c3 += __shfl_down(c3, o);
+        if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = c3;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            long long c = 0;
+            for (int k = 0; k < LOSS_THREADS / 64; ++k) c += s_cnt[k];
+            partials[blockIdx.x] = c;
+        }
+        return;
+    }
     const long long per = ((n + it.cnblocks - 1) / it.cnblocks + 15) / 16 * 16;
     const long long begin = min(n, per * bi), end = min(n, begin + per);
     const uint8_t* v = it.mask;
@@ -94,7 +125,7 @@ __device__ inline float multi_divisor(const MultiArgs& a, const long long* count
 {
     long long n = 0;
     for (int i = 0; i < a.n_items; ++i)
-        if (a.it[i].total == t) n += a.it[i].clamp ? max(counts[i], 1LL) : counts[i];
+        if (a.it[i].total == t) n += a.it[i].clamp == 1 ? max(counts[i], 1LL) : counts[i];
     return (float)max(n, 1LL);
 }
 
@@ -113,10 +144,10 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_expect(MultiArgs a, cons
     for (int i = w; i < a.n_items; i += LOSS_THREADS / 64) {
         const MultiItem& it = a.it[i];
         long long c = 0;
-        if (it.count_mode == 1 && partials) { for (int k = l; k < it.cnblocks; k += 64) c += partials[it.cblock0 + k]; }
+        if ((it.count_mode == 1 || it.count_mode == 3) && partials) { for (int k = l; k < it.cnblocks; k += 64) c += partials[it.cblock0 + k]; }
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-        if (l == 0) s_count[i] = it.count_mode == 1 ? c : (long long)it.B * it.P;
+        if (l == 0) s_count[i] = (it.count_mode == 1 || it.count_mode == 3) ? c : (long long)it.B * it.P;
     }
     __syncthreads();
     if ((int)threadIdx.x < a.n_totals) {
@@ -404,14 +435,16 @@ int multi_plan(const nmsa_loss_item* items, int n_items, int n_totals, MultiPlan
                 if (!s.pred || s.total < 0 || s.total >= n_totals || loss_bad_shape(s.B, s.H, s.W) || s.C <= 0)
                     return NMSA_ERR_ARG;
                 if (s.dtype != NMSA_F32 && s.dtype != NMSA_BF16 && s.dtype != NMSA_F16) return NMSA_ERR_ARG;
-                if (s.kind < NMSA_LOSS_CE || s.kind > NMSA_LOSS_VONMISES) return NMSA_ERR_ARG;
+                if (s.kind < NMSA_LOSS_CE || s.kind > NMSA_LOSS_COS_EMB) return NMSA_ERR_ARG;
                 if (s.kind != NMSA_LOSS_CE && !s.target) return NMSA_ERR_ARG;
-                if (s.kind == NMSA_LOSS_CE && !s.mask) return NMSA_ERR_ARG;
+                if ((s.kind == NMSA_LOSS_CE || s.kind == NMSA_LOSS_COS_EMB) && !s.mask) return NMSA_ERR_ARG;
                 if (s.kind == NMSA_LOSS_VONMISES && s.C != 2) return NMSA_ERR_ARG;
+                if (s.clamp_count < 0 || s.clamp_count > 2) return NMSA_ERR_ARG;
                 it.pred = s.pred; it.target = s.target; it.mask = (const uint8_t*)s.mask; it.weights = s.weights;
                 it.grad = s.grad;
                 it.kind = s.kind; it.dtype = s.dtype; it.B = s.B; it.C = s.C; it.P = s.H * s.W;
-                it.total = s.total; it.clamp = s.clamp_count != 0; it.param = s.param;
+                it.total = s.total; it.clamp = s.clamp_count; it.param = s.param;
+                it.L = s.reserved;
                 it.first_of_total = !seen_total[s.total];
                 seen_total[s.total] = true;
                 const uintptr_t al = (uintptr_t)s.pred | (uintptr_t)s.grad | (uintptr_t)s.target;
@@ -431,14 +464,26 @@ int multi_plan(const nmsa_loss_item* items, int n_items, int n_totals, MultiPlan
                         it.nbx = loss_grid_x(it.P, pxt);
                         if (it.in_launch && s.C > pl.max_c) pl.max_c = s.C;
                     }
+                } else if (s.kind == NMSA_LOSS_COS_EMB) {
+                    // pred [B, D = C, H, W], target = LUT f32 [B, L = reserved, D], mask = indices i32
+                    if (s.reserved <= 0 || s.clamp_count < 0 || s.clamp_count > 2) return NMSA_ERR_ARG;
+                    if (!nmsa_loss_cos_emb_fwd_grad_supported(s.dtype, s.C, s.H, s.W, s.reserved))
+                        return NMSA_ERR_UNSUPPORTED;
+                    const int pxt = (s.dtype == NMSA_F32) ? 2 : 4;
+                    if (it.P % pxt != 0 || ((((uintptr_t)s.pred | (uintptr_t)s.grad) & 7) != 0))
+                        return NMSA_ERR_UNSUPPORTED;
+                    it.vec = 1;
+                    it.in_launch = 0;
+                    it.nbx = cos_split_blocks(s.B, it.P, s.dtype);
+                    it.count_mode = 3; it.lo = 1; it.hi = s.reserved;
                 } else {
                     it.vec = (it.P % 4 == 0) && (((al | (uintptr_t)s.mask) & 15) == 0);
                     it.nbx = loss_grid_x(it.P, 8);
                     it.count_mode = s.kind == NMSA_LOSS_FOCAL ? 2 : (s.mask ? 1 : 0);
                     it.lo = 1; it.hi = 255;
                 }
-                if (it.count_mode == 1) {
-                    const long long n = (long long)it.B * it.P;
+                if (it.count_mode == 1 || it.count_mode == 3) {
+                    const long long n = (long long)it.B * it.P * (it.count_mode == 3 ? 4 : 1);    // bytes
                     long long cb = (n / 16 + LOSS_THREADS * 4 - 1) / (LOSS_THREADS * 4);
                     it.cnblocks = (int)(cb < 1 ? 1 : cb > MULTI_COUNT_MAX_BLOCKS ? MULTI_COUNT_MAX_BLOCKS : cb);
                 } else {
@@ -547,7 +592,11 @@ extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_i
     for (int i = 0; i < n_items; ++i) {                 // cross entropies outside the joint launch
         const MultiItem& it = a.it[i];
         if (it.in_launch) continue;
-        if (it.C > CE_FUSED_MAX_C) {
+        if (it.kind == NMSA_LOSS_COS_EMB) {
+            rc = launch_cos_split(true, it.pred, it.dtype, (const int32_t*)it.mask, (const float*)it.target, it.B,
+                                  it.C, it.P, it.L, expect + 2 * it.total, nullptr, nullptr, it.grad,
+                                  partials + it.block0, status, stream);
+        } else if (it.C > CE_FUSED_MAX_C) {
             rc = launch_ce_split(true, it.pred, it.dtype, it.mask, it.weights, it.B, it.C, it.P, it.param,
                                  expect + 2 * it.total, nullptr, nullptr, it.grad, partials + it.block0, status,
                                  stream);
@@ -586,6 +635,13 @@ extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n
     for (int i = 0; i < n_items; ++i) {
         const MultiItem& it = a.it[i];
         if (it.in_launch || !it.grad) continue;
+        if (it.kind == NMSA_LOSS_COS_EMB) {
+            rc = launch_cos_split(false, it.pred, it.dtype, (const int32_t*)it.mask, (const float*)it.target, it.B,
+                                  it.C, it.P, it.L, grad_scales + i, expect + 2 * it.total, nullptr, it.grad,
+                                  nullptr, nullptr, stream);
+            if (rc) return rc;
+            continue;
+        }
         rc = nmsa_loss_ce_bwd_unless(it.pred, it.dtype, it.mask, it.weights, it.B, it.C, 1, it.P, it.param,
                                      grad_scales + i, it.grad, expect + 2 * it.total, nullptr, stream_);
         if (rc) return rc;

@@ -23,7 +23,7 @@ import torch
 
 from .. import _lib as L
 
-KIND = {'ce': 0, 'mse': 1, 'l1': 2, 'focal': 3, 'vonmises': 4}
+KIND = {'ce': 0, 'mse': 1, 'l1': 2, 'focal': 3, 'vonmises': 4, 'cos': 5}
 MAX_ITEMS, MAX_TOTALS = 16, 8
 
 
@@ -96,7 +96,22 @@ def supported(items: Sequence[dict]) -> bool:
             return False
         if it['kind'] == 'ce' and p.shape[1] > 255:
             return False
+        if it['kind'] == 'cos' and not cos_supported(p, it['target']):
+            return False
     return True
+
+
+def cos_supported(pred: torch.Tensor, lut: torch.Tensor) -> bool:
+    """the one-pass cosine kernel (csrc/losses_cos.hip) takes this prediction / LUT: D % 64 == 0,
+    D <= 512, the image's LUT within the LDS of a CU, whole groups of 4 (f32: 2) pixels"""
+    if not (pred.is_cuda and pred.ndim == 4 and lut.ndim == 3 and pred.dtype in
+            (torch.float32, torch.bfloat16, torch.float16)):
+        return False
+    B, D, H, W = pred.shape
+    pxt = 2 if pred.dtype == torch.float32 else 4
+    if (H * W) % pxt or lut.shape[0] != B or lut.shape[2] != D:
+        return False
+    return bool(L.lib().nmsa_loss_cos_emb_fwd_grad_supported(L.float_dtype_code(pred), D, H, W, lut.shape[1]))
 
 
 def _u8(t: Optional[torch.Tensor], dev) -> Optional[torch.Tensor]:
@@ -137,13 +152,19 @@ class MultiLossFunction(torch.autograd.Function):
             a = arr[i]
             a.kind, a.dtype = KIND[kind], L.float_dtype_code(x)
             a.B, a.C, a.H, a.W = B, Cc, H, W
-            a.total, a.clamp_count = int(it['total']), int(bool(it.get('clamp', False)))
+            a.total, a.clamp_count = int(it['total']), int(it.get('clamp', 0))      # 0 | 1 (True) | 2: item loss only
             a.param = float(it.get('param', 0.0))
             tgt, msk, wts = it.get('target'), it.get('mask'), it.get('weights')
             if kind == 'ce':
                 msk = labels_u8(msk, dev)
                 tgt = None
                 wts = None if wts is None else wts.to(dev, torch.float32).contiguous()
+            elif kind == 'cos':
+                # target = per-image LUT [B, L, D], mask = indices [B, H, W] (0 = no target)
+                tgt = tgt.to(dev, torch.float32).contiguous()
+                msk = msk.to(dev, torch.int32).contiguous()
+                a.reserved = int(tgt.shape[1])
+                wts = None
             else:
                 tgt = tgt.to(dev, torch.float32).contiguous()
                 msk = _u8(msk, dev)
@@ -219,8 +240,10 @@ class MultiLossResult:
 
 
 def multi_loss(items: Sequence[dict], n_totals: int, spec: SpecState) -> MultiLossResult:
-    """items: dicts with kind ('ce' | 'mse' | 'l1' | 'focal' | 'vonmises'), pred, target (not CE),
-    mask (labels for CE), weights (CE), param (label smoothing | kappa), total, clamp."""
+    """items: dicts with kind ('ce' | 'mse' | 'l1' | 'focal' | 'vonmises' | 'cos'), pred, target (not
+    CE; the LUT [B, L, D] for 'cos'), mask (labels for CE, int indices for 'cos'), weights (CE),
+    param (label smoothing | kappa), total, clamp (True / 1: max(count, 1) divides the item's loss
+    and enters the total's divisor; 2: the item's loss only)."""
     desc = {'items': list(items), 'n_totals': n_totals, 'spec': spec, 'grad_enabled': torch.is_grad_enabled()}
     outs = MultiLossFunction.apply(desc, *[it['pred'] for it in items])
     return MultiLossResult(outs, desc)

@@ -19,6 +19,13 @@ class CosineEmbeddingLoss(LossBase):
         """planar [B,D,H,W] prediction, int indices [B,H,W] (0 = no target) and the
         per-image LUT [B,L,D]: the gathers of task_helper/dense_visual_embedding.py:110-171
         folded into the kernel.  -> (sum, number of valid px)"""
+        from . import _multi
+        if self._can_speculate(input_) and _multi.cos_supported(input_, lut):
+            # forward + gradient in ONE pass over the prediction (csrc/losses_cos.hip), the gradient
+            # written for this instance's learned expectation of the upstream factor and
+            # confirmed or recomputed in backward
+            loss, n, _ = self._speculative_single('cos', input_, lut, indices)
+            return loss, n
         return F_.cosine_embedding_lut_sum(input_, indices, lut)
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor,

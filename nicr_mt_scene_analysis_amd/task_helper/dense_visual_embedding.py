@@ -8,6 +8,8 @@ from typing import Any, Dict, List, Sequence, Tuple, Union
 import numpy as np
 import torch
 
+from ..loss import _functional as F_
+
 from ..data.preprocessing.multiscale_supervision import get_downscale
 from ..data.preprocessing.resize import get_fullres
 from ..data.preprocessing.resize import get_fullres_key
@@ -81,6 +83,22 @@ class DenseVisualEmbeddingTaskHelper(TaskHelperBase):
         luts = self.collect_targets_for_loss(batch=batch, batch_key='dense_visual_embedding_lut',
                                              downscales=downscales)
         outs = []
+        if self._loss_name == 'cos_emb' and F_.speculation_enabled() and F_.wants_gradient(preds[0]):
+            # every scale in ONE call: forward + gradient in one pass over each prediction, the
+            # gradient written for the learned upstream factor of the total (loss/_multi.py)
+            from ..loss import _multi
+            items = []
+            for pred, lut in zip(preds, luts):
+                indices = self._get_spatial_target_for_prediction(
+                    batch, 'dense_visual_embedding_indices', pred)
+                lut_t = lut if isinstance(lut, torch.Tensor) and lut.ndim == 3 \
+                    else _stack_luts(lut, pred.device)
+                # per scale loss / max(n, 1); the total divides by max(sum of n, 1)
+                items.append({'kind': 'cos', 'pred': pred.contiguous(), 'target': lut_t, 'mask': indices,
+                              'total': 0, 'clamp': 2})
+            if _multi.supported(items):
+                return self.multi_losses(items, [f'dense_visual_embedding_loss_{k}' for k in keys],
+                                         ('dense_visual_embedding',))
         for pred, lut in zip(preds, luts):
             indices = self._get_spatial_target_for_prediction(
                 batch, 'dense_visual_embedding_indices', pred)
