@@ -413,14 +413,18 @@ def secondary_cos_emb(dev, B=8, D=512, H=768, W=1024, L=64):
         l, n = cos.lut_sum(pred, idx, lut)
         (l / n).backward()
     n_px = B * H * W
+    from nicr_mt_scene_analysis_amd.loss import _multi as _m
+    one_pass = bool(_m.cos_supported(pred, lut))
     with torch.no_grad():
         ms_f = hip_timed(fwd, reps=5, warm=2)
     ms_fb = hip_timed(fwd_bwd, reps=5, warm=2)
-    return {'shape': f'B={B} D={D} {W}x{H} L={L}', 'pred_dtype': 'bfloat16',
+    return {'shape': f'B={B} D={D} {W}x{H} L={L}', 'pred_dtype': 'bfloat16', 'one_pass_kernel': one_pass,
             'fwd': _leg(ms_f, n_px, 2 * D + 4),
             'fwd_bwd': _leg(ms_fb, n_px, 2 * D + 4 + 2 * D,
-                            moved_bytes_per_px=3 * 2 * D + 8,
-                            note='the backward re-reads the prediction: 3x2D+8 B/px moved')}
+                            moved_bytes_per_px=(2 * 2 * D + 8) if one_pass else (3 * 2 * D + 8),
+                            note=('forward + gradient in ONE pass over the prediction (k_cos_split: the column '
+                                  'stays in the registers of D / 64 waves): 2x2D+8 B/px moved') if one_pass else
+                                 'the backward re-reads the prediction: 3x2D+8 B/px moved')}
 
 
 def secondary_cfg5_full(ops, syn, dev, B=16, C=150, H=768, W=1024, K=48, D=512, L=64):

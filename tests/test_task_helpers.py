@@ -290,6 +290,59 @@ def test_dve_task_helper_loss():
     assert torch.isfinite(pred.grad).all()
 
 
+def test_dve_task_helper_multiscale_one_call():
+    """embedding dimensions the one-pass cosine kernel takes (D = 64): main + two side outputs go
+    through ONE multi-loss call; per-scale losses and the total (sum of sums / sum of counts)
+    against torch in fp64, the trainer's loss weight is learned after one step"""
+    from nicr_mt_scene_analysis_amd.task_helper import DenseVisualEmbeddingTaskHelper
+    from nicr_mt_scene_analysis_amd.loss import reset_speculation_state, speculation_stats
+    reset_speculation_state()
+    g = torch.Generator(device='cuda').manual_seed(4)
+    B, D, H, W, NL = 2, 64, 16, 32, 6
+    luts = torch.nn.functional.normalize(torch.randn((B, NL, D), device='cuda', generator=g), dim=-1)
+    idx = torch.randint(0, NL + 1, (B, H // 4, W // 4), device='cuda', generator=g, dtype=torch.int32)
+    idx = idx.repeat_interleave(4, 1).repeat_interleave(4, 2).contiguous()
+    batch = {'dense_visual_embedding_lut': luts, 'dense_visual_embedding_indices': idx}
+    for sc in (2, 4):
+        batch[f'_down_{sc}'] = {'dense_visual_embedding_indices': idx[:, ::sc, ::sc].contiguous(),
+                               'dense_visual_embedding_lut': luts}
+    preds = [torch.randn((B, D, H // sc, W // sc), device='cuda', generator=g).requires_grad_(True)
+             for sc in (1, 2, 4)]
+    post = {'dense_visual_embedding_output': preds[0], 'dense_visual_embedding_side_outputs': tuple(preds[1:])}
+    helper = DenseVisualEmbeddingTaskHelper(n_classes=5)
+    helper.initialize(torch.device('cuda'))
+
+    def reference(p, ix):
+        valid = ix != 0
+        rows = p.detach().permute(0, 2, 3, 1)[valid].double()
+        tgt = luts[torch.where(valid)[0], (ix[valid] - 1).long()].double()
+        return torch.nn.functional.cosine_embedding_loss(rows, tgt, torch.ones(len(rows), device='cuda'),
+                                                         reduction='sum'), len(rows)
+    refs = [reference(p, idx[:, ::sc, ::sc]) for p, sc in zip(preds, (1, 2, 4))]
+    s0 = speculation_stats()
+    for step in range(3):
+        for p in preds:
+            p.grad = None
+        losses, _ = helper.training_step(batch, step, post)
+        assert list(losses) == ['dense_visual_embedding_loss_main', 'dense_visual_embedding_loss_down_2',
+                                'dense_visual_embedding_loss_down_4', 'dense_visual_embedding_total_loss']
+        for (l, n), k in zip(refs, ('main', 'down_2', 'down_4')):
+            np.testing.assert_allclose(float(losses[f'dense_visual_embedding_loss_{k}']), float(l) / n, rtol=RTOL)
+        np.testing.assert_allclose(float(losses['dense_visual_embedding_total_loss']),
+                                   float(sum(l for l, _ in refs)) / sum(n for _, n in refs), rtol=RTOL)
+        (0.25 * losses['dense_visual_embedding_total_loss']).backward()
+    s1 = speculation_stats()
+    assert (s1['confirmed'] - s0['confirmed'], s1['recomputed'] - s0['recomputed']) == (2, 1)
+    # gradient of the main scale against autograd on the gathered rows
+    pr = preds[0].detach().double().requires_grad_(True)
+    valid = idx != 0
+    rows = pr.permute(0, 2, 3, 1)[valid]
+    tgt = luts[torch.where(valid)[0], (idx[valid] - 1).long()].double()
+    (0.25 * torch.nn.functional.cosine_embedding_loss(rows, tgt, torch.ones(len(rows), device='cuda'),
+                                                      reduction='sum') / sum(n for _, n in refs)).backward()
+    np.testing.assert_allclose(preds[0].grad.double().cpu().numpy(), pr.grad.cpu().numpy(), rtol=2e-5, atol=1e-10)
+
+
 def test_accumulate_losses_zero_elements_warns():
     from nicr_mt_scene_analysis_amd.task_helper import SemanticTaskHelper
     h = SemanticTaskHelper(3)

@@ -204,3 +204,73 @@ def test_ce_c150_full_size_vs_oracle():
     got = xs.grad[:, :, rows].double()
     atol = max(2 ** -7 * float(xr.grad.abs().max()) * 0.05, 4e-6 * float(w.max()) / int(n))
     np.testing.assert_allclose(got.cpu().numpy(), xr.grad.cpu().numpy(), rtol=2 ** -7, atol=atol)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize('D,L', [(64, 1), (128, 64), (320, 9), (512, 64)])
+@pytest.mark.parametrize('hw', [(4, 68), (24, 44), (3, 1000)])          # last tile ragged / several tiles
+def test_cos_split_one_pass_confirms_and_recomputes(dtype, D, L, hw):
+    """k_cos_split (forward + gradient in one pass, csrc/losses_cos.hip): the shapes it takes go
+    through it (one backward check confirmed, none recomputed), loss / count / gradient equal
+    torch in fp64; an upstream factor it did not expect is recomputed by the same kernel with the
+    identical result; the forward-only call and the two-kernel path agree with it"""
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
+    H, W = hw
+    B = 2
+    g = _gen(D + W)
+    x = torch.randn((B, D, H, W), device='cuda', generator=g).to(dtype)
+    lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
+    idx = _index_map('noise' if W == 44 else 'segments', B, H, W, L, g)
+    assert _multi.cos_supported(x, lut)
+    ref_loss, ref_n, ref_grad = _cos_reference(x, idx, lut)
+    cos = CosineEmbeddingLoss()
+    xs = x.clone().requires_grad_(True)
+    before = _stats()
+    loss, n = cos.lut_sum(xs, idx, lut)
+    (loss / n.clamp(min=1)).backward()
+    after = _stats()
+    assert (after['confirmed'] - before['confirmed'], after['recomputed'] - before['recomputed']) == (1, 0)
+    assert int(n) == ref_n
+    np.testing.assert_allclose(float(loss), ref_loss, rtol=RTOL, atol=1e-6)
+    tol = _grad_tol(dtype)
+    atol = tol * float(ref_grad.abs().max()) * 0.05 + (6e-8 if dtype == torch.float16 else 1e-12)
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol, atol=atol)
+    # an unannounced factor: one miss (recomputed, same bits up to the factor), then learned
+    xw = x.clone().requires_grad_(True)
+    lw, nw = cos.lut_sum(xw, idx, lut)
+    (4.0 * (lw / nw.clamp(min=1))).backward()
+    assert _stats()['recomputed'] - after['recomputed'] == 1
+    np.testing.assert_allclose(xw.grad.double().cpu().numpy(), 4.0 * ref_grad.cpu().numpy(), rtol=tol, atol=4 * atol)
+    xw2 = x.clone().requires_grad_(True)
+    lw2, nw2 = cos.lut_sum(xw2, idx, lut)
+    (4.0 * (lw2 / nw2.clamp(min=1))).backward()
+    assert _stats()['recomputed'] - after['recomputed'] == 1               # confirmed this time
+    assert torch.equal(xw2.grad, xw.grad)
+    # forward only (two-kernel forward) and the two-kernel backward agree
+    with torch.no_grad():
+        lf, nf = cos.lut_sum(x, idx, lut)
+    assert int(nf) == ref_n
+    np.testing.assert_allclose(float(lf), float(loss), rtol=1e-6, atol=1e-6)
+
+
+def test_cos_split_falls_back_where_it_cannot_run():
+    """D not a multiple of 64, D > 512, a LUT beyond the LDS, a pixel count that is no multiple of
+    4: the two-kernel path answers (same results, no expectation involved)"""
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
+    g = _gen(77)
+    for (B, D, H, W, L) in ((1, 96, 8, 16, 5), (1, 576, 4, 16, 5), (1, 512, 4, 16, 200), (1, 128, 3, 7, 4)):
+        x = torch.randn((B, D, H, W), device='cuda', generator=g).to(torch.bfloat16)
+        lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
+        idx = _index_map('segments', B, H, W, L, g)
+        assert not _multi.cos_supported(x, lut), (D, H, W, L)
+        ref_loss, ref_n, ref_grad = _cos_reference(x, idx, lut)
+        xs = x.clone().requires_grad_(True)
+        before = _stats()
+        loss, n = CosineEmbeddingLoss().lut_sum(xs, idx, lut)
+        (loss / n.clamp(min=1)).backward()
+        assert _stats() == before
+        assert int(n) == ref_n
+        np.testing.assert_allclose(float(loss), ref_loss, rtol=RTOL, atol=1e-6)
+        tol = _grad_tol(torch.bfloat16)
+        np.testing.assert_allclose(xs.grad.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol,
+                                   atol=tol * float(ref_grad.abs().max()) * 0.05 + 1e-12)
