@@ -42,7 +42,7 @@ __device__ __forceinline__ void block_partial_wide(double acc, long long cnt, Lo
     }
 }
 
-template <int DTYPE, int MODE, int PROBE = 0>          // MODE 0: loss + gradient, 2: gradient only
+template <int DTYPE, int MODE>                         // MODE 0: loss + gradient, 2: gradient only
 __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
     const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
     int D, int P, int L, int vec, int tiles_per_wg,
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
                 const float x = plane_px<DTYPE>(r[i], j);
-                xy[j] = fmaf(x, s_lut[row[PROBE ? 0 : j] + i], xy[j]);
+                xy[j] = fmaf(x, s_lut[row[j] + i], xy[j]);
                 xx[j] = fmaf(x, x, xx[j]);
             }
         }
@@ -188,7 +188,7 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
             float o[PXT];
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
-                o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[PROBE ? 0 : j] + i]);
+                o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
             if (store) store_plane(i, off, o);
             if (COSS_PREFETCH) request_plane(i, qoff);         // (the last tile re-reads itself: no branch in the walk)
         }
@@ -265,14 +265,11 @@ int coss_launch(const void* pred, int dtype, const int32_t* indices, const float
     int gx, tpw;
     coss_geometry(B, P, dtype, &gx, &tpw);
     const size_t lds = coss_lds_bytes(D, L, nw, pxt);
-    static const int probe = loss_env_int("NMSA_COS_PROBE", 0);      // timing probes only (wrong results)
-#define COSS_P(DT, PR) do { int rc_ = allow_dynamic_lds(k_cos_split<DT, MODE, PR>, lds); if (rc_) return rc_;        \
-        hipLaunchKernelGGL((k_cos_split<DT, MODE, PR>), dim3(gx, B), dim3(64 * nw), lds, stream, pred, indices, lut, \
+#define COSS(DT) do { int rc_ = allow_dynamic_lds(k_cos_split<DT, MODE>, lds); if (rc_) return rc_;              \
+        hipLaunchKernelGGL((k_cos_split<DT, MODE>), dim3(gx, B), dim3(64 * nw), lds, stream, pred, indices, lut, \
                            D, P, L, 1, tpw, gscale, grad, partials, status, computed_for, counters); } while (0)
-#define COSS(DT) do { if (probe == 1 && DT == NMSA_BF16) COSS_P(NMSA_BF16, 1); else COSS_P(DT, 0); } while (0)
     NMSA_DISPATCH_DTYPE(dtype, COSS)
 #undef COSS
-#undef COSS_P
     return check_launch();
 }
 
