@@ -16,7 +16,8 @@ import torch   # noqa: F401  (must be loaded first: shares libamdhip64 with us)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, 'csrc')
-LIB_PATH = os.path.join(CSRC_DIR, 'libnmsa_hip.so')
+# NMSA_LIB_PATH: another build of the library (same-box A/B measurements against an older build)
+LIB_PATH = os.environ.get('NMSA_LIB_PATH') or os.path.join(CSRC_DIR, 'libnmsa_hip.so')
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), 'include', 'nmsa.h')
 
 NMSA_F32, NMSA_BF16, NMSA_F16 = 0, 1, 2
