@@ -114,6 +114,9 @@ def test_task_helper_totals_confirm_forward_written_gradients(monkeypatch):
     """with `backward_scale` as the starting value of the learned upstream factors every total's
     backward pass confirms from the first step (one forward call per helper for all scales), and
     the gradients are those of the two-kernel path"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as _F
+    if not _F.speculation_enabled():
+        pytest.skip('NMSA_SPECULATIVE_GRAD=0: forward-written gradients are switched off')
     from nicr_mt_scene_analysis_amd.loss import _functional as F_
     from nicr_mt_scene_analysis_amd.loss import reset_speculation_state, speculation_stats
     from nicr_mt_scene_analysis_amd.task_helper import InstanceTaskHelper, SemanticTaskHelper
@@ -294,6 +297,9 @@ def test_dve_task_helper_multiscale_one_call():
     """embedding dimensions the one-pass cosine kernel takes (D = 64): main + two side outputs go
     through ONE multi-loss call; per-scale losses and the total (sum of sums / sum of counts)
     against torch in fp64, the trainer's loss weight is learned after one step"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as _F
+    if not _F.speculation_enabled():
+        pytest.skip('NMSA_SPECULATIVE_GRAD=0: forward-written gradients are switched off')
     from nicr_mt_scene_analysis_amd.task_helper import DenseVisualEmbeddingTaskHelper
     from nicr_mt_scene_analysis_amd.loss import reset_speculation_state, speculation_stats
     reset_speculation_state()
