@@ -593,3 +593,97 @@ def test_multi_loss_second_backward_through_a_retained_graph():
     pr = p.detach().double().requires_grad_(True)
     ((pr * m.unsqueeze(1) - y.double()).abs().mean(dim=1).sum() / int(m.sum())).backward()
     np.testing.assert_allclose(g1.double().cpu().numpy(), pr.grad.cpu().numpy(), rtol=2e-5, atol=1e-9)
+
+
+@pytest.mark.parametrize('seed', range(10))
+def test_multi_loss_fuzz_random_item_mixes(seed):
+    """random mixes of items — kinds, class counts (register-resident, split and mixed variants in
+    one call), dtypes, shapes, totals, cosine items, with random upstream factors per total:
+    sums, counts, totals and gradients of ONE call against torch in fp64 item by item"""
+    from nicr_mt_scene_analysis_amd.loss import _multi
+    rng = np.random.default_rng(1000 + seed)
+    g = _gen(500 + seed)
+    n_items = int(rng.integers(2, 9))
+    n_totals = int(rng.integers(1, min(n_items, 4) + 1))
+    items, refs = [], []
+    for i in range(n_items):
+        kind = ['ce', 'mse', 'l1', 'vonmises', 'cos'][int(rng.integers(0, 5))]
+        dtype = [torch.float32, torch.bfloat16, torch.float16][int(rng.integers(0, 3))]
+        B = int(rng.integers(1, 4))
+        H, W = int(rng.integers(1, 7)) * 4, int(rng.integers(1, 12)) * 4
+        total = i if i < n_totals else int(rng.integers(0, n_totals))
+        it = {'kind': kind, 'total': total}
+        if kind == 'ce':
+            C = int(rng.choice([2, 7, 19, 24, 40, 48, 49, 70, 150]))
+            x = (torch.randn((B, C, H, W), device='cuda', generator=g) * 3).to(dtype)
+            t = torch.randint(0, C + 1, (B, H, W), device='cuda', generator=g).to(torch.uint8)
+            w = torch.rand(C, device='cuda', generator=g) + 0.5 if rng.random() < 0.7 else None
+            it.update(pred=x, mask=t, weights=w)
+
+            def ref(xd, t=t, w=w):
+                return torch.nn.functional.cross_entropy(xd, t.long() - 1, weight=None if w is None else w.double(),
+                                                         ignore_index=-1, reduction='sum'), int((t != 0).sum())
+        elif kind in ('mse', 'l1'):
+            Cc = 1 if kind == 'mse' else 2
+            shape = (B, H, W) if Cc == 1 else (B, Cc, H, W)
+            x = torch.randn(shape, device='cuda', generator=g).to(dtype)
+            y = torch.randn(shape, device='cuda', generator=g)
+            m = torch.rand((B, H, W), device='cuda', generator=g) < 0.6 if rng.random() < 0.8 else None
+            it.update(pred=x, target=y, mask=m)
+
+            def ref(xd, y=y, m=m, kind=kind, Cc=Cc, B=B, H=H, W=W):
+                mm = torch.ones((B, H, W), device='cuda', dtype=torch.bool) if m is None else m
+                xm = xd * (mm if Cc == 1 else mm.unsqueeze(1))
+                d = xm - y.double()
+                v = (d ** 2) if kind == 'mse' else d.abs()
+                return (v if Cc == 1 else v.mean(dim=1)).sum(), int(mm.sum())
+        elif kind == 'vonmises':
+            x = torch.randn((B, 2, H, W), device='cuda', generator=g).to(dtype)
+            y = torch.nn.functional.normalize(torch.randn((B, 2, H, W), device='cuda', generator=g), dim=1)
+            m = torch.rand((B, H, W), device='cuda', generator=g) < 0.4
+            kappa = float(rng.choice([1.0, 2.5]))
+            it.update(pred=x, target=y, mask=m, param=kappa, clamp=True)
+
+            def ref(xd, y=y, m=m, kappa=kappa):
+                return (1 - torch.exp(kappa * ((xd * y.double()).sum(dim=1) - 1)))[m].sum(), max(int(m.sum()), 1)
+        else:
+            D, NL = int(rng.choice([64, 128])), int(rng.integers(1, 9))
+            x = torch.randn((B, D, H, W), device='cuda', generator=g).to(dtype)
+            lut = torch.nn.functional.normalize(torch.randn((B, NL, D), device='cuda', generator=g), dim=-1)
+            ix = torch.randint(0, NL + 1, (B, H, W), device='cuda', generator=g, dtype=torch.int32)
+            it.update(pred=x, target=lut, mask=ix, clamp=2)
+
+            def ref(xd, lut=lut, ix=ix):
+                valid = ix != 0
+                rows = xd.permute(0, 2, 3, 1)[valid]
+                tgt = lut[torch.where(valid)[0], (ix[valid] - 1).long()].double()
+                if len(rows) == 0:
+                    return xd.sum() * 0, 0
+                return torch.nn.functional.cosine_embedding_loss(rows, tgt, torch.ones(len(rows), device='cuda'),
+                                                                 reduction='sum'), len(rows)
+        items.append(it)
+        refs.append(ref)
+    assert _multi.supported(items)
+    leaves = [it['pred'].clone().requires_grad_(True) for it in items]
+    for it, lf in zip(items, leaves):
+        it['pred'] = lf
+    factors = torch.tensor(rng.choice([1.0, 0.5, 2.0, 3.0], size=n_totals), dtype=torch.float32, device='cuda')
+    spec = _multi.SpecState(n_totals)
+    res = _multi.multi_loss(items, n_totals, spec)
+    (res.total_losses * factors).sum().backward()
+    dbl = [lf.detach().double().requires_grad_(True) for lf in leaves]
+    vals = [r(d) for r, d in zip(refs, dbl)]
+    div = [max(sum(n for (_, n), it in zip(vals, items) if it['total'] == t), 1) for t in range(n_totals)]
+    sum(float(factors[t]) * sum(l for (l, _), it in zip(vals, items) if it['total'] == t) / div[t]
+        for t in range(n_totals)).backward()
+    counts = res.counts.tolist()
+    for i, ((l, n), it) in enumerate(zip(vals, items)):
+        n_raw = n if it['kind'] != 'vonmises' else int(it['mask'].sum())
+        assert counts[i] == n_raw, (i, it['kind'], counts[i], n_raw)
+        np.testing.assert_allclose(float(res.sums[i]), float(l), rtol=2e-5, atol=1e-5)
+    np.testing.assert_allclose(res.divisors.tolist(), [float(d) for d in div])
+    for i, (lf, d, it) in enumerate(zip(leaves, dbl, items)):
+        gd = d.grad if d.grad is not None else torch.zeros_like(d)
+        tol = _grad_tol(lf.dtype)
+        err = (lf.grad.double() - gd).abs() - tol * gd.abs()
+        assert float(err.max()) <= max(1e-6, 0.05 * tol * float(gd.abs().max())), (i, it['kind'], float(err.max()))
