@@ -456,14 +456,19 @@ def test_argmax_band_residual_on_natural_logits():
         d = x - m                                                       # fp32, like ATen's x - max
         cls = torch.arange(x.shape[1], device='cuda').view(1, -1, 1, 1)
         band = ((d < -2.0 ** -25) & (d >= -2.0 ** -23) & (cls < am)).any(dim=1)
+        # (one binade further out the probabilities are 1-2 ulp apart: whether they still collapse
+        # depends on the last bit of the host's vectorised exp — not asserted, only counted)
+        margin = ((d < -2.0 ** -23) & (d >= -2.0 ** -22) & (cls < am)).any(dim=1)
         n_band = int(band.sum())
         # torch's softmax -> max on this machine's CPU: the op the reference runs (semantic.py:52-53)
         ref = torch.softmax(x.cpu(), dim=1).max(dim=1)[1].cuda()
         wrong = ref != got
         mismatch_in_band = int((wrong & band).sum())
-        mismatch_elsewhere = int((wrong & ~band).sum())
+        mismatch_elsewhere = int((wrong & ~band & ~margin).sum())
         report[name] = {'columns': band.numel(), 'band_columns': n_band,
                         'band_columns_differing_from_torch_cpu': mismatch_in_band,
+                        'margin_columns': int(margin.sum()),
+                        'margin_columns_differing': int((wrong & margin & ~band).sum()),
                         'other_columns_differing': mismatch_elsewhere}
         assert mismatch_elsewhere == 0, report
         assert n_band <= band.numel() * 1e-5, report                       # < 10 per million
