@@ -428,10 +428,14 @@ def test_argmax_tie_band_boundary_hip(oracle):
         xe[:, 0, 1] = -top                                    # (a negative twin of the maximum: no tie)
         xe = xe.to(dt)
         assert (xe[:, 1, :, ::2].float() == top - 2.0 ** -25).all()      # representable
-        want_e = torch.softmax(xe.float(), dim=1).max(dim=1)[1].numpy().astype(np.uint8)
-        rule_e, _ = probability_tie_rule(xe.float().numpy())
-        assert (rule_e == want_e).all()
+        want_e, _ = probability_tie_rule(xe.float().numpy())
         assert (want_e[..., ::2] == 1).all() and (want_e[..., 1::2] == 3).all()
+        # (torch on this host: exp(-2^-25) is 1 - 2^-25 + ..., just above the midpoint between
+        # 1 - 2^-24 and 1.0 — a correctly rounded exp gives 1.0, a 1-ulp one may not)
+        torch_e = torch.softmax(xe.float(), dim=1).max(dim=1)[1].numpy().astype(np.uint8)
+        if not (torch_e == want_e).all():
+            import warnings
+            warnings.warn(f"torch's CPU softmax -> max does not collapse a 2^-25 gap on this host ({dt})")
         for idx in all_paths(xe.cuda()):
             assert (idx == want_e).all(), dt
 
