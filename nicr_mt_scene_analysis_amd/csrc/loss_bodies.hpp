@@ -314,6 +314,35 @@ __device__ __forceinline__ float plane_px(const u32x2_s r, int j)
     return f16_to_f32((uint16_t)((j & 1) ? (w >> 16) : (w & 0xFFFFu)));
 }
 
+// The register tile after the sum-of-exp2 walk: the exponentials e = 2^((x - max) log2e) REPLACE the
+// logits, so the gradient walk multiplies instead of calling v_exp_f32 a second time per element —
+// f32 tiles: as they are (exact); bf16 tiles: as fp16 pairs (e <= 1, relative error 2^-11: three
+// bits below the half ulp of the bf16 gradient they end up in).  f16 tiles keep their logits and
+// exp_px computes e again: an fp16 copy would be no finer than the f16 gradient itself.  The
+// target class, where p - 1 would cancel, is computed from its logit in full precision either way.
+typedef _Float16 f16x2_s __attribute__((ext_vector_type(2)));
+typedef float f32x2_s __attribute__((ext_vector_type(2)));
+template <int DTYPE>
+__device__ __forceinline__ void pack_exps(u32x2_s& r, const float* e)
+{
+    if (DTYPE == NMSA_F32) { r.x = __float_as_uint(e[0]); r.y = __float_as_uint(e[1]); }
+    if (DTYPE == NMSA_BF16) {
+        const f32x2_s a = {e[0], e[1]}, b = {e[2], e[3]};
+        r.x = __builtin_bit_cast(uint32_t, __builtin_convertvector(a, f16x2_s));
+        r.y = __builtin_bit_cast(uint32_t, __builtin_convertvector(b, f16x2_s));
+    }
+}
+// e of pixel j; k0 = -max log2e (only the f16 tile, which still holds the logit, needs it)
+template <int DTYPE>
+__device__ __forceinline__ float exp_px(const u32x2_s r, int j, float k0)
+{
+    if (DTYPE == NMSA_F32) return __uint_as_float(j == 0 ? r.x : r.y);
+    const f16x2_s h = __builtin_bit_cast(f16x2_s, (j < 2) ? r.x : r.y);
+    const float v = (float)((j & 1) ? h.y : h.x);
+    if (DTYPE == NMSA_BF16) return v;
+    return __builtin_amdgcn_exp2f(fmaf(v, LOG2E, k0));
+}
+
 template <int DTYPE>
 __device__ __forceinline__ void st_plane8(void* base, size_t off, int nvalid, bool vec, const float* v)
 {
@@ -407,29 +436,52 @@ __device__ __forceinline__ void ce_fused_body(
 #pragma unroll
         for (int j = 0; j < PXT; ++j) k0[j] = -m[j] * LOG2E;
         if (DTYPE != NMSA_F32) keep_packed(r);
+        if (MODE == 1) {
 #pragma unroll
-        for (int c = 0; c < NP; ++c) {
-            if (c < C) {
+            for (int c = 0; c < NP; ++c) {
+                if (c < C) {
 #pragma unroll
-                for (int j = 0; j < PXT; ++j) {
-                    const float x = plane_px<DTYPE>(r[c], j);
-                    s[j] += __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
-                    if (SMOOTH) swx[j] = fmaf(s_w[c], x, swx[j]);
-                    if (MODE == 1) xt[j] = (t[j] == c) ? x : xt[j];             // forward only: no third walk
+                    for (int j = 0; j < PXT; ++j) {
+                        const float x = plane_px<DTYPE>(r[c], j);
+                        s[j] += __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                        if (SMOOTH) swx[j] = fmaf(s_w[c], x, swx[j]);
+                        xt[j] = (t[j] == c) ? x : xt[j];                   // forward only: no third walk
+                    }
                 }
             }
-        }
-        float ag[PXT], abg[PXT];
+        } else {
+            // sum of exp2; the exponentials take the logits' place in the tile (pack_exps)
 #pragma unroll
-        for (int j = 0; j < PXT; ++j) {
-            k0[j] = -(fmaf(m[j], LOG2E, __log2f(s[j])));                   // p = 2^(x log2e + k0)
-            const bool on = t[j] >= 0 && t[j] < C;
-            const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
-            ag[j] = g * a;
-            abg[j] = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
-        }
-        if (DTYPE != NMSA_F32) keep_packed(r);
-        if (MODE != 1) {
+            for (int c = 0; c < NP; ++c) {
+                if (c < C) {
+                    float e[PXT];
+#pragma unroll
+                    for (int j = 0; j < PXT; ++j) {
+                        const float x = plane_px<DTYPE>(r[c], j);
+                        e[j] = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                        s[j] += e[j];
+                        if (SMOOTH) swx[j] = fmaf(s_w[c], x, swx[j]);
+                        xt[j] = (t[j] == c) ? x : xt[j];
+                    }
+                    pack_exps<DTYPE>(r[c], e);
+                }
+            }
+            // per pixel: abg / s for the walk, and the target class' gradient from its logit
+            float abgs[PXT], qt[PXT];
+            bool smooth_on[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                const float k1 = -(fmaf(m[j], LOG2E, __log2f(s[j])));      // p = 2^(x log2e + k1)
+                const bool on = t[j] >= 0 && t[j] < C;
+                const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
+                const float ag = g * a;
+                const float abg = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
+                smooth_on[j] = SMOOTH && abg != 0.f;
+                abgs[j] = abg / s[j];
+                const float pt = __builtin_amdgcn_exp2f(fmaf(xt[j], LOG2E, k1));
+                qt[j] = fmaf(abg, pt, smooth_on[j] ? -(g * (ls / C) * s_w[on ? t[j] : 0]) : 0.f) - ag;
+            }
+            if (DTYPE != NMSA_F32) keep_packed(r);
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
                 if (c < C) {
@@ -437,13 +489,8 @@ __device__ __forceinline__ void ce_fused_body(
                     const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) {
-                        const float x = plane_px<DTYPE>(r[c], j);
-                        const float pj = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
-                        float q = fmaf(abg[j], pj, (SMOOTH && abg[j] != 0.f) ? -bjg : 0.f);
-                        const bool hit = t[j] == c;
-                        q -= hit ? ag[j] : 0.f;
-                        xt[j] = hit ? x : xt[j];
-                        o[j] = q;
+                        const float q = fmaf(abgs[j], exp_px<DTYPE>(r[c], j, k0[j]), smooth_on[j] ? -bjg : 0.f);
+                        o[j] = (t[j] == c) ? qt[j] : q;
                     }
                     if (write_grad) st_plane8<DTYPE>(grad, img + (size_t)c * P + p0, nvalid, vec, o);
                 }
