@@ -183,7 +183,7 @@ __device__ __forceinline__ void ce_scan(const void* logits, size_t img, int P, i
             const int tj = TRACK_T ? t[j] - c : 0;
             float g = v[0][j];
 #pragma unroll
-            for (int u = 1; u < U; ++u) g = fmaxf(g, v[u][j]);
+            for (int u = 1; u < U; ++u) g = fmaxf(g, v[u][j]);       // (the compiler folds these into v_max3_f32)
             const float mn = fmaxf(m[j], g);
             const float k = -mn * LOG2E;
             float acc = s[j] * __builtin_amdgcn_exp2f(fmaf(m[j], LOG2E, k));        // rescale once per group
@@ -430,7 +430,7 @@ __device__ __forceinline__ void ce_fused_body(
         for (int c = 0; c < NP; ++c) {
             if (c < C) {
 #pragma unroll
-                for (int j = 0; j < PXT; ++j) m[j] = fmaxf(m[j], plane_px<DTYPE>(r[c], j));
+                for (int j = 0; j < PXT; ++j) m[j] = vmax(m[j], plane_px<DTYPE>(r[c], j));
             }
         }
 #pragma unroll

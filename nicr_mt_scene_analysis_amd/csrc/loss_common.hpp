@@ -50,6 +50,17 @@ __device__ __forceinline__ uint32_t pack16(float a, float b)
     return (uint32_t)f32_to_f16(a) | ((uint32_t)f32_to_f16(b) << 16);
 }
 
+// max of two floats as ONE v_max_f32.  `fmaxf` costs three: LLVM canonicalises both operands first
+// (`v_max_f32 x, x, x`) because either might be a signalling NaN — and the running maximum gets
+// re-canonicalised in every basic block.  The instruction itself already returns the other
+// operand for a NaN (IEEE mode), which is fmaxf's rule.
+__device__ __forceinline__ float vmax(float a, float b)
+{
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
 // Speculative gradients (forward kernels write the gradient for an EXPECTED upstream scale).
 // The backward kernels are launched with `computed_for` = that expected scale: when the real
 // upstream gradient is bit-equal, the gradient buffer is already right and every workgroup

@@ -75,7 +75,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
     for (int i = 0; i < NP; ++i) {
         if (i < nc) {
 #pragma unroll
-            for (int j = 0; j < PXT; ++j) m[j] = fmaxf(m[j], plane_px<DTYPE>(r[i], j));
+            for (int j = 0; j < PXT; ++j) m[j] = vmax(m[j], plane_px<DTYPE>(r[i], j));
         }
     }
     // ---- the column maximum over the four waves ----------------------------------------------
@@ -86,7 +86,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
     for (int j = 0; j < PXT; ++j) {
         float mm = s_m[l * PXT + j];
 #pragma unroll
-        for (int ww = 1; ww < NWV; ++ww) mm = fmaxf(mm, s_m[ww * TPX + l * PXT + j]);
+        for (int ww = 1; ww < NWV; ++ww) mm = vmax(mm, s_m[ww * TPX + l * PXT + j]);
         m[j] = mm;
         k0[j] = -mm * LOG2E;
     }
