@@ -770,8 +770,7 @@ def main():
         from tools import bench_support
         metrics = bench_support.MetricAccumulators(C + 1, dev, inp, rank, world_size=world,
                                                    side_stream=not args.no_side_stream,
-                                                   sync_every_step=args.metric_sync == 'step',
-                                                   exercise_collective=launched)
+                                                   sync_every_step=args.metric_sync == 'step')
 
     events = []
     # consecutive batches are independent: they alternate over `--streams` HIP streams so that
@@ -892,8 +891,8 @@ def main():
                    'parallelism': f'dp{world} (images sharded, accumulators all-reduced '
                                   f'{"every step" if args.metric_sync == "step" else "once per run, timed"})'},
         'collective': {'backend': ('rccl' if backend == 'nccl' else backend), 'rccl_ranks': rccl_ranks,
-                       'payload_bytes': int(metrics._packed.numel() * 8)
-                       if metrics is not None and metrics._packed is not None else 0,
+                       'payload_bytes': metrics.payload_bytes if metrics is not None else 0,
+                       'calls': 'Metric.sync(): one all-reduce per state dtype (int64, float64)',
                        'totals_identical_on_all_ranks': totals_identical}
         if dist is not None else None,
         'roofline': roofline,

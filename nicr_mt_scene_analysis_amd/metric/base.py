@@ -8,8 +8,17 @@ into ONE flat device buffer per dtype, so that
   * `sync()` is one in-place all-reduce per dtype (RCCL when the process group
     is 'nccl', gloo in the CPU tests) — no packing kernels, no copies,
   * `zero_()` / `reset()` is one memset per dtype.
+
+Distributed semantics are torchmetrics' (what `dist_reduce_fx='sum'` means under an initialised
+process group): `compute()` is wrapped per instance — with world size > 1 it caches the rank-local
+states, sums them over the ranks, computes and restores the local states (`sync_context`), so every
+rank reports the GLOBAL metric while `update()` keeps accumulating locally; a state read outside
+`compute()` (the confusion-matrix artifacts of the task helpers) is rank-local, as in the reference.
+`Metric(sync_on_compute=False)` switches that off; `sync()` / `unsync()` do it by hand.
 """
-from typing import Dict, List, Optional
+import contextlib
+import functools
+from typing import Dict, Iterator, List, Optional
 
 import torch
 
@@ -17,8 +26,15 @@ import torch
 class Metric(torch.nn.Module):
     full_state_update = False
 
-    def __init__(self, device: Optional[torch.device] = None, **kwargs) -> None:
+    def __init__(self, device: Optional[torch.device] = None, sync_on_compute: bool = True,
+                 process_group=None, **kwargs) -> None:
         super().__init__()
+        self.sync_on_compute = sync_on_compute
+        self.process_group = process_group
+        self._is_synced = False
+        self._cache: Optional[Dict[torch.dtype, torch.Tensor]] = None
+        # per instance, like torchmetrics: `super().compute()` inside a subclass stays unwrapped
+        self.compute = self._wrap_compute(self.compute)
         self._state_defaults: Dict[str, torch.Tensor] = {}
         self._state_reduce: Dict[str, Optional[str]] = {}
         self._flat: Optional[Dict[torch.dtype, torch.Tensor]] = None
@@ -70,6 +86,8 @@ class Metric(torch.nn.Module):
 
     def reset(self) -> None:
         self._pack()
+        self._cache = None
+        self._is_synced = False
         all_zero = all(not bool(d.any()) for d in self._state_defaults.values())
         if all_zero:
             self.zero_()
@@ -84,20 +102,63 @@ class Metric(torch.nn.Module):
         self._flat = None
         return self
 
-    def sync(self, process_group=None) -> None:
-        """Sum the states over the ranks: one in-place all-reduce per dtype."""
+    # ------------------------------------------------------------------ distributed
+    def compute(self, *args, **kwargs):
+        raise NotImplementedError
+
+    def _wrap_compute(self, compute):
+        @functools.wraps(compute)
+        def wrapped(*args, **kwargs):
+            with self.sync_context(should_sync=self.sync_on_compute):
+                return compute(*args, **kwargs)
+        return wrapped
+
+    def _world_size(self, process_group=None) -> int:
         import torch.distributed as dist
         if not (dist.is_available() and dist.is_initialized()):
-            return
-        if dist.get_world_size(process_group) == 1:
+            return 0                                # no process group: nothing to sum over
+        return dist.get_world_size(process_group)
+
+    def sync(self, process_group=None, should_sync: bool = True) -> None:
+        """Sum the states over the ranks: one in-place all-reduce per dtype.  The rank-local
+        states are kept aside for `unsync()`.  A no-op without an initialised process group or
+        when the states are summed already (like torchmetrics, a one-rank group does run the
+        collective: the single-GPU rehearsal of the multi-rank path)."""
+        import torch.distributed as dist
+        process_group = process_group if process_group is not None else self.process_group
+        if not should_sync or self._is_synced or self._world_size(process_group) == 0:
             return
         if any(fx not in ('sum', None) for fx in self._state_reduce.values()):
             raise NotImplementedError('only dist_reduce_fx="sum" states exist on this path')
         backend = dist.get_backend(process_group)
-        for buf in self._pack().values():
+        flat = self._pack()
+        self._cache = {dtype: buf.clone() for dtype, buf in flat.items()}
+        for buf in flat.values():
             if backend == 'nccl' or buf.device.type == 'cpu':
                 dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=process_group)
             else:                                   # gloo with device states (tests)
                 host = buf.cpu()
                 dist.all_reduce(host, op=dist.ReduceOp.SUM, group=process_group)
                 buf.copy_(host)
+        self._is_synced = True
+
+    def unsync(self, should_unsync: bool = True) -> None:
+        """Back to the rank-local states `sync()` put aside (accumulation goes on per rank)."""
+        if not should_unsync or not self._is_synced:
+            return
+        for dtype, buf in self._pack().items():
+            buf.copy_(self._cache[dtype])
+        self._cache = None
+        self._is_synced = False
+
+    @contextlib.contextmanager
+    def sync_context(self, process_group=None, should_sync: bool = True,
+                     should_unsync: bool = True) -> Iterator[None]:
+        """States summed over the ranks inside the block, rank-local again behind it.  States
+        that were summed by hand before (`sync()`) stay as they are."""
+        mine = should_sync and not self._is_synced
+        self.sync(process_group=process_group, should_sync=should_sync)
+        try:
+            yield
+        finally:
+            self.unsync(should_unsync=mine and should_unsync)

@@ -32,8 +32,8 @@ def confmat_update(confmat: torch.Tensor, status: torch.Tensor, preds: torch.Ten
 
 class MeanIntersectionOverUnion(Metric):
     def __init__(self, n_classes: int, ignore_first_class: bool = False,
-                 device: Optional[torch.device] = None) -> None:
-        super().__init__(device=device)
+                 device: Optional[torch.device] = None, **kwargs) -> None:
+        super().__init__(device=device, **kwargs)
         self.add_state('confmat', torch.zeros((n_classes, n_classes), dtype=torch.int64),
                        dist_reduce_fx='sum')
         self._n_classes = n_classes

@@ -39,8 +39,9 @@ class PanopticQuality(Metric):
         is_thing: Union[torch.Tensor, List[bool]],
         num_workers=None,        # reference: size of the spawn pool; unused on the GPU
         device: Optional[torch.device] = None,
+        **kwargs,                # Metric: sync_on_compute, process_group
     ) -> None:
-        super().__init__(device=device)
+        super().__init__(device=device, **kwargs)
         self.num_categories = num_categories
         self.ignored_label = ignored_label
         self.max_instances_per_category = max_instances_per_category

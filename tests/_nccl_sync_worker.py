@@ -33,6 +33,32 @@ assert torch.equal(miou.confmat, torch.stack(gathered).sum(0)), 'confmat != sum 
 assert miou.confmat.dtype == torch.int64 and pq.tp_per_class.dtype == torch.float64
 if world == 1:
     assert torch.equal(pq.tp_per_class, before[1]) and torch.equal(pq.iou_per_class, before[2])
+# the same collective through the task helpers: `validation_epoch_end` -> `compute()` sums the
+# states over the ranks (torchmetrics' sync_context), logs the global metric and leaves the
+# rank-local states behind for the reset
+from nicr_mt_scene_analysis_amd.task_helper import PanopticTaskHelper, SemanticTaskHelper   # noqa: E402
+pan = PanopticTaskHelper(semantic_n_classes=5, semantic_classes_is_thing=[False, False, True, True, True])
+pan.initialize(dev)
+sem = SemanticTaskHelper(n_classes=4)
+sem.initialize(dev)
+pan._mae_pq_deeplab.update(pred * 65536, None, None, tgt * 65536, None, None,
+                           miou=pan._metric_iou, semantic_target=tgt.to(torch.uint8), pred_div=65536)
+sem._metric_iou.update_masked_void((pred - 1).clamp_(min=0), tgt.to(torch.uint8))
+local_tp = pan._mae_pq_deeplab.tp_per_class.clone()
+local_cm = pan._metric_iou.confmat.clone()
+tp_all = [torch.zeros_like(local_tp) for _ in range(world)]
+dist.all_gather(tp_all, local_tp)
+res = pan._mae_pq_deeplab.compute(suffix='_deeplab')          # synced inside, local again behind it
+assert torch.equal(pan._mae_pq_deeplab.tp_per_class, local_tp) and not pan._mae_pq_deeplab._is_synced
+pan._mae_pq_deeplab.sync()
+assert torch.equal(pan._mae_pq_deeplab.tp_per_class, torch.stack(tp_all).sum(0))
+pan._mae_pq_deeplab.unsync()
+artifacts, _, logs = pan.validation_epoch_end()
+assert torch.equal(artifacts['panoptic_deeplab_semantic_cm'], local_cm)
+assert torch.equal(logs['panoptic_all_deeplab_pq'], res['all_deeplab_pq'])
+_, _, sem_logs = sem.validation_epoch_end()
+assert 0.0 <= float(sem_logs['semantic_miou']) <= 1.0 and 0.0 <= float(logs['panoptic_deeplab_semantic_miou']) <= 1.0
+assert int(pan._metric_iou.confmat.sum()) == 0
 print(f'RCCL_SYNC_OK rank {rank} of {world} confmat_sum {int(miou.confmat.sum())}', flush=True)
 dist.barrier()
 dist.destroy_process_group()

@@ -403,25 +403,46 @@ def test_pq_with_orientation_mae():
 
 
 @gpu
-def test_bench_accumulators_packed_reduce_path():
-    """bench.py's MetricAccumulators: the multi-rank path (step-local states -> one packed
-    float64 buffer -> [all-reduce] -> totals) gives the same totals as direct accumulation."""
+def test_bench_accumulators_reduce_through_metric_sync():
+    """bench.py's MetricAccumulators under a (one-rank, gloo) process group: both schedules —
+    `Metric.sync()` after every step into replicated totals, and local accumulation with ONE
+    sync in finalize() — give the totals of direct accumulation without a group."""
+    import socket
+    import torch.distributed as dist
     from nicr_mt_scene_analysis_amd import ops
     from tools.bench_support import MetricAccumulators
     from nicr_mt_scene_analysis_amd.testing import synthetic as syn
     inp = syn.make_panoptic_inputs_torch(2, 8, 96, 128, n_centers=6, seed=3, device='cuda')
-    a = MetricAccumulators(9, torch.device('cuda'), inp, world_size=1, side_stream=False)
-    b = MetricAccumulators(9, torch.device('cuda'), inp, world_size=2, side_stream=True)
-    pan = ops.panoptic_pipeline(inp['semantic_logits'], inp['instance_center'],
-                                inp['instance_offset'], inp['semantic_classes_is_thing'])['panoptic']
-    for _ in range(3):
-        a.update_and_reduce(pan)
-        b.update_and_reduce(pan, dist=None)
-    b.wait()
-    torch.cuda.synchronize()
-    assert a.total_confmat.sum() > 0
-    assert torch.equal(a.total_confmat, b.total_confmat)
-    assert torch.equal(a.total_pq, b.total_pq)
+    a = MetricAccumulators(9, torch.device('cuda'), inp, side_stream=False)
+    assert not a.sync_every_step                        # no group yet: straight into the totals
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group('gloo', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1)
+    try:
+        b = MetricAccumulators(9, torch.device('cuda'), inp, side_stream=True, sync_every_step=True)
+        c = MetricAccumulators(9, torch.device('cuda'), inp, side_stream=True, sync_every_step=False)
+        assert b.sync_every_step and not c.sync_every_step
+        assert b.payload_bytes == (9 * 9 + 4 * 9) * 8
+        pan = ops.panoptic_pipeline(inp['semantic_logits'], inp['instance_center'],
+                                    inp['instance_offset'], inp['semantic_classes_is_thing'])['panoptic']
+        for _ in range(3):
+            a.update_and_reduce(pan)
+            b.update_and_reduce(pan, dist)
+            c.update_and_reduce(pan, dist)
+        assert not c.miou._is_synced
+        c.finalize(dist)
+        c.finalize(dist)                                # idempotent
+        assert c.miou._is_synced and c.pq._is_synced    # the states ARE the summed totals now
+        b.wait()
+        c.wait()
+        torch.cuda.synchronize()
+        assert a.total_confmat.sum() > 0
+        for other in (b, c):
+            assert torch.equal(a.total_confmat, other.total_confmat)
+            assert torch.equal(a.total_pq, other.total_pq)
+    finally:
+        dist.destroy_process_group()
 
 
 @gpu
@@ -473,46 +494,3 @@ def test_compare_and_accumulate_function(oracle):
     assert np.array_equal(iou.cpu().numpy(), w_iou) and np.array_equal(tp.cpu().numpy(), w_tp)
     assert np.array_equal(fn.cpu().numpy(), w_fn) and np.array_equal(fp.cpu().numpy(), w_fp)
     assert matched == set(w_m)
-
-
-@gpu
-def test_bench_accumulators_local_accumulation_then_one_reduce():
-    """bench.py's default at N > 1: local accumulation, ONE all-reduce in finalize().  A stand-in
-    for torch.distributed that doubles the buffer plays two identical ranks."""
-    from nicr_mt_scene_analysis_amd import ops
-    from tools.bench_support import MetricAccumulators
-    from nicr_mt_scene_analysis_amd.testing import synthetic as syn
-
-    class TwoIdenticalRanks:
-        calls = 0
-
-        class ReduceOp:
-            SUM = 'sum'
-
-        @staticmethod
-        def get_backend():
-            return 'nccl'
-
-        @classmethod
-        def all_reduce(cls, buf, op=None):
-            cls.calls += 1
-            buf.mul_(2)
-
-    inp = syn.make_panoptic_inputs_torch(2, 8, 96, 128, n_centers=6, seed=3, device='cuda')
-    a = MetricAccumulators(9, torch.device('cuda'), inp, world_size=1, side_stream=False)
-    b = MetricAccumulators(9, torch.device('cuda'), inp, world_size=2, side_stream=True,
-                           sync_every_step=False)
-    pan = ops.panoptic_pipeline(inp['semantic_logits'], inp['instance_center'],
-                                inp['instance_offset'], inp['semantic_classes_is_thing'])['panoptic']
-    for _ in range(3):
-        a.update_and_reduce(pan)
-        b.update_and_reduce(pan, dist=TwoIdenticalRanks)
-    assert TwoIdenticalRanks.calls == 0                 # nothing per step
-    b.finalize(TwoIdenticalRanks)
-    b.finalize(TwoIdenticalRanks)                       # idempotent
-    b.wait()
-    torch.cuda.synchronize()
-    assert TwoIdenticalRanks.calls == 1
-    assert a.total_confmat.sum() > 0
-    assert torch.equal(2 * a.total_confmat, b.total_confmat)
-    assert torch.equal(2 * a.total_pq, b.total_pq)

@@ -1,12 +1,11 @@
 """Streaming metric accumulation for bench.py (BASELINE.json configs[3]).
 
 Every step each rank updates accumulators from its shard of the batch (HIP kernels).
-With more than one rank the step-local accumulators are summed over the ranks with ONE
-all-reduce (RCCL over xGMI): the int64 confusion matrix (step-local counts < 2^53, exact in
-float64) and the float64 PQ vectors travel in one packed float64 buffer of ~15 KB — the only
-collective on the path — and are added to the replicated running totals; with a single rank
-the kernels accumulate into the totals directly.  Mirrors
-`dist_reduce_fx='sum'` of reference metric/miou.py:21-25 and metric/pq.py:228-246.
+Under a process group the accumulators are summed over the ranks by the package's own
+`Metric.sync()` — one in-place all-reduce per state dtype (RCCL over xGMI): the int64 confusion
+matrix and the float64 PQ vectors, ~15 KB together, the only collective on the path — once after
+the last step (default) or after every step.  Mirrors `dist_reduce_fx='sum'` of reference
+metric/miou.py:21-25 and metric/pq.py:228-246.
 
 The metric kernels are enqueued on a side HIP stream: they only depend on the panoptic
 map of their own step, so the latency-bound per-image kernels (matching, accumulation,
@@ -24,35 +23,31 @@ from nicr_mt_scene_analysis_amd.metric.pq import PanopticQuality
 class MetricAccumulators:
     def __init__(self, n_classes_with_void: int, device, inputs, rank: int = 0,
                  max_instances_per_category: int = 1 << 16, world_size: int = 1,
-                 side_stream: bool = True, sync_every_step: bool = True,
-                 exercise_collective: bool = False) -> None:
-        """sync_every_step=False: ranks accumulate locally and `finalize()` sums the totals
+                 side_stream: bool = True, sync_every_step: bool = True) -> None:
+        """sync_every_step=False: ranks accumulate locally and `finalize()` sums the states
         over the ranks ONCE — the torchmetrics behaviour of the reference (`dist_reduce_fx`
-        is applied by `compute()`, metric/miou.py:21-25)."""
+        is applied by `compute()`, metric/miou.py:21-25).  The collective is the package's own
+        `Metric.sync()` (one in-place all-reduce per state dtype: int64 confusion matrix,
+        float64 PQ vectors) — the call `compute()` makes under an initialised process group."""
         self.max_inst = max_instances_per_category
-        self.fused_metrics = not __import__('os').environ.get('NMSA_BENCH_SEPARATE_METRICS')
-        # exercise_collective: take the multi-rank code path (pack, all-reduce, unpack) also in
-        # a 1-rank process group — how a 1-GPU box rehearses the RCCL leg of `bench.py --gpus N`
-        if exercise_collective:
-            world_size = max(world_size, 2)
-        self.reduce_world = world_size
-        self.world_size = world_size if sync_every_step else 1      # per-step behaviour
+        self.fused_metrics = not os.environ.get('NMSA_BENCH_SEPARATE_METRICS')
+        import torch.distributed as dist_
+        # without a process group the kernels accumulate straight into the totals
+        self.sync_every_step = sync_every_step and dist_.is_available() and dist_.is_initialized()
         n = n_classes_with_void
         is_thing = [False] + [bool(x) for x in inputs['semantic_classes_is_thing'].cpu().tolist()]
-        self.miou = MeanIntersectionOverUnion(n, ignore_first_class=True, device=device)
-        self.pq = PanopticQuality(n, 0, self.max_inst, 256 ** 3, is_thing, device=device)
-        # flat state buffers (same packing as Metric._pack); totals only when all-reducing
-        self._step_flat = [next(iter(self.miou._pack().values())),
-                           next(iter(self.pq._pack().values()))]
-        # per-step reduction keeps separate running totals; local accumulation adds straight
-        # into the metric states and `finalize()` reduces those in place
-        self._total_flat = [torch.zeros_like(f) for f in self._step_flat] \
-            if self.world_size > 1 else self._step_flat
-        n_conf = self._step_flat[0].numel()
-        self._packed = torch.zeros((n_conf + self._step_flat[1].numel(),), dtype=torch.float64,
-                                   device=device) if world_size > 1 else None
+        # the bench reads the summed states themselves, so the metrics do not sum again in compute()
+        self.miou = MeanIntersectionOverUnion(n, ignore_first_class=True, device=device,
+                                              sync_on_compute=False)
+        self.pq = PanopticQuality(n, 0, self.max_inst, 256 ** 3, is_thing, device=device,
+                                  sync_on_compute=False)
+        flat = [next(iter(self.miou._pack().values())), next(iter(self.pq._pack().values()))]
+        self.payload_bytes = sum(f.numel() * f.element_size() for f in flat)
+        # per-step reduction: the states hold ONE step, summed over the ranks, and are added to
+        # replicated running totals; otherwise the states are the (local, then summed) totals
+        self._step_flat = flat
+        self._total_flat = [torch.zeros_like(f) for f in flat] if self.sync_every_step else flat
         self._finalized = False
-        self._n_conf = n_conf
         # NMSA_BENCH_METRIC_PRIORITY=-1: a high-priority side stream (the metric chain of a batch
         # then does not queue behind the next batch's streaming kernels)
         prio = int(os.environ.get('NMSA_BENCH_METRIC_PRIORITY', '0'))
@@ -71,17 +66,17 @@ class MetricAccumulators:
                                              dtype=torch.int64).to(torch.uint8)
         torch.cuda.synchronize(device)
 
+    def _side(self, device):
+        cur = torch.cuda.current_stream(device)
+        return cur, (self.stream if self.stream is not None else cur)
+
     def update_and_reduce(self, panoptic_pred: torch.Tensor, dist=None) -> None:
-        cur = torch.cuda.current_stream(panoptic_pred.device)
-        stream = self.stream if self.stream is not None else cur
+        cur, stream = self._side(panoptic_pred.device)
         if stream is not cur:
             self._ready.record(cur)
             stream.wait_event(self._ready)
             panoptic_pred.record_stream(stream)       # caching allocator: used on the side stream
         with torch.cuda.stream(stream):
-            if self.world_size > 1:
-                self.miou.zero_()
-                self.pq.zero_()
             # miou.update(pan // max_inst, semantic target)   (task_helper/panoptic.py:123-126)
             # pq.update(pan, panoptic target)                  (task_helper/panoptic.py:111-118)
             # -> one pass over the prediction for both accumulators
@@ -91,49 +86,38 @@ class MetricAccumulators:
             else:
                 self.miou.update_from_panoptic(panoptic_pred, self.target_semantic, self.max_inst)
                 self.pq.update(panoptic_pred, self.target_panoptic)
-            if self.world_size > 1:
-                n = self._n_conf
-                self._packed[:n].copy_(self._step_flat[0])            # i64 -> f64, exact
-                self._packed[n:].copy_(self._step_flat[1])
-                if dist is not None:
-                    self._all_reduce(dist, self._packed)
-                self._total_flat[0] += self._packed[:n].to(torch.int64)
-                self._total_flat[1] += self._packed[n:]
+            if self.sync_every_step:
+                self.miou.sync()
+                self.pq.sync()
+                for total, step in zip(self._total_flat, self._step_flat):
+                    total += step
+                self.miou.reset()                   # next step starts from zero, not synced
+                self.pq.reset()
 
     def warm_collective(self, dist=None) -> None:
-        """untimed: run the packed all-reduce once on scratch data so that communicator set-up
+        """untimed: one all-reduce per state dtype on scratch buffers so that communicator set-up
         and the first-use costs of the collective do not land in the timed region"""
-        if dist is None or self._packed is None:
+        if dist is None:
             return
-        cur = torch.cuda.current_stream(self._packed.device)
-        stream = self.stream if self.stream is not None else cur
+        _, stream = self._side(self._step_flat[0].device)
         with torch.cuda.stream(stream):
-            self._all_reduce(dist, torch.zeros_like(self._packed))
+            for f in self._step_flat:
+                scratch = torch.zeros_like(f)
+                if dist.get_backend() == 'nccl':
+                    dist.all_reduce(scratch, op=dist.ReduceOp.SUM)
+                else:
+                    dist.all_reduce(scratch.cpu(), op=dist.ReduceOp.SUM)
 
     def finalize(self, dist=None) -> None:
-        """end of the epoch: with local accumulation, sum the totals over the ranks (one
-        all-reduce); a no-op when every step was already reduced or there is one rank"""
-        if self.world_size > 1 or self.reduce_world == 1 or self._finalized or dist is None:
+        """end of the epoch: with local accumulation, sum the states over the ranks
+        (`Metric.sync()`); a no-op when every step was already reduced or without a group"""
+        if self.sync_every_step or self._finalized or dist is None:
             return
-        cur = torch.cuda.current_stream(self._packed.device)
-        stream = self.stream if self.stream is not None else cur
+        _, stream = self._side(self._step_flat[0].device)
         with torch.cuda.stream(stream):
-            n = self._n_conf
-            self._packed[:n].copy_(self._total_flat[0])               # < 2^53: exact in f64
-            self._packed[n:].copy_(self._total_flat[1])
-            self._all_reduce(dist, self._packed)
-            self._total_flat[0].copy_(self._packed[:n].to(torch.int64))
-            self._total_flat[1].copy_(self._packed[n:])
+            self.miou.sync()
+            self.pq.sync()
         self._finalized = True
-
-    @staticmethod
-    def _all_reduce(dist, buf: torch.Tensor) -> None:
-        if dist.get_backend() == 'nccl':
-            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
-        else:                                   # gloo rehearsal with device states
-            host = buf.cpu()
-            dist.all_reduce(host, op=dist.ReduceOp.SUM)
-            buf.copy_(host)
 
     def wait(self) -> None:
         """make the current stream wait for everything enqueued on the side stream"""

@@ -8,7 +8,7 @@ B, C, H, W = 32, 40, 480, 640
 inp = syn.make_panoptic_inputs_torch(B, C, H, W, n_centers=24, seed=1234, device=dev)
 logits, center, offset = inp['semantic_logits'], inp['instance_center'], inp['instance_offset']
 is_thing = inp['semantic_classes_is_thing']
-metrics = bench_support.MetricAccumulators(C + 1, dev, inp, 0, world_size=1, side_stream=True, sync_every_step=False, exercise_collective=False)
+metrics = bench_support.MetricAccumulators(C + 1, dev, inp, 0, side_stream=True, sync_every_step=False)
 streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
 def step(i):
     with torch.cuda.stream(streams[i % 2]):
