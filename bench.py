@@ -390,6 +390,36 @@ def secondary_ce(dev, B=16, C=150, H=768, W=1024):
             'backward_launches': {k: spec1[k] - spec0[k] for k in spec1}}
 
 
+def cos_oracle_check(cos, emb, idx, lut, n_cols=4096):
+    """after the timing: image 0 of the SAME batch (same launch geometry: the other images' indices
+    are zeroed) through the loss + backward, against the C oracle — loss sum 1e-5, count exact,
+    gradient on sampled pixel columns to bf16 rounding, images without targets exactly zero"""
+    from oracle import oracle as orc
+    B, D, H, W = emb.shape
+    idx0 = idx.clone()
+    idx0[1:] = 0
+    emb.grad = None
+    l0, n0 = cos.lut_sum(emb, idx0, lut)
+    (l0 / n0).backward()
+    torch.cuda.synchronize()
+    want, want_n, want_grad = orc.loss_cosine_embedding(
+        emb[0:1].detach().float().cpu().numpy(), idx0[0:1].cpu().numpy(), lut[0:1].cpu().numpy(), want_grad=True)
+    rs = np.random.default_rng(5)
+    cols = np.unique(np.concatenate([rs.integers(0, H * W, n_cols), [0, 1, 255, 256, H * W - 1]]))
+    got = emb.grad[0].reshape(D, H * W)[:, torch.from_numpy(cols).to(emb.device)].float().cpu().numpy()
+    ref = want_grad.reshape(D, H * W)[:, cols] / max(want_n, 1)
+    scale = float(np.abs(ref).max())
+    err = np.abs(got - ref) / (np.abs(ref) + 0.05 * scale)
+    loss_rel = abs(float(l0) - want) / max(abs(want), 1e-30)
+    others_zero = bool(B == 1 or not emb.grad[B - 1].any())
+    ok = bool(loss_rel <= 1e-5 and int(n0) == want_n and float(err.max()) <= 2 ** -7 and others_zero)
+    emb.grad = None
+    return {'matches_oracle': ok, 'loss_rel_err': float(loss_rel), 'count_exact': bool(int(n0) == want_n),
+            'grad_cols_checked': int(cols.size), 'grad_max_rel_err': float(err.max()),
+            'what': 'image 0 of the timed batch at the timed launch geometry vs the C oracle '
+                    '(loss 1e-5, gradient to bf16 rounding 2^-7)'}
+
+
 def secondary_cos_emb(dev, B=8, D=512, H=768, W=1024, L=64):
     """BASELINE configs[4]: dense visual-embedding cosine loss at the DVEFormer shape
     (2D+4 B/px forward, +2D gradient write backward, bf16 predictions)"""
@@ -419,6 +449,7 @@ def secondary_cos_emb(dev, B=8, D=512, H=768, W=1024, L=64):
         ms_f = hip_timed(fwd, reps=5, warm=2)
     ms_fb = hip_timed(fwd_bwd, reps=5, warm=2)
     return {'shape': f'B={B} D={D} {W}x{H} L={L}', 'pred_dtype': 'bfloat16', 'one_pass_kernel': one_pass,
+            'oracle_check': cos_oracle_check(cos, pred, idx, lut),
             'fwd': _leg(ms_f, n_px, 2 * D + 4),
             'fwd_bwd': _leg(ms_fb, n_px, 2 * D + 4 + 2 * D,
                             moved_bytes_per_px=(2 * 2 * D + 8) if one_pass else (3 * 2 * D + 8),
@@ -493,6 +524,7 @@ def secondary_cfg5_full(ops, syn, dev, B=16, C=150, H=768, W=1024, K=48, D=512, 
                shape=f'B={B} C={C} {W}x{H} D={D} L={L}', pred_dtype='bfloat16',
                what='panoptic pipeline + mIoU/PQ updates + multi-task losses fwd+bwd + cosine-embedding '
                     'loss fwd+bwd, one stream, HIP events around the whole step')
+    out['cos_oracle_check'] = cos_oracle_check(cos, emb, idx, lut)
     del inp, a, emb, logits
     torch.cuda.empty_cache()
     return out

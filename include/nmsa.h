@@ -578,7 +578,11 @@ int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
  * nmsa_multitask_loss_bwd_unless turns the upstream gradients of the three outputs into one
  * upstream scale per item, compares it with the expectation on the device (launch 1: also
  * updates w) and recomputes only the items that differ (launch 2: a small grid that walks the
- * block list and is gone at once when every gradient stands).
+ * block list and is gone at once when every gradient stands).  A NaN expectation ("the forward
+ * pass wrote no gradient") is never confirmed — not even by an upstream gradient that is the same
+ * NaN: gradient-only launches always write, so a NaN upstream comes out as NaN gradients.
+ * `spec` (and `counters`) may be NULL there: a recompute nobody predicted (a second backward
+ * through a retained graph) leaves the caller's record and the tally alone.
  *   items        HOST array; pointers inside are device pointers.  kind NMSA_LOSS_*; CE: pred =
  *                logits [B,C,H,W], mask = labels u8 [B,H,W] (0 = void), weights f32 [C] or NULL,
  *                param = label smoothing; MSE / L1 / FOCAL: pred [B,C,H,W] (C = 1 for [B,H,W]),

@@ -316,10 +316,16 @@ __device__ __forceinline__ float plane_px(const u32x2_s r, int j)
 
 // The register tile after the sum-of-exp2 walk: the exponentials e = 2^((x - max) log2e) REPLACE the
 // logits, so the gradient walk multiplies instead of calling v_exp_f32 a second time per element —
-// f32 tiles: as they are (exact); bf16 tiles: as fp16 pairs (e <= 1, relative error 2^-11: three
-// bits below the half ulp of the bf16 gradient they end up in).  f16 tiles keep their logits and
+// f32 tiles: as they are (exact); bf16 tiles: as fp16 pairs of e * 2^14 (CE_EXP_SHIFT: the scale is
+// folded into the exponent's offset, the sum is scaled back exactly and the per-pixel factor
+// abg / s carries the 2^-14), so every e >= 2^-28 is an fp16 NORMAL with relative error 2^-11 —
+// three bits below the half ulp of the bf16 gradient it ends up in; unscaled, classes more than
+// 9.7 below the maximum would land in fp16 subnormals (3 % off at e = 1e-6, zero below 3e-8).
+// Smaller e (gaps beyond 19.4) fade out through the subnormals: absolute error <= 2^-39 of the
+// maximum's probability.  f16 tiles keep their logits and
 // exp_px computes e again: an fp16 copy would be no finer than the f16 gradient itself.  The
 // target class, where p - 1 would cancel, is computed from its logit in full precision either way.
+constexpr float CE_EXP_SHIFT = 14.0f;                  // bf16 tiles: e is kept as e * 2^14 in fp16
 typedef _Float16 f16x2_s __attribute__((ext_vector_type(2)));
 typedef float f32x2_s __attribute__((ext_vector_type(2)));
 template <int DTYPE>
@@ -407,7 +413,7 @@ __device__ __forceinline__ void ce_fused_body(
     __syncthreads();
     float wsum = 0.f;
     if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
-    const bool write_grad = MODE != 1 && g == g && grad != nullptr;
+    const bool write_grad = MODE != 1 && (MODE == 2 || g == g) && grad != nullptr;
     const size_t img = (size_t)b * C * P;
     double acc = 0.0, accw = 0.0;
     long long cnt = 0;
@@ -450,7 +456,12 @@ __device__ __forceinline__ void ce_fused_body(
                 }
             }
         } else {
-            // sum of exp2; the exponentials take the logits' place in the tile (pack_exps)
+            // sum of exp2; the exponentials take the logits' place in the tile (pack_exps; bf16
+            // tiles: scaled by 2^14 through the exponent offset, see pack_exps)
+            constexpr bool SHIFTED = DTYPE == NMSA_BF16;
+            float k0s[PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) k0s[j] = SHIFTED ? k0[j] + CE_EXP_SHIFT : k0[j];
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
                 if (c < C) {
@@ -458,7 +469,7 @@ __device__ __forceinline__ void ce_fused_body(
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) {
                         const float x = plane_px<DTYPE>(r[c], j);
-                        e[j] = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0[j]));
+                        e[j] = __builtin_amdgcn_exp2f(fmaf(x, LOG2E, k0s[j]));
                         s[j] += e[j];
                         if (SMOOTH) swx[j] = fmaf(s_w[c], x, swx[j]);
                         xt[j] = (t[j] == c) ? x : xt[j];
@@ -471,13 +482,14 @@ __device__ __forceinline__ void ce_fused_body(
             bool smooth_on[PXT];
 #pragma unroll
             for (int j = 0; j < PXT; ++j) {
+                if (SHIFTED) s[j] *= 0x1p-14f;                             // exact: s >= 1
                 const float k1 = -(fmaf(m[j], LOG2E, __log2f(s[j])));      // p = 2^(x log2e + k1)
                 const bool on = t[j] >= 0 && t[j] < C;
                 const float a = on ? (1.0f - ls) * s_w[t[j]] : 0.f;
                 const float ag = g * a;
                 const float abg = on ? g * (a + (SMOOTH ? (ls / C) * wsum : 0.f)) : 0.f;
                 smooth_on[j] = SMOOTH && abg != 0.f;
-                abgs[j] = abg / s[j];
+                abgs[j] = SHIFTED ? (abg / s[j]) * 0x1p-14f : abg / s[j];  // the tile holds e * 2^14
                 const float pt = __builtin_amdgcn_exp2f(fmaf(xt[j], LOG2E, k1));
                 qt[j] = fmaf(abg, pt, smooth_on[j] ? -(g * (ls / C) * s_w[on ? t[j] : 0]) : 0.f) - ag;
             }
@@ -554,7 +566,7 @@ __device__ __attribute__((noinline)) void elem_fused_body(
     double acc = 0.0; long long cnt = 0;
     const float invC = 1.0f / C;
     const float g = gs / C;
-    const bool write_grad = MODE != 1 && gs == gs && grad != nullptr;
+    const bool write_grad = MODE != 1 && (MODE == 2 || gs == gs) && grad != nullptr;
     for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
         const int nvalid = min(4, P - p0);
         bool mk[4];
@@ -595,7 +607,7 @@ __device__ __attribute__((noinline)) void vm_fused_body(
     int bx, int nbx, int b)
 {
     constexpr bool LOSS = MODE != 2;
-    const bool write_grad = MODE != 1 && g == g && grad != nullptr;
+    const bool write_grad = MODE != 1 && (MODE == 2 || g == g) && grad != nullptr;
     double acc = 0.0; long long cnt = 0;
     for (int p0 = (bx * LOSS_THREADS + threadIdx.x) * 4; p0 < P; p0 += nbx * LOSS_THREADS * 4) {
         const int nvalid = min(4, P - p0);

@@ -70,7 +70,10 @@ __device__ __forceinline__ bool grad_already_computed(const float* __restrict__ 
                                                       int* __restrict__ counters)
 {
     if (!computed_for) return false;
-    const bool same = __float_as_uint(*gscale) == __float_as_uint(*computed_for);
+    // a NaN in `computed_for` means "the forward pass wrote no gradient": never confirmed, even
+    // when the real upstream gradient is that very NaN (it must come out as NaN gradients)
+    const float e = *computed_for;
+    const bool same = e == e && __float_as_uint(*gscale) == __float_as_uint(e);
     if (counters && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
         atomicAdd(&counters[same ? 0 : 1], 1);
     return same;

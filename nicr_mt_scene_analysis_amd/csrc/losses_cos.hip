@@ -79,7 +79,7 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
 
     const float EPS = 1e-12f;
     const float g = grad ? *expected_gscale : __int_as_float(0x7fc00000);
-    const bool write_grad = g == g;
+    const bool write_grad = grad && (MODE == 2 || g == g);
     const size_t img = (size_t)b * D * P;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();
     const int c0 = w * NP;
@@ -107,11 +107,15 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
         const char* pb = pred_b + (size_t)(c0 + i) * P * ESIZE;          // wave-uniform
         r[i] = __builtin_nontemporal_load((const u32x2_s*)(pb + off));
     };
-    auto store_plane = [&](int i, uint32_t off, const float o[PXT]) {
+    // pixels without a target get exactly +0 (the reference gathers the valid rows only): the
+    // masks clear their lanes of the packed words, so a non-finite prediction there cannot leak
+    // a 0 * inf = NaN into the gradient
+    auto store_plane = [&](int i, uint32_t off, const float o[PXT], uint32_t mx, uint32_t my) {
         char* gb = grad_b + (size_t)(c0 + i) * P * ESIZE;               // wave-uniform
         u32x2_s v;
         if (DTYPE == NMSA_F32) { v.x = __float_as_uint(o[0]); v.y = __float_as_uint(o[1]); }
         else { v.x = pack16<DTYPE>(o[0], o[1]); v.y = pack16<DTYPE>(o[2], o[3]); }
+        v.x &= mx; v.y &= my;
         __builtin_nontemporal_store(v, (u32x2_s*)(gb + off));
     };
     auto request = [&](int tile) {                     // all planes of `tile` into r[]
@@ -182,6 +186,12 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
         const bool more = COSS_PREFETCH && tile + 1 < t_end;        // wave-uniform
         const uint32_t off = lane_offset(tile), qoff = lane_offset(more ? tile + 1 : tile);
         const bool store = alive && write_grad;
+        uint32_t mx, my;
+        if (DTYPE == NMSA_F32) { mx = on[0] ? ~0u : 0u; my = on[1] ? ~0u : 0u; }
+        else {
+            mx = (on[0] ? 0xFFFFu : 0u) | (on[PXT > 2 ? 1 : 0] ? 0xFFFF0000u : 0u);
+            my = (on[PXT > 2 ? 2 : 0] ? 0xFFFFu : 0u) | (on[PXT > 2 ? 3 : 0] ? 0xFFFF0000u : 0u);
+        }
         if (DTYPE != NMSA_F32) keep_packed(r);
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
@@ -189,7 +199,7 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
                 o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
-            if (store) store_plane(i, off, o);
+            if (store) store_plane(i, off, o, mx, my);
             if (COSS_PREFETCH) request_plane(i, qoff);         // (the last tile re-reads itself: no branch in the walk)
         }
     }
@@ -250,6 +260,14 @@ void coss_geometry(int B, int P, int dtype, int* gx, int* tpw)
     if (per_img > 4096) per_img = 4096;
     if (per_img < 1) per_img = 1;
     *tpw = (n_tiles + per_img - 1) / per_img;
+    // NMSA_COS_SPLIT_RUN=k (read at every call: tests switch it inside one process): runs of k
+    // tiles per workgroup whatever the image size, so that small shapes reach the tile hand-over
+    // of the gradient walk, the ragged last tile inside a run and the clamped lane offsets
+    const char* run = getenv("NMSA_COS_SPLIT_RUN");
+    if (run && atoi(run) > 0) {
+        *tpw = atoi(run);
+        if ((n_tiles + *tpw - 1) / *tpw > 4096) *tpw = (n_tiles + 4095) / 4096;
+    }
     *gx = (n_tiles + *tpw - 1) / *tpw;
 }
 

@@ -202,11 +202,11 @@ __global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, c
     if (t >= a.n_totals) return;
     int first = -1;
     for (int i = 0; i < a.n_items; ++i) if (a.it[i].total == t && a.it[i].grad && first < 0) first = i;
-    if (first < 0) return;
+    if (first < 0 || !spec) return;          // no record: a recompute nobody predicted (retained graph)
     int32_t* r = spec + 8 * t;
     const float g = gs[first], e = expect[2 * t], nf = expect[2 * t + 1];
     const float g_prev = __int_as_float(r[3]), n_prev = __int_as_float(r[4]);
-    const bool same = __float_as_int(g) == __float_as_int(e);
+    const bool same = e == e && __float_as_int(g) == __float_as_int(e);     // NaN: no expectation
     if (counters) atomicAdd(&counters[same ? 0 : 1], 1);       // per-device tally (statistics only)
     if (same) { r[0] += 1; r[6] = 0; }
     else {
@@ -246,8 +246,9 @@ __attribute__((amdgpu_waves_per_eu((CE_NG <= 5) ? 4 : 3, (CE_NG <= 5) ? 8 : 3)))
         bool any = false;
         for (int i = 0; i < a.n_items; ++i) {
             const MultiItem& it = a.it[i];
+            const float e = expect[2 * it.total];
             any = any || (it.in_launch && it.grad &&
-                          __float_as_int(gs[i]) != __float_as_int(expect[2 * it.total]));
+                          (!(e == e) || __float_as_int(gs[i]) != __float_as_int(e)));
         }
         if (!any) return;
     }
@@ -263,7 +264,7 @@ __attribute__((amdgpu_waves_per_eu((CE_NG <= 5) ? 4 : 3, (CE_NG <= 5) ? 8 : 3)))
         if (!LOSS) {
             if (!it.grad) continue;
             const float gr = gs[i];
-            if (__float_as_int(gr) == __float_as_int(g)) continue;         // the forward's gradient stands
+            if (g == g && __float_as_int(gr) == __float_as_int(g)) continue;   // the forward's gradient stands
             g = gr;
         }
         LossPartial* slot = partials ? partials + blk : nullptr;
@@ -621,7 +622,7 @@ extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n
                                               int32_t* counters, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
-    if (!counts || !grad_scales || !expect || !spec) return NMSA_ERR_ARG;
+    if (!counts || !grad_scales || !expect) return NMSA_ERR_ARG;
     MultiPlan pl;
     int rc = multi_plan(items, n_items, n_totals, pl);
     if (rc) return rc;

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_split(
     if (SMOOTH) for (int c = 0; c < C; ++c) wsum += s_w[c];
     // (no gradient buffer: forward only; a NaN expectation writes no gradient either)
     const float g = grad ? *expected_gscale : __int_as_float(0x7fc00000);
-    const bool write_grad = g == g && grad != nullptr;
+    const bool write_grad = (MODE == 2 || g == g) && grad != nullptr;
     const int b = blockIdx.y;
     const size_t img = (size_t)b * C * P;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();

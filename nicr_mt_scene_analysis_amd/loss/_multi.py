@@ -193,6 +193,9 @@ class MultiLossFunction(torch.autograd.Function):
                                                  L.ptr(counts), L.ptr(aux), L.ptr(out), L.ptr(status),
                                                  L.ptr(ws), nbytes, L.stream_ptr(dev)),
                 'nmsa_multitask_loss_fwd_grad')
+        # the predictions through save_for_backward: an in-place change between forward and a
+        # recomputing backward is caught by autograd's version check (the kernels read them again)
+        ctx.save_for_backward(*preds)
         ctx.arr, ctx.keep, ctx.grads = arr, keep, grads
         ctx.has_grad = [g is not None for g in grads]
         ctx.n_totals, ctx.rec, ctx.expect, ctx.counts = n_totals, rec, expect, counts
@@ -206,14 +209,18 @@ class MultiLossFunction(torch.autograd.Function):
         # cloning them: a logits-sized copy per prediction otherwise)
         grads, ctx.grads = ctx.grads, None
         expect = ctx.expect
+        rec = ctx.rec
+        ctx.saved_tensors                      # version check of the predictions
         if grads is None:
             # a second backward pass through the same graph (retain_graph=True): the buffers of
             # the first one belong to autograd now -> fresh ones, and no expectation to confirm
             grads = [torch.empty_like(k[0]) if has else None for k, has in zip(ctx.keep, ctx.has_grad)]
             for a, gbuf in zip(ctx.arr, grads):
                 a.grad = gbuf.data_ptr() if gbuf is not None else None
+            # (and nothing was predicted: the caller's record and the tally are left alone)
             expect = ctx.expect.clone()
             expect[:, 0] = float('nan')
+            rec = None
         n = len(grads)
         up = [None if g is None else g.detach().to(torch.float32).contiguous()
               for g in (g_sums, g_items, g_totals)]
@@ -221,7 +228,8 @@ class MultiLossFunction(torch.autograd.Function):
         from ._functional import _counters_ptr
         L.check(L.lib().nmsa_multitask_loss_bwd_unless(
             ctx.arr, n, ctx.n_totals, *(None if g is None else L.ptr(g) for g in up), L.ptr(ctx.counts),
-            L.ptr(expect), L.ptr(ctx.rec), L.ptr(gs), _counters_ptr(dev), L.stream_ptr(dev)),
+            L.ptr(expect), L.ptr(rec), L.ptr(gs), None if rec is None else _counters_ptr(dev),
+            L.stream_ptr(dev)),
             'nmsa_multitask_loss_bwd_unless')
         return (None, *grads)
 

@@ -19,7 +19,14 @@ class LossBase(torch.nn.Module):
         return res.sums[0], res.counts[0], res.aux[0]
 
     def _can_speculate(self, input_) -> bool:
+        """forward-written gradient for THIS call?  Not for a list of several scales: their sums
+        are divided by the SUMMED counts afterwards (base.py:161-182), an upstream factor this
+        instance's single record cannot predict per scale — those calls take the two-kernel path
+        at once instead of paying for mispredicted gradients until the record switches itself
+        off (the task helpers put all scales into one multi-loss call with one total instead)."""
         from . import _functional as F_
+        if self.__dict__.get('_several_scales', False):
+            return False
         return input_.is_cuda and input_.numel() > 0 and F_.speculation_enabled() and F_.wants_gradient(input_)
 
     def _compute_loss(self, input_, target):
@@ -32,10 +39,12 @@ class LossBase(torch.nn.Module):
         loss/_functional.py `expected_scale`); losses that can write their gradient in the
         forward pass do so, the others ignore it"""
         pairs = []
+        self.__dict__['_several_scales'] = len(input_tensors) > 1
         for i, (prediction, target) in enumerate(zip(input_tensors, target_tensors)):
             if expected_scales is None or expected_scales[i] is None:
                 pairs.append(self._compute_loss(prediction, target))
             else:
                 pairs.append(self._compute_loss(prediction, target,
                                                 expected_scale=expected_scales[i]))
+        self.__dict__['_several_scales'] = False
         return tuple(pairs)

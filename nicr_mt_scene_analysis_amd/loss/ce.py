@@ -25,14 +25,13 @@ class CrossEntropyLossSemantic(LossBase):
 
     def _compute_loss(self, input_: torch.Tensor, target: torch.Tensor, expected_scale=None
                       ) -> Tuple[torch.Tensor, torch.Tensor]:
-        if expected_scale is None and self._can_speculate(input_) and input_.ndim == 4 and \
-                input_.shape[1] <= 255:
+        # (the ESANet reduction divides by the weight sum, not by a count: nothing to expect)
+        if expected_scale is None and not self._weighted_reduction and self._can_speculate(input_) \
+                and input_.ndim == 4 and input_.shape[1] <= 255:
             # forward sum + gradient in one pass for the upstream gradient this instance has
             # learned to expect (callers divide the sum by a count of the targets)
             loss, n_elements, weight_sum = self._speculative_single(
                 'ce', input_, None, mask=target, weights=self._weights, param=self._label_smoothing)
-            if self._weighted_reduction:
-                loss = loss / weight_sum.to(loss.dtype)
             return loss, n_elements
         loss, n_elements, weight_sum = F_.cross_entropy_sum(
             input_, target, self._weights, self._label_smoothing, expected_scale)

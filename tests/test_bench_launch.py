@@ -108,6 +108,9 @@ def test_bench_secondary_legs_run_on_small_shapes():
             if key == 'backward_launches':
                 # the loss leg's forward-written gradients must all have been confirmed
                 assert entry['confirmed'] > 0 and entry['recomputed'] == 0, entry
+            elif key == 'oracle_check':
+                # the timed cosine legs compare image 0 with the C oracle after the timing
+                assert entry['matches_oracle'] and entry['count_exact'], entry
             elif isinstance(entry, dict):
                 n += 1
                 assert entry['ms'] == entry['ms'] or key == 'step_two_batches_in_flight', (name, key)

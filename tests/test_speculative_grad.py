@@ -687,3 +687,89 @@ def test_multi_loss_fuzz_random_item_mixes(seed):
         tol = _grad_tol(lf.dtype)
         err = (lf.grad.double() - gd).abs() - tol * gd.abs()
         assert float(err.max()) <= max(1e-6, 0.05 * tol * float(gd.abs().max())), (i, it['kind'], float(err.max()))
+
+
+def test_nan_upstream_gradient_is_never_taken_for_the_missing_expectation():
+    """"no expectation" is a NaN in the expectation slot.  A real upstream gradient that is that
+    NaN (NaN loss weight) must not be confirmed against it: the recompute runs and the gradients
+    are NaN — what autograd gives for the reference — instead of the uninitialised buffer"""
+    from nicr_mt_scene_analysis_amd.loss import _multi
+    g = _gen(3)
+    x = torch.rand((2, 1, 16, 32), device='cuda', generator=g)
+    tgt = torch.rand((2, 1, 16, 32), device='cuda', generator=g)
+    tgt[:, :, 4, 4] = 1.0
+    logits, labels, w = _ce_case(2, 7, 16, 32, torch.float32, seed=9)
+    for kind in ('focal', 'mse'):
+        spec = _multi.SpecState(2)
+        if kind == 'mse':
+            spec.records('cuda')[0, 5] |= 1                 # the total's expectation is switched off
+        xs = x.clone().requires_grad_(True)
+        ls = logits.clone().requires_grad_(True)
+        res = _multi.multi_loss([{'kind': kind, 'pred': xs, 'target': tgt, 'mask': None, 'total': 0},
+                                 {'kind': 'ce', 'pred': ls, 'mask': labels, 'weights': w, 'total': 1}], 2, spec)
+        nan = torch.tensor(float('nan'), device='cuda')
+        (res.total_losses[0] * nan + res.total_losses[1]).backward()
+        assert torch.isnan(xs.grad).all(), kind
+        assert torch.isfinite(ls.grad).all() and ls.grad.abs().sum() > 0
+
+
+def test_second_backward_through_a_retained_graph_leaves_the_record_alone():
+    from nicr_mt_scene_analysis_amd.loss import _multi
+    logits, labels, w = _ce_case(2, 7, 16, 32, torch.float32, seed=11)
+    spec = _multi.SpecState(1)
+    ls = logits.clone().requires_grad_(True)
+    res = _multi.multi_loss([{'kind': 'ce', 'pred': ls, 'mask': labels, 'weights': w, 'total': 0}], 1, spec)
+    before = _stats()
+    res.total_losses[0].backward(retain_graph=True)
+    first = ls.grad.clone()
+    assert _delta(before) == (1, 0) and spec.stats() == {'confirmed': 1, 'recomputed': 0}
+    rec = spec.records('cuda').clone()
+    for _ in range(10):                                   # e.g. a gradient penalty loop
+        ls.grad = None
+        res.total_losses[0].backward(retain_graph=True)
+        assert torch.equal(ls.grad, first)
+    assert torch.equal(spec.records('cuda'), rec)         # not a miss: nothing was predicted
+    assert _delta(before) == (1, 0)
+    # an in-place change of the prediction between forward and a recomputing backward is caught
+    with torch.no_grad():
+        ls.add_(1.0)
+    with pytest.raises(RuntimeError, match='modified by an inplace operation'):
+        res.total_losses[0].backward()
+
+
+def test_lists_of_several_scales_take_the_plain_path():
+    """LossBase.forward over several scales (outside the task helpers' one-call path): the sums
+    are divided by the SUMMED counts later, which one record per instance cannot predict per
+    scale -> no forward-written gradient, no misses, results as ever"""
+    from nicr_mt_scene_analysis_amd.loss import CrossEntropyLossSemantic, MSELoss
+    logits, labels, w = _ce_case(2, 7, 16, 32, torch.float32, seed=13)
+    small = logits[:, :, ::2, ::2].contiguous()
+    small_labels = labels[:, ::2, ::2].contiguous()
+    ce = CrossEntropyLossSemantic(weights=w)
+    for _ in range(3):
+        a = logits.clone().requires_grad_(True)
+        b = small.clone().requires_grad_(True)
+        before = _stats()
+        (l0, n0), (l1, n1) = ce([a, b], [labels, small_labels])
+        ((l0 + l1) / (n0 + n1)).backward()
+        assert _delta(before) == (0, 0)
+    ra = logits.double().requires_grad_(True)
+    rb = small.double().requires_grad_(True)
+    ref = sum(torch.nn.functional.cross_entropy(p, t.long() - 1, weight=w.double(), reduction='sum',
+                                                ignore_index=-1) for p, t in ((ra, labels), (rb, small_labels)))
+    (ref / int(n0 + n1)).backward()
+    np.testing.assert_allclose(a.grad.double().cpu().numpy(), ra.grad.cpu().numpy(), rtol=2e-5, atol=1e-10)
+    # a single-scale call still speculates (and is confirmed)
+    a = logits.clone().requires_grad_(True)
+    before = _stats()
+    (l0, n0), = ce([a], [labels])
+    (l0 / n0).backward()
+    assert _delta(before) == (1, 0)
+    # the ESANet reduction divides by the weight sum: no expectation either
+    cew = CrossEntropyLossSemantic(weights=w, weighted_reduction=True)
+    a = logits.clone().requires_grad_(True)
+    before = _stats()
+    (l0, n0), = cew([a], [labels])
+    l0.backward()
+    assert _delta(before) == (0, 0)
+    del MSELoss

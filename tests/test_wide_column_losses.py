@@ -280,3 +280,185 @@ def test_cos_split_falls_back_where_it_cannot_run():
         tol = _grad_tol(torch.bfloat16)
         np.testing.assert_allclose(xs.grad.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol,
                                    atol=tol * float(ref_grad.abs().max()) * 0.05 + 1e-12)
+
+
+@pytest.fixture
+def cos_split_run():
+    """NMSA_COS_SPLIT_RUN (tiles per workgroup of k_cos_split, read by the library at every call)"""
+    import os
+    prev = os.environ.get('NMSA_COS_SPLIT_RUN')
+
+    def set_run(k):
+        if k is None:
+            os.environ.pop('NMSA_COS_SPLIT_RUN', None)
+        else:
+            os.environ['NMSA_COS_SPLIT_RUN'] = str(k)
+    yield set_run
+    set_run(prev)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize('D,L', [(64, 3), (256, 17), (512, 64)])
+@pytest.mark.parametrize('hw,run', [((8, 200), 3), ((9, 444), 5), ((33, 100), 4), ((6, 1000), 64)])
+def test_cos_split_runs_of_several_tiles_per_workgroup(dtype, D, L, hw, run, cos_split_run):
+    """the production geometry of k_cos_split on small shapes: every workgroup walks a RUN of
+    tiles (at configs[4] 96 of them; by default small images get one tile per workgroup), so the
+    register hand-over to the next tile inside the gradient walk, the ragged last tile inside a
+    run, the clamped lane offsets past the image and the last run being shorter are all compared
+    with torch's fp64 op — and bit for bit with the one-tile-per-workgroup geometry"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as _F
+    if not _F.speculation_enabled():
+        pytest.skip('NMSA_SPECULATIVE_GRAD=0: forward-written gradients are switched off')
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
+    H, W = hw
+    B = 2
+    g = _gen(D + W + run)
+    x = torch.randn((B, D, H, W), device='cuda', generator=g).to(dtype)
+    lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
+    idx = _index_map('noise' if W == 444 else 'segments', B, H, W, L, g)
+    assert _multi.cos_supported(x, lut)
+    tile = 128 if dtype == torch.float32 else 256
+    n_tiles = -(-H * W // tile)
+    assert n_tiles >= 3 and (run >= n_tiles or n_tiles % run != 0 or (H * W) % tile != 0)
+    ref_loss, ref_n, ref_grad = _cos_reference(x, idx, lut)
+    results = []
+    for k in (run, 1):
+        cos_split_run(k)
+        cos = CosineEmbeddingLoss()
+        xs = x.clone().requires_grad_(True)
+        before = _stats()
+        loss, n = cos.lut_sum(xs, idx, lut)
+        (loss / n.clamp(min=1)).backward()
+        after = _stats()
+        assert (after['confirmed'] - before['confirmed'], after['recomputed'] - before['recomputed']) == (1, 0)
+        assert int(n) == ref_n
+        np.testing.assert_allclose(float(loss), ref_loss, rtol=RTOL, atol=1e-6)
+        tol = _grad_tol(dtype)
+        atol = tol * float(ref_grad.abs().max()) * 0.05 + (6e-8 if dtype == torch.float16 else 1e-12)
+        np.testing.assert_allclose(xs.grad.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol, atol=atol)
+        # the recomputing launch (gradient only) walks the same runs
+        xw = x.clone().requires_grad_(True)
+        lw, nw = cos.lut_sum(xw, idx, lut)
+        (0.5 * (lw / nw.clamp(min=1))).backward()
+        np.testing.assert_allclose(xw.grad.double().cpu().numpy(), 0.5 * ref_grad.cpu().numpy(), rtol=tol, atol=atol)
+        results.append((xs.grad.clone(), xw.grad.clone()))
+    # per-pixel arithmetic does not depend on the geometry: identical bits
+    assert torch.equal(results[0][0], results[1][0]) and torch.equal(results[0][1], results[1][1])
+
+
+def _segment_indices(B, H, W, L, g, cell=(37, 53)):
+    """segment-style index map: blobs of ~cell pixels with an index in [0, L] (0 = no target)"""
+    ch, cw = cell
+    idx = torch.randint(0, L + 1, (B, -(-H // ch), -(-W // cw)), device='cuda', generator=g, dtype=torch.int32)
+    return idx.repeat_interleave(ch, 1).repeat_interleave(cw, 2)[:, :H, :W].contiguous()
+
+
+@pytest.mark.parametrize('hw', [(768, 1024), (765, 1020)])
+def test_cos_split_full_size_image_vs_oracle(hw):
+    """configs[4]: ONE full-size image (512 x 768 x 1024 bf16, L = 64, segment-style indices; the
+    second shape has H*W % 256 != 0: a ragged last tile at the end of the last run) through
+    k_cos_split at the geometry it was built for (runs of ~12 tiles per workgroup at B = 1, of 96
+    at B = 16) against the C oracle (reference loss/cos_emb.py:21-56 +
+    task_helper/dense_visual_embedding.py:110-171): sum rtol 1e-5, n exact, the gradient on 4096
+    sampled pixel columns (incl. the first and last pixels) element-wise to bf16 rounding, and
+    EVERY element through three f64 projections: per-plane sums, per-pixel sums, a signed sum"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as _F
+    if not _F.speculation_enabled():
+        pytest.skip('NMSA_SPECULATIVE_GRAD=0')
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
+    from oracle import oracle as orc
+    H, W = hw
+    B, D, L = 1, 512, 64
+    g = _gen(H)
+    x = torch.randn((B, D, H, W), device='cuda', generator=g).to(torch.bfloat16)
+    lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
+    idx = _segment_indices(B, H, W, L, g)
+    assert _multi.cos_supported(x, lut)
+    cos = CosineEmbeddingLoss()
+    xs = x.clone().requires_grad_(True)
+    before = _stats()
+    loss, n = cos.lut_sum(xs, idx, lut)
+    (loss / n.clamp(min=1)).backward()
+    after = _stats()
+    assert (after['confirmed'] - before['confirmed'], after['recomputed'] - before['recomputed']) == (1, 0)
+    want, want_n, want_grad = orc.loss_cosine_embedding(x.float().cpu().numpy(), idx.cpu().numpy(),
+                                                        lut.cpu().numpy(), want_grad=True)
+    assert int(n) == want_n and want_n > 0.9 * H * W
+    np.testing.assert_allclose(float(loss), want, rtol=RTOL)
+    want_grad = want_grad.reshape(D, H * W) / want_n             # the oracle's gradient is d sum / d x
+    got = xs.grad.float().cpu().numpy().reshape(D, H * W)
+    rs = np.random.default_rng(H)
+    cols = np.unique(np.concatenate([rs.integers(0, H * W, 4096), [0, 1, 2, 3, 255, 256, H * W - 1, H * W - 4]]))
+    scale = float(np.abs(want_grad[:, cols]).max())
+    np.testing.assert_allclose(got[:, cols], want_grad[:, cols], rtol=2 ** -7, atol=2 ** -8 * 0.05 * scale)
+    # pixels without a target: exactly zero, everywhere
+    off = (idx.reshape(-1) == 0).cpu().numpy()
+    assert off.any() and not got[:, off].any()
+    # projections over all 4e8 elements (f64 accumulation; bf16 rounding errors average out)
+    g64 = got.astype(np.float64)
+    w64 = want_grad.astype(np.float64)
+    def close(a, b, what):
+        err = np.abs(a - b).max()
+        ref = np.abs(b).max()
+        assert err <= 2e-3 * ref, (what, err, ref)
+    close(g64.sum(axis=1), w64.sum(axis=1), 'per-plane sums')
+    close(np.abs(g64).sum(axis=0), np.abs(w64).sum(axis=0), 'per-pixel |.| sums')
+    sign = np.where((np.arange(D)[:, None] + np.arange(H * W)[None, :]) % 3 == 0, 1.0, -0.5)
+    close(np.array([(g64 * sign).sum()]), np.array([(w64 * sign).sum()]) + 0.0, 'signed sum')
+
+
+def test_cos_split_non_finite_prediction_without_target_gets_zero_gradient():
+    """a pixel without a target (index 0) gets exactly 0 — also when the prediction there is
+    inf / NaN (the reference gathers the valid rows only; 0 * inf must not leak a NaN)"""
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
+    g = _gen(5)
+    B, D, H, W, L = 1, 128, 4, 64, 5
+    for dtype in (torch.float32, torch.bfloat16):
+        x = torch.randn((B, D, H, W), device='cuda', generator=g).to(dtype)
+        lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
+        idx = _index_map('segments', B, H, W, L, g)
+        idx[0, 1, 3] = 0
+        idx[0, 2, 10] = 0
+        x[0, 7, 1, 3] = float('inf')
+        x[0, 9, 2, 10] = float('nan')
+        assert _multi.cos_supported(x, lut)
+        xs = x.clone().requires_grad_(True)
+        loss, n = CosineEmbeddingLoss().lut_sum(xs, idx, lut)
+        (loss / n.clamp(min=1)).backward()
+        assert torch.isfinite(loss) and torch.isfinite(xs.grad).all()
+        assert not xs.grad[0, :, 1, 3].any() and not xs.grad[0, :, 2, 10].any()
+        clean = torch.nan_to_num(x, nan=0.0, posinf=0.0)
+        _, _, ref_grad = _cos_reference(clean, idx, lut)
+        tol = _grad_tol(dtype)
+        np.testing.assert_allclose(xs.grad.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol,
+                                   atol=tol * float(ref_grad.abs().max()) * 0.05 + 1e-12)
+
+
+def test_ce_bf16_far_classes_keep_their_gradient():
+    """bf16 logits with classes 12 ... 20 below the maximum: their exponentials (1e-9 ... 6e-6)
+    are kept as fp16 in the register tile — scaled, so they are fp16 normals; the gradient of
+    every class equals torch's fp32 softmax gradient rounded to bf16 (element-wise)"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    B, C, H, W = 1, 40, 8, 64
+    g = _gen(40)
+    gaps = 12.0 + 8.0 * torch.rand((B, C, H, W), device='cuda', generator=g)
+    x = -gaps
+    top = torch.randint(0, C, (B, 1, H, W), device='cuda', generator=g)
+    x.scatter_(1, top, 0.0)
+    x = (x + torch.randn((B, 1, H, W), device='cuda', generator=g)).to(torch.bfloat16)
+    t = torch.randint(1, C + 1, (B, H, W), device='cuda', generator=g).to(torch.uint8)
+    n = F_.count_u8(t, 1, C)
+    xs = x.clone().requires_grad_(True)
+    loss, n_el, _ = F_.cross_entropy_sum(xs, t, None, 0.0, expected_scale=F_.expected_scale(n))
+    (loss / n_el).backward()
+    xr = x.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t.long() - 1, reduction='sum')
+    (ref / int(n)).backward()
+    want = xr.grad.to(torch.bfloat16).float()
+    got = xs.grad.float()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL)
+    # one bf16 ulp (2^-8 relative) — rounding of a value computed two ways —, no absolute slack
+    # beyond the smallest gradients that exist here (1e-9 / n)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2 ** -7, atol=1e-9 / int(n) * 0.1)
+    small = (xr.grad.abs() < 1e-5 / int(n)) & (xr.grad != 0)
+    assert int(small.sum()) > 1000 and bool((got[small] != 0).all())
