@@ -758,7 +758,8 @@ def test_lists_of_several_scales_take_the_plain_path():
     ref = sum(torch.nn.functional.cross_entropy(p, t.long() - 1, weight=w.double(), reduction='sum',
                                                 ignore_index=-1) for p, t in ((ra, labels), (rb, small_labels)))
     (ref / int(n0 + n1)).backward()
-    np.testing.assert_allclose(a.grad.double().cpu().numpy(), ra.grad.cpu().numpy(), rtol=2e-5, atol=1e-10)
+    np.testing.assert_allclose(a.grad.double().cpu().numpy(), ra.grad.cpu().numpy(), rtol=2e-5,
+                               atol=2e-6 * float(ra.grad.abs().max()))        # fp32 softmax next to p - 1
     # a single-scale call still speculates (and is confirmed)
     a = logits.clone().requires_grad_(True)
     before = _stats()
