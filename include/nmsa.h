@@ -539,11 +539,16 @@ int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t* indices, c
                           int B, int D, int H, int W, int L,
                           const float* grad_scale, const float* dots, void* grad_pred,
                           nmsa_stream_t stream);
-/* forward + gradient in ONE pass over the prediction (k_cos_split: the D-column of a pixel
- * stays in the registers of the D / 64 waves of a workgroup, the image's LUT in LDS): D % 64 == 0,
- * D <= 512, LUT + exchange buffers within the CU's LDS, H*W a multiple of 4 (2 for f32), 8-byte
- * aligned planes.  The gradient is written for *expected_gscale; nmsa_loss_cos_emb_bwd_unless
- * confirms it (bit-equal *grad_scale) or recomputes. */
+/* forward + gradient in ONE pass over the prediction: the D-column of a pixel stays in the
+ * registers of D / 64 waves between the reduction and the gradient.  D % 64 == 0, H*W a multiple
+ * of 4 (2 for f32), 8-byte aligned planes, and either D <= 512 with the image's fp32 LUT + the
+ * exchange buffers within the CU's LDS (k_cos_split: one workgroup per column) or D <= 1024
+ * (k_cos_parts: the column over ceil(D / 256) cooperating workgroups that exchange their partial
+ * sums as 8-byte {value, tag} granules through the workspace; DVEFormer's D = 768).  The gradient
+ * is written for *expected_gscale; nmsa_loss_cos_emb_bwd_unless confirms it (bit-equal
+ * *grad_scale) or recomputes — it takes the forward call's workspace (NULL is fine for
+ * D <= 512).  Status bit 32: a cooperating workgroup did not answer within ~2 s (sum and
+ * gradient are NaN then). */
 int nmsa_loss_cos_emb_fwd_grad_supported(int dtype, int D, int H, int W, int L);
 size_t nmsa_loss_cos_emb_fwd_grad_workspace_bytes(int B, int D, int H, int W, int L);
 int nmsa_loss_cos_emb_fwd_grad(const void* pred, int dtype, const int32_t* indices, const float* lut,
@@ -553,7 +558,7 @@ int nmsa_loss_cos_emb_fwd_grad(const void* pred, int dtype, const int32_t* indic
 int nmsa_loss_cos_emb_bwd_unless(const void* pred, int dtype, const int32_t* indices, const float* lut,
                                  int B, int D, int H, int W, int L, const float* grad_scale,
                                  void* grad_pred, const float* computed_for, int32_t* counters,
-                                 nmsa_stream_t stream);
+                                 void* workspace, size_t workspace_bytes, nmsa_stream_t stream);
 /* 1 when the (L, D, H*W) combination runs the LDS-LUT kernel that can keep `dots` */
 int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
 
@@ -583,6 +588,8 @@ int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
  * NaN: gradient-only launches always write, so a NaN upstream comes out as NaN gradients.
  * `spec` (and `counters`) may be NULL there: a recompute nobody predicted (a second backward
  * through a retained graph) leaves the caller's record and the tally alone.
+ * `workspace`: the forward call's buffer, contents dead by then (used as the granule exchange of
+ * cosine items with D > 512; may be NULL without such items).
  *   items        HOST array; pointers inside are device pointers.  kind NMSA_LOSS_*; CE: pred =
  *                logits [B,C,H,W], mask = labels u8 [B,H,W] (0 = void), weights f32 [C] or NULL,
  *                param = label smoothing; MSE / L1 / FOCAL: pred [B,C,H,W] (C = 1 for [B,H,W]),
@@ -638,7 +645,8 @@ int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items_host, int n_items
                                    const float* grad_sums, const float* grad_item_losses,
                                    const float* grad_total_losses, const int64_t* counts,
                                    const float* expect, int32_t* spec, float* grad_scales,
-                                   int32_t* counters, nmsa_stream_t stream);
+                                   int32_t* counters, void* workspace, size_t workspace_bytes,
+                                   nmsa_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -109,10 +109,10 @@ _SIGNATURES = {
     'nmsa_loss_cos_emb_fwd_grad_supported': (_i, [_i, _i, _i, _i, _i]),
     'nmsa_loss_cos_emb_fwd_grad_workspace_bytes': (_sz, [_i, _i, _i, _i, _i]),
     'nmsa_loss_cos_emb_fwd_grad': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'nmsa_loss_cos_emb_bwd_unless': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
+    'nmsa_loss_cos_emb_bwd_unless': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_multitask_loss_workspace_bytes': (_sz, [_vp, _i]),
     'nmsa_multitask_loss_fwd_grad': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    'nmsa_multitask_loss_bwd_unless': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    'nmsa_multitask_loss_bwd_unless': (_i, [_vp, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_loss_masked_fwd_grad': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp,
                                        _sz, _vp]),
     'nmsa_loss_masked_bwd_unless': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp,

@@ -91,10 +91,13 @@ int launch_ce_split(bool loss, const void* logits, int dtype, const uint8_t* tar
                     const float* computed_for, int32_t* counters, void* grad,
                     LossPartial* partials, int32_t* status, hipStream_t stream);
 // losses_cos.hip: cosine-embedding loss, forward + gradient in one pass (k_cos_split)
-int cos_split_blocks(int B, int P, int dtype);
+// (k_cos_split, or k_cos_parts for columns beyond one workgroup: `xch` = its granule exchange buffer)
+int cos_split_blocks(int B, int D, int P, int L, int dtype);
+size_t cos_split_xch_bytes(int B, int D, int P, int L, int dtype);
 int launch_cos_split(bool loss, const void* pred, int dtype, const int32_t* indices, const float* lut,
                      int B, int D, int P, int L, const float* gscale, const float* computed_for,
-                     int32_t* counters, void* grad, LossPartial* partials, int32_t* status, hipStream_t stream);
+                     int32_t* counters, void* grad, LossPartial* partials, int32_t* status,
+                     void* xch, size_t xch_bytes, hipStream_t stream);
 int loss_finalize(const LossPartial* partials, int n, double* sum, double* aux, int64_t* count,
                   hipStream_t stream);
 int loss_env_int(const char* name, int dflt);

@@ -209,6 +209,239 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Columns beyond one workgroup (D = 768: a 197 KB LUT, 12 waves of 64 planes): k_cos_parts.
+// The column is split over NS = ceil(D / 256) COOPERATING workgroups ("parts") of four waves;
+// part q keeps the planes [256 q, 256 q + 256) of the same tiles in its registers and only those
+// LUT columns in its LDS (66 KB at L = 64: two workgroups per CU, so one part's exchange wait is
+// the other workgroup's streaming time).  What the parts owe each other per tile is 2 x PXT
+// partial sums per lane.  They travel as 8-byte {value, tag} granules: one sc1 (write-through)
+// store per granule by wave 0, polled with sc1 loads by the partners' wave 0 — a granule is
+// written and read whole, so it validates itself and no fence is needed (MI355X_MICROARCH.md,
+// hand-off price list: 1-3 us per hop against ~20 us of streaming per tile).  Every part adds the
+// partial sums in part order: all parts get the same bits.  Two slots per part (tile parity): a
+// part publishes tile t + 1 only after it has read its partners' tile t, which they published
+// after reading tile t - 1 of everybody.
+// Forward progress: partners are neighbours in blockIdx.x; workgroups are dispatched in index
+// order, so every earlier group is complete or fully resident and the grid drains whatever else
+// runs on the chip.  Should a partner still not answer within ~2 s the wait gives up for good and
+// poisons sums and gradients with NaN (every wave reaches the end; the failure is loud).
+constexpr int COSP_WAVES = 4;
+constexpr int COSP_COLS = COSP_WAVES * COSS_NP;        // 256 planes per part
+constexpr int COSP_MAX_PARTS = 4;                      // D <= 1024
+constexpr int COSP_GRAN = 2 * 4 * 64;                  // granules per (slot, part): 2 sums x 4 px x 64 lanes
+
+template <int DTYPE, int MODE>                         // MODE 0: loss + gradient, 2: gradient only
+__global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
+    const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
+    int D, int P, int L, int NS, int tiles_per_wg,
+    const float* __restrict__ expected_gscale, void* __restrict__ grad,
+    LossPartial* __restrict__ partials, int* __restrict__ status,
+    const float* __restrict__ computed_for, int* __restrict__ counters,
+    unsigned long long* __restrict__ xch)
+{
+    constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
+    constexpr int NP = COSS_NP;
+    constexpr int NW = COSP_WAVES;
+    constexpr int TPX = 64 * PXT;
+    constexpr bool LOSS = MODE != 2;
+    extern __shared__ float s_mem[];       // [L][257] LUT columns of this part | yy[L] | xy[NW][TPX] | xx[NW][TPX] | tot[2 PXT][64]
+    if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
+    const int part = blockIdx.x % NS, group = blockIdx.x / NS;
+    const int d0 = part * COSP_COLS;
+    const int DP = min(COSP_COLS, D - d0);             // my columns (a multiple of 64)
+    constexpr int ld = COSP_COLS + 1;
+    float* s_lut = s_mem;
+    float* s_yy = s_lut + (size_t)L * ld;
+    float* s_xy = s_yy + ((L + 3) & ~3);
+    float* s_xx = s_xy + NW * TPX;
+    float* s_tot = s_xx + NW * TPX;
+    const int b = blockIdx.y;
+    const float* lut_b = lut + (size_t)b * L * D;
+    for (int i = threadIdx.x; i < L * DP; i += blockDim.x) {
+        const int r = i / DP, d = i - r * DP;
+        s_lut[r * ld + d] = lut_b[(size_t)r * D + d0 + d];
+    }
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();
+    for (int r = w; r < L; r += NW) {                  // |y|^2 over the WHOLE row (all parts: same bits)
+        float yy = 0.f;
+        for (int d = l; d < D; d += 64) { const float v = lut_b[(size_t)r * D + d]; yy = fmaf(v, v, yy); }
+        yy = wave_reduce_sum(yy);
+        if (l == 0) s_yy[r] = yy;
+    }
+    __syncthreads();
+
+    const float EPS = 1e-12f;
+    const float g = grad ? *expected_gscale : __int_as_float(0x7fc00000);
+    const bool write_grad = grad && (MODE == 2 || g == g);
+    const size_t img = (size_t)b * D * P;
+    const int nwa = DP / NP;                           // waves of this part that hold planes
+    const bool active = w < nwa;                       // wave-uniform
+    const int c0 = d0 + w * NP;                        // my first plane
+    const int lc0 = w * NP;                            // ... as a column of s_lut
+    double acc = 0.0;
+    long long cnt = 0;
+    bool bad = false;
+    bool dead = false;                                 // a partner did not answer: stop waiting
+    const int n_tiles = (P + TPX - 1) / TPX;
+    const int t_begin = group * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+    if (t_begin >= t_end) { if (LOSS) block_partial_wide(0.0, 0, partials); return; }
+    const size_t gid = (size_t)blockIdx.y * (gridDim.x / NS) + group;
+
+    constexpr int ESIZE = (DTYPE == NMSA_F32) ? 4 : 2;
+    const char* pred_b = (const char*)pred + img * ESIZE;
+    char* grad_b = (char*)grad + img * ESIZE;
+    u32x2_s r[NP];
+    auto lane_offset = [&](int tile) -> uint32_t {
+        const int p0 = (tile * 64 + l) * PXT;
+        return (uint32_t)((p0 < P ? p0 : 0) * ESIZE);
+    };
+    auto request_plane = [&](int i, uint32_t off) {
+        const char* pb = pred_b + (size_t)(c0 + i) * P * ESIZE;          // wave-uniform
+        r[i] = __builtin_nontemporal_load((const u32x2_s*)(pb + off));
+    };
+    auto store_plane = [&](int i, uint32_t off, const float o[PXT], uint32_t mx, uint32_t my) {
+        char* gb = grad_b + (size_t)(c0 + i) * P * ESIZE;               // wave-uniform
+        u32x2_s v;
+        if (DTYPE == NMSA_F32) { v.x = __float_as_uint(o[0]); v.y = __float_as_uint(o[1]); }
+        else { v.x = pack16<DTYPE>(o[0], o[1]); v.y = pack16<DTYPE>(o[2], o[3]); }
+        v.x &= mx; v.y &= my;
+        __builtin_nontemporal_store(v, (u32x2_s*)(gb + off));
+    };
+#pragma unroll
+    for (int i = 0; i < NP; ++i) r[i] = u32x2_s{0u, 0u};
+    if (active) {
+        const uint32_t off = lane_offset(t_begin);
+#pragma unroll
+        for (int i = 0; i < NP; ++i) request_plane(i, off);
+    }
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        const int p0 = (tile * 64 + l) * PXT;
+        const bool alive = p0 < P;
+        const int nvalid = alive ? min(PXT, P - p0) : 0;
+        int row[PXT], ridx[PXT];
+        bool on[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const int ix = (j < nvalid) ? indices[(size_t)b * P + p0 + j] : 0;
+            if (ix < 0 || ix > L) bad = true;
+            on[j] = ix > 0 && ix <= L;
+            ridx[j] = on[j] ? ix - 1 : 0;
+            row[j] = ridx[j] * ld + lc0;
+        }
+        // ---- pass 1: partial x.y and |x|^2 over my planes --------------------------------------
+        float xy[PXT], xx[PXT];
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) { xy[j] = 0.f; xx[j] = 0.f; }
+        if (active) {
+            if (DTYPE != NMSA_F32) keep_packed(r);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+#pragma unroll
+                for (int j = 0; j < PXT; ++j) {
+                    const float x = plane_px<DTYPE>(r[i], j);
+                    xy[j] = fmaf(x, s_lut[row[j] + i], xy[j]);
+                    xx[j] = fmaf(x, x, xx[j]);
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) { s_xy[w * TPX + l * PXT + j] = xy[j]; s_xx[w * TPX + l * PXT + j] = xx[j]; }
+        __syncthreads();
+        // ---- wave 0: the part's sums -> granules -> the sums over all parts ----------------------
+        if (w == 0) {
+            float v[2 * PXT], tot[2 * PXT];
+#pragma unroll
+            for (int j = 0; j < PXT; ++j) {
+                float a = s_xy[l * PXT + j], c = s_xx[l * PXT + j];
+                for (int ww = 1; ww < nwa; ++ww) { a += s_xy[ww * TPX + l * PXT + j]; c += s_xx[ww * TPX + l * PXT + j]; }
+                v[j] = a; v[PXT + j] = c;
+            }
+            const uint32_t seq = (uint32_t)(tile - t_begin) + 1u;
+            unsigned long long* slot = xch + (gid * 2 + ((tile - t_begin) & 1)) * NS * COSP_GRAN;
+            unsigned long long* mine = slot + (size_t)part * COSP_GRAN;
+#pragma unroll
+            for (int k = 0; k < 2 * PXT; ++k)
+                __hip_atomic_store(mine + k * 64 + l, ((unsigned long long)seq << 32) | __float_as_uint(v[k]),
+                                   __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int k = 0; k < 2 * PXT; ++k) tot[k] = 0.f;
+            for (int q = 0; q < NS; ++q) {             // in part order: every part adds the same way
+                if (q == part) {
+#pragma unroll
+                    for (int k = 0; k < 2 * PXT; ++k) tot[k] += v[k];
+                    continue;
+                }
+                const unsigned long long* theirs = slot + (size_t)q * COSP_GRAN;
+                unsigned long long gr[2 * PXT];
+                // poll the LAST granule of the partner's eight stores (one load per lane and
+                // round), then read them all; every granule is checked — store order is no promise
+                const long long t0 = dead ? 0 : (long long)wall_clock64();
+                for (;;) {
+                    const unsigned long long probe = __hip_atomic_load(theirs + (2 * PXT - 1) * 64 + l,
+                                                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (__all((uint32_t)(probe >> 32) == seq)) {
+                        bool ok = true;
+#pragma unroll
+                        for (int k = 0; k < 2 * PXT; ++k)
+                            gr[k] = __hip_atomic_load(theirs + k * 64 + l, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+                        for (int k = 0; k < 2 * PXT; ++k) ok = ok && (uint32_t)(gr[k] >> 32) == seq;
+                        if (__all(ok)) break;
+                    }
+                    if (dead) break;                                                  // (wave-uniform)
+                    __builtin_amdgcn_s_sleep(8);
+                    if (__any((long long)wall_clock64() - t0 > 200000000LL)) dead = true;     // ~2 s at 100 MHz
+                }
+#pragma unroll
+                for (int k = 0; k < 2 * PXT; ++k)
+                    tot[k] += dead ? __int_as_float(0x7fc00000) : __uint_as_float((uint32_t)gr[k]);
+            }
+#pragma unroll
+            for (int k = 0; k < 2 * PXT; ++k) s_tot[k * 64 + l] = tot[k];
+        }
+        __syncthreads();
+        float k1[PXT], k2[PXT];
+        float ploss = 0.f;
+#pragma unroll
+        for (int j = 0; j < PXT; ++j) {
+            const float sxy = s_tot[j * 64 + l], sxx = s_tot[(PXT + j) * 64 + l];
+            const float den = sqrtf((sxx + EPS) * (s_yy[ridx[j]] + EPS));
+            k1[j] = on[j] ? -g / den : 0.f;
+            k2[j] = on[j] ? g * sxy / ((sxx + EPS) * den) : 0.f;
+            if (LOSS && w == 0 && part == 0 && on[j]) { ploss += 1.0f - sxy / den; ++cnt; }
+        }
+        acc += ploss;
+        // ---- pass 2: the gradient of my planes; each register then takes the next tile's plane ----
+        if (active) {
+            const bool more = tile + 1 < t_end;                         // wave-uniform
+            const uint32_t off = lane_offset(tile), qoff = lane_offset(more ? tile + 1 : tile);
+            const bool store = alive && write_grad;
+            uint32_t mx, my;
+            if (DTYPE == NMSA_F32) { mx = on[0] ? ~0u : 0u; my = on[1] ? ~0u : 0u; }
+            else {
+                mx = (on[0] ? 0xFFFFu : 0u) | (on[PXT > 2 ? 1 : 0] ? 0xFFFF0000u : 0u);
+                my = (on[PXT > 2 ? 2 : 0] ? 0xFFFFu : 0u) | (on[PXT > 2 ? 3 : 0] ? 0xFFFF0000u : 0u);
+            }
+            if (DTYPE != NMSA_F32) keep_packed(r);
+#pragma unroll
+            for (int i = 0; i < NP; ++i) {
+                float o[PXT];
+#pragma unroll
+                for (int j = 0; j < PXT; ++j)
+                    o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
+                if (store) store_plane(i, off, o, mx, my);
+                request_plane(i, qoff);                                 // (the last tile re-reads itself)
+            }
+        }
+    }
+    if (LOSS) {
+        if (bad) atomicOr(status, 8);
+        if (dead) atomicOr(status, 32);
+        block_partial_wide(acc, cnt, partials);
+    }
+}
 }  // namespace nmsa
 
 using namespace nmsa;
@@ -220,42 +453,56 @@ size_t coss_lds_bytes(int D, int L, int nw, int pxt)
     return ((size_t)L * (D + 1) + ((L + 3) & ~3) + (size_t)2 * nw * 64 * pxt) * sizeof(float);
 }
 
-}  // namespace
+size_t cosp_lds_bytes(int L, int pxt)
+{
+    return ((size_t)L * (COSP_COLS + 1) + ((L + 3) & ~3) + (size_t)2 * COSP_WAVES * 64 * pxt +
+            (size_t)2 * pxt * 64) * sizeof(float);
+}
 
-// 1 when the one-pass kernel takes this shape: the image's fp32 LUT and the exchange buffers fit
-// the LDS of a CU, the column fits the waves of one workgroup
-extern "C" int nmsa_loss_cos_emb_fwd_grad_supported(int dtype, int D, int H, int W, int L)
+// which one-pass kernel takes this shape: 1 = k_cos_split (the whole column in one workgroup:
+// D <= 512, the image's whole fp32 LUT in LDS), 2 = k_cos_parts (the column over up to four
+// cooperating workgroups, D <= 1024), 0 = none.  NMSA_COS_SPLIT=0: none; NMSA_COS_PARTS=0: never
+// the parts kernel, =1: the parts kernel wherever it can run (same-box A/B at D <= 512)
+int cos_kernel(int dtype, int D, int L)
 {
     if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return 0;
-    if (D <= 0 || L <= 0 || H <= 0 || W <= 0) return 0;
-    if (D % COSS_NP != 0) return 0;                     // whole groups of 64 planes per wave
-    const int nw = D / COSS_NP;
-    if (nw > COSS_MAX_WAVES) return 0;
+    if (D <= 0 || L <= 0 || D % COSS_NP != 0) return 0;          // whole groups of 64 planes per wave
     static const int on = loss_env_int("NMSA_COS_SPLIT", 1);
+    const char* pe = getenv("NMSA_COS_PARTS");         // read at every call: tests switch it
+    const int parts = (pe && *pe) ? atoi(pe) : -1;
     if (!on) return 0;
-    return coss_lds_bytes(D, L, nw, dtype == NMSA_F32 ? 2 : 4) <= (size_t)158 * 1024;
+    const int pxt = dtype == NMSA_F32 ? 2 : 4;
+    const int nw = D / COSS_NP;
+    const bool split_ok = nw <= COSS_MAX_WAVES && coss_lds_bytes(D, L, nw, pxt) <= (size_t)158 * 1024;
+    const bool parts_ok = parts != 0 && D <= COSP_COLS * COSP_MAX_PARTS && cosp_lds_bytes(L, pxt) <= (size_t)158 * 1024;
+    if (parts == 1 && parts_ok) return 2;
+    if (split_ok) return 1;
+    return parts_ok ? 2 : 0;
 }
 
-extern "C" size_t nmsa_loss_cos_emb_fwd_grad_workspace_bytes(int B, int D, int H, int W, int L)
-{
-    (void)D; (void)L;
-    if (B <= 0 || H <= 0 || W <= 0) return 0;
-    const int nb = cos_split_blocks(B, H * W, NMSA_F32) > cos_split_blocks(B, H * W, NMSA_BF16)
-                       ? cos_split_blocks(B, H * W, NMSA_F32) : cos_split_blocks(B, H * W, NMSA_BF16);
-    return (size_t)B * nb * sizeof(LossPartial) + 64;
-}
+int cosp_parts(int D) { return (D + COSP_COLS - 1) / COSP_COLS; }
 
-namespace {
-
-// workgroups per image and tiles per workgroup: one workgroup per CU is resident (the LUT fills
-// the LDS), a few workgroups per CU over the whole batch, each walking a run of consecutive
-// tiles of one image
-void coss_geometry(int B, int P, int dtype, int* gx, int* tpw)
+// workgroups per image and tiles per workgroup.  k_cos_split: one workgroup per CU is resident
+// (the LUT fills the LDS), a few workgroups per CU over the whole batch, each walking a run of
+// consecutive tiles of one image.  k_cos_parts: groups of NS workgroups; as many groups as fill
+// the chip's workgroup slots `rounds` times (rounded DOWN: a few idle slots in the last round cost
+// less than a round of their own).
+void coss_geometry(int B, int D, int P, int L, int dtype, int* gx, int* tpw, int* ns)
 {
     const int pxt = (dtype == NMSA_F32) ? 2 : 4;
     const int n_tiles = (P + 64 * pxt - 1) / (64 * pxt);
-    static const int per_cu = loss_env_int("NMSA_COS_SPLIT_WGS_PER_CU", 2);
-    int per_img = (256 * (per_cu < 1 ? 1 : per_cu) + B - 1) / B;
+    int per_img;
+    *ns = 1;
+    if (cos_kernel(dtype, D, L) == 2) {
+        *ns = cosp_parts(D);
+        static const int rounds = loss_env_int("NMSA_COS_PARTS_ROUNDS", 2);
+        const int per_cu = (int)((size_t)160 * 1024 / cosp_lds_bytes(L, pxt)) >= 2 ? 2 : 1;
+        const int groups = 256 * per_cu * (rounds < 1 ? 1 : rounds) / *ns;
+        per_img = groups / B;
+    } else {
+        static const int per_cu = loss_env_int("NMSA_COS_SPLIT_WGS_PER_CU", 2);
+        per_img = (256 * (per_cu < 1 ? 1 : per_cu) + B - 1) / B;
+    }
     if (per_img > n_tiles) per_img = n_tiles;
     if (per_img > 4096) per_img = 4096;
     if (per_img < 1) per_img = 1;
@@ -268,20 +515,36 @@ void coss_geometry(int B, int P, int dtype, int* gx, int* tpw)
         *tpw = atoi(run);
         if ((n_tiles + *tpw - 1) / *tpw > 4096) *tpw = (n_tiles + 4095) / 4096;
     }
-    *gx = (n_tiles + *tpw - 1) / *tpw;
+    *gx = (n_tiles + *tpw - 1) / *tpw;                  // groups per image
 }
 
 template <int MODE>
 int coss_launch(const void* pred, int dtype, const int32_t* indices, const float* lut, int B, int D, int P,
                 int L, const float* gscale, void* grad, LossPartial* partials, int32_t* status,
-                const float* computed_for, int32_t* counters, hipStream_t stream)
+                const float* computed_for, int32_t* counters, void* xch, size_t xch_bytes, hipStream_t stream)
 {
     const int pxt = (dtype == NMSA_F32) ? 2 : 4;
-    const int nw = D / COSS_NP;
-    // the kernel only has the 8-byte plane accesses: whole groups of PXT pixels, aligned planes
+    const int which = cos_kernel(dtype, D, L);
+    if (!which) return NMSA_ERR_UNSUPPORTED;
+    // the kernels only have the 8-byte plane accesses: whole groups of PXT pixels, aligned planes
     if (P % pxt != 0 || ((((uintptr_t)pred | (uintptr_t)grad) & 7) != 0)) return NMSA_ERR_UNSUPPORTED;
-    int gx, tpw;
-    coss_geometry(B, P, dtype, &gx, &tpw);
+    int gx, tpw, ns;
+    coss_geometry(B, D, P, L, dtype, &gx, &tpw, &ns);
+    if (which == 2) {
+        const size_t need = (size_t)B * gx * 2 * ns * COSP_GRAN * sizeof(unsigned long long);
+        if (!xch || xch_bytes < need || (((uintptr_t)xch) & 7)) return NMSA_ERR_WORKSPACE;
+        // tags start at 1: a zeroed buffer holds no valid granule
+        if (check_hip(hipMemsetAsync(xch, 0, need, stream))) return NMSA_ERR_LAUNCH;
+        const size_t lds = cosp_lds_bytes(L, pxt);
+#define COSP(DT) do { int rc_ = allow_dynamic_lds(k_cos_parts<DT, MODE>, lds); if (rc_) return rc_;              \
+        hipLaunchKernelGGL((k_cos_parts<DT, MODE>), dim3(gx * ns, B), dim3(64 * COSP_WAVES), lds, stream, pred, \
+                           indices, lut, D, P, L, ns, tpw, gscale, grad, partials, status, computed_for,        \
+                           counters, (unsigned long long*)xch); } while (0)
+        NMSA_DISPATCH_DTYPE(dtype, COSP)
+#undef COSP
+        return check_launch();
+    }
+    const int nw = D / COSS_NP;
     const size_t lds = coss_lds_bytes(D, L, nw, pxt);
 #define COSS(DT) do { int rc_ = allow_dynamic_lds(k_cos_split<DT, MODE>, lds); if (rc_) return rc_;              \
         hipLaunchKernelGGL((k_cos_split<DT, MODE>), dim3(gx, B), dim3(64 * nw), lds, stream, pred, indices, lut, \
@@ -293,26 +556,69 @@ int coss_launch(const void* pred, int dtype, const int32_t* indices, const float
 
 }  // namespace
 
+// 1 when a one-pass kernel takes this shape: D % 64 == 0 and either the image's fp32 LUT and the
+// exchange buffers fit the LDS of a CU with the column in the waves of one workgroup (D <= 512),
+// or the column splits over up to four cooperating workgroups (D <= 1024)
+extern "C" int nmsa_loss_cos_emb_fwd_grad_supported(int dtype, int D, int H, int W, int L)
+{
+    if (H <= 0 || W <= 0) return 0;
+    return cos_kernel(dtype, D, L) != 0;
+}
+
 namespace nmsa {
 
-int cos_split_blocks(int B, int P, int dtype)
+int cos_split_blocks(int B, int D, int P, int L, int dtype)     // partial slots per image
 {
-    int gx, tpw;
-    coss_geometry(B, P, dtype, &gx, &tpw);
-    return gx;
+    int gx, tpw, ns;
+    coss_geometry(B, D, P, L, dtype, &gx, &tpw, &ns);
+    return gx * ns;
+}
+
+// bytes of the granule exchange buffer of k_cos_parts (0: the shape runs in one workgroup)
+size_t cos_split_xch_bytes(int B, int D, int P, int L, int dtype)
+{
+    if (cos_kernel(dtype, D, L) != 2) return 0;
+    int gx, tpw, ns;
+    coss_geometry(B, D, P, L, dtype, &gx, &tpw, &ns);
+    return (size_t)B * gx * 2 * ns * COSP_GRAN * sizeof(unsigned long long);
 }
 
 int launch_cos_split(bool loss, const void* pred, int dtype, const int32_t* indices, const float* lut,
                      int B, int D, int P, int L, const float* gscale, const float* computed_for,
-                     int32_t* counters, void* grad, LossPartial* partials, int32_t* status, hipStream_t stream)
+                     int32_t* counters, void* grad, LossPartial* partials, int32_t* status,
+                     void* xch, size_t xch_bytes, hipStream_t stream)
 {
     return loss ? coss_launch<0>(pred, dtype, indices, lut, B, D, P, L, gscale, grad, partials, status,
-                                 computed_for, counters, stream)
+                                 computed_for, counters, xch, xch_bytes, stream)
                 : coss_launch<2>(pred, dtype, indices, lut, B, D, P, L, gscale, grad, partials, status,
-                                 computed_for, counters, stream);
+                                 computed_for, counters, xch, xch_bytes, stream);
 }
 
 }  // namespace nmsa
+
+namespace {
+size_t cos_partial_bytes(int B, int D, int P, int L)
+{
+    // (dtype-independent bound: the f32 geometry has the most tiles)
+    int nb = cos_split_blocks(B, D, P, L, NMSA_F32);
+    const int nb16 = cos_split_blocks(B, D, P, L, NMSA_BF16);
+    if (nb16 > nb) nb = nb16;
+    return ((size_t)B * nb * sizeof(LossPartial) + 63) & ~(size_t)63;
+}
+size_t cos_xch_max(int B, int D, int P, int L)
+{
+    const size_t a = cos_split_xch_bytes(B, D, P, L, NMSA_F32), b = cos_split_xch_bytes(B, D, P, L, NMSA_BF16);
+    return a > b ? a : b;
+}
+}  // namespace
+
+// [ block partials | granule exchange of k_cos_parts ]; nmsa_loss_cos_emb_bwd_unless takes the
+// same buffer (it only uses the exchange part)
+extern "C" size_t nmsa_loss_cos_emb_fwd_grad_workspace_bytes(int B, int D, int H, int W, int L)
+{
+    if (B <= 0 || H <= 0 || W <= 0 || D <= 0 || L <= 0) return 0;
+    return cos_partial_bytes(B, D, H * W, L) + cos_xch_max(B, D, H * W, L) + 64;
+}
 
 // forward sum + n_rows + the gradient for the EXPECTED upstream scale *expected_gscale (a NaN:
 // no gradient is written), one pass over the prediction
@@ -328,23 +634,25 @@ extern "C" int nmsa_loss_cos_emb_fwd_grad(const void* pred, int dtype, const int
     if (!nmsa_loss_cos_emb_fwd_grad_supported(dtype, D, H, W, L)) return NMSA_ERR_UNSUPPORTED;
     if (workspace_bytes < nmsa_loss_cos_emb_fwd_grad_workspace_bytes(B, D, H, W, L)) return NMSA_ERR_WORKSPACE;
     LossPartial* partials = (LossPartial*)workspace;
+    const size_t pbytes = cos_partial_bytes(B, D, H * W, L);
     int rc = coss_launch<0>(pred, dtype, indices, lut, B, D, H * W, L, expected_gscale, grad_pred, partials,
-                            status, nullptr, nullptr, stream);
+                            status, nullptr, nullptr, (char*)workspace + pbytes, workspace_bytes - pbytes, stream);
     if (rc) return rc;
-    return loss_finalize(partials, cos_split_blocks(B, H * W, dtype) * B, loss_sum, nullptr, n_rows, stream);
+    return loss_finalize(partials, cos_split_blocks(B, D, H * W, L, dtype) * B, loss_sum, nullptr, n_rows, stream);
 }
 
 // confirms the gradient nmsa_loss_cos_emb_fwd_grad wrote (returns at once when *grad_scale is
-// bit-equal to *computed_for) or recomputes it
+// bit-equal to *computed_for) or recomputes it; `workspace`: the forward call's buffer (only
+// columns beyond 512 use it: NULL is fine below)
 extern "C" int nmsa_loss_cos_emb_bwd_unless(const void* pred, int dtype, const int32_t* indices, const float* lut,
                                             int B, int D, int H, int W, int L, const float* grad_scale,
                                             void* grad_pred, const float* computed_for, int32_t* counters,
-                                            nmsa_stream_t stream_)
+                                            void* workspace, size_t workspace_bytes, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !indices || !lut || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
     if (loss_bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
     if (!nmsa_loss_cos_emb_fwd_grad_supported(dtype, D, H, W, L)) return NMSA_ERR_UNSUPPORTED;
     return coss_launch<2>(pred, dtype, indices, lut, B, D, H * W, L, grad_scale, grad_pred, nullptr, nullptr,
-                          computed_for, counters, stream);
+                          computed_for, counters, workspace, workspace_bytes, stream);
 }

@@ -475,7 +475,7 @@ int multi_plan(const nmsa_loss_item* items, int n_items, int n_totals, MultiPlan
                         return NMSA_ERR_UNSUPPORTED;
                     it.vec = 1;
                     it.in_launch = 0;
-                    it.nbx = cos_split_blocks(s.B, it.P, s.dtype);
+                    it.nbx = cos_split_blocks(s.B, s.C, it.P, s.reserved, s.dtype);
                     it.count_mode = 3; it.lo = 1; it.hi = s.reserved;
                 } else {
                     it.vec = (it.P % 4 == 0) && (((al | (uintptr_t)s.mask) & 15) == 0);
@@ -540,10 +540,27 @@ int multi_launch_joint(const MultiPlan& pl, const float* expect, const float* gs
 }  // namespace
 
 namespace {
+// granule exchange buffer of the cosine items whose column spans several workgroups (k_cos_parts):
+// their launches follow each other on the stream, so they share one buffer
+size_t multi_xch_bytes(const MultiPlan& pl)
+{
+    size_t n = 0;
+    for (int i = 0; i < pl.args.n_items; ++i) {
+        const MultiItem& it = pl.args.it[i];
+        if (it.kind != NMSA_LOSS_COS_EMB) continue;
+        const size_t x = cos_split_xch_bytes(it.B, it.C, it.P, it.L, it.dtype);
+        if (x > n) n = x;
+    }
+    return n;
+}
+size_t multi_main_bytes(const MultiPlan& pl)
+{
+    return ((multi_partial_blocks(pl) + (size_t)MULTI_MAX_ITEMS * MULTI_FIN_SPLIT) * sizeof(LossPartial) +
+            (size_t)pl.n_count_blocks * sizeof(long long) + 64 + 63) & ~(size_t)63;
+}
 size_t multi_workspace_bytes(const MultiPlan& pl)
 {
-    return (multi_partial_blocks(pl) + (size_t)MULTI_MAX_ITEMS * MULTI_FIN_SPLIT) * sizeof(LossPartial) +
-           (size_t)pl.n_count_blocks * sizeof(long long) + 64;
+    return multi_main_bytes(pl) + multi_xch_bytes(pl);
 }
 }  // namespace
 
@@ -573,6 +590,8 @@ extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_i
     LossPartial* slices = partials + nb;
     long long* cpart = (long long*)(slices + (size_t)MULTI_MAX_ITEMS * MULTI_FIN_SPLIT);
     unsigned int* ticket = (unsigned int*)(cpart + pl.n_count_blocks);
+    void* xch = (char*)workspace + multi_main_bytes(pl);
+    const size_t xch_bytes = multi_xch_bytes(pl);
     const MultiArgs& a = pl.args;
     bool any_grad = false;
     for (int i = 0; i < n_items; ++i) any_grad = any_grad || a.it[i].grad != nullptr;
@@ -596,7 +615,7 @@ extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_i
         if (it.kind == NMSA_LOSS_COS_EMB) {
             rc = launch_cos_split(true, it.pred, it.dtype, (const int32_t*)it.mask, (const float*)it.target, it.B,
                                   it.C, it.P, it.L, expect + 2 * it.total, nullptr, nullptr, it.grad,
-                                  partials + it.block0, status, stream);
+                                  partials + it.block0, status, xch, xch_bytes, stream);
         } else if (it.C > CE_FUSED_MAX_C) {
             rc = launch_ce_split(true, it.pred, it.dtype, it.mask, it.weights, it.B, it.C, it.P, it.param,
                                  expect + 2 * it.total, nullptr, nullptr, it.grad, partials + it.block0, status,
@@ -619,13 +638,17 @@ extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n
                                               const float* grad_sums, const float* grad_item_losses,
                                               const float* grad_total_losses, const int64_t* counts,
                                               const float* expect, int32_t* spec, float* grad_scales,
-                                              int32_t* counters, nmsa_stream_t stream_)
+                                              int32_t* counters, void* workspace, size_t workspace_bytes,
+                                              nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!counts || !grad_scales || !expect) return NMSA_ERR_ARG;
     MultiPlan pl;
     int rc = multi_plan(items, n_items, n_totals, pl);
     if (rc) return rc;
+    // the forward call's workspace (its contents are dead by now): only cosine items whose column
+    // spans several workgroups use it, as their granule exchange buffer
+    if (multi_xch_bytes(pl) > 0 && (!workspace || workspace_bytes < multi_xch_bytes(pl))) return NMSA_ERR_WORKSPACE;
     const MultiArgs& a = pl.args;
     hipLaunchKernelGGL(k_multi_spec, dim3(1), dim3(64), 0, stream, a, grad_sums, grad_item_losses,
                        grad_total_losses, (const long long*)counts, expect, spec, grad_scales, counters);
@@ -639,7 +662,7 @@ extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n
         if (it.kind == NMSA_LOSS_COS_EMB) {
             rc = launch_cos_split(false, it.pred, it.dtype, (const int32_t*)it.mask, (const float*)it.target, it.B,
                                   it.C, it.P, it.L, grad_scales + i, expect + 2 * it.total, nullptr, it.grad,
-                                  nullptr, nullptr, stream);
+                                  nullptr, nullptr, workspace, workspace_bytes, stream);
             if (rc) return rc;
             continue;
         }

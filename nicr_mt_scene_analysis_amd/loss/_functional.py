@@ -70,6 +70,10 @@ def check_loss_status() -> None:
     index outside [0, L] (host sync)"""
     for dev, st in _STATUS.items():
         v = int(st[0].item())
+        if v & 32:
+            st[0] = 0
+            raise RuntimeError(f'loss kernels on {dev}: a cooperating workgroup of the wide-column cosine '
+                               'loss (k_cos_parts) did not answer; that call returned NaN')
         if v:
             st[0] = 0
             raise IndexError(f'loss kernels on {dev}: target label / LUT index out of range '

@@ -102,8 +102,9 @@ def supported(items: Sequence[dict]) -> bool:
 
 
 def cos_supported(pred: torch.Tensor, lut: torch.Tensor) -> bool:
-    """the one-pass cosine kernel (csrc/losses_cos.hip) takes this prediction / LUT: D % 64 == 0,
-    D <= 512, the image's LUT within the LDS of a CU, whole groups of 4 (f32: 2) pixels"""
+    """a one-pass cosine kernel (csrc/losses_cos.hip) takes this prediction / LUT: D % 64 == 0,
+    whole groups of 4 (f32: 2) pixels, and D <= 512 with the image's LUT within the LDS of a CU
+    (k_cos_split) or D <= 1024 (k_cos_parts: the column over cooperating workgroups)"""
     if not (pred.is_cuda and pred.ndim == 4 and lut.ndim == 3 and pred.dtype in
             (torch.float32, torch.bfloat16, torch.float16)):
         return False
@@ -199,6 +200,9 @@ class MultiLossFunction(torch.autograd.Function):
         ctx.arr, ctx.keep, ctx.grads = arr, keep, grads
         ctx.has_grad = [g is not None for g in grads]
         ctx.n_totals, ctx.rec, ctx.expect, ctx.counts = n_totals, rec, expect, counts
+        # backward borrows the workspace (the granule exchange of wide cosine columns); only kept
+        # alive when a cosine item exists
+        ctx.ws = ws if any(it['kind'] == 'cos' for it in items) else None
         desc['counts'], desc['aux'], desc['divisors'], desc['packed'] = counts, aux, expect[:, 1], out
         return out[:n], out[n:2 * n], out[2 * n:]
 
@@ -229,7 +233,7 @@ class MultiLossFunction(torch.autograd.Function):
         L.check(L.lib().nmsa_multitask_loss_bwd_unless(
             ctx.arr, n, ctx.n_totals, *(None if g is None else L.ptr(g) for g in up), L.ptr(ctx.counts),
             L.ptr(expect), L.ptr(rec), L.ptr(gs), None if rec is None else _counters_ptr(dev),
-            L.stream_ptr(dev)),
+            L.ptr(ctx.ws), 0 if ctx.ws is None else ctx.ws.numel(), L.stream_ptr(dev)),
             'nmsa_multitask_loss_bwd_unless')
         return (None, *grads)
 

@@ -251,7 +251,7 @@ def test_multitask_loss_bad_arguments(env):
 
     def bwd(arr, counts_=counts, gs_=gs):
         return lib.nmsa_multitask_loss_bwd_unless(arr, 1, 1, None, None, p(g_tot), p(counts_), p(expect),
-                                                  p(spec), p(gs_), None, st)
+                                                  p(spec), p(gs_), None, None, 0, st)
     assert fwd(good) == 0 and bwd(good) == 0
     assert bwd(good, counts_=None) == ERR_ARG
     assert bwd(good, gs_=None) == ERR_ARG

@@ -210,7 +210,7 @@ def test_ce_c150_full_size_vs_oracle():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
-@pytest.mark.parametrize('D,L', [(64, 1), (128, 64), (320, 9), (512, 64)])
+@pytest.mark.parametrize('D,L', [(64, 1), (128, 64), (320, 9), (512, 64), (576, 5), (768, 64), (1024, 33)])
 @pytest.mark.parametrize('hw', [(4, 68), (24, 44), (3, 1000)])          # last tile ragged / several tiles
 def test_cos_split_one_pass_confirms_and_recomputes(dtype, D, L, hw):
     """k_cos_split (forward + gradient in one pass, csrc/losses_cos.hip): the shapes it takes go
@@ -260,11 +260,11 @@ def test_cos_split_one_pass_confirms_and_recomputes(dtype, D, L, hw):
 
 
 def test_cos_split_falls_back_where_it_cannot_run():
-    """D not a multiple of 64, D > 512, a LUT beyond the LDS, a pixel count that is no multiple of
+    """D not a multiple of 64, D > 1024, a LUT beyond the LDS, a pixel count that is no multiple of
     4: the two-kernel path answers (same results, no expectation involved)"""
     from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
     g = _gen(77)
-    for (B, D, H, W, L) in ((1, 96, 8, 16, 5), (1, 576, 4, 16, 5), (1, 512, 4, 16, 200), (1, 128, 3, 7, 4)):
+    for (B, D, H, W, L) in ((1, 96, 8, 16, 5), (1, 1088, 4, 16, 5), (1, 512, 4, 16, 200), (1, 128, 3, 7, 4)):
         x = torch.randn((B, D, H, W), device='cuda', generator=g).to(torch.bfloat16)
         lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
         idx = _index_map('segments', B, H, W, L, g)
@@ -297,10 +297,27 @@ def cos_split_run():
     set_run(prev)
 
 
+@pytest.fixture
+def cos_parts_env():
+    """NMSA_COS_PARTS (read by the library at every call): 1 = k_cos_parts wherever it can run"""
+    import os
+    prev = os.environ.get('NMSA_COS_PARTS')
+
+    def set_parts(v):
+        if v is None:
+            os.environ.pop('NMSA_COS_PARTS', None)
+        else:
+            os.environ['NMSA_COS_PARTS'] = str(v)
+    yield set_parts
+    set_parts(prev)
+
+
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
-@pytest.mark.parametrize('D,L', [(64, 3), (256, 17), (512, 64)])
+@pytest.mark.parametrize('D,L,parts', [(64, 3, None), (256, 17, None), (512, 64, None), (768, 64, None),
+                                       (640, 9, None), (1024, 21, None),
+                                       (128, 5, 1), (320, 17, 1), (512, 64, 1)])
 @pytest.mark.parametrize('hw,run', [((8, 200), 3), ((9, 444), 5), ((33, 100), 4), ((6, 1000), 64)])
-def test_cos_split_runs_of_several_tiles_per_workgroup(dtype, D, L, hw, run, cos_split_run):
+def test_cos_split_runs_of_several_tiles_per_workgroup(dtype, D, L, parts, hw, run, cos_split_run, cos_parts_env):
     """the production geometry of k_cos_split on small shapes: every workgroup walks a RUN of
     tiles (at configs[4] 96 of them; by default small images get one tile per workgroup), so the
     register hand-over to the next tile inside the gradient walk, the ragged last tile inside a
@@ -310,6 +327,9 @@ def test_cos_split_runs_of_several_tiles_per_workgroup(dtype, D, L, hw, run, cos
     if not _F.speculation_enabled():
         pytest.skip('NMSA_SPECULATIVE_GRAD=0: forward-written gradients are switched off')
     from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
+    # parts = 1: the cooperating-workgroups kernel (k_cos_parts: columns beyond 512 planes) also on
+    # columns one workgroup could hold — one part, a part with idle waves (320 = 256 + 64), two parts
+    cos_parts_env(parts)
     H, W = hw
     B = 2
     g = _gen(D + W + run)
@@ -353,9 +373,10 @@ def _segment_indices(B, H, W, L, g, cell=(37, 53)):
     return idx.repeat_interleave(ch, 1).repeat_interleave(cw, 2)[:, :H, :W].contiguous()
 
 
-@pytest.mark.parametrize('hw', [(768, 1024), (765, 1020)])
-def test_cos_split_full_size_image_vs_oracle(hw):
-    """configs[4]: ONE full-size image (512 x 768 x 1024 bf16, L = 64, segment-style indices; the
+@pytest.mark.parametrize('hw,D', [((768, 1024), 512), ((765, 1020), 512), ((768, 1024), 768), ((765, 1020), 768)])
+def test_cos_split_full_size_image_vs_oracle(hw, D):
+    """configs[4]: ONE full-size image (D x 768 x 1024 bf16, D = 512: k_cos_split, D = 768: the
+    cooperating workgroups of k_cos_parts; L = 64, segment-style indices; the
     second shape has H*W % 256 != 0: a ragged last tile at the end of the last run) through
     k_cos_split at the geometry it was built for (runs of ~12 tiles per workgroup at B = 1, of 96
     at B = 16) against the C oracle (reference loss/cos_emb.py:21-56 +
@@ -368,7 +389,7 @@ def test_cos_split_full_size_image_vs_oracle(hw):
     from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
     from oracle import oracle as orc
     H, W = hw
-    B, D, L = 1, 512, 64
+    B, L = 1, 64
     g = _gen(H)
     x = torch.randn((B, D, H, W), device='cuda', generator=g).to(torch.bfloat16)
     lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
