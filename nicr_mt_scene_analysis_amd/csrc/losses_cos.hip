@@ -235,7 +235,7 @@ constexpr int COSP_GRAN = 2 * 4 * 64;                  // granules per (slot, pa
 template <int DTYPE, int MODE>                         // MODE 0: loss + gradient, 2: gradient only
 __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
-    int D, int P, int L, int NS, int tiles_per_wg,
+    int B, int D, int P, int L, int NS, int tiles_per_wg,
     const float* __restrict__ expected_gscale, void* __restrict__ grad,
     LossPartial* __restrict__ partials, int* __restrict__ status,
     const float* __restrict__ computed_for, int* __restrict__ counters,
@@ -248,7 +248,11 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     constexpr bool LOSS = MODE != 2;
     extern __shared__ float s_mem[];       // [L][257] LUT columns of this part | yy[L] | xy[NW][TPX] | xx[NW][TPX] | tot[2 PXT][64]
     if (!LOSS && grad_already_computed(expected_gscale, computed_for, counters)) return;
-    const int part = blockIdx.x % NS, group = blockIdx.x / NS;
+    // the tiles of the whole batch form ONE sequence (image after image) cut into equal runs, one
+    // per group: every workgroup slot of the chip gets the same amount of work whatever B is; a
+    // run that crosses into the next image restages that image's LUT columns (from L2)
+    const int wg = blockIdx.y * gridDim.x + blockIdx.x;
+    const int part = wg % NS, group = wg / NS;
     const int d0 = part * COSP_COLS;
     const int DP = min(COSP_COLS, D - d0);             // my columns (a multiple of 64)
     constexpr int ld = COSP_COLS + 1;
@@ -257,25 +261,24 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     float* s_xy = s_yy + ((L + 3) & ~3);
     float* s_xx = s_xy + NW * TPX;
     float* s_tot = s_xx + NW * TPX;
-    const int b = blockIdx.y;
-    const float* lut_b = lut + (size_t)b * L * D;
-    for (int i = threadIdx.x; i < L * DP; i += blockDim.x) {
-        const int r = i / DP, d = i - r * DP;
-        s_lut[r * ld + d] = lut_b[(size_t)r * D + d0 + d];
-    }
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();
-    for (int r = w; r < L; r += NW) {                  // |y|^2 over the WHOLE row (all parts: same bits)
-        float yy = 0.f;
-        for (int d = l; d < D; d += 64) { const float v = lut_b[(size_t)r * D + d]; yy = fmaf(v, v, yy); }
-        yy = wave_reduce_sum(yy);
-        if (l == 0) s_yy[r] = yy;
-    }
-    __syncthreads();
+    auto stage_lut = [&](int b) {
+        const float* lut_b = lut + (size_t)b * L * D;
+        for (int i = threadIdx.x; i < L * DP; i += blockDim.x) {
+            const int r = i / DP, d = i - r * DP;
+            s_lut[r * ld + d] = lut_b[(size_t)r * D + d0 + d];
+        }
+        for (int r = w; r < L; r += NW) {              // |y|^2 over the WHOLE row (all parts: same bits)
+            float yy = 0.f;
+            for (int d = l; d < D; d += 64) { const float v = lut_b[(size_t)r * D + d]; yy = fmaf(v, v, yy); }
+            yy = wave_reduce_sum(yy);
+            if (l == 0) s_yy[r] = yy;
+        }
+    };
 
     const float EPS = 1e-12f;
     const float g = grad ? *expected_gscale : __int_as_float(0x7fc00000);
     const bool write_grad = grad && (MODE == 2 || g == g);
-    const size_t img = (size_t)b * D * P;
     const int nwa = DP / NP;                           // waves of this part that hold planes
     const bool active = w < nwa;                       // wave-uniform
     const int c0 = d0 + w * NP;                        // my first plane
@@ -284,24 +287,25 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     long long cnt = 0;
     bool bad = false;
     bool dead = false;                                 // a partner did not answer: stop waiting
-    const int n_tiles = (P + TPX - 1) / TPX;
-    const int t_begin = group * tiles_per_wg, t_end = min(n_tiles, t_begin + tiles_per_wg);
+    const int n_tiles = (P + TPX - 1) / TPX;           // per image
+    const long long t_total = (long long)B * n_tiles;
+    const long long t_begin = (long long)group * tiles_per_wg;
+    const long long t_end = t_begin + tiles_per_wg < t_total ? t_begin + tiles_per_wg : t_total;
     if (t_begin >= t_end) { if (LOSS) block_partial_wide(0.0, 0, partials); return; }
-    const size_t gid = (size_t)blockIdx.y * (gridDim.x / NS) + group;
+    const size_t gid = (size_t)group;
 
     constexpr int ESIZE = (DTYPE == NMSA_F32) ? 4 : 2;
-    const char* pred_b = (const char*)pred + img * ESIZE;
-    char* grad_b = (char*)grad + img * ESIZE;
+    const size_t img_bytes = (size_t)D * P * ESIZE;
     u32x2_s r[NP];
     auto lane_offset = [&](int tile) -> uint32_t {
         const int p0 = (tile * 64 + l) * PXT;
         return (uint32_t)((p0 < P ? p0 : 0) * ESIZE);
     };
-    auto request_plane = [&](int i, uint32_t off) {
+    auto request_plane = [&](int i, const char* pred_b, uint32_t off) {
         const char* pb = pred_b + (size_t)(c0 + i) * P * ESIZE;          // wave-uniform
         r[i] = __builtin_nontemporal_load((const u32x2_s*)(pb + off));
     };
-    auto store_plane = [&](int i, uint32_t off, const float o[PXT], uint32_t mx, uint32_t my) {
+    auto store_plane = [&](int i, char* grad_b, uint32_t off, const float o[PXT], uint32_t mx, uint32_t my) {
         char* gb = grad_b + (size_t)(c0 + i) * P * ESIZE;               // wave-uniform
         u32x2_s v;
         if (DTYPE == NMSA_F32) { v.x = __float_as_uint(o[0]); v.y = __float_as_uint(o[1]); }
@@ -312,11 +316,20 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
 #pragma unroll
     for (int i = 0; i < NP; ++i) r[i] = u32x2_s{0u, 0u};
     if (active) {
-        const uint32_t off = lane_offset(t_begin);
+        const int b0 = (int)(t_begin / n_tiles);
+        const uint32_t off = lane_offset((int)(t_begin - (long long)b0 * n_tiles));
 #pragma unroll
-        for (int i = 0; i < NP; ++i) request_plane(i, off);
+        for (int i = 0; i < NP; ++i) request_plane(i, (const char*)pred + b0 * img_bytes, off);
     }
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    int b_staged = -1;
+    for (long long gt = t_begin; gt < t_end; ++gt) {
+        const int b = (int)(gt / n_tiles), tile = (int)(gt - (long long)b * n_tiles);
+        if (b != b_staged) {                            // first tile, or the run enters the next image
+            if (b_staged >= 0) __syncthreads();         // every wave is done with the old LUT
+            stage_lut(b);
+            __syncthreads();
+            b_staged = b;
+        }
         const int p0 = (tile * 64 + l) * PXT;
         const bool alive = p0 < P;
         const int nvalid = alive ? min(PXT, P - p0) : 0;
@@ -358,8 +371,8 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
                 for (int ww = 1; ww < nwa; ++ww) { a += s_xy[ww * TPX + l * PXT + j]; c += s_xx[ww * TPX + l * PXT + j]; }
                 v[j] = a; v[PXT + j] = c;
             }
-            const uint32_t seq = (uint32_t)(tile - t_begin) + 1u;
-            unsigned long long* slot = xch + (gid * 2 + ((tile - t_begin) & 1)) * NS * COSP_GRAN;
+            const uint32_t seq = (uint32_t)(gt - t_begin) + 1u;
+            unsigned long long* slot = xch + (gid * 2 + ((gt - t_begin) & 1)) * NS * COSP_GRAN;
             unsigned long long* mine = slot + (size_t)part * COSP_GRAN;
 #pragma unroll
             for (int k = 0; k < 2 * PXT; ++k)
@@ -415,8 +428,11 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
         acc += ploss;
         // ---- pass 2: the gradient of my planes; each register then takes the next tile's plane ----
         if (active) {
-            const bool more = tile + 1 < t_end;                         // wave-uniform
-            const uint32_t off = lane_offset(tile), qoff = lane_offset(more ? tile + 1 : tile);
+            const long long gn = gt + 1 < t_end ? gt + 1 : gt;          // (the last tile re-reads itself)
+            const int bn = (int)(gn / n_tiles);
+            const uint32_t off = lane_offset(tile), qoff = lane_offset((int)(gn - (long long)bn * n_tiles));
+            const char* pred_n = (const char*)pred + bn * img_bytes;
+            char* grad_b = (char*)grad + b * img_bytes;
             const bool store = alive && write_grad;
             uint32_t mx, my;
             if (DTYPE == NMSA_F32) { mx = on[0] ? ~0u : 0u; my = on[1] ? ~0u : 0u; }
@@ -431,8 +447,8 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
 #pragma unroll
                 for (int j = 0; j < PXT; ++j)
                     o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
-                if (store) store_plane(i, off, o, mx, my);
-                request_plane(i, qoff);                                 // (the last tile re-reads itself)
+                if (store) store_plane(i, grad_b, off, o, mx, my);
+                request_plane(i, pred_n, qoff);
             }
         }
     }
@@ -476,6 +492,10 @@ int cos_kernel(int dtype, int D, int L)
     const bool split_ok = nw <= COSS_MAX_WAVES && coss_lds_bytes(D, L, nw, pxt) <= (size_t)158 * 1024;
     const bool parts_ok = parts != 0 && D <= COSP_COLS * COSP_MAX_PARTS && cosp_lds_bytes(L, pxt) <= (size_t)158 * 1024;
     if (parts == 1 && parts_ok) return 2;
+    // 512 planes fit one workgroup, but two cooperating half-columns with two workgroups per CU
+    // stream 7 % faster (one's exchange wait is the other's streaming time): measured at B = 16
+    if (split_ok && parts_ok && parts == -1 && D > COSP_COLS && 2 * cosp_lds_bytes(L, pxt) <= (size_t)160 * 1024)
+        return 2;
     if (split_ok) return 1;
     return parts_ok ? 2 : 0;
 }
@@ -494,11 +514,25 @@ void coss_geometry(int B, int D, int P, int L, int dtype, int* gx, int* tpw, int
     int per_img;
     *ns = 1;
     if (cos_kernel(dtype, D, L) == 2) {
+        // k_cos_parts cuts the tiles of the WHOLE batch into G equal runs, G = the groups of NS
+        // workgroups that fill the chip's workgroup slots (`rounds` times); the grid is
+        // (gx * NS, B) >= G * NS workgroups, the surplus ones find an empty run
         *ns = cosp_parts(D);
-        static const int rounds = loss_env_int("NMSA_COS_PARTS_ROUNDS", 2);
+        const char* re = getenv("NMSA_COS_PARTS_ROUNDS");              // (per call: same-process A/B)
+        const int rounds = (re && *re) ? atoi(re) : 1;
         const int per_cu = (int)((size_t)160 * 1024 / cosp_lds_bytes(L, pxt)) >= 2 ? 2 : 1;
-        const int groups = 256 * per_cu * (rounds < 1 ? 1 : rounds) / *ns;
-        per_img = groups / B;
+        long long G = 256 * per_cu * (rounds < 1 ? 1 : rounds) / *ns;
+        const long long t_total = (long long)B * n_tiles;
+        if (G > t_total) G = t_total;
+        if (G < 1) G = 1;
+        long long run_len = (t_total + G - 1) / G;
+        const char* run = getenv("NMSA_COS_SPLIT_RUN");
+        if (run && atoi(run) > 0) run_len = atoi(run);
+        if ((t_total + run_len - 1) / run_len > (1 << 20)) run_len = (t_total + (1 << 20) - 1) >> 20;
+        G = (t_total + run_len - 1) / run_len;
+        *tpw = (int)run_len;
+        *gx = (int)((G + B - 1) / B);                   // groups "per image": gx * B >= G
+        return;
     } else {
         static const int per_cu = loss_env_int("NMSA_COS_SPLIT_WGS_PER_CU", 2);
         per_img = (256 * (per_cu < 1 ? 1 : per_cu) + B - 1) / B;
@@ -538,7 +572,7 @@ int coss_launch(const void* pred, int dtype, const int32_t* indices, const float
         const size_t lds = cosp_lds_bytes(L, pxt);
 #define COSP(DT) do { int rc_ = allow_dynamic_lds(k_cos_parts<DT, MODE>, lds); if (rc_) return rc_;              \
         hipLaunchKernelGGL((k_cos_parts<DT, MODE>), dim3(gx * ns, B), dim3(64 * COSP_WAVES), lds, stream, pred, \
-                           indices, lut, D, P, L, ns, tpw, gscale, grad, partials, status, computed_for,        \
+                           indices, lut, B, D, P, L, ns, tpw, gscale, grad, partials, status, computed_for,     \
                            counters, (unsigned long long*)xch); } while (0)
         NMSA_DISPATCH_DTYPE(dtype, COSP)
 #undef COSP
