@@ -86,13 +86,14 @@ __device__ __forceinline__ float4 load_px4(const void* base, size_t elem_off, in
 // on two kinds of columns, both re-evaluated exactly by the functions below (rare, re-read):
 //  * a NaN, a +inf, or nothing but -inf: softmax is all-NaN and torch.max returns index 0;
 //    a column with some -inf entries is an ordinary one;
-//  * classes within 2^-25 of the maximum: exp(x_c - max) rounds to exactly 1.0f, so they share
-//    the maximum's probability and the LOWEST such index wins.  Two distinct logits can only be
-//    that close where the format's spacing is <= 2^-25, i.e. for |max| < tie_band_magnitude —
-//    the trigger, one compare per pixel.  (Gaps in (2^-25, 2^-23] collapse or not with ATen's
-//    exp / division rounding, build- and device-dependent: the larger logit is kept)
+//  * a class BELOW the maximum's index whose logit is so close to the maximum (<= 2^-23) that
+//    ATen's fp32 softmax gives both the same probability: the lower index wins.  Decided with
+//    the reference's own arithmetic (argmax_state.hpp: class_by_probability); such gaps only
+//    exist where the format's spacing is <= 2^-23, i.e. for |max| <= tie_band_magnitude — the
+//    trigger, one compare per pixel.
 // class of one column by the reference's rule, given its maximum m (the running maximum of the
-// fast path; with a NaN / +inf in the column the answer is 0 whatever m is): one walk
+// fast path; with a NaN / +inf in the column the answer is 0 whatever m is): one walk unless an
+// earlier class is a candidate for a probability tie
 template <int DTYPE>
 __device__ __noinline__ int column_class(const void* logits, size_t col0, int P, int C, float m)
 {
@@ -102,7 +103,7 @@ __device__ __noinline__ int column_class(const void* logits, size_t col0, int P,
         return (DTYPE == NMSA_BF16) ? bf16_to_f32(h) : f16_to_f32(h);
     };
     bool nan_or_pinf = false, any_finite = false;
-    int first = C;
+    int first = C, am = C;                          // lowest candidate / first index of the maximum
     int c = 0;
     for (; c + 4 <= C; c += 4) {                    // 4 loads in flight
         float v[4];
@@ -112,16 +113,20 @@ __device__ __noinline__ int column_class(const void* logits, size_t col0, int P,
         for (int u = 0; u < 4; ++u) {
             nan_or_pinf |= (v[u] != v[u]) || (v[u] == INFINITY);
             any_finite |= fabsf(v[u]) < INFINITY;
-            if (first == C && __fsub_rn(v[u], m) >= -0x1p-25f) first = c + u;
+            if (first == C && __fsub_rn(v[u], m) >= TIE_CANDIDATE_GAP) first = c + u;
+            if (am == C && v[u] == m) am = c + u;
         }
     }
     for (; c < C; ++c) {
         const float v = ld(c);
         nan_or_pinf |= (v != v) || (v == INFINITY);
         any_finite |= fabsf(v) < INFINITY;
-        if (first == C && __fsub_rn(v, m) >= -0x1p-25f) first = c;
+        if (first == C && __fsub_rn(v, m) >= TIE_CANDIDATE_GAP) first = c;
+        if (am == C && v == m) am = c;
     }
-    return (nan_or_pinf || !any_finite || first == C) ? 0 : first;
+    if (nan_or_pinf || !any_finite || am == C) return 0;
+    if (first >= am) return am;                     // nobody below the maximum's index comes close
+    return class_by_probability(ld, C, m, am, first, nullptr);
 }
 
 // Exact argmax + score of one column (the group-wise fast path of the WITH_SCORE kernels came
@@ -150,9 +155,12 @@ __device__ __noinline__ float2 column_exact(const void* logits, size_t col0, int
     for (int c = 0; c < C; ++c) {
         const float v = ld(c);
         se += (v == -INFINITY) ? 0.f : __expf(v - m);
-        if (c < first && __fsub_rn(v, m) >= -0x1p-25f) first = c;
+        if (c < first && __fsub_rn(v, m) >= TIE_CANDIDATE_GAP) first = c;
     }
-    return make_float2(1.0f / se, __int_as_float(first));
+    if (first >= am) return make_float2(1.0f / se, __int_as_float(am));
+    float pm;
+    const int cls = class_by_probability(ld, C, m, am, first, &pm);
+    return make_float2(pm, __int_as_float(cls));
 }
 
 // classes c0 .. c0+3 of the 4 pixels of a lane (WITH_SCORE: one rescale per group, see

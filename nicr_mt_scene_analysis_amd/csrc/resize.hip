@@ -414,18 +414,24 @@ __device__ __noinline__ float2 resized_column_exact(
         if (v > m) { m = v; am = c; }
     }
     if (nan_or_pinf || !any_finite) return make_float2(__int_as_float(0x7fc00000), __int_as_float(0));
-    float se = 0.f;
-    int first = am;           // lowest class whose probability equals the maximum's (panoptic.hip)
-    for (int c = 0; c < C; ++c) {
+    auto ld = [&](int c) -> float {
         const size_t pc = (size_t)c * plane_stride;
-        const float v = round_to_storage<DTYPE>(bilerp(
+        return round_to_storage<DTYPE>(bilerp(
             ld_elem<DTYPE>(logits, pc + o00), ld_elem<DTYPE>(logits, pc + o01),
             ld_elem<DTYPE>(logits, pc + o10), ld_elem<DTYPE>(logits, pc + o11),
             wx0, wx1, wy0, wy1));
+    };
+    float se = 0.f;
+    int first = am;           // lowest earlier class that may share the maximum's probability
+    for (int c = 0; c < C; ++c) {
+        const float v = ld(c);
         se += (v == -INFINITY) ? 0.f : __expf(v - m);
-        if (c < first && __fsub_rn(v, m) >= -0x1p-25f) first = c;
+        if (c < first && __fsub_rn(v, m) >= TIE_CANDIDATE_GAP) first = c;
     }
-    return make_float2(1.0f / se, __int_as_float(first));
+    if (first >= am) return make_float2(1.0f / se, __int_as_float(am));
+    float pm;                 // decided with the reference's own arithmetic (argmax_state.hpp)
+    const int cls = class_by_probability(ld, C, m, am, first, &pm);
+    return make_float2(pm, __int_as_float(cls));
 }
 
 template <int DTYPE, int MODE, int K16>

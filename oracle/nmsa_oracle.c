@@ -32,16 +32,38 @@ int orc_version(void) { return 1; }
 /*     model/postprocessing/semantic.py:52-53  softmax(dim=1) -> max(dim=1)    */
 /* idx  : first index attaining the maximum PROBABILITY (torch.max tie rule). */
 /*        softmax is monotone, so that is the first maximum of the logits —    */
-/*        except that exp(x_c - max) is exactly 1.0f for every class within    */
-/*        2^-25 of the maximum (exp(-d) rounds to 1 for d <= 2^-25): those      */
-/*        classes share the maximum's probability and the LOWEST such index    */
-/*        wins.  Gaps in (2^-25, 2^-23] collapse or not depending on ATen's    */
-/*        exp / division rounding (build- and device-dependent): there the     */
-/*        larger logit is kept (DESIGN.md "argmax boundary").                  */
+/*        except where a LOWER class < 1.5 * 2^-24 below the maximum gets      */
+/*        the maximum's fp32 probability.  That is decided with the arithmetic */
+/*        of ATen's CPU softmax over a non-last dim (vec_softmax: per pixel,   */
+/*        sequentially over the classes): e_c = Sleef expf_u10(x_c - max) in   */
+/*        its FMA form, S = ((e_0 + e_1) + ...) in fp32, p_c = e_c / S.  The   */
+/*        reference-run fixture tests/golden/argmax_ties.npz pins it (all 1680 */
+/*        near-tie columns incl. the gaps in (2^-25, 2^-23], two whole maps).  */
 /*        Non-finite maximum (NaN anywhere, +inf, or all -inf) makes every     */
 /*        softmax output NaN in the reference -> torch.max returns index 0.    */
 /* score: 1 / sum_c exp(x_c - max)  (fp64 accumulate, rounded once).           */
 /* ------------------------------------------------------------------------- */
+static float aten_vec_expf(float d)          /* Sleef_expf16_u10 as bundled with torch (FMA build) */
+{
+    if (!(d >= -104.0f)) return 0.0f;
+    const volatile float dq = d * 1.442695040888963407359924681001892137426645954152985934135449406931f;
+    const float q = rintf(dq);
+    float s = fmaf(q, -0.693145751953125f, d);
+    s = fmaf(q, -1.428606765330187045e-06f, s);
+    float u = 0.000198527617612853646278381f;
+    u = fmaf(u, s, 0.00139304355252534151077271f);
+    u = fmaf(u, s, 0.00833336077630519866943359f);
+    u = fmaf(u, s, 0.0416664853692054748535156f);
+    u = fmaf(u, s, 0.166666671633720397949219f);
+    u = fmaf(u, s, 0.5f);
+    const volatile float s2 = s * s;
+    const volatile float t = fmaf(s2, u, s);
+    const volatile float r = t + 1.0f;
+    const int qi = (int)q, qh = qi >> 1;
+    const volatile float r1 = r * ldexpf(1.0f, qh);
+    return r1 * ldexpf(1.0f, qi - qh);
+}
+
 int orc_semantic_argmax(const float* logits, int B, int C, int H, int W,
                         int64_t* idx, float* score)
 {
@@ -65,9 +87,23 @@ int orc_semantic_argmax(const float* logits, int B, int C, int H, int W,
             double s = 0.0;
             for (int c = 0; c < C; ++c)
                 s += exp((double)lb[(int64_t)c * P + p] - (double)m);
-            for (int c = 0; c < am; ++c) {
+            int cand = 0;
+            for (int c = 0; c < am && !cand; ++c) {
                 const volatile float d = lb[(int64_t)c * P + p] - m;      /* fp32, as ATen */
-                if (d >= -0x1p-25f) { am = c; break; }
+                if (d >= -0x1p-23f) cand = 1;
+            }
+            if (cand) {                       /* a lower class may share the maximum's probability */
+                volatile float S = 0.0f;
+                for (int c = 0; c < C; ++c) {
+                    const volatile float d = lb[(int64_t)c * P + p] - m;
+                    S = S + aten_vec_expf(d);
+                }
+                const volatile float pm = 1.0f / S;
+                for (int c = 0; c < am; ++c) {
+                    const volatile float d = lb[(int64_t)c * P + p] - m;
+                    const volatile float pc = aten_vec_expf(d) / S;
+                    if (pc == pm) { am = c; break; }
+                }
             }
             if (idx) idx[b * P + p] = am;
             if (score) score[b * P + p] = (float)(1.0 / s);

@@ -63,17 +63,34 @@ def check_cos_emb_large_grad(name, p, g, grad, rtol, atol, sums_rtol):
     np.testing.assert_allclose(got, want, rtol=0, atol=sums_rtol * scale, err_msg=name)
 
 
-def probability_tie_rule(logits):
-    """a1, numpy restatement of the rule oracle and kernels implement for max(softmax(x)):
-    per pixel the LOWEST class within 2^-25 (fp32 subtraction) of the maximum logit.
-    -> (rule index, mask of pixels where a lower-indexed class sits between 2^-25 and 2^-23
-    below the maximum: there the reference's own answer depends on ATen's rounding)"""
+def aten_softmax_argmax(logits):
+    """a1, numpy restatement (independent of the C oracle and of the kernels) of the reference's
+    `softmax(dim=1)` -> `max(dim=1)` (semantic.py:52-53) in ATen's CPU arithmetic: per pixel,
+    sequentially over the classes, e = Sleef expf_u10(x - max) in its FMA form, S = fp32 running
+    sum, p = e / S; first index of the largest p.  -> (index uint8, max p float32)"""
     import numpy as np
-    x = np.asarray(logits, np.float32)
-    m = x.max(axis=1, keepdims=True)
-    d = (x - m).astype(np.float32)                           # <= 0, fp32 like ATen's x - max
-    C = x.shape[1]
-    cls = np.arange(C).reshape(1, C, 1, 1)
-    rule = np.where(d >= -np.float32(2.0 ** -25), cls, C).min(axis=1)
-    between = (d < -np.float32(2.0 ** -25)) & (d >= -np.float32(2.0 ** -23)) & (cls < rule[:, None])
-    return rule.astype(np.uint8), between.any(axis=1)
+    f32 = np.float32
+    ld = np.longdouble
+
+    def fma(a, b, c):                    # exact product, one rounding (64-bit significand in between)
+        return (np.asarray(a, ld) * np.asarray(b, ld) + np.asarray(c, ld)).astype(f32)
+
+    x = np.asarray(logits, f32)
+    d0 = (x - x.max(axis=1, keepdims=True)).astype(f32)
+    d = np.maximum(d0, f32(-104.0))                  # (below Sleef's cut-off the result is 0: see the end)
+    q = np.rint((d * f32(1.442695040888963407359924681001892137426645954152985934135449406931)).astype(f32))
+    s = fma(q, f32(-0.693145751953125), d)
+    s = fma(q, f32(-1.428606765330187045e-06), s)
+    u = np.full_like(s, f32(0.000198527617612853646278381))
+    for c in (0.00139304355252534151077271, 0.00833336077630519866943359, 0.0416664853692054748535156,
+              0.166666671633720397949219, 0.5):
+        u = fma(u, s, f32(c))
+    u = (fma((s * s).astype(f32), u, s) + f32(1.0)).astype(f32)
+    qi = q.astype(np.int32)
+    e = (np.ldexp(u, qi >> 1).astype(f32) * np.ldexp(f32(1.0), qi - (qi >> 1)).astype(f32)).astype(f32)
+    e = np.where(d0 >= f32(-104.0), e, f32(0.0)).astype(f32)
+    S = np.zeros_like(e[:, 0])
+    for c in range(e.shape[1]):
+        S = (S + e[:, c]).astype(f32)
+    p = (e / S[:, None]).astype(f32)
+    return p.argmax(axis=1).astype(np.uint8), p.max(axis=1)

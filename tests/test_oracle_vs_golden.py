@@ -231,43 +231,57 @@ def test_losses(oracle):
 
 
 def test_argmax_tie_band_boundary(oracle):
-    """a1: the reference takes max(softmax(x)) (semantic.py:52-53).  softmax is monotone, so
-    that is argmax(x) with first-index ties — except that exp(x_c - max) is exactly 1.0f for
-    every class within 2^-25 of the maximum: those classes share the maximum's probability and
-    the LOWEST index wins.  Oracle and kernels implement exactly that.
-    tests/golden/argmax_ties.npz (reference-run): adversarial columns with the top-2 logits
-    delta apart (c1 < c2, x[c2] > x[c1]):
-      * delta <= 2^-25: the reference returns c1 on every column — and so does the oracle;
-      * delta > 2^-23: the reference returns c2 on every column — and so does the oracle;
-      * in between it depends on the rounding of ATen's exp and of its division by the softmax
-        denominator (17 % of the fixture's columns return c1): build- and device-dependent,
-        the oracle keeps the larger logit c2.
-    plus whole maps: 'tiny' (every class within 2^-25: index 0 almost everywhere) and 'small'
-    (4 classes per pixel on a 2^-26 grid)."""
-    from _golden import probability_tie_rule
+    """a1: the reference takes max(softmax(x)) (semantic.py:52-53).  softmax is monotone, so that
+    is argmax(x) with first-index ties — except where a lower-indexed class sits so close below
+    the maximum that ATen's fp32 softmax gives both the same probability.  The oracle decides
+    those columns with ATen's own arithmetic (Sleef expf_u10, sequential fp32 sum, IEEE division).
+    tests/golden/argmax_ties.npz (reference-run): 1680 adversarial columns with the top-2 logits
+    delta apart (c1 < c2, x[c2] > x[c1]) — EVERY column must come out as the reference's, the 229
+    with delta in (2^-25, 2^-23] included (38 of them return the lower index) —, two whole maps
+    ('tiny': every class within 2^-25, 'small': 4 classes per pixel on a 2^-26 grid) and their
+    full-resolution twins (the same rule on the bilinearly interpolated logits)."""
+    from _golden import aten_softmax_argmax
     g = load('argmax_ties')
     idx, _ = oracle.semantic_argmax(g['logits'])
     idx, ref = idx.reshape(-1), g['ref_idx'].reshape(-1)
     delta, c1, c2 = g['delta'], g['c1'], g['c2']
     outside = delta > 2.0 ** -23
     assert outside.sum() > 1000 and (ref[outside] == c2[outside]).all()
-    assert (idx[outside] == ref[outside]).all()
     zone_a = delta <= 2.0 ** -25
     assert zone_a.sum() > 300 and (ref[zone_a] == c1[zone_a]).all()
-    assert (idx[zone_a] == ref[zone_a]).all()
     zone_b = ~outside & ~zone_a
-    assert 0 < (ref[zone_b] == c1[zone_b]).sum() < zone_b.sum()
-    assert (idx[zone_b] == c2[zone_b]).all()               # documented: the larger logit
+    assert zone_b.sum() == 229 and (ref[zone_b] == c1[zone_b]).sum() == 38
+    assert (idx == ref).all()                                 # all 1680, the in-between ones too
+    assert (aten_softmax_argmax(g['logits'])[0].reshape(-1) == ref).all()     # numpy twin
     assert int(g['natural_blobby'][1]) == 0                # bench-like logits: never observed
     assert int(g['natural_small'][1]) <= 20 and int(g['natural_small'][0]) > 8_000_000
     for name in ('tiny', 'small'):
         x, ref = g[f'{name}_logits'], g[f'{name}_ref_idx']
-        rule, between = probability_tie_rule(x)
         got, _ = oracle.semantic_argmax(x)
-        assert (got == rule).all(), name
-        settled = ~between                                  # the reference's answer is forced
-        assert settled.mean() > 0.5 and (ref[settled] == rule[settled]).all(), name
+        assert (got == ref).all(), name
+        assert (aten_softmax_argmax(x)[0] == ref).all(), name
         assert (ref != x.argmax(axis=1)).sum() > 900, name  # the rule matters on these maps
+        ref_full = g[f'{name}_ref_idx_fullres']
+        up = oracle.resize_bilinear(x, ref_full.shape[-2:], None)
+        got_full, _ = oracle.semantic_argmax(up)
+        assert (got_full == ref_full).all(), name
+
+
+def test_argmax_probability_of_the_maximum_and_far_classes(oracle):
+    """the restated softmax arithmetic away from the ties: classes 100 and more below the maximum
+    (Sleef's cut-off at -104, the two-factor ldexp), -inf entries, ordinary columns — oracle index
+    == numpy twin == plain argmax, and the twin's maximum probability equals torch's softmax"""
+    import torch
+    from _golden import aten_softmax_argmax
+    rng = np.random.default_rng(3)
+    x = (rng.standard_normal((2, 19, 16, 16)) * 30).astype(np.float32)
+    x[0, 3, :4] = -np.inf
+    x[1, :, 5, 5] = rng.standard_normal(19).astype(np.float32) * 1e-3 - 110.0
+    idx, _ = oracle.semantic_argmax(x)
+    twin, pmax = aten_softmax_argmax(x)
+    assert (idx == twin).all() and (idx == x.argmax(axis=1)).all()
+    want = torch.softmax(torch.from_numpy(x), dim=1).max(dim=1)[0].numpy()
+    np.testing.assert_allclose(pmax, want, rtol=2e-7)
 
 
 def test_cosine_embedding_large_dims(oracle):
