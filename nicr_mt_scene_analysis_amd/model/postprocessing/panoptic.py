@@ -66,13 +66,17 @@ class PanopticPostprocessing(DensePostprocessingBase):
 
         self._normalized_offset = normalized_offset
         self._compute_scores = compute_scores
-        # extension: True = `postprocess` never waits for the GPU.  The small per-image tables
-        # travel with an asynchronous copy and the Python objects built from them (id dicts,
-        # instance meta, orientation dicts) wait for it when first read.  The one thing the
-        # eager mode does with those tables up front — re-running with a larger center table
-        # when more than `_max_centers` tied centers survive — then surfaces as a RuntimeError
-        # at that first read instead.
+        # Host synchronisation.  The only thing `postprocess` must know before it returns is
+        # whether more than `_max_centers` tied centers survived the top-k (then it re-runs with a
+        # larger table): the center COUNTS travel on a copy stream right behind the selection
+        # kernel (tens of microseconds into the call) and are awaited while the streaming kernels
+        # run, so the call returns with the GPU still busy and consecutive calls pipeline.  The
+        # per-image tables behind the Python objects (id dicts, instance meta, orientation dicts)
+        # travel with an asynchronous copy and are awaited when first read.
+        # extension `defer_host_sync=True`: not even the counts are awaited — an overflow then
+        # surfaces as a RuntimeError at the first read of a host-built entry.
         self._defer_host_sync = defer_host_sync
+        self._count_slots: Dict[tuple, dict] = {}
         self._pinned_ring: Dict[tuple, list] = {}
         self._pinned_next: Dict[tuple, int] = {}
         self._max_instances_per_category = 1 << 16
@@ -115,7 +119,7 @@ class PanopticPostprocessing(DensePostprocessingBase):
 
         # ---- the hot path: 5 launches; ONE device->host copy (= the one sync) of the small
         #      per-image tables, cut to the number of columns recent batches needed -----------
-        def run():
+        def run(on_centers=None):
             return ops.panoptic_pipeline(
                 s_output, center_heatmap, center_offset, thing_lut,
                 threshold=post._heatmap_threshold,
@@ -127,23 +131,23 @@ class PanopticPostprocessing(DensePostprocessingBase):
                 max_instances_per_category=self._max_instances_per_category,
                 void_label=0, max_centers=post._max_centers,
                 want_score=self._compute_scores, want_foreground=True,
-                want_panoptic_semantic=False)
+                want_panoptic_semantic=False, on_centers=on_centers)
         if self._defer_host_sync:
             p = run()
-            tables = _HostTables(self._fetch_tables_async(p, post))
+            tables = _HostTables(self._fetch_tables_async(p, post, checked=False))
         else:
             while True:
-                p = run()
-                host = self._fetch_tables(p, self._host_columns)
-                n_max = max(host['n_centers'], default=0)
+                peek = {}
+                p = run(on_centers=lambda cen: peek.update(self._peek_center_counts(cen)))
+                peek['done'].synchronize()             # long there: the streaming kernels still run
+                n_max = int(peek['host'].max()) if peek['host'].numel() else 0
                 if n_max > post._max_centers:          # center table overflow: re-run, larger
                     post._max_centers = 1 << (n_max - 1).bit_length()
                     continue
-                if n_max > host['columns']:            # rare: more instances than columns fetched
+                if n_max > self._host_columns:         # more instances than table columns fetched so far
                     self._host_columns = 1 << (n_max - 1).bit_length()
-                    host = self._fetch_tables(p, self._host_columns)
                 break
-            tables = _HostTables(lambda: host)
+            tables = _HostTables(self._fetch_tables_async(p, post, checked=True))
 
         # ---- semantic entries (semantic.py:46-80) -------------------------------------
         r = LazyDict(semantic_output=s_output, semantic_side_outputs=s_side_outputs)
@@ -237,7 +241,28 @@ class PanopticPostprocessing(DensePostprocessingBase):
             B, K, kc, L.ptr(flat_dev), L.stream_ptr(flat_dev.device)), 'nmsa_pack_tables')
         return PanopticPostprocessing._split_tables(flat_dev.cpu().numpy(), B, kc, ka, ki)
 
-    def _fetch_tables_async(self, p, post):
+    def _peek_center_counts(self, cen) -> dict:
+        """asynchronous copy of the per-image center counts (B int32) on a copy stream, behind the
+        selection kernel only -> {'host': pinned tensor, 'done': event}"""
+        n = cen['n_centers']
+        dev = n.device
+        key = (dev, n.shape[0])
+        slot = self._count_slots.get(key)
+        if slot is None:
+            slot = self._count_slots[key] = {
+                'host': torch.empty(n.shape, dtype=n.dtype, pin_memory=True),
+                'stream': torch.cuda.Stream(device=dev), 'ready': torch.cuda.Event(),
+                'done': torch.cuda.Event()}
+        cur = torch.cuda.current_stream(dev)
+        slot['ready'].record(cur)
+        with torch.cuda.stream(slot['stream']):
+            slot['stream'].wait_event(slot['ready'])
+            slot['host'].copy_(n, non_blocking=True)
+            slot['done'].record(slot['stream'])
+        n.record_stream(slot['stream'])
+        return {'host': slot['host'], 'done': slot['done']}
+
+    def _fetch_tables_async(self, p, post, checked: bool = False):
         """`defer_host_sync`: pack + asynchronous copy into pinned host memory now; the returned
         function waits for the copy (first read of a host-built entry) and parses it"""
         B, K = p['center_scores'].shape
@@ -275,7 +300,7 @@ class PanopticPostprocessing(DensePostprocessingBase):
                 slot['detach'] = None
             host = self._split_tables(state['flat'], B, kc, ka, ki)
             n_max = max(host['n_centers'], default=0)
-            if n_max > max_centers:
+            if n_max > max_centers and not checked:    # (checked: the caller has seen the counts)
                 post._max_centers = 1 << (n_max - 1).bit_length()
                 raise RuntimeError(
                     f'{n_max} centers survived the top-k ties but the center table held '

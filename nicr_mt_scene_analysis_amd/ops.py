@@ -227,8 +227,13 @@ def panoptic_pipeline(
     want_foreground: bool = True,
     want_panoptic_semantic: bool = False,
     fused_kernel_events: Optional[list] = None,
+    on_centers=None,
 ) -> Dict[str, torch.Tensor]:
     """center-NMS -> fused argmax/grouping/votes -> assign -> paint.
+
+    `on_centers`: called with the center tables right after the top-k selection is queued (the
+    postprocessing API starts the asynchronous copy of the center counts there, so that its
+    overflow check never waits for the streaming kernels behind it).
 
     `fused_kernel_events`: if a list is given, a (start, end) pair of HIP events
     recorded on the launch stream around the dominant kernel is appended
@@ -254,6 +259,8 @@ def panoptic_pipeline(
         fg_for_nms = thing[pre['idx_u8'].long()]
     cen = center_nms_topk(center_heatmap, fg_for_nms, threshold, kernel_size, top_k,
                           apply_foreground_mask, max_centers)
+    if on_centers is not None:
+        on_centers(cen)
 
     sem_u8 = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
     inst = torch.empty((B, H, W), dtype=torch.uint8, device=dev)
