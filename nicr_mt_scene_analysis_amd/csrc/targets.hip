@@ -282,20 +282,26 @@ __global__ __launch_bounds__(256) void k_tg_stats(
         if (WITH_MOMENTS) {
             // same split for the coordinate sums: a lane with one instance in one row contributes
             // (4y, 4x + 6); the sum over a run is a difference of two wave prefix sums
+            // (runs are cut at row changes — the key carries the row — so a run of n lanes is
+            // 4n consecutive pixels of ONE row starting at x0: sum y = 4 n y0, sum x =
+            // n (4 x0 + 6) + 16 n (n - 1) / 2: closed forms at the run head, no wave scans)
             const bool lane_uniform = d[0] == d[1] && d[1] == d[2] && d[2] == d[3] && x0 + 3 < W;
             const int dj = lane_uniform ? d[0] : -1;
-            const int ly = dj >= 0 ? 4 * y0 : 0, lx = dj >= 0 ? 4 * x0 + 6 : 0;
-            const int cy = mw_wave_scan(ly), cx = mw_wave_scan(lx);           // inclusive
-            const bool head = wave_run_head(dj, rl, rlast);
-            const int ey = __shfl(cy, rlast), ex = __shfl(cx, rlast);
-            if (head)
-                add_moments(dj, (unsigned long long)(ey - cy + ly), (unsigned long long)(ex - cx + lx));
+            const int rk = dj >= 0 ? (dj | (y0 << 12)) : -1;          // cap <= 4096, y0 < 32768
+            if (wave_run_head(rk, rl, rlast)) {
+                const unsigned long long n = (unsigned long long)rl;
+                add_moments(dj, 4ull * n * (unsigned long long)y0,
+                            n * (unsigned long long)(4 * x0 + 6) + 8ull * n * (n - 1ull));
+            }
             if (!lane_uniform) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (d[j] < 0) continue;
-                    const int pj = x0 + j;
-                    add_moments(d[j], (unsigned long long)(y0 + pj / W), (unsigned long long)(pj % W));
+                    const int pj = x0 + j;                     // < W + 3: at most one row further
+                    const bool wrap = pj >= W;                 // (W < 4: the generic division below)
+                    if (W >= 4) add_moments(d[j], (unsigned long long)(y0 + (wrap ? 1 : 0)),
+                                            (unsigned long long)(wrap ? pj - W : pj));
+                    else add_moments(d[j], (unsigned long long)(y0 + pj / W), (unsigned long long)(pj % W));
                 }
             }
         }
@@ -322,32 +328,47 @@ __global__ __launch_bounds__(1024) void k_tg_decide(
     TgView v = tg_view(ws, b, cap, NC);
     const int n_dense = v.counters[0];
     const int per = cap / 1024;                      // cap is a multiple of 1024
+    // majority class per present instance: one WAVE per slot, lane = class (a few dozen instances
+    // per image: one thread per slot would leave 1000 threads idle behind 41 dependent loads)
+    __shared__ int s_enc[4096];
+    for (int slot = t >> 6; slot < n_dense; slot += 16) {
+        const uint32_t* row = v.votes + (size_t)slot * NC;
+        uint32_t total = 0;
+        long long best = -1;                          // (count << 32) | ~class: max = larger count, lower class
+        for (int c = lane_id(); c < NC; c += 64) {
+            const uint32_t x = row[c];
+            total += x;
+            const long long key = ((long long)x << 32) | (uint32_t)(0x7fffffff - c);
+            best = key > best ? key : best;
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            total += __shfl_down(total, o);
+            const long long other = __shfl_down(best, o);
+            best = other > best ? other : best;
+        }
+        if (lane_id() == 0) {
+            const int c_best = 0x7fffffff - (int)(uint32_t)(best & 0xffffffffll);   // np.bincount(..).argmax()
+            const bool thing = is_thing_class ? (is_thing_class[c_best] != 0) : true;
+            const int e = thing && total > 0;
+            s_enc[slot] = e;
+            if (e) {
+                // int(np.mean(rows)), int(np.mean(cols)): exact integer floor (instance.py:210-211)
+                v.center_yx[2 * slot] = (int)(v.sum_y[slot] / total);
+                v.center_yx[2 * slot + 1] = (int)(v.sum_x[slot] / total);
+            }
+        }
+    }
+    __syncthreads();
     int enc[4], present[4];
     int n_enc = 0, n_skip = 0;
     for (int j = 0; j < per; ++j) {
         const int slot = t * per + j;
-        enc[j] = 0;
         present[j] = slot < n_dense;
-        if (!present[j]) { v.enc[slot] = 0; continue; }
-        const uint32_t* row = v.votes + (size_t)slot * NC;
-        uint32_t total = 0;
-        int64_t best = -1;
-        int c_best = 0;
-        for (int c = 0; c < NC; ++c) {
-            const uint32_t x = row[c];
-            total += x;
-            if ((int64_t)x > best) { best = x; c_best = c; }      // np.bincount(..).argmax()
-        }
-        const bool thing = is_thing_class ? (is_thing_class[c_best] != 0) : true;
-        enc[j] = thing && total > 0;
+        enc[j] = present[j] ? s_enc[slot] : 0;
         v.enc[slot] = enc[j];
-        if (enc[j]) {
-            // int(np.mean(rows)), int(np.mean(cols)): exact integer floor (instance.py:210-211)
-            v.center_yx[2 * slot] = (int)(v.sum_y[slot] / total);
-            v.center_yx[2 * slot + 1] = (int)(v.sum_x[slot] / total);
-        }
         n_enc += enc[j];
-        n_skip += !enc[j];
+        n_skip += present[j] && !enc[j];
     }
     int tot_enc, tot_skip;
     int pe = mw_block_scan(n_enc, scratch, &tot_enc) - n_enc;
@@ -517,6 +538,162 @@ __global__ __launch_bounds__(TGP_THREADS) void k_tg_paint(
     }
 }
 
+// ---- paint on 2-d pixel tiles (the fast layout: uint8 / int32 labels, W % 4 == 0) ---------------
+// A workgroup covers a 128 x 8 pixel TILE instead of 1024 consecutive pixels (1.6 rows of a
+// 640-px image): the centers whose patch reaches the tile are culled in BOTH directions (a
+// (6 sigma + 3)^2 patch reaches 3 % of the tiles, 11 % of the row segments), more than half of
+// the tiles meet no patch at all and skip the heat-map table altogether; the label loads are
+// issued first and the dependent rank / center lookups run while the candidates are collected.
+constexpr int TGT_W = 128, TGT_ROWS = 8;     // rows per pass of the 256 threads; a tile is G passes high
+
+template <bool NORMALIZED, int G>
+__global__ __launch_bounds__(TGP_THREADS) void k_tg_paint_tile(
+    const uint8_t* __restrict__ sem, const int32_t* __restrict__ ins,
+    const uint8_t* __restrict__ is_stuff_class, const float* __restrict__ gauss_lut, int lut_n,
+    int radius, int H, int W, int tiles_x, int cap, int NC, unsigned char* __restrict__ ws,
+    float* __restrict__ center, void* __restrict__ offset, uint8_t* __restrict__ foreground,
+    uint8_t* __restrict__ center_mask)
+{
+    extern __shared__ int tg_lds[];              // [cap * 2] candidate centers, then the table
+    __shared__ int s_n;
+    constexpr int TGT_H = TGT_ROWS * G;
+    const int b = blockIdx.y;
+    const int P = H * W;
+    TgView v = tg_view(ws, b, cap, NC);
+    int* s_cand = tg_lds;
+    float* s_lut = (float*)(tg_lds + 2 * cap);
+    const bool lut_in_lds = lut_n <= TGP_LUT_LDS;
+    const int ty = blockIdx.x / tiles_x, tx = blockIdx.x - ty * tiles_x;
+    const int x = tx * TGT_W + (threadIdx.x & 31) * 4;
+    // a thread owns G groups of 4 pixels, TGT_ROWS rows apart: their label loads and the dependent
+    // rank / center lookups are all in flight together (the kernel is a chain of latencies)
+    int y[G];
+    bool inside[G];
+    size_t o[G];
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned char u8x4_t __attribute__((ext_vector_type(4)));
+    i32x4_t id4[G];
+    u8x4_t sm4[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        y[g] = ty * TGT_H + g * TGT_ROWS + (threadIdx.x >> 5);
+        inside[g] = y[g] < H && x < W;                        // W % 4 == 0: whole groups of 4
+        o[g] = (size_t)b * P + (size_t)y[g] * W + x;
+        id4[g] = i32x4_t{0, 0, 0, 0};
+        sm4[g] = u8x4_t{0, 0, 0, 0};
+        if (inside[g]) {
+            id4[g] = *(const i32x4_t*)(ins + o[g]);
+            if (center_mask && is_stuff_class) sm4[g] = *(const u8x4_t*)(sem + o[g]);
+        }
+    }
+    const int n_enc = v.counters[1];
+    const int y_lo = ty * TGT_H - radius, y_hi = ty * TGT_H + TGT_H - 1 + radius;
+    const int x_lo = tx * TGT_W - radius, x_hi = tx * TGT_W + TGT_W - 1 + radius;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    for (int i0 = 0; i0 < n_enc; i0 += TGP_THREADS) {
+        const int i = i0 + threadIdx.x;
+        int cy = 0, cx = 0;
+        bool keep = false;
+        if (i < n_enc) {
+            cy = v.enc_list[2 * i];
+            cx = v.enc_list[2 * i + 1];
+            keep = cy >= y_lo && cy <= y_hi && cx >= x_lo && cx <= x_hi;
+        }
+        const unsigned long long m = __ballot(keep);
+        int base = 0;
+        if (lane_id() == 0 && m) base = atomicAdd(&s_n, __popcll(m));
+        base = __shfl(base, 0);
+        if (keep) {
+            const int at = base + __popcll(m & ((1ull << lane_id()) - 1ull));
+            s_cand[2 * at] = cy;
+            s_cand[2 * at + 1] = cx;
+        }
+    }
+    // the dense rank of every group's first instance id while the candidates settle
+    int d_first[G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        const int i0 = id4[g].x;
+        d_first[g] = (i0 > 0 && i0 <= MW_MAX_ID) ? id_rank_dense(v.bitmap, v.prefix, i0) : cap;
+    }
+    __syncthreads();
+    const int n_cand = s_n;
+    if (n_cand > 0 && lut_in_lds) {                           // (uniform over the workgroup)
+        for (int i = threadIdx.x; i < lut_n; i += TGP_THREADS) s_lut[i] = gauss_lut[i];
+        __syncthreads();
+    }
+    const float* lut = lut_in_lds ? s_lut : gauss_lut;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (!inside[g]) continue;
+        // heat-map: max over the patches that cover the pixel (instance.py:213-229)
+        float hm[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int i = 0; i < n_cand; ++i) {
+            const int dy = y[g] - s_cand[2 * i], dx0 = x - s_cand[2 * i + 1];
+            if (abs(dy) > radius) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int dx = dx0 + j;
+                if (abs(dx) <= radius) hm[j] = fmaxf(hm[j], lut[dy * dy + dx * dx]);
+            }
+        }
+        // offsets / foreground (instance.py:201-206,232-237)
+        const int id[4] = {id4[g].x, id4[g].y, id4[g].z, id4[g].w};
+        const int sm[4] = {sm4[g].x, sm4[g].y, sm4[g].z, sm4[g].w};
+        uint8_t fg[4], cm[4];
+        int oy[4], ox[4];
+        int id_prev = -1, cy_prev = 0, cx_prev = 0;
+        bool enc_prev = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fg[j] = 0; oy[j] = 0; ox[j] = 0;
+            if (id[j] > 0 && id[j] <= MW_MAX_ID) {
+                if (id[j] != id_prev) {
+                    const int d = (j == 0) ? d_first[g] : id_rank_dense(v.bitmap, v.prefix, id[j]);
+                    enc_prev = d < cap && v.enc[d];
+                    if (enc_prev) { cy_prev = v.center_yx[2 * d]; cx_prev = v.center_yx[2 * d + 1]; }
+                    id_prev = id[j];
+                }
+                if (enc_prev) {
+                    fg[j] = 1;
+                    oy[j] = (int)(int16_t)(cy_prev - y[g]);                // int16 image (instance.py:180)
+                    ox[j] = (int)(int16_t)(cx_prev - (x + j));
+                }
+            }
+            cm[j] = fg[j];
+            if (center_mask && is_stuff_class && sm[j] < NC && is_stuff_class[sm[j]])
+                cm[j] = 1;                                                 // instance.py:263-269
+        }
+        const size_t oo = (size_t)b * 2 * P + (size_t)y[g] * W + x;
+        typedef float f32x4_t __attribute__((ext_vector_type(4)));
+        typedef short i16x4_t __attribute__((ext_vector_type(4)));
+        f32x4_t h4; h4.x = hm[0]; h4.y = hm[1]; h4.z = hm[2]; h4.w = hm[3];
+        *(f32x4_t*)(center + o[g]) = h4;
+        if (NORMALIZED) {
+            f32x4_t a, c;                                                  // instance.py:239-243
+            a.x = __fdiv_rn((float)oy[0], (float)H); a.y = __fdiv_rn((float)oy[1], (float)H);
+            a.z = __fdiv_rn((float)oy[2], (float)H); a.w = __fdiv_rn((float)oy[3], (float)H);
+            c.x = __fdiv_rn((float)ox[0], (float)W); c.y = __fdiv_rn((float)ox[1], (float)W);
+            c.z = __fdiv_rn((float)ox[2], (float)W); c.w = __fdiv_rn((float)ox[3], (float)W);
+            *(f32x4_t*)((float*)offset + oo) = a;
+            *(f32x4_t*)((float*)offset + oo + P) = c;
+        } else {
+            i16x4_t a, c;
+            a.x = (short)oy[0]; a.y = (short)oy[1]; a.z = (short)oy[2]; a.w = (short)oy[3];
+            c.x = (short)ox[0]; c.y = (short)ox[1]; c.z = (short)ox[2]; c.w = (short)ox[3];
+            *(i16x4_t*)((int16_t*)offset + oo) = a;
+            *(i16x4_t*)((int16_t*)offset + oo + P) = c;
+        }
+        u8x4_t f4; f4.x = fg[0]; f4.y = fg[1]; f4.z = fg[2]; f4.w = fg[3];
+        *(u8x4_t*)(foreground + o[g]) = f4;
+        if (center_mask) {
+            u8x4_t c4; c4.x = cm[0]; c4.y = cm[1]; c4.z = cm[2]; c4.w = cm[3];
+            *(u8x4_t*)(center_mask + o[g]) = c4;
+        }
+    }
+}
+
 // ---- naive merge: ranks of the (instance, class) segments ------------------------------------------
 // One workgroup per image, thread c owns class c: walks the instances in ascending id order and
 // replaces every non-zero histogram entry by the running per-class counter
@@ -531,21 +708,34 @@ __global__ __launch_bounds__(1024) void k_tg_naive_ranks(
     const int b = blockIdx.x, t = threadIdx.x;
     TgView v = tg_view(ws, b, cap, NC);
     const int n_dense = v.counters[0];
+    // the histogram rows in use usually fit the LDS (a few dozen instances x NC classes): stage
+    // them with coalesced loads, run the per-class counters there, write the ranks back — instead
+    // of n_dense dependent read-modify-writes per class in global memory
+    constexpr int NR_LDS = 12288;
+    __shared__ uint32_t s_tab[NR_LDS];
+    const int n_cells = n_dense * NC;
+    const bool in_lds = n_cells <= NR_LDS;
+    uint32_t* tab = in_lds ? s_tab : v.votes;
+    if (in_lds) {
+        for (int i = t; i < n_cells; i += 1024) s_tab[i] = v.votes[i];
+        __syncthreads();
+    }
     for (int c = t; c < NC; c += 1024) {
         uint32_t run = 0;
         for (int d = 0; d < n_dense; ++d) {
-            uint32_t* cell = &v.votes[(size_t)d * NC + c];
+            uint32_t* cell = &tab[(size_t)d * NC + c];
             if (c == 0) { *cell = 0; continue; }              // void is ignored (:73-74)
             if (*cell) *cell = ++run;
         }
     }
     __syncthreads();
+    if (in_lds) for (int i = t; i < n_cells; i += 1024) v.votes[i] = s_tab[i];
     const int per = cap / 1024;
     int cnt = 0;
     for (int j = 0; j < per; ++j) {
         const int slot = t * per + j;
         if (slot >= n_dense) continue;
-        for (int c = 1; c < NC; ++c) cnt += v.votes[(size_t)slot * NC + c] != 0;
+        for (int c = 1; c < NC; ++c) cnt += tab[(size_t)slot * NC + c] != 0;
     }
     int total;
     int pos = mw_block_scan(cnt, scratch, &total) - cnt;
@@ -553,7 +743,7 @@ __global__ __launch_bounds__(1024) void k_tg_naive_ranks(
         const int slot = t * per + j;
         if (slot >= n_dense) continue;
         for (int c = 1; c < NC; ++c) {
-            const uint32_t r = v.votes[(size_t)slot * NC + c];
+            const uint32_t r = tab[(size_t)slot * NC + c];
             if (!r) continue;
             if (pos < pair_cap) {
                 ids_pan[(size_t)b * pair_cap + pos] = (int64_t)c * max_inst + r;
@@ -820,7 +1010,10 @@ bool tg_fast(const void* sem, int sem_dtype, const void* ins, int ins_dtype, int
 
 int tg_grid_x(int P)
 {
-    int gx = (P + TG_PX_PER_BLOCK - 1) / TG_PX_PER_BLOCK;
+    // 1024-px chunks per workgroup: 2 halve the table set-up / flush per pixel (instance targets
+    // 108 -> 99 us at B=32 640x480; 4 the same, 8 slower)
+    static const int iters = getenv("NMSA_TG_ITERS") ? atoi(getenv("NMSA_TG_ITERS")) : 2;
+    int gx = (P + TG_PX_PER_BLOCK * iters - 1) / (TG_PX_PER_BLOCK * iters);
     return gx > 1024 ? 1024 : gx;
 }
 
@@ -907,6 +1100,23 @@ extern "C" int nmsa_instance_targets(const void* semantic, int sem_dtype, const 
     hipLaunchKernelGGL((k_tg_paint<N, F>), grid, dim3(TGP_THREADS), lds, stream, semantic, sem_dtype,  \
                        instance, ins_dtype, is_stuff_class, gauss_lut, lut_n, radius, H, W, cap,       \
                        n_classes, ws, center, offset, foreground, center_mask)
+    static const int tiled = getenv("NMSA_TG_PAINT_TILED") ? atoi(getenv("NMSA_TG_PAINT_TILED")) : 2;
+    if (fast && tiled && W % 4 == 0) {
+        // 128 x (8 G) pixel tiles, G = NMSA_TG_PAINT_TILED groups of 4 pixels per thread
+        const int G = tiled >= 4 ? 4 : tiled >= 2 ? 2 : 1;
+        const int tiles_x = (W + TGT_W - 1) / TGT_W, tiles_y = (H + TGT_ROWS * G - 1) / (TGT_ROWS * G);
+        const dim3 tgrid(tiles_x * tiles_y, B);
+        const size_t tlds = (size_t)cap * 2 * sizeof(int) + (lut_n <= TGP_LUT_LDS ? (size_t)lut_n * 4 : 0);
+#define NMSA_LAUNCH_TGT(N, GG)                                                                          \
+        hipLaunchKernelGGL((k_tg_paint_tile<N, GG>), tgrid, dim3(TGP_THREADS), tlds, stream,            \
+                           (const uint8_t*)semantic, (const int32_t*)instance, is_stuff_class, gauss_lut, \
+                           lut_n, radius, H, W, tiles_x, cap, n_classes, ws, center, offset, foreground,  \
+                           center_mask)
+        if (normalized_offset) { if (G == 4) NMSA_LAUNCH_TGT(true, 4); else if (G == 2) NMSA_LAUNCH_TGT(true, 2); else NMSA_LAUNCH_TGT(true, 1); }
+        else { if (G == 4) NMSA_LAUNCH_TGT(false, 4); else if (G == 2) NMSA_LAUNCH_TGT(false, 2); else NMSA_LAUNCH_TGT(false, 1); }
+#undef NMSA_LAUNCH_TGT
+        return check_launch();
+    }
     if (normalized_offset) { if (fast) NMSA_LAUNCH_TGP(true, true); else NMSA_LAUNCH_TGP(true, false); }
     else { if (fast) NMSA_LAUNCH_TGP(false, true); else NMSA_LAUNCH_TGP(false, false); }
 #undef NMSA_LAUNCH_TGP
