@@ -203,16 +203,24 @@ __global__ __launch_bounds__(1024) void k_nms_strip(
 template <int NR_ROWS, bool HALF>
 __global__ __launch_bounds__(256) void k_nms_rows3(
     const float* __restrict__ center, uint32_t* __restrict__ cand_bits,
-    int H, int W, int words_per_image, float thr)
+    int H, int W, int words_per_image, float thr, int blocks_per_image, int n_blocks)
 {
     constexpr int LPB = HALF ? 32 : 64;                    // lanes per band
     constexpr int BW = LPB * 4;                            // band width in pixels
-    const int b = blockIdx.y;
+    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its
+    // own L2); every XCD gets one contiguous range of row groups, so that the halo rows a wave
+    // shares with the row groups above and below are L2 hits instead of second fetches through
+    // the fabric (FETCH_SIZE 1.42x -> see profiles/r04*)
+    const int per_xcd = (n_blocks + 7) >> 3;
+    const int logical = n_blocks > 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    if (n_blocks > 0 && logical >= n_blocks) return;
+    const int b = n_blocks > 0 ? logical / blocks_per_image : (int)blockIdx.y;
+    const int bx = n_blocks > 0 ? logical - b * blocks_per_image : (int)blockIdx.x;
     const int lane = lane_id();
     const int l = lane & (LPB - 1);                        // lane within its band
     const int sub = HALF ? (lane >> 5) : 0;
     const int bands = (W + BW - 1) / BW;
-    const int wave = blockIdx.x * 4 + (int)(threadIdx.x >> 6);
+    const int wave = bx * 4 + (int)(threadIdx.x >> 6);
     const int seg = wave / bands, band = wave - seg * bands;
     const int y0 = (seg * (HALF ? 2 : 1) + sub) * NR_ROWS;
     if ((seg * (HALF ? 2 : 1)) * NR_ROWS >= H) return;     // whole wave
@@ -533,12 +541,17 @@ extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
         static const int nr = getenv("NMSA_NMS_NR") ? atoi(getenv("NMSA_NMS_NR")) : 4;
         static const int half_env = getenv("NMSA_NMS_HALF") ? atoi(getenv("NMSA_NMS_HALF")) : -1;
         const bool half = half_env >= 0 ? (half_env != 0 && W % 128 == 0) : (W % 256 != 0 && W % 128 == 0);
-#define NMSA_ROWS3(NR) do { if (half) { const int waves = (W / 128) * ((H + 2 * NR - 1) / (2 * NR));     \
-        hipLaunchKernelGGL((k_nms_rows3<NR, true>), dim3((waves + 3) / 4, B), dim3(256), 0, stream, center,  \
-                           bits, H, W, words, threshold); } else {                                         \
-        const int waves = ((W + 255) / 256) * ((H + NR - 1) / NR);                                          \
-        hipLaunchKernelGGL((k_nms_rows3<NR, false>), dim3((waves + 3) / 4, B), dim3(256), 0, stream, center, \
-                           bits, H, W, words, threshold); } } while (0)
+        static const int xcd = getenv("NMSA_NMS_XCD") ? atoi(getenv("NMSA_NMS_XCD")) : 1;
+#define NMSA_ROWS3(NR) do {                                                                                 \
+        const int waves = half ? (W / 128) * ((H + 2 * NR - 1) / (2 * NR)) : ((W + 255) / 256) * ((H + NR - 1) / NR); \
+        const int bpi = (waves + 3) / 4;                                                                    \
+        const long long nb = (long long)bpi * B;                                                            \
+        const bool remap = xcd && nb < (1ll << 30);                                                         \
+        const dim3 grid_ = remap ? dim3((unsigned)(((nb + 7) / 8) * 8)) : dim3(bpi, B);                     \
+        if (half) hipLaunchKernelGGL((k_nms_rows3<NR, true>), grid_, dim3(256), 0, stream, center, bits, H, W, \
+                                     words, threshold, bpi, remap ? (int)nb : 0);                            \
+        else hipLaunchKernelGGL((k_nms_rows3<NR, false>), grid_, dim3(256), 0, stream, center, bits, H, W,   \
+                                words, threshold, bpi, remap ? (int)nb : 0); } while (0)
         if (nr == 8) NMSA_ROWS3(8); else NMSA_ROWS3(4);
 #undef NMSA_ROWS3
     } else if ((W % 32) == 0 && pad <= NMS_PAD_MAX && strip_lds <= 64 * 1024) {
