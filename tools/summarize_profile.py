@@ -26,7 +26,7 @@ WIDE_STREAM = ('k_panoptic_fused', 'k_paint', 'k_paint2', 'k_semantic_argmax', '
                'k_nms_rows3', 'k_ce_fwd', 'k_ce_bwd', 'k_elem_fwd', 'k_elem_bwd', 'k_vm_fwd',
                'k_vm_bwd', 'k_cos_emb_lds', 'k_ce_fused', 'k_elem_fused', 'k_vm_fused', 'k_count_u8',
                # LDS-DMA loads (`global_load_lds_dwordx4`) count like 16-B register loads
-               'k_resized_tile', 'k_ce_split', 'k_multi_loss', 'k_multi_count', 'k_cos_split')
+               'k_resized_tile', 'k_ce_split', 'k_multi_loss', 'k_multi_count', 'k_cos_split', 'k_cos_parts')
 
 
 def is_wide(kernel):
