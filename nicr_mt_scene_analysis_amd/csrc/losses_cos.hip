@@ -223,10 +223,13 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
 // partial sums in part order: all parts get the same bits.  Two slots per part (tile parity): a
 // part publishes tile t + 1 only after it has read its partners' tile t, which they published
 // after reading tile t - 1 of everybody.
-// Forward progress: partners are neighbours in blockIdx.x; workgroups are dispatched in index
-// order, so every earlier group is complete or fully resident and the grid drains whatever else
-// runs on the chip.  Should a partner still not answer within ~2 s the wait gives up for good and
-// poisons sums and gradients with NaN (every wave reaches the end; the failure is loud).
+// Forward progress: the launch geometry (coss_geometry) never asks for more workgroups than the
+// chip holds at once (256 CUs x the workgroups per CU the LDS footprint allows), so whatever the
+// dispatch order, once foreign kernels have drained every workgroup of the grid is resident and
+// every partner answers.  (Only the test override NMSA_COS_SPLIT_RUN makes larger grids; those
+// rely on partners being neighbours in the linear workgroup id and on dispatch in id order.)
+// Should a partner still not answer within ~2 s the wait gives up for good and poisons sums and
+// gradients with NaN, status bit 32 (every wave reaches the end; the failure is loud).
 constexpr int COSP_WAVES = 4;
 constexpr int COSP_COLS = COSP_WAVES * COSS_NP;        // 256 planes per part
 constexpr int COSP_MAX_PARTS = 4;                      // D <= 1024

@@ -10,7 +10,7 @@ into ONE flat device buffer per dtype, so that
   * `zero_()` / `reset()` is one memset per dtype.
 
 Distributed semantics are torchmetrics' (what `dist_reduce_fx='sum'` means under an initialised
-process group): `compute()` is wrapped per instance — with world size > 1 it caches the rank-local
+process group): every subclass's `compute()` is wrapped — under a process group it caches the rank-local
 states, sums them over the ranks, computes and restores the local states (`sync_context`), so every
 rank reports the GLOBAL metric while `update()` keeps accumulating locally; a state read outside
 `compute()` (the confusion-matrix artifacts of the task helpers) is rank-local, as in the reference.
@@ -33,8 +33,7 @@ class Metric(torch.nn.Module):
         self.process_group = process_group
         self._is_synced = False
         self._cache: Optional[Dict[torch.dtype, torch.Tensor]] = None
-        # per instance, like torchmetrics: `super().compute()` inside a subclass stays unwrapped
-        self.compute = self._wrap_compute(self.compute)
+        self._compute_depth = 0
         self._state_defaults: Dict[str, torch.Tensor] = {}
         self._state_reduce: Dict[str, Optional[str]] = {}
         self._flat: Optional[Dict[torch.dtype, torch.Tensor]] = None
@@ -106,12 +105,27 @@ class Metric(torch.nn.Module):
     def compute(self, *args, **kwargs):
         raise NotImplementedError
 
-    def _wrap_compute(self, compute):
+    def __init_subclass__(cls, **kwargs):
+        """every subclass's own `compute` runs inside a `sync_context` — at class level (copies,
+        pickles and `deepcopy` of a metric keep working: nothing is bound to an instance), the
+        OUTERMOST call only: `super().compute()` inside a subclass must not sum a second time"""
+        super().__init_subclass__(**kwargs)
+        compute = cls.__dict__.get('compute')
+        if compute is None or getattr(compute, '_nmsa_sync_wrapped', False):
+            return
+
         @functools.wraps(compute)
-        def wrapped(*args, **kwargs):
-            with self.sync_context(should_sync=self.sync_on_compute):
-                return compute(*args, **kwargs)
-        return wrapped
+        def wrapped(self, *args, **kw):
+            if self._compute_depth:
+                return compute(self, *args, **kw)
+            self._compute_depth += 1
+            try:
+                with self.sync_context(should_sync=self.sync_on_compute):
+                    return compute(self, *args, **kw)
+            finally:
+                self._compute_depth -= 1
+        wrapped._nmsa_sync_wrapped = True
+        cls.compute = wrapped
 
     def _world_size(self, process_group=None) -> int:
         import torch.distributed as dist

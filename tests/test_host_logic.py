@@ -387,3 +387,22 @@ def test_bench_self_launch_command_and_host_cores(monkeypatch):
     cores = bench.host_cores()
     assert 1 <= cores['usable'] <= cores['affinity'] <= max(cores['nproc'], cores['affinity'])
     assert cores['cgroup_quota'] is None or cores['usable'] <= max(1, round(cores['cgroup_quota']))
+
+
+def test_metric_copies_keep_their_own_compute():
+    """the rank-sync wrapper of `compute()` lives on the class: deepcopy / pickle of a metric give
+    independent metrics (a wrapper bound to the instance would keep computing the original)"""
+    import copy
+    import pickle
+    import torch
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion
+    from nicr_mt_scene_analysis_amd.metric.mae import PanopticQualityWithOrientationMAE
+    m = MeanIntersectionOverUnion(3, device='cpu')
+    m.confmat += torch.eye(3, dtype=torch.int64)
+    clone = copy.deepcopy(m)
+    clone.confmat += 5
+    assert float(m.compute()) == 1.0 and float(clone.compute()) < 0.5
+    assert float(pickle.loads(pickle.dumps(m)).compute()) == 1.0
+    q = PanopticQualityWithOrientationMAE(3, 0, 65536, 256 ** 3, [False, True, True], device='cpu')
+    r = q.compute(suffix='_x')                       # subclass compute -> super().compute(): one context
+    assert 'mae_x_rad' in r and 'all_x_pq' in r and q._compute_depth == 0 and not q._is_synced
