@@ -94,6 +94,60 @@ def test_fuzz_pipeline_vs_oracle(oracle, p):
     check_pipeline(oracle, p)
 
 
+@settings(max_examples=_n(25), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), C=st.integers(2, 48), scale=st.sampled_from([1.0, 0.5, 0.03, 1e-4]),
+       spread=st.sampled_from([0.2, 2.0, 8.0, 40.0, 120.0]), dtype=st.sampled_from(['float32', 'float32', 'bfloat16', 'float16']))
+def test_fuzz_argmax_probability_ties(oracle, seed, C, scale, spread, dtype):
+    """a1 where it is decided by ATen's fp32 softmax arithmetic: columns whose maximum lies in
+    (-scale, scale) with 1-3 lower-indexed classes 1..6 ulps below it and the other classes up to
+    `spread` below (every column its own softmax denominator; 120: beyond Sleef's cut-off) — the
+    kernels (stand-alone, with score, fused) against the C oracle, two independent restatements
+    of the same arithmetic, and a sample against the numpy twin"""
+    from _golden import aten_softmax_argmax
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    H, W = 24, 64
+    tdt = getattr(torch, dtype)
+    top = ((rng.random((1, 1, H, W)) * 2 - 1) * scale).astype(np.float32)
+    top = torch.from_numpy(top).to(tdt).float().numpy()                   # representable maxima
+    x = top - (rng.random((1, C, H, W)) * spread + 0.05 * spread).astype(np.float32)
+    x = torch.from_numpy(x).to(tdt).float().numpy()
+    am = rng.integers(0, C, (1, 1, H, W))
+    np.put_along_axis(x, am, top, axis=1)
+    info = {'float32': np.float32, 'bfloat16': None, 'float16': np.float16}[dtype]
+    for _ in range(3):                                                    # near-maximum classes
+        c = rng.integers(0, C, (1, 1, H, W))
+        k = rng.integers(1, 7, (1, 1, H, W))
+        if info is not None:
+            near = top.astype(info)
+            for _k in range(6):
+                near = np.where(k > _k, np.nextafter(near, info(-np.inf)), near)
+            near = near.astype(np.float32)
+        else:                                                             # bf16: step the 16-bit pattern
+            bits = (top.view(np.uint32) >> 16).astype(np.int64)
+            sign = np.where(top < 0, 1, -1) * np.where(top == 0, 0, 1)
+            bits = np.where(top == 0, 0x8000 + k, bits + sign * k)        # below +0: the negatives
+            near = ((bits.astype(np.uint32) & 0xFFFF) << 16).view(np.float32).reshape(top.shape)
+        keep = (c != am) & (near < top)
+        np.put_along_axis(x, c, np.where(keep, near, np.take_along_axis(x, c, axis=1)), axis=1)
+    xt = torch.from_numpy(x).to(tdt)
+    assert torch.equal(xt.float(), torch.from_numpy(x))
+    want, _ = oracle.semantic_argmax(x)
+    want = want.astype(np.uint8)
+    xd = xt.cuda()
+    got = [ops.semantic_argmax(xd, want_u8=True, want_i64=False, want_score=False)['idx_u8'],
+           ops.semantic_argmax(xd, want_u8=True, want_i64=False, want_score=True)['idx_u8'],
+           ops.panoptic_pipeline(xd, torch.zeros((1, 1, H, W), device='cuda'),
+                                 torch.zeros((1, 2, H, W), device='cuda'),
+                                 torch.zeros((C,), dtype=torch.bool, device='cuda'))['semantic_idx_u8']]
+    for g in got:
+        assert (g.cpu().numpy() == want).all()
+    twin, _ = aten_softmax_argmax(x[:, :, :4])
+    assert (twin == want[:, :4]).all()
+    _EFFECTIVE['argmax_ties'] = _EFFECTIVE.get('argmax_ties', 0) + int((want != x.argmax(axis=1)).sum())
+
+
 @settings(max_examples=_n(40), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture,
                                  HealthCheck.data_too_large])
@@ -801,3 +855,5 @@ def test_fuzz_effective_cases():
     for name in ('scores', 'grouping', 'cos_large', 'pq_many'):
         if name in _EFFECTIVE:
             assert _EFFECTIVE[name] >= 10, _EFFECTIVE
+    if 'argmax_ties' in _EFFECTIVE:          # pixels where the probability rule beats the plain argmax
+        assert _EFFECTIVE['argmax_ties'] >= 100, _EFFECTIVE
