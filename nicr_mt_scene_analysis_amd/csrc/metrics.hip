@@ -694,11 +694,34 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     if (tid == 0) list_n_all[b * PQ_LIST_STRIDE] = 0;  // the list is consumed: clean for the next update
 }
 
-__global__ __launch_bounds__(64) void k_pq_accumulate(
+// (the workgroups behind the first `num_categories` sum the confusion-matrix slabs of
+// k_pq_count<true> — k_confmat_reduce's arithmetic, independent of the matching — so the chain of
+// an update is count -> match -> this: one launch less to wait for wave slots)
+__global__ __launch_bounds__(256) void k_pq_accumulate(
     const double* __restrict__ img_state, int B, int num_categories,
     double* __restrict__ iou, double* __restrict__ tp,
-    double* __restrict__ fn, double* __restrict__ fp)
+    double* __restrict__ fn, double* __restrict__ fp,
+    const uint32_t* __restrict__ cm_slab, int cm_slabs, int cm_bins,
+    unsigned long long* __restrict__ confmat)
 {
+    if ((int)blockIdx.x >= num_categories) {
+        const int rb = blockIdx.x - num_categories;
+        const int i = (rb / CM_REDUCE_GROUPS) * 256 + threadIdx.x;
+        if (i >= cm_bins) return;
+        unsigned long long acc = 0;
+        int k = rb % CM_REDUCE_GROUPS;
+        for (; k + 7 * CM_REDUCE_GROUPS < cm_slabs; k += 8 * CM_REDUCE_GROUPS) {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = cm_slab[(size_t)(k + u * CM_REDUCE_GROUPS) * cm_bins + i];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc += v[u];
+        }
+        for (; k < cm_slabs; k += CM_REDUCE_GROUPS) acc += cm_slab[(size_t)k * cm_bins + i];
+        if (acc) atomicAdd(&confmat[i], acc);
+        return;
+    }
+    if (threadIdx.x >= 64) return;                     // one wave per category (no workgroup barrier below)
     __shared__ double buf[4][64];
     const int c = blockIdx.x, l = threadIdx.x;
     double a0 = iou[c], a1 = tp[c], a2 = fn[c], a3 = fp[c];
@@ -709,14 +732,14 @@ __global__ __launch_bounds__(64) void k_pq_accumulate(
 #pragma unroll
             for (int k = 0; k < 4; ++k) buf[k][l] = s[k * num_categories + c];
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier(); __threadfence_block();
         if (l == 0) {
             const int nb = min(64, B - b0);
             for (int j = 0; j < nb; ++j) {              // image order, like pq.py:291-296
                 a0 += buf[0][j]; a1 += buf[1][j]; a2 += buf[2][j]; a3 += buf[3][j];
             }
         }
-        __syncthreads();
+        __builtin_amdgcn_wave_barrier(); __threadfence_block();
     }
     if (l == 0) { iou[c] = a0; tp[c] = a1; fn[c] = a2; fp[c] = a3; }
 }
@@ -861,21 +884,17 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
     }
     rc = check_launch();
     if (rc) return rc;
-    if (target_sem) {
-        const int nbins = cm_n * cm_n;
-        hipLaunchKernelGGL(k_confmat_reduce, dim3((nbins + 255) / 256, CM_REDUCE_GROUPS), dim3(256), 0,
-                           stream, (const uint32_t*)cm_workspace, (int)(grid.x * grid.y), nbins,
-                           (unsigned long long*)confmat);
-        if ((rc = check_launch())) return rc;
-    }
     hipLaunchKernelGGL(k_pq_match, dim3(B), dim3(PQ_MATCH_THREADS), 0, stream, ws, cap, num_categories,
                        ignored_label, max_instances_per_category, offset, void_segment_id,
                        img_state, matches, match_capacity, n_matches, status, list_n);
     rc = check_launch();
     if (rc) return rc;
-    hipLaunchKernelGGL(k_pq_accumulate, dim3(num_categories), dim3(64), 0, stream,
+    const int nbins = target_sem ? cm_n * cm_n : 0;
+    const int extra = target_sem ? ((nbins + 255) / 256) * CM_REDUCE_GROUPS : 0;
+    hipLaunchKernelGGL(k_pq_accumulate, dim3(num_categories + extra), dim3(256), 0, stream,
                        img_state, B, num_categories, iou_per_class, tp_per_class, fn_per_class,
-                       fp_per_class);
+                       fp_per_class, (const uint32_t*)cm_workspace, (int)(grid.x * grid.y), nbins,
+                       (unsigned long long*)confmat);
     return check_launch();
 }
 
