@@ -540,11 +540,12 @@ int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t* indices, c
                           const float* grad_scale, const float* dots, void* grad_pred,
                           nmsa_stream_t stream);
 /* forward + gradient in ONE pass over the prediction: the D-column of a pixel stays in the
- * registers of D / 64 waves between the reduction and the gradient.  D % 64 == 0, H*W a multiple
- * of 4 (2 for f32), 8-byte aligned planes, and either D <= 512 with the image's fp32 LUT + the
- * exchange buffers within the CU's LDS (k_cos_split: one workgroup per column) or D <= 1024
- * (k_cos_parts: the column over ceil(D / 256) cooperating workgroups that exchange their partial
- * sums as 8-byte {value, tag} granules through the workspace; DVEFormer's D = 768).  The gradient
+ * registers of ceil(D / 64) waves between the reduction and the gradient.  H*W a multiple of 4
+ * (2 for f32), 8-byte aligned planes, and either D % 64 == 0, D <= 512 with the image's fp32 LUT +
+ * the exchange buffers within the CU's LDS (k_cos_split: one workgroup per column) or D <= 1024,
+ * any D (k_cos_parts: the column over ceil(D / 256) cooperating workgroups that exchange their
+ * partial sums as 8-byte {value, tag} granules through the workspace; DVEFormer's D = 768; a
+ * ragged last wave when D % 64 != 0).  The gradient
  * is written for *expected_gscale; nmsa_loss_cos_emb_bwd_unless confirms it (bit-equal
  * *grad_scale) or recomputes — it takes the forward call's workspace (NULL is fine for
  * D <= 512).  Status bit 32: a cooperating workgroup did not answer within ~2 s (sum and

@@ -235,7 +235,10 @@ constexpr int COSP_COLS = COSP_WAVES * COSS_NP;        // 256 planes per part
 constexpr int COSP_MAX_PARTS = 4;                      // D <= 1024
 constexpr int COSP_GRAN = 2 * 4 * 64;                  // granules per (slot, part): 2 sums x 4 px x 64 lanes
 
-template <int DTYPE, int MODE>                         // MODE 0: loss + gradient, 2: gradient only
+// RAGGED: D is no multiple of 64 — the last wave that holds planes holds fewer than 64; its walks
+// test every plane against the wave's plane count (wave-uniform branches).  Compiled apart so that
+// the walks of the usual shapes stay free of branches.
+template <int DTYPE, int MODE, bool RAGGED>            // MODE 0: loss + gradient, 2: gradient only
 __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
     int B, int D, int P, int L, int NS, int tiles_per_wg,
@@ -257,7 +260,7 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
     const int part = wg % NS, group = wg / NS;
     const int d0 = part * COSP_COLS;
-    const int DP = min(COSP_COLS, D - d0);             // my columns (a multiple of 64)
+    const int DP = min(COSP_COLS, D - d0);             // my columns (a multiple of 64 unless RAGGED)
     constexpr int ld = COSP_COLS + 1;
     float* s_lut = s_mem;
     float* s_yy = s_lut + (size_t)L * ld;
@@ -267,9 +270,10 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), l = lane_id();
     auto stage_lut = [&](int b) {
         const float* lut_b = lut + (size_t)b * L * D;
-        for (int i = threadIdx.x; i < L * DP; i += blockDim.x) {
-            const int r = i / DP, d = i - r * DP;
-            s_lut[r * ld + d] = lut_b[(size_t)r * D + d0 + d];
+        const int DPW = RAGGED ? ((DP + NP - 1) / NP) * NP : DP;       // zeros behind a ragged end: 0 * x = 0
+        for (int i = threadIdx.x; i < L * DPW; i += blockDim.x) {
+            const int r = i / DPW, d = i - r * DPW;
+            s_lut[r * ld + d] = d < DP ? lut_b[(size_t)r * D + d0 + d] : 0.f;
         }
         for (int r = w; r < L; r += NW) {              // |y|^2 over the WHOLE row (all parts: same bits)
             float yy = 0.f;
@@ -282,8 +286,9 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     const float EPS = 1e-12f;
     const float g = grad ? *expected_gscale : __int_as_float(0x7fc00000);
     const bool write_grad = grad && (MODE == 2 || g == g);
-    const int nwa = DP / NP;                           // waves of this part that hold planes
+    const int nwa = (DP + NP - 1) / NP;                // waves of this part that hold planes
     const bool active = w < nwa;                       // wave-uniform
+    const int nc = RAGGED ? min(NP, DP - w * NP) : NP; // planes of this wave (<= 0: none)
     const int c0 = d0 + w * NP;                        // my first plane
     const int lc0 = w * NP;                            // ... as a column of s_lut
     double acc = 0.0;
@@ -322,7 +327,7 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
         const int b0 = (int)(t_begin / n_tiles);
         const uint32_t off = lane_offset((int)(t_begin - (long long)b0 * n_tiles));
 #pragma unroll
-        for (int i = 0; i < NP; ++i) request_plane(i, (const char*)pred + b0 * img_bytes, off);
+        for (int i = 0; i < NP; ++i) if (!RAGGED || i < nc) request_plane(i, (const char*)pred + b0 * img_bytes, off);
     }
     int b_staged = -1;
     for (long long gt = t_begin; gt < t_end; ++gt) {
@@ -446,12 +451,14 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
             if (DTYPE != NMSA_F32) keep_packed(r);
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                float o[PXT];
+                if (!RAGGED || i < nc) {                                // wave-uniform
+                    float o[PXT];
 #pragma unroll
-                for (int j = 0; j < PXT; ++j)
-                    o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
-                if (store) store_plane(i, grad_b, off, o, mx, my);
-                request_plane(i, pred_n, qoff);
+                    for (int j = 0; j < PXT; ++j)
+                        o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
+                    if (store) store_plane(i, grad_b, off, o, mx, my);
+                    request_plane(i, pred_n, qoff);
+                }
             }
         }
     }
@@ -485,14 +492,15 @@ size_t cosp_lds_bytes(int L, int pxt)
 int cos_kernel(int dtype, int D, int L)
 {
     if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return 0;
-    if (D <= 0 || L <= 0 || D % COSS_NP != 0) return 0;          // whole groups of 64 planes per wave
+    if (D <= 0 || L <= 0) return 0;
+    const bool ragged = D % COSS_NP != 0;                          // (k_cos_split: whole groups of 64 planes only)
     static const int on = loss_env_int("NMSA_COS_SPLIT", 1);
     const char* pe = getenv("NMSA_COS_PARTS");         // read at every call: tests switch it
     const int parts = (pe && *pe) ? atoi(pe) : -1;
     if (!on) return 0;
     const int pxt = dtype == NMSA_F32 ? 2 : 4;
     const int nw = D / COSS_NP;
-    const bool split_ok = nw <= COSS_MAX_WAVES && coss_lds_bytes(D, L, nw, pxt) <= (size_t)158 * 1024;
+    const bool split_ok = !ragged && nw <= COSS_MAX_WAVES && coss_lds_bytes(D, L, nw, pxt) <= (size_t)158 * 1024;
     const bool parts_ok = parts != 0 && D <= COSP_COLS * COSP_MAX_PARTS && cosp_lds_bytes(L, pxt) <= (size_t)158 * 1024;
     if (parts == 1 && parts_ok) return 2;
     // 512 planes fit one workgroup, but two cooperating half-columns with two workgroups per CU
@@ -573,12 +581,14 @@ int coss_launch(const void* pred, int dtype, const int32_t* indices, const float
         // tags start at 1: a zeroed buffer holds no valid granule
         if (check_hip(hipMemsetAsync(xch, 0, need, stream))) return NMSA_ERR_LAUNCH;
         const size_t lds = cosp_lds_bytes(L, pxt);
-#define COSP(DT) do { int rc_ = allow_dynamic_lds(k_cos_parts<DT, MODE>, lds); if (rc_) return rc_;              \
-        hipLaunchKernelGGL((k_cos_parts<DT, MODE>), dim3(gx * ns, B), dim3(64 * COSP_WAVES), lds, stream, pred, \
+#define COSP_(DT, RG) do { int rc_ = allow_dynamic_lds(k_cos_parts<DT, MODE, RG>, lds); if (rc_) return rc_;       \
+        hipLaunchKernelGGL((k_cos_parts<DT, MODE, RG>), dim3(gx * ns, B), dim3(64 * COSP_WAVES), lds, stream, pred, \
                            indices, lut, B, D, P, L, ns, tpw, gscale, grad, partials, status, computed_for,     \
                            counters, (unsigned long long*)xch); } while (0)
+#define COSP(DT) do { if (D % COSS_NP != 0) COSP_(DT, true); else COSP_(DT, false); } while (0)
         NMSA_DISPATCH_DTYPE(dtype, COSP)
 #undef COSP
+#undef COSP_
         return check_launch();
     }
     const int nw = D / COSS_NP;

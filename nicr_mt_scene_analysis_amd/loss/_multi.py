@@ -102,9 +102,10 @@ def supported(items: Sequence[dict]) -> bool:
 
 
 def cos_supported(pred: torch.Tensor, lut: torch.Tensor) -> bool:
-    """a one-pass cosine kernel (csrc/losses_cos.hip) takes this prediction / LUT: D % 64 == 0,
-    whole groups of 4 (f32: 2) pixels, and D <= 512 with the image's LUT within the LDS of a CU
-    (k_cos_split) or D <= 1024 (k_cos_parts: the column over cooperating workgroups)"""
+    """a one-pass cosine kernel (csrc/losses_cos.hip) takes this prediction / LUT: whole groups of
+    4 (f32: 2) pixels, D <= 1024 (k_cos_parts: the column over cooperating workgroups; any D, a
+    ragged last wave when D % 64 != 0) or D % 64 == 0, D <= 512 with the image's LUT within the LDS
+    of a CU (k_cos_split)"""
     if not (pred.is_cuda and pred.ndim == 4 and lut.ndim == 3 and pred.dtype in
             (torch.float32, torch.bfloat16, torch.float16)):
         return False

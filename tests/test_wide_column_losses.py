@@ -210,7 +210,8 @@ def test_ce_c150_full_size_vs_oracle():
 
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
-@pytest.mark.parametrize('D,L', [(64, 1), (128, 64), (320, 9), (512, 64), (576, 5), (768, 64), (1024, 33)])
+@pytest.mark.parametrize('D,L', [(64, 1), (128, 64), (320, 9), (512, 64), (576, 5), (768, 64), (1024, 33),
+                                 (96, 5), (300, 17), (700, 64), (1001, 8)])        # D % 64 != 0: a ragged last wave
 @pytest.mark.parametrize('hw', [(4, 68), (24, 44), (3, 1000)])          # last tile ragged / several tiles
 def test_cos_split_one_pass_confirms_and_recomputes(dtype, D, L, hw):
     """k_cos_split (forward + gradient in one pass, csrc/losses_cos.hip): the shapes it takes go
@@ -260,11 +261,11 @@ def test_cos_split_one_pass_confirms_and_recomputes(dtype, D, L, hw):
 
 
 def test_cos_split_falls_back_where_it_cannot_run():
-    """D not a multiple of 64, D > 1024, a LUT beyond the LDS, a pixel count that is no multiple of
-    4: the two-kernel path answers (same results, no expectation involved)"""
+    """D > 1024, a LUT beyond the LDS, a pixel count that is no multiple of 4: the two-kernel path
+    answers (same results, no expectation involved)"""
     from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi
     g = _gen(77)
-    for (B, D, H, W, L) in ((1, 96, 8, 16, 5), (1, 1088, 4, 16, 5), (1, 512, 4, 16, 200), (1, 128, 3, 7, 4)):
+    for (B, D, H, W, L) in ((1, 1030, 8, 16, 5), (1, 1088, 4, 16, 5), (1, 512, 4, 16, 200), (1, 128, 3, 7, 4)):
         x = torch.randn((B, D, H, W), device='cuda', generator=g).to(torch.bfloat16)
         lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
         idx = _index_map('segments', B, H, W, L, g)
@@ -314,7 +315,7 @@ def cos_parts_env():
 
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
 @pytest.mark.parametrize('D,L,parts', [(64, 3, None), (256, 17, None), (512, 64, None), (768, 64, None),
-                                       (640, 9, None), (1024, 21, None),
+                                       (640, 9, None), (1024, 21, None), (200, 9, None), (833, 30, None),
                                        (128, 5, 1), (320, 17, 1), (512, 64, 1)])
 @pytest.mark.parametrize('hw,run', [((8, 200), 3), ((9, 444), 5), ((33, 100), 4), ((6, 1000), 64)])
 def test_cos_split_runs_of_several_tiles_per_workgroup(dtype, D, L, parts, hw, run, cos_split_run, cos_parts_env):
