@@ -213,7 +213,7 @@ def secondary_pipeline(ops, syn, dev, B, C, H, W, K, dtype, with_metrics=True, o
     ev = []
 
     def step():
-        r = ops.panoptic_pipeline(*a, fused_kernel_events=ev)
+        r = ops.panoptic_pipeline(*a, want_foreground=False, fused_kernel_events=ev)
         if m is not None:
             m.update_and_reduce(r['panoptic'])
     ms = hip_timed(step, reps=20, warm=5)
@@ -225,7 +225,7 @@ def secondary_pipeline(ops, syn, dev, B, C, H, W, K, dtype, with_metrics=True, o
 
     def step2(i):
         with torch.cuda.stream(streams[i % 2]):
-            r = ops.panoptic_pipeline(*a)
+            r = ops.panoptic_pipeline(*a, want_foreground=False)
             if m2 is not None:
                 m2.update_and_reduce(r['panoptic'])
     ms2 = float('nan')
@@ -507,7 +507,7 @@ def secondary_cfg5_full(ops, syn, dev, B=16, C=150, H=768, W=1024, K=48, D=512, 
     leaves = (logits, center, offset, ori, emb)
 
     def step():
-        r = ops.panoptic_pipeline(*a)
+        r = ops.panoptic_pipeline(*a, want_foreground=False)
         metrics.update_and_reduce(r['panoptic'])
         for t in leaves:
             t.grad = None
@@ -812,7 +812,9 @@ def main():
 
     def step(i, record):
         with torch.cuda.stream(streams[i % len(streams)]):
-            r = ops.panoptic_pipeline(logits, center, offset, is_thing,
+            # (the foreground mask — a lookup of the class map, 1 B/px more to store — is not part of
+            # the step: neither the merge nor the metrics read it; the API builds it when read)
+            r = ops.panoptic_pipeline(logits, center, offset, is_thing, want_foreground=False,
                                       fused_kernel_events=events if record else None)
             if metrics is not None:
                 metrics.update_and_reduce(r['panoptic'], dist)
@@ -890,7 +892,8 @@ def main():
     # the same kernel without the metric kernels overlapping on the side stream (untimed)
     iso_events = []
     for _ in range(20):
-        ops.panoptic_pipeline(logits, center, offset, is_thing, fused_kernel_events=iso_events)
+        ops.panoptic_pipeline(logits, center, offset, is_thing, want_foreground=False,
+                              fused_kernel_events=iso_events)
     torch.cuda.synchronize()
     iso_ms = float(np.mean([a.elapsed_time(b) for a, b in iso_events[2:]]))
     # HBM bytes per launch from the committed PMC passes of this command (separate

@@ -558,13 +558,19 @@ __global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(W
 
         // ---- stores --------------------------------------------------------------------
         if (VEC && active) {
-            *(uchar4*)(sem_u8 + (size_t)b * P + p0) =
-                make_uchar4((uint8_t)cls[0], (uint8_t)cls[1], (uint8_t)cls[2], (uint8_t)cls[3]);
-            *(uchar4*)(inst + (size_t)b * P + p0) =
-                make_uchar4((uint8_t)id[0], (uint8_t)id[1], (uint8_t)id[2], (uint8_t)id[3]);
-            if (fg_out)
-                *(uchar4*)(fg_out + (size_t)b * P + p0) =
-                    make_uchar4(fg[0], fg[1], fg[2], fg[3]);
+            typedef unsigned char u8x4_t __attribute__((ext_vector_type(4)));
+            const u8x4_t s4 = {(uint8_t)cls[0], (uint8_t)cls[1], (uint8_t)cls[2], (uint8_t)cls[3]};
+            const u8x4_t i4 = {(uint8_t)id[0], (uint8_t)id[1], (uint8_t)id[2], (uint8_t)id[3]};
+            const u8x4_t f4 = {(uint8_t)fg[0], (uint8_t)fg[1], (uint8_t)fg[2], (uint8_t)fg[3]};
+            if (ablate & 8) {                   // experiment: streaming stores for the u8 maps
+                __builtin_nontemporal_store(s4, (u8x4_t*)(sem_u8 + (size_t)b * P + p0));
+                __builtin_nontemporal_store(i4, (u8x4_t*)(inst + (size_t)b * P + p0));
+                if (fg_out) __builtin_nontemporal_store(f4, (u8x4_t*)(fg_out + (size_t)b * P + p0));
+            } else {
+                *(u8x4_t*)(sem_u8 + (size_t)b * P + p0) = s4;
+                *(u8x4_t*)(inst + (size_t)b * P + p0) = i4;
+                if (fg_out) *(u8x4_t*)(fg_out + (size_t)b * P + p0) = f4;
+            }
             if (WITH_SCORE)
                 *(float4*)(score + (size_t)b * P + p0) =
                     make_float4(st.se[0], st.se[1], st.se[2], st.se[3]);

@@ -130,7 +130,7 @@ class PanopticPostprocessing(DensePostprocessingBase):
                 distance_threshold=post._offset_distance_threshold,
                 max_instances_per_category=self._max_instances_per_category,
                 void_label=0, max_centers=post._max_centers,
-                want_score=self._compute_scores, want_foreground=True,
+                want_score=self._compute_scores, want_foreground=False,
                 want_panoptic_semantic=False, on_centers=on_centers)
         if self._defer_host_sync:
             p = run()
@@ -169,7 +169,10 @@ class PanopticPostprocessing(DensePostprocessingBase):
         # ---- panoptic entries (panoptic.py:118-167) ---------------------------------------
         panoptic_seg = p['panoptic']
         instance_seg = p['instance']
-        r['panoptic_foreground_mask'] = p['foreground']
+        # foreground = "the pixel's class is a thing" (panoptic.py:123-127): a lookup of the class map,
+        # built when somebody reads it — the fused pass does not store a third per-pixel map
+        # (small stores are what a read-dominated stream pays most for: DESIGN.md 5)
+        r.set_lazy('panoptic_foreground_mask', lambda: thing_lut[sem_u8.long()].to(torch.bool))
         r['panoptic_segmentation_deeplab'] = panoptic_seg
         # id dicts / instance meta: Python objects built from the host tables when first read
         r.set_lazy('panoptic_segmentation_deeplab_ids',

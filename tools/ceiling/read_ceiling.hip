@@ -41,6 +41,43 @@ __global__ __launch_bounds__(256) void k_planes(const float* __restrict__ x, int
     if (acc == 123.456f) out[blockIdx.x] = acc;
 }
 
+// the same walk + what the fused kernel stores: NS u8 maps (uchar4 per lane) and optionally two more
+// 16-B loads per lane at the END of the walk (the offset planes)
+template <int U, int NS, bool TAIL_LOADS>
+__global__ __launch_bounds__(256) void k_planes_store(const float* __restrict__ x, int C, size_t P,
+                                                      const float* __restrict__ off, unsigned char* __restrict__ o8)
+{
+    const size_t b = blockIdx.y;
+    const size_t p0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    const float* base = x + b * C * P + p0;
+    float acc = 0.f;
+    for (int c = 0; c < C; c += U) {
+        f4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) v[u] = __builtin_nontemporal_load((const f4*)(base + (size_t)(c + u) * P));
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc = fmaxf(acc, fmaxf(fmaxf(v[u].x, v[u].y), fmaxf(v[u].z, v[u].w)));
+    }
+    if (TAIL_LOADS) {
+        const f4 a = __builtin_nontemporal_load((const f4*)(off + b * 2 * P + p0));
+        const f4 c2 = __builtin_nontemporal_load((const f4*)(off + b * 2 * P + P + p0));
+        acc += a.x + c2.y;
+    }
+    typedef unsigned char u8x4 __attribute__((ext_vector_type(4)));
+    typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+    const unsigned char q = (unsigned char)acc;
+    if (NS == 12) {                   // ONE 8-byte store per lane: two u8 maps packed as u16
+        *(u16x4*)(o8 + (b * P + p0) * 2) = u16x4{q, q, q, q};
+    } else if (NS >= 20) {            // NS - 20 maps, non-temporal stores
+#pragma unroll
+        for (int k = 0; k < NS - 20; ++k)
+            __builtin_nontemporal_store(u8x4{q, q, q, q}, (u8x4*)(o8 + ((size_t)k * gridDim.y + b) * P + p0));
+    } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) *(u8x4*)(o8 + ((size_t)k * gridDim.y + b) * P + p0) = u8x4{q, q, q, q};
+    }
+}
+
 #define CK(e) do { hipError_t e_ = (e); if (e_ != hipSuccess) { printf("hip error %d line %d\n", (int)e_, __LINE__); exit(1); } } while (0)
 
 template <typename F>
@@ -71,5 +108,10 @@ int main()
     LIN(4, true) LIN(8, true) LIN(16, true) LIN(8, false)
 #define PL(U, NT) { printf("planes U=%d nt=%d:", U, NT); float ms = timeit([&] { hipLaunchKernelGGL((k_planes<U, NT>), dim3(P / 1024, B), dim3(256), 0, 0, x, C, P, out); }, 20); printf("  -> %.2f TB/s\n", gb / ms); }
     PL(4, true) PL(8, true) PL(10, true) PL(8, false)
+    float* off; unsigned char* o8;
+    CK(hipMalloc(&off, (size_t)B * 2 * P * 4)); CK(hipMalloc(&o8, (size_t)3 * B * P));
+    CK(hipMemset(off, 0, (size_t)B * 2 * P * 4));
+#define PS(NS, TL) { printf("planes U=8 + %d u8 stores, tail loads %d:", NS, TL); float ms = timeit([&] { hipLaunchKernelGGL((k_planes_store<8, NS, TL>), dim3(P / 1024, B), dim3(256), 0, 0, x, C, P, off, o8); }, 20); printf("  -> %.2f TB/s of the logits\n", gb / ms); }
+    PS(1, false) PS(2, false) PS(3, false) PS(12, false) PS(22, false) PS(23, false) PS(3, true) PS(2, true) PS(12, true)
     return 0;
 }

@@ -29,7 +29,7 @@ events = []
 
 def step(i):
     with torch.cuda.stream(streams[i % 2]):
-        r = ops.panoptic_pipeline(logits, center, offset, is_thing,
+        r = ops.panoptic_pipeline(logits, center, offset, is_thing, want_foreground=not os.environ.get('DIAG_NO_FG'),
                                   fused_kernel_events=events if EVENTS else None)
         metrics.update_and_reduce(r['panoptic'], None)
     return r
