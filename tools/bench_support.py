@@ -132,6 +132,16 @@ class MetricAccumulators:
                 self.miou.reset()                   # next step starts from zero, not synced
                 self.pq.reset()
 
+    def enqueue(self, panoptic_pred: torch.Tensor) -> None:
+        """the update kernels of the first accumulator set on the CURRENT stream, nothing else
+        (what a hipGraph of the metric chain captures)"""
+        miou, pq = self._sets[0]
+        if self.fused_metrics:
+            pq.update_with_miou(panoptic_pred, self.target_panoptic, miou, self.target_semantic, self.max_inst)
+        else:
+            miou.update_from_panoptic(panoptic_pred, self.target_semantic, self.max_inst)
+            pq.update(panoptic_pred, self.target_panoptic)
+
     def warm_collective(self, dist=None) -> None:
         """untimed: one all-reduce per state dtype on scratch buffers so that communicator set-up
         and the first-use costs of the collective do not land in the timed region"""
