@@ -17,7 +17,9 @@ B=32 per GPU, C=40, 640x480), followed — when the metric accumulators are
 enabled — by the mIoU confusion-matrix + PQ updates of configs[3].  Images are
 independent units, so ranks shard the batch (weak scaling: 32 images per GPU)
 with no data-path collective; only the few-KB metric accumulators are
-all-reduced (RCCL) inside the timed region.
+all-reduced (RCCL) inside the timed region.  Behind the warm-up the step is captured into
+hipGraphs (pipeline per batch stream + metric chain) and replayed; `--no-graph` launches every
+kernel from Python.
 
 Prints ONE JSON line on rank 0 (see DESIGN.md "Measurement").  At N=1 the line also
 carries `secondary`: the other BASELINE.json configurations (bf16 logits, configs[2] losses,
