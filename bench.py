@@ -878,7 +878,8 @@ def main():
     gc.disable()                               # no collector pause inside the (few-ms) timed region
     # the live duration of the dominant kernel is sampled on every 4th step (+ the last): each pair
     # of event records costs the pipeline ~4 us, 1.2 % of a K = 20 run when every step carries one
-    sampled = [i % 4 == 0 or i == args.steps - 1 for i in range(args.steps)]
+    # (not the first step: a replayed step reaches the GPU ~30 us sooner than an eager one)
+    sampled = [i % 4 == 2 or i == args.steps - 1 for i in range(args.steps)]
     done = [torch.cuda.Event() for _ in range(len(streams) + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
