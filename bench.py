@@ -878,8 +878,11 @@ def main():
     gc.disable()                               # no collector pause inside the (few-ms) timed region
     # the live duration of the dominant kernel is sampled on every 4th step (+ the last): each pair
     # of event records costs the pipeline ~4 us, 1.2 % of a K = 20 run when every step carries one
-    # (not the first step: a replayed step reaches the GPU ~30 us sooner than an eager one)
-    sampled = [i % 4 == 2 or i == args.steps - 1 for i in range(args.steps)]
+    # (neither the first nor the last step: a replayed step reaches the GPU at once, an eager one
+    # over the ~0.17 ms its launches take from Python — at the head and in the tail that is idle time)
+    sampled = [i % 4 == 2 and i < args.steps - 1 for i in range(args.steps)]
+    if not any(sampled):
+        sampled[args.steps // 2] = True
     done = [torch.cuda.Event() for _ in range(len(streams) + 1)]
     t0 = time.perf_counter()
     for i in range(args.steps):
