@@ -837,21 +837,30 @@ def main():
     graphs = None
     use_graph = (not args.no_graph and len(streams) >= 1
                  and (metrics is None or (metrics.stream is not None and not metrics.sync_every_step)))
+    graph_error = None
     if use_graph:
-        torch.cuda.synchronize()
-        graphs = []
-        for st in streams:
-            gp = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gp, stream=st):
-                out = ops.panoptic_pipeline(logits, center, offset, is_thing, want_foreground=False)
-            gm = None
-            if metrics is not None:
-                torch.cuda.synchronize()
-                gm = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gm, stream=metrics.stream):
-                    metrics.enqueue(out['panoptic'])
-            graphs.append((gp, gm, out, torch.cuda.Event()))
-        torch.cuda.synchronize()
+        # (thread-local capture mode: the RCCL watchdog thread of a launched run polls events
+        # while we capture; a failed capture falls back to the eager loop and says so in the line)
+        try:
+            torch.cuda.synchronize()
+            graphs = []
+            for st in streams:
+                gp = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gp, stream=st, capture_error_mode='thread_local'):
+                    out = ops.panoptic_pipeline(logits, center, offset, is_thing, want_foreground=False)
+                gm = None
+                if metrics is not None:
+                    torch.cuda.synchronize()
+                    gm = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gm, stream=metrics.stream, capture_error_mode='thread_local'):
+                        metrics.enqueue(out['panoptic'])
+                graphs.append((gp, gm, out, torch.cuda.Event()))
+            torch.cuda.synchronize()
+        except Exception as e:                  # noqa: BLE001 — any capture problem: measure eagerly
+            graphs = None
+            graph_error = f'{type(e).__name__}: {e}'[:200]
+            print(f'bench.py: hipGraph capture failed, eager loop instead: {graph_error}', file=sys.stderr, flush=True)
+            torch.cuda.synchronize()
 
     def graph_step(i):
         gp, gm, out, ready = graphs[i % len(streams)]
@@ -997,7 +1006,7 @@ def main():
                    'batches_in_flight': len(streams),
                    'launch': ('hipGraph replay (pipeline graph + metric-chain graph per step); the steps '
                               'that carry event records are launched kernel by kernel') if graphs is not None
-                   else 'kernel by kernel from Python',
+                   else 'kernel by kernel from Python' + (f' (graph capture failed: {graph_error})' if graph_error else ''),
                    'parallelism': f'dp{world} (images sharded, accumulators all-reduced '
                                   f'{"every step" if args.metric_sync == "step" else "once per run, timed"})'},
         'collective': {'backend': ('rccl' if backend == 'nccl' else backend), 'rccl_ranks': rccl_ranks,
