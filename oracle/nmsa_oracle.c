@@ -9,8 +9,9 @@
  * (oracle/gen_golden.py -> tests/golden/ *.npz) and against the known-answer
  * tables of the reference's tests (tests/test_metrics.py:76-446).
  *
- * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load
- * this library.  The product path (nicr_mt_scene_analysis_amd) never does.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (the timed CPU
+ * baseline and, behind the timed regions, its checks of GPU results) may load this
+ * library.  The product path (nicr_mt_scene_analysis_amd) never does.
  *
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off: every float op below is
  * a single IEEE-754 rounding unless written as fmaf()).

@@ -1,8 +1,10 @@
 """
 TEST INFRASTRUCTURE — numpy front-end of the C oracle (oracle/nmsa_oracle.c).
 
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import
-this module; the product package never does.
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg (the timed
+CPU baseline and, behind the timed regions, the checks of GPU results against it:
+`gpu_matches_oracle_bit_exact`, `oracle_check` of the cosine legs) import this
+module — as the checker, never as the thing measured; the product package never does.
 """
 import ctypes as C
 import os
