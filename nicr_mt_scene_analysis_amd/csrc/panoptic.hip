@@ -86,10 +86,10 @@ __device__ __forceinline__ float4 load_px4(const void* base, size_t elem_off, in
 // on two kinds of columns, both re-evaluated exactly by the functions below (rare, re-read):
 //  * a NaN, a +inf, or nothing but -inf: softmax is all-NaN and torch.max returns index 0;
 //    a column with some -inf entries is an ordinary one;
-//  * a class BELOW the maximum's index whose logit is so close to the maximum (<= 2^-23) that
-//    ATen's fp32 softmax gives both the same probability: the lower index wins.  Decided with
-//    the reference's own arithmetic (argmax_state.hpp: class_by_probability); such gaps only
-//    exist where the format's spacing is <= 2^-23, i.e. for |max| <= tie_band_magnitude — the
+//  * a class BELOW the maximum's index whose logit is so close to the maximum (< 1.5 * 2^-24)
+//    that ATen's fp32 softmax gives both the same probability: the lower index wins.  Decided
+//    with the reference's own arithmetic (argmax_state.hpp: class_by_probability); such gaps only
+//    exist where the format's spacing is <= 2^-24, i.e. for |max| <= tie_band_magnitude — the
 //    trigger, one compare per pixel.
 // class of one column by the reference's rule, given its maximum m (the running maximum of the
 // fast path; with a NaN / +inf in the column the answer is 0 whatever m is): one walk unless an
