@@ -222,10 +222,14 @@ __device__ __forceinline__ uint32_t hash_id(int64_t k)
 }
 
 // insert-or-add; returns false when no slot was found within `max_probe` probes
+// (`#pragma unroll 1`: with the probe counts constant at the call sites the compiler unrolled these
+// loops completely — k_pq_count was 37 900 instructions with 5 400 SGPR spills to lane registers,
+// now 5 700 and 14; the hot path, a hit in the home slot, never enters them)
 __device__ __forceinline__ bool table_add(int64_t* keys, uint32_t* cnts, uint32_t mask,
                                           int64_t key, uint32_t n, int max_probe)
 {
     uint32_t slot = hash_id(key) & mask;
+#pragma unroll 1
     for (int probe = 0; probe < max_probe; ++probe) {
         const int64_t cur = *(volatile int64_t*)&keys[slot];
         if (cur == key) { atomicAdd(&cnts[slot], n); return true; }
@@ -250,6 +254,7 @@ __device__ __forceinline__ bool table_add_listed(int64_t* keys, uint32_t* cnts, 
                                                  int* list_n, uint32_t* list_slots, int list_cap)
 {
     uint32_t slot = hash_id(key) & mask;
+#pragma unroll 1
     for (int probe = 0; probe < max_probe; ++probe) {
         const int64_t cur = *(volatile int64_t*)&keys[slot];
         if (cur == key) { atomicAdd(&cnts[slot], n); return true; }

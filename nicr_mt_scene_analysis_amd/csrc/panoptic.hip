@@ -367,10 +367,14 @@ __device__ __forceinline__ void group4(const Centers& cen, int n,
 // dynamic LDS: float2 centers[max_centers] (used with > 64 centers only) | i32 vote_key[FUSED_VOTE_SLOTS]
 //              | u32 vote_cnt[FUSED_VOTE_SLOTS]
 // `ablate`: diagnostics only (NMSA_FUSED_ABLATE; bits 1 no votes, 2 no search, 4 no offset loads)
+// occupancy: capped at 5 waves per SIMD.  The kernel alone runs as fast with 5 as with 7 or 8
+// (0.2766-0.277 vs 0.2776-0.2784 ms isolated, same box), and the free wave slots let the small
+// kernels of the same step (NMS rows, metric chain) start beside it: whole step +0.6-0.9 % at
+// K = 50 in three interleaved same-box passes; 4 waves: -7 %.
 // =================================================================================
 template <int DTYPE, bool VEC, bool WITH_SCORE, int UNROLL = 8, bool NT = true,
           bool EARLY_OFFSETS = false, bool TILED = false, int TILE_LOG2W = 6>
-__global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(WITH_SCORE ? 5 : 7, 8))) void k_panoptic_fused(
+__global__ __launch_bounds__(FUSED_THREADS) __attribute__((amdgpu_waves_per_eu(5, WITH_SCORE ? 8 : 5))) void k_panoptic_fused(
     const void* __restrict__ logits, const float* __restrict__ offset,
     const int32_t* __restrict__ centers_yx, const int32_t* __restrict__ n_centers,
     const uint8_t* __restrict__ is_thing,
