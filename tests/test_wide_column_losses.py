@@ -116,7 +116,7 @@ def _ce_case(B, C, H, W, dtype, seed, void_frac=0.2):
 @pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
 @pytest.mark.parametrize('C', [49, 64, 150, 151, 255])
 @pytest.mark.parametrize('label_smoothing', [0.0, 0.1])
-@pytest.mark.parametrize('shape', [(2, 24, 36), (1, 8, 1000), (3, 5, 8)])
+@pytest.mark.parametrize('shape', [(2, 24, 36), (1, 8, 1000), (3, 5, 8), (2, 7, 9)])    # last: rows not readable as 8-byte pieces
 def test_ce_split_vs_torch_fp64(dtype, C, label_smoothing, shape):
     from nicr_mt_scene_analysis_amd.loss import _functional as _F
     if not _F.speculation_enabled():
@@ -161,6 +161,72 @@ def test_ce_split_vs_torch_fp64(dtype, C, label_smoothing, shape):
     np.testing.assert_allclose(float(loss_u), float(ref), rtol=RTOL)
     np.testing.assert_allclose(xu.grad.double().cpu().numpy(), xs.grad.double().cpu().numpy(),
                                rtol=tol, atol=atol)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float32, torch.float16])
+@pytest.mark.parametrize('C,hw', [(150, (40, 96)), (64, (33, 64)), (255, (16, 128))])
+def test_ce_split_piecewise_constant_labels(dtype, C, hw):
+    """label maps of real scenes are piecewise constant: most class planes of a wave's 64 x PXT pixels
+    have no target pixel and k_ce_split skips their target selects (the wave-uniform `present`
+    mask); blocks of 8 x 16 pixels, a void stripe, one block row of a single class"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    H, W = hw
+    B = 2
+    g = _gen(C + H)
+    x = (torch.randn((B, C, H, W), device='cuda', generator=g) * 3).to(dtype)
+    coarse = torch.randint(1, C + 1, (B, (H + 7) // 8, (W + 15) // 16), device='cuda', generator=g)
+    t = coarse.repeat_interleave(8, 1).repeat_interleave(16, 2)[:, :H, :W].contiguous()
+    t[:, :, 5:9] = 0
+    t[:, 8:16] = C                                       # the last class: held by the last wave only
+    t = t.to(torch.uint8)
+    w = torch.rand(C, device='cuda', generator=g) + 0.5
+    n = F_.count_u8(t, 1, C)
+    xs = x.clone().requires_grad_(True)
+    loss, n_el, wsum = F_.cross_entropy_sum(xs, t, w, 0.0, expected_scale=F_.expected_scale(n))
+    (loss / n_el).backward()
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t.long() - 1, weight=w.double(), reduction='sum', ignore_index=-1)
+    (ref / int(n)).backward()
+    assert int(n_el) == int(n)
+    np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL)
+    tol = _grad_tol(dtype)
+    atol = max(tol * float(xr.grad.abs().max()) * 0.05, 4e-6 * float(w.max()) / int(n),
+               6e-8 if dtype == torch.float16 else 0.0)
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(), rtol=tol, atol=atol)
+    # the target elements themselves (p - 1 cancels there): taken from the logit, tight
+    tgt = (t.long() - 1).clamp(min=0).unsqueeze(1)
+    got_t = xs.grad.double().gather(1, tgt)[t.unsqueeze(1) != 0]
+    want_t = xr.grad.gather(1, tgt)[t.unsqueeze(1) != 0]
+    np.testing.assert_allclose(got_t.cpu().numpy(), want_t.cpu().numpy(), rtol=tol, atol=atol)
+
+
+def test_ce_split_bf16_far_classes_keep_their_gradient():
+    """the wide kernel keeps the exponentials of its sum walk in the register tile as well (bf16:
+    fp16 pairs of e * 2^14): classes 12 ... 20 below the maximum still get torch's fp32 softmax
+    gradient rounded to bf16, element-wise, at 150 classes"""
+    from nicr_mt_scene_analysis_amd.loss import _functional as F_
+    B, C, H, W = 1, 150, 8, 64
+    g = _gen(151)
+    gaps = 12.0 + 8.0 * torch.rand((B, C, H, W), device='cuda', generator=g)
+    x = -gaps
+    top = torch.randint(0, C, (B, 1, H, W), device='cuda', generator=g)
+    x.scatter_(1, top, 0.0)
+    x = (x + torch.randn((B, 1, H, W), device='cuda', generator=g)).to(torch.bfloat16)
+    t = torch.randint(1, C + 1, (B, H, W), device='cuda', generator=g).to(torch.uint8)
+    n = F_.count_u8(t, 1, C)
+    xs = x.clone().requires_grad_(True)
+    loss, n_el, _ = F_.cross_entropy_sum(xs, t, None, 0.0, expected_scale=F_.expected_scale(n))
+    (loss / n_el).backward()
+    xr = x.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t.long() - 1, reduction='sum')
+    (ref / int(n)).backward()
+    want = xr.grad.to(torch.bfloat16).float()
+    got = xs.grad.float()
+    np.testing.assert_allclose(float(loss), float(ref), rtol=RTOL)
+    np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2 ** -7, atol=1e-9 / int(n) * 0.1)
+    small = (xr.grad.abs() < 1e-5 / int(n)) & (xr.grad != 0)
+    assert int(small.sum()) > 1000 and bool((got[small] != 0).all())
+
 
 
 def test_ce_split_minus_infinity_logits():
