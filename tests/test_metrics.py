@@ -446,10 +446,13 @@ def test_bench_accumulators_reduce_through_metric_sync():
 
 
 @gpu
+@pytest.mark.parametrize('max_inst,offset', [(1 << 16, 256 ** 3), (1000, 10 ** 7)])
 @pytest.mark.parametrize('shape', [(3, 48, 64), (2, 37, 41), (1, 480, 640)])
-def test_fused_pq_confmat_equals_separate_updates(shape):
+def test_fused_pq_confmat_equals_separate_updates(shape, max_inst, offset):
     """nmsa_pq_update_with_confmat (one pass over the prediction) == nmsa_pq_update +
-    nmsa_confmat_update, bit for bit, incl. odd sizes (scalar path) and repeated updates"""
+    nmsa_confmat_update, bit for bit, incl. odd sizes (scalar path) and repeated updates; with the
+    reference's power-of-two divisor / offset (shifts, branch-free range tests) and with decimal
+    ones (the generic instantiation: 64-bit division and multiply)"""
     from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
     B, H, W = shape
     n = 9
@@ -459,15 +462,15 @@ def test_fused_pq_confmat_equals_separate_updates(shape):
     def blocky(hi):
         c = torch.randint(0, hi, (B, (H + 7) // 8, (W + 7) // 8), device='cuda', generator=g)
         return c.repeat_interleave(8, 1).repeat_interleave(8, 2)[:, :H, :W].contiguous()
-    pred = blocky(n) * 65536 + blocky(3)
-    tgt = blocky(n) * 65536 + blocky(3)
+    pred = blocky(n) * max_inst + blocky(3)
+    tgt = blocky(n) * max_inst + blocky(3)
     tsem = blocky(n).to(torch.uint8)
-    pq_a, pq_b = (PanopticQuality(n, 0, 1 << 16, 256 ** 3, is_thing, device='cuda') for _ in range(2))
+    pq_a, pq_b = (PanopticQuality(n, 0, max_inst, offset, is_thing, device='cuda') for _ in range(2))
     mi_a, mi_b = (MeanIntersectionOverUnion(n, device='cuda') for _ in range(2))
     for _ in range(2):
         pq_a.update(pred, tgt)
-        mi_a.update_from_panoptic(pred, tsem, 65536)
-        pq_b.update_with_miou(pred, tgt, mi_b, tsem, 65536)
+        mi_a.update_from_panoptic(pred, tsem, max_inst)
+        pq_b.update_with_miou(pred, tgt, mi_b, tsem, max_inst)
     torch.cuda.synchronize()
     assert mi_a.confmat.sum() == 2 * B * H * W
     assert torch.equal(mi_a.confmat, mi_b.confmat)
@@ -476,9 +479,18 @@ def test_fused_pq_confmat_equals_separate_updates(shape):
     # a label outside the matrix is reported through the mIoU status word
     bad = tsem.clone()
     bad[0, 0, 0] = 200
-    pq_b.update_with_miou(pred, tgt, mi_b, bad, 65536)
+    pq_b.update_with_miou(pred, tgt, mi_b, bad, max_inst)
     with pytest.raises(ValueError):
         mi_b.compute()
+    # so are a negative prediction and a class beyond the matrix (bincount's errors in the reference)
+    for wrong in (-5, (n + 3) * max_inst):
+        mi_c = MeanIntersectionOverUnion(n, device='cuda')
+        pq_c = PanopticQuality(n, 0, max_inst, offset, is_thing, device='cuda')
+        p2 = pred.clone()
+        p2[-1, -1, -1] = wrong
+        pq_c.update_with_miou(p2, tgt, mi_c, tsem, max_inst)
+        with pytest.raises(ValueError):
+            mi_c.compute()
 
 
 @gpu
