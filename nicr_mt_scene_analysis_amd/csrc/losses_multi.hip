@@ -232,9 +232,15 @@ __global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, c
 // the element-wise and von Mises bodies are selected at run time (they are small).
 // (up to 40 class planes in registers: 4 waves per SIMD as in k_ce_fused — the calls of the small
 // bodies cost the allocator 16 registers otherwise and one wave per SIMD with them)
+#ifndef NMSA_MULTI_FWD_U
+#define NMSA_MULTI_FWD_U 4          // 16-bit logits: class planes per group of the forward-only walk
+#endif
+#ifndef NMSA_MULTI_FWD_WAVES
+#define NMSA_MULTI_FWD_WAVES 5      // forward-only launches: the streaming CE walk needs few registers
+#endif
 template <int CE_DT, int CE_NG, bool CE_SM, int MODE>        // MODE as in ce_fused_body
 __global__ __launch_bounds__(LOSS_THREADS)
-__attribute__((amdgpu_waves_per_eu((CE_NG <= 5) ? 4 : 3, (CE_NG <= 5) ? 8 : 3))) void k_multi_loss(
+__attribute__((amdgpu_waves_per_eu((MODE == 1) ? NMSA_MULTI_FWD_WAVES : (CE_NG <= 5) ? 4 : 3, (MODE != 1 && CE_NG > 5) ? 3 : 8))) void k_multi_loss(
     MultiArgs a, const float* __restrict__ expect, const float* __restrict__ gs,
     LossPartial* __restrict__ partials, int* __restrict__ status)
 {
@@ -277,7 +283,9 @@ __attribute__((amdgpu_waves_per_eu((CE_NG <= 5) ? 4 : 3, (CE_NG <= 5) ? 8 : 3)))
                     // flight, few registers) is faster than the register-resident column
                     constexpr int FPX = (CE_DT == NMSA_F32) ? 4 : 8;
                     const int vec16 = (it.P % FPX == 0) && ((((uintptr_t)it.pred) & 15) == 0);
-                    ce_fwd_body<CE_DT, FPX, CE_SM, (CE_DT == NMSA_F32) ? 8 : 4>(
+                    // (two inlined copies with `vec` folded to a constant — no per-plane branch in the
+                    // hot one — were measured SLOWER: 0.51 vs 0.45 ms for the forward-only call)
+                    ce_fwd_body<CE_DT, FPX, CE_SM, (CE_DT == NMSA_F32) ? 8 : NMSA_MULTI_FWD_U>(
                         it.pred, (const uint8_t*)it.mask, it.weights, it.C, it.P, it.param, vec16, slot, status,
                         nullptr, s_w, bx, it.nbx, b);
                 } else if constexpr (CE_NG != 0) {
