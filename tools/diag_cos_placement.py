@@ -20,7 +20,7 @@ idx = torch.randint(0, L + 1, (B, H // 16, W // 16), device=dev, generator=g, dt
 idx = idx.repeat_interleave(16, 1).repeat_interleave(16, 2).contiguous()
 lut = torch.nn.functional.normalize(torch.randn((B, L, D), device=dev, generator=g), dim=-1)
 cos = CosineEmbeddingLoss()
-spacers = [0, 1 << 20, 3 << 20, 257 << 20, 1 << 30, 5 << 30]
+spacers = [0, 1 << 20, 3 << 20, 257 << 20, 1 << 30, 5 << 30] + [(2 * k + 1) << 21 for k in range(10)]
 for trial, sp in enumerate(spacers):
     torch.cuda.empty_cache()
     keep = torch.empty(sp, device=dev, dtype=torch.uint8) if sp else None
@@ -34,6 +34,7 @@ for trial, sp in enumerate(spacers):
         l, n = cos.lut_sum(pred, idx, lut)
         (l / n).backward()
     ms = [bench.hip_timed(fwd_bwd, reps=3, warm=1) for _ in range(3)]
-    print(f'trial {trial}: spacer {sp >> 20:5d} MiB, pred at {pred.data_ptr():#x}: '
-          + ' '.join(f'{m:.3f}' for m in ms) + ' ms', flush=True)
+    gp = pred.grad.data_ptr()
+    print(f'trial {trial}: spacer {sp >> 20:5d} MiB, pred at {pred.data_ptr():#x}, gradient at {gp:#x} '
+          f'(+{(gp - pred.data_ptr()) >> 21} x 2 MiB): ' + ' '.join(f'{m:.3f}' for m in ms) + ' ms', flush=True)
     del pred, keep
