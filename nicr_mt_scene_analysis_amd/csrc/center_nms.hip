@@ -379,19 +379,26 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_compact(
     const uint32_t* gbits = cand_bits + (size_t)b * words_per_image;
     const uint8_t* fgb = fg ? fg + (size_t)b * P : nullptr;
     if (LDS_BITS) {
-        for (int i0 = threadIdx.x; i0 < words_per_image; i0 += 4 * SEL_THREADS) {
-            uint32_t v[4];
+        // 16-byte pieces, 4 in flight per thread: the 38 KB mask of a 640x480 image is ONE round trip
+        // for the 1024 threads (4-byte loads: three)
+        const int nquads = ((((uintptr_t)gbits) & 15) == 0) ? (words_per_image >> 2) : 0;
+        for (int i0 = threadIdx.x; i0 < nquads; i0 += 4 * SEL_THREADS) {
+            uint4 v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * SEL_THREADS;
-                v[u] = (i < words_per_image) ? gbits[i] : 0u;
+                v[u] = (i < nquads) ? ((const uint4*)gbits)[i] : make_uint4(0u, 0u, 0u, 0u);
             }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * SEL_THREADS;
-                if (i < words_per_image) s_bits[i] = v[u];
+                if (i < nquads) {
+                    s_bits[4 * i] = v[u].x; s_bits[4 * i + 1] = v[u].y;
+                    s_bits[4 * i + 2] = v[u].z; s_bits[4 * i + 3] = v[u].w;
+                }
             }
         }
+        for (int i = 4 * nquads + threadIdx.x; i < words_per_image; i += SEL_THREADS) s_bits[i] = gbits[i];
         __syncthreads();
     }
     const uint32_t* bits = LDS_BITS ? (const uint32_t*)s_bits : gbits;

@@ -935,23 +935,32 @@ __global__ __launch_bounds__(ASSIGN_THREADS) void k_assign(
         const int nr = min(rows_per_pass, 256 - r0);
         const int nwords = nr * NC;
         uint32_t* src = tab + (size_t)r0 * NC;
-        // 8 independent loads in flight per thread (a load -> LDS store chain per word would pay
-        // one memory latency per iteration)
-        for (int i0 = t; i0 < nwords; i0 += 8 * ASSIGN_THREADS) {
-            uint32_t v[8];
+        // 8 independent 16-byte loads in flight per thread (a load -> LDS store chain per word
+        // would pay one memory latency per iteration; with 4-byte loads the 42 KB of a 41-class
+        // table were six round trips for the 256 threads, now two): rows start 16-byte aligned
+        // (256 NC words per image; checked here, an unaligned pass reads word by word)
+        const int nquads = ((((uintptr_t)src) & 15) == 0) ? (nwords >> 2) : 0;
+        for (int i0 = t; i0 < nquads; i0 += 8 * ASSIGN_THREADS) {
+            uint4 v[8];
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * ASSIGN_THREADS;
-                v[u] = (i < nwords) ? src[i] : 0u;
+                v[u] = (i < nquads) ? ((const uint4*)src)[i] : make_uint4(0u, 0u, 0u, 0u);
             }
 #pragma unroll
             for (int u = 0; u < 8; ++u) {
                 const int i = i0 + u * ASSIGN_THREADS;
-                if (i < nwords) {
-                    s_rows[i] = v[u];
-                    if (clear_votes && v[u]) src[i] = 0;
+                if (i < nquads) {
+                    s_rows[4 * i] = v[u].x; s_rows[4 * i + 1] = v[u].y;
+                    s_rows[4 * i + 2] = v[u].z; s_rows[4 * i + 3] = v[u].w;
+                    if (clear_votes && (v[u].x | v[u].y | v[u].z | v[u].w)) ((uint4*)src)[i] = make_uint4(0u, 0u, 0u, 0u);
                 }
             }
+        }
+        for (int i = 4 * nquads + t; i < nwords; i += ASSIGN_THREADS) {        // (ragged end / unaligned pass)
+            const uint32_t v = src[i];
+            s_rows[i] = v;
+            if (clear_votes && v) src[i] = 0;
         }
         __syncthreads();
         // four lanes per row: each scans a contiguous quarter of the classes, then the quarters
