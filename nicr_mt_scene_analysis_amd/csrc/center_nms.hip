@@ -358,6 +358,7 @@ constexpr int SEL_BINS = 2048;
 // every pass re-reads the thread's contiguous word range from L2, one dependent load per word
 // (11.7 us at 640x480, 31.6 us at 1024x768 — five passes of 10 / 24 words per thread).
 constexpr int SEL_LDS_WORDS = 36 * 1024;          // 144 KB: images up to 1.18 Mpx
+constexpr int SEL_LIST_CAP = 2048;                // candidates kept as an LDS list (<= 32 per thread)
 
 template <bool LDS_BITS>
 __global__ __launch_bounds__(SEL_THREADS) void k_select_compact(
@@ -365,7 +366,7 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_compact(
     const uint32_t* __restrict__ cand_bits,
     int H, int W, int words_per_image, int topk, int apply_fg, int max_centers,
     int32_t* __restrict__ centers_yx, int32_t* __restrict__ n_centers,
-    float* __restrict__ scores, uint8_t* __restrict__ center_mask)
+    float* __restrict__ scores, uint8_t* __restrict__ center_mask, int list_cap)
 {
     __shared__ int hist[SEL_BINS];
     __shared__ int scratch[32];
@@ -412,7 +413,29 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_compact(
     int cnt = 0;
     for (int w = w_begin; w < w_end; ++w) cnt += __popc(bits[w]);
     int total;
-    block_inclusive_scan(cnt, scratch, &total);
+    const int cnt_incl = block_inclusive_scan(cnt, scratch, &total);
+
+    // ---- the candidates as a LIST in LDS (raster order): position + key, gathered ONCE.  The
+    //      radix passes and the compaction then walk a dense, evenly split list instead of every
+    //      thread's mask words with one dependent global gather per pass (five in all) ----------
+    uint32_t* s_lpos = s_bits + words_per_image;
+    uint32_t* s_lkey = s_lpos + list_cap;
+    const bool use_list = LDS_BITS && total <= list_cap;      // block-uniform
+    if (use_list) {
+        int at = cnt_incl - cnt;
+        for (int w = w_begin; w < w_end; ++w) {
+            uint32_t m = bits[w];
+            while (m) {
+                const int bit = __ffs((int)m) - 1;
+                m &= m - 1;
+                const int p = (w << 5) + bit;
+                s_lpos[at] = (uint32_t)p;
+                s_lkey[at] = cand_key(img[p]);
+                ++at;
+            }
+        }
+        __syncthreads();
+    }
 
     // ---- k-th largest candidate key (torch.topk(...)[..., -1], clamp(min=0)) --
     uint32_t key_kth = 0;
@@ -428,14 +451,22 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_compact(
             const uint32_t prefix = s_prefix;
             // bits above (shift + nbits) must equal the prefix found so far
             const int hi_shift = shift + nbits[pass];
-            for (int w = w_begin; w < w_end; ++w) {
-                uint32_t m = bits[w];
-                while (m) {
-                    const int bit = __ffs((int)m) - 1;
-                    m &= m - 1;
-                    const uint32_t k = cand_key(img[(w << 5) + bit]);
+            if (use_list) {
+                for (int e = threadIdx.x; e < total; e += SEL_THREADS) {
+                    const uint32_t k = s_lkey[e];
                     const bool match = (hi_shift >= 32) || ((k >> hi_shift) == (prefix >> hi_shift));
                     if (match) atomicAdd(&hist[(k >> shift) & (nb - 1)], 1);
+                }
+            } else {
+                for (int w = w_begin; w < w_end; ++w) {
+                    uint32_t m = bits[w];
+                    while (m) {
+                        const int bit = __ffs((int)m) - 1;
+                        m &= m - 1;
+                        const uint32_t k = cand_key(img[(w << 5) + bit]);
+                        const bool match = (hi_shift >= 32) || ((k >> hi_shift) == (prefix >> hi_shift));
+                        if (match) atomicAdd(&hist[(k >> shift) & (nb - 1)], 1);
+                    }
                 }
             }
             __syncthreads();
@@ -466,6 +497,36 @@ __global__ __launch_bounds__(SEL_THREADS) void k_select_compact(
         if (apply_fg && !fgb[p]) return false;
         return cand_key(img[p]) >= key_kth;
     };
+    if (use_list) {
+        // contiguous list ranges per thread keep the raster order; every entry is looked at once
+        // (its keep flag stays in a register mask: at most 32 entries per thread with
+        // list_cap <= 32 * SEL_THREADS)
+        const int per = (total + SEL_THREADS - 1) / SEL_THREADS;
+        const int e0 = min((int)threadIdx.x * per, total), e1 = min(e0 + per, total);
+        uint32_t keep = 0u;
+        for (int e = e0; e < e1; ++e) {
+            const bool k = s_lkey[e] >= key_kth && (!apply_fg || fgb[s_lpos[e]]);
+            keep |= k ? (1u << (e - e0)) : 0u;
+        }
+        const int mine_l = __popc(keep);
+        int n_total_l;
+        const int incl_l = block_inclusive_scan(mine_l, scratch, &n_total_l);
+        int pos_l = incl_l - mine_l;
+        for (int e = e0; e < e1; ++e) {
+            if (!((keep >> (e - e0)) & 1u)) continue;
+            const int p = (int)s_lpos[e];
+            if (pos_l < max_centers) {
+                const int y = p / W;
+                centers_yx[((size_t)b * max_centers + pos_l) * 2 + 0] = y;
+                centers_yx[((size_t)b * max_centers + pos_l) * 2 + 1] = p - y * W;
+                scores[(size_t)b * max_centers + pos_l] = img[p];
+            }
+            if (center_mask) center_mask[(size_t)b * P + p] = 1;
+            ++pos_l;
+        }
+        if (threadIdx.x == 0) n_centers[b] = n_total_l;
+        return;
+    }
     int mine = 0;
     for (int w = w_begin; w < w_end; ++w) {
         uint32_t m = bits[w];
@@ -591,17 +652,19 @@ extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
     if (rc) return rc;
     // the LDS copy of the candidate mask needs a grant above 64 KB for large images; without
     // it (denied, another device) the global-memory variant runs instead
-    const size_t sel_lds = (size_t)words * sizeof(uint32_t);
+    // + the candidate list (position, key) behind the mask when both fit: SEL_LIST_CAP entries
+    const int list_cap = (words + 2 * SEL_LIST_CAP <= SEL_LDS_WORDS) ? SEL_LIST_CAP : 0;
+    const size_t sel_lds = ((size_t)words + 2 * (size_t)list_cap) * sizeof(uint32_t);
     if (words <= SEL_LDS_WORDS &&
         (sel_lds <= 48 * 1024 ||
          allow_dynamic_lds(k_select_compact<true>, SEL_LDS_WORDS * sizeof(uint32_t)) == NMSA_OK)) {
         hipLaunchKernelGGL(k_select_compact<true>, dim3(B), dim3(SEL_THREADS), sel_lds,
                            stream, center, apply_fg ? fg : nullptr, bits, H, W, words, topk, apply_fg,
-                           max_centers, centers_yx, n_centers, scores, center_mask);
+                           max_centers, centers_yx, n_centers, scores, center_mask, list_cap);
     } else {
         hipLaunchKernelGGL(k_select_compact<false>, dim3(B), dim3(SEL_THREADS), 0, stream,
                            center, apply_fg ? fg : nullptr, bits, H, W, words, topk, apply_fg,
-                           max_centers, centers_yx, n_centers, scores, center_mask);
+                           max_centers, centers_yx, n_centers, scores, center_mask, 0);
     }
     return check_launch();
 }

@@ -222,6 +222,40 @@ def test_centers_many_candidates_vs_oracle(ops, oracle):
             assert (r['scores'].cpu().numpy()[b, :n[b]] == scores[b, :n[b]]).all()
 
 
+def test_centers_candidate_list_sizes_vs_oracle(ops, oracle):
+    """k_select_compact keeps up to 2048 candidates per image as a list in LDS (raster order, keys
+    gathered once) and walks the mask words beyond that: candidate counts on both sides of the
+    capacity, exactly at it, heavy ties, top-k below / at / above the count, with the foreground
+    filter, at sizes whose mask is not a whole number of 16-byte pieces"""
+    rng = np.random.default_rng(11)
+    for (H, W), n_peaks in (((480, 640), 1500), ((480, 640), 2048), ((480, 640), 2049), ((480, 640), 2600),
+                            ((96, 200), 300), ((37, 101), 90), ((768, 1024), 2000)):
+        heat = np.zeros((2, H, W), np.float32)
+        for b in range(2):
+            # isolated peaks on a 3-px lattice: every one of them survives the 3x3 NMS
+            ys, xs = np.meshgrid(np.arange(1, H - 1, 3), np.arange(1, W - 1, 3), indexing='ij')
+            pick = rng.choice(ys.size, size=min(n_peaks, ys.size), replace=False)
+            vals = 0.2 + 0.8 * rng.random(pick.size)
+            if b == 1:
+                vals = np.round(vals * 8) / 8                       # heavy ties around the k-th value
+            heat[b, ys.ravel()[pick], xs.ravel()[pick]] = vals.astype(np.float32)
+        fg = (rng.random((2, H, W)) < 0.7).astype(np.uint8)
+        total = int((heat[0] > 0).sum())
+        for k in (1, 64, total - 1, total, total + 5):
+            for apply_fg in (False, True):
+                cyx, n, scores, mask = oracle.center_nms_topk(heat, fg=fg, ksize=3, topk=k, apply_fg=apply_fg,
+                                                              max_centers=4096)
+                r = ops.center_nms_topk(dev(heat), dev(fg), kernel_size=3, top_k=k,
+                                        apply_foreground_mask=apply_fg, max_centers=4096, want_mask=True)
+                torch.cuda.synchronize()
+                what = (H, W, n_peaks, k, apply_fg)
+                assert (r['n_centers'].cpu().numpy() == n).all(), what
+                assert (r['center_mask'].cpu().numpy() == mask).all(), what
+                for b in range(2):
+                    assert (r['centers_yx'].cpu().numpy()[b, :n[b]] == cyx[b, :n[b]]).all(), what
+                    assert (r['scores'].cpu().numpy()[b, :n[b]] == scores[b, :n[b]]).all(), what
+
+
 def test_grouping_adversarial(ops):
     g = load('grouping_adversarial')
     for name in jload(g['names']):
