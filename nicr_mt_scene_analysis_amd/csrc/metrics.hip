@@ -548,6 +548,7 @@ __device__ __forceinline__ int block_incl_scan_i(int v, int* scratch, int* total
 constexpr int PQ_MATCH_THREADS = 1024;
 constexpr int PQ_MAX_CATEGORIES = 1024;
 constexpr int PQ_TP_CAP = 1024;             // matched pairs per image
+constexpr int PQ_E_LDS = 2048;              // intersections per image whose list entry stays in LDS
 
 // One workgroup per image.  The image's intersection table stays where k_pq_count built it
 // (global memory, L2-resident: 12 B x cap); its non-empty slots are first compacted into an
@@ -570,8 +571,20 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     __shared__ int fnI[PQ_MAX_CATEGORIES], fpI[PQ_MAX_CATEGORIES];
     __shared__ int64_t ignKeys[64];
     __shared__ int nIgn, nTPs, nEnt;
+    // the first PQ_E_LDS entries of the image's intersection list live in LDS (a few hundred on
+    // label maps of real scenes); the list in the workspace takes what is beyond
+    __shared__ int64_t sK[PQ_E_LDS];
+    __shared__ uint32_t sC[PQ_E_LDS], sS[PQ_E_LDS];
 
     const int b = blockIdx.x, tid = threadIdx.x;
+    // offset and max_inst are powers of two in the reference's use (256^3, 2^16): floor division
+    // and floor modulo are then an arithmetic shift and a mask — a 64-bit integer division is
+    // ~150 instructions, and an entry went through ten of them in a row
+    const int off_sh = (offset > 0 && (offset & (offset - 1)) == 0) ? (63 - __clzll((long long)offset)) : -1;
+    const int inst_sh = (max_inst > 0 && (max_inst & (max_inst - 1)) == 0) ? (63 - __clzll((long long)max_inst)) : -1;
+    auto div_off = [&](int64_t a) -> int64_t { return off_sh >= 0 ? (a >> off_sh) : floordiv64(a, offset); };
+    auto mod_off = [&](int64_t a) -> int64_t { return off_sh >= 0 ? (a & (offset - 1)) : floormod64(a, offset); };
+    auto div_inst = [&](int64_t a) -> int64_t { return inst_sh >= 0 ? (a >> inst_sh) : floordiv64(a, max_inst); };
     int64_t* gk = pq_keys(ws, b, cap);
     uint32_t* gc = pq_cnts(ws, b, cap);
     int64_t* eK = pq_list_keys(ws, b, cap);            // entry list: key, count, table slot
@@ -592,26 +605,30 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     if (tid == 0) nEnt = nListed;
     for (int e = tid; e < min(nListed, ecap); e += PQ_MATCH_THREADS) {
         const uint32_t slot = eS[e];
-        eK[e] = gk[slot];
-        eC[e] = gc[slot];
+        if (e < PQ_E_LDS) { sS[e] = slot; sK[e] = gk[slot]; sC[e] = gc[slot]; }
+        else { eK[e] = gk[slot]; eC[e] = gc[slot]; }
     }
     __syncthreads();
     if (nEnt > ecap) st |= ST_TABLE_OVERFLOW;          // table more than half full
     const int nE = min(nEnt, ecap);
     __threadfence_block();
+    auto entry_key = [&](int e) -> int64_t { return e < PQ_E_LDS ? sK[e] : eK[e]; };
+    auto entry_count = [&](int e) -> uint32_t { return e < PQ_E_LDS ? sC[e] : eC[e]; };
+    auto entry_slot = [&](int e) -> uint32_t { return e < PQ_E_LDS ? sS[e] : eS[e]; };
 
     // ---- 1. segment areas = marginals of the intersection table (pq.py:83-84) ------------
     for (int e = tid; e < nE; e += PQ_MATCH_THREADS) {
-        const int64_t iid = eK[e];
-        const int64_t gt = floordiv64(iid, offset), pr = floormod64(iid, offset);
-        if (!table_add(kT, cT, PQ_T_CAP - 1, gt, eC[e], PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
-        if (!table_add(kP, cP, PQ_P_CAP - 1, pr, eC[e], PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
+        const int64_t iid = entry_key(e);
+        const uint32_t cnt_e = entry_count(e);
+        const int64_t gt = div_off(iid), pr = mod_off(iid);
+        if (!table_add(kT, cT, PQ_T_CAP - 1, gt, cnt_e, PQ_T_CAP)) st |= ST_TABLE_OVERFLOW;
+        if (!table_add(kP, cP, PQ_P_CAP - 1, pr, cnt_e, PQ_P_CAP)) st |= ST_TABLE_OVERFLOW;
     }
     __syncthreads();
     // ignored segments: target ids whose category is the ignored label (pq.py:89-93)
     for (int s = tid; s < PQ_T_CAP; s += PQ_MATCH_THREADS) {
         const int64_t k = kT[s];
-        if (k != KEY_EMPTY && floordiv64(k, max_inst) == ignored_label) {
+        if (k != KEY_EMPTY && div_inst(k) == ignored_label) {
             const int at = atomicAdd(&nIgn, 1);
             if (at < 64) ignKeys[at] = k;
         }
@@ -619,10 +636,10 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
 
     // ---- 2. TP decision per intersection (pq.py:119-153), unordered TP list --------------
     for (int e = tid; e < nE; e += PQ_MATCH_THREADS) {
-        const int64_t iid = eK[e];
+        const int64_t iid = entry_key(e);
         if (iid == void_segment_id) continue;                               // :120-121
-        const int64_t gt = floordiv64(iid, offset), pr = floormod64(iid, offset);
-        const int64_t gcat = floordiv64(gt, max_inst), pcat = floordiv64(pr, max_inst);
+        const int64_t gt = div_off(iid), pr = mod_off(iid);
+        const int64_t gcat = div_inst(gt), pcat = div_inst(pr);
         if (gcat != pcat) continue;                                         // :128-129
         // prediction_void_overlap (pq.py:35-44)
         const int64_t vid = (int64_t)((uint64_t)void_segment_id * (uint64_t)offset + (uint64_t)pr);
@@ -631,7 +648,7 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
         const int sT = table_find(kT, PQ_T_CAP - 1, gt);
         const int sP = table_find(kP, PQ_P_CAP - 1, pr);
         if (sT < 0 || sP < 0) { st |= ST_MISSING_KEY; continue; }
-        const int64_t ia = eC[e];
+        const int64_t ia = entry_count(e);
         const int64_t uni = (int64_t)cT[sT] + (int64_t)cP[sP] - ia - r;     // :143
         const double iou = (double)ia / (double)uni;                        // :145
         if (iou > 0.5) {                                                    // :147
@@ -669,7 +686,7 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     for (int s = tid; s < PQ_T_CAP; s += PQ_MATCH_THREADS) {
         const int64_t k = kT[s];
         if (k == KEY_EMPTY || fT[s]) continue;
-        const int64_t cat = floordiv64(k, max_inst);
+        const int64_t cat = div_inst(k);
         if (cat == ignored_label) continue;
         if (cat < 0 || cat >= num_categories) { st |= ST_CATEGORY_RANGE; continue; }
         atomicAdd(&fnI[cat], 1);
@@ -687,7 +704,7 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
             if (sI >= 0) pio += gc[sI];
         }
         if ((double)pio / (double)cP[s] > 0.5) continue;
-        const int64_t cat = floordiv64(k, max_inst);
+        const int64_t cat = div_inst(k);
         if (cat < 0 || cat >= num_categories) { st |= ST_CATEGORY_RANGE; continue; }
         atomicAdd(&fpI[cat], 1);
     }
@@ -700,8 +717,8 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     // ---- 7. matched (gt, pred) pairs in id order (for the orientation MAE) -------------------
     if (matches) {
         for (int i = tid; i < nTPc && i < match_cap; i += PQ_MATCH_THREADS) {
-            matches[((size_t)b * match_cap + i) * 2 + 0] = floordiv64(tpKeyS[i], offset);
-            matches[((size_t)b * match_cap + i) * 2 + 1] = floormod64(tpKeyS[i], offset);
+            matches[((size_t)b * match_cap + i) * 2 + 0] = div_off(tpKeyS[i]);
+            matches[((size_t)b * match_cap + i) * 2 + 1] = mod_off(tpKeyS[i]);
         }
     }
     if (tid == 0 && n_matches) n_matches[b] = nTP;
@@ -712,7 +729,7 @@ __global__ __launch_bounds__(PQ_MATCH_THREADS) void k_pq_match(
     if (nEnt > ecap) {                                 // overflowed: the list is incomplete
         for (int i = tid; i < cap; i += PQ_MATCH_THREADS) { gk[i] = KEY_EMPTY; gc[i] = 0; }
     } else {
-        for (int e = tid; e < nE; e += PQ_MATCH_THREADS) { gk[eS[e]] = KEY_EMPTY; gc[eS[e]] = 0; }
+        for (int e = tid; e < nE; e += PQ_MATCH_THREADS) { const uint32_t sl = entry_slot(e); gk[sl] = KEY_EMPTY; gc[sl] = 0; }
     }
     if (tid == 0) list_n_all[b * PQ_LIST_STRIDE] = 0;  // the list is consumed: clean for the next update
 }
