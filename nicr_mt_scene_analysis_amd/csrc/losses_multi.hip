@@ -237,10 +237,11 @@ __global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, c
 #endif
 #ifndef NMSA_MULTI_FWD_WAVES
 #define NMSA_MULTI_FWD_WAVES 5      // forward-only launches: the streaming CE walk needs few registers
+                                    // (96 without label smoothing; with it 4 waves: no scratch)
 #endif
 template <int CE_DT, int CE_NG, bool CE_SM, int MODE>        // MODE as in ce_fused_body
 __global__ __launch_bounds__(LOSS_THREADS)
-__attribute__((amdgpu_waves_per_eu((MODE == 1) ? NMSA_MULTI_FWD_WAVES : (CE_NG <= 5) ? 4 : 3, (MODE != 1 && CE_NG > 5) ? 3 : 8))) void k_multi_loss(
+__attribute__((amdgpu_waves_per_eu((MODE == 1) ? (CE_SM ? 4 : NMSA_MULTI_FWD_WAVES) : (CE_NG <= 5) ? 4 : 3, (MODE != 1 && CE_NG > 5) ? 3 : 8))) void k_multi_loss(
     MultiArgs a, const float* __restrict__ expect, const float* __restrict__ gs,
     LossPartial* __restrict__ partials, int* __restrict__ status)
 {
