@@ -422,9 +422,13 @@ __device__ __forceinline__ void ce_fused_body(
     if (p0 < P) {
         const int nvalid = min(PXT, P - p0);
         u32x2_s r[NP];
+        // (`c < C` is compared again in every walk — a scalar compare and branch per plane; one
+        // compare kept across the four walks is NP lane masks in scalar registers: 108 spilled)
+        int C0 = C;
+        asm volatile("" : "+s"(C0));
 #pragma unroll
         for (int c = 0; c < NP; ++c)
-            if (c < C) r[c] = ld_plane8<DTYPE>(logits, img + (size_t)c * P + p0, nvalid, vec);
+            if (c < C0) r[c] = ld_plane8<DTYPE>(logits, img + (size_t)c * P + p0, nvalid, vec);
         int t[PXT];
 #pragma unroll
         for (int j = 0; j < PXT; ++j)
@@ -432,9 +436,11 @@ __device__ __forceinline__ void ce_fused_body(
         float m[PXT], s[PXT], swx[PXT], xt[PXT], k0[PXT];
 #pragma unroll
         for (int j = 0; j < PXT; ++j) { m[j] = -INFINITY; s[j] = 0.f; swx[j] = 0.f; xt[j] = 0.f; }
+        int C1 = C;
+        asm volatile("" : "+s"(C1));
 #pragma unroll
         for (int c = 0; c < NP; ++c) {
-            if (c < C) {
+            if (c < C1) {
 #pragma unroll
                 for (int j = 0; j < PXT; ++j) m[j] = vmax(m[j], plane_px<DTYPE>(r[c], j));
             }
@@ -442,10 +448,12 @@ __device__ __forceinline__ void ce_fused_body(
 #pragma unroll
         for (int j = 0; j < PXT; ++j) k0[j] = -m[j] * LOG2E;
         if (DTYPE != NMSA_F32) keep_packed(r);
+        int C2 = C, C3 = C;
+        asm volatile("" : "+s"(C2));
         if (MODE == 1) {
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
-                if (c < C) {
+                if (c < C2) {
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) {
                         const float x = plane_px<DTYPE>(r[c], j);
@@ -464,7 +472,7 @@ __device__ __forceinline__ void ce_fused_body(
             for (int j = 0; j < PXT; ++j) k0s[j] = SHIFTED ? k0[j] + CE_EXP_SHIFT : k0[j];
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
-                if (c < C) {
+                if (c < C2) {
                     float e[PXT];
 #pragma unroll
                     for (int j = 0; j < PXT; ++j) {
@@ -494,9 +502,10 @@ __device__ __forceinline__ void ce_fused_body(
                 qt[j] = fmaf(abg, pt, smooth_on[j] ? -(g * (ls / C) * s_w[on ? t[j] : 0]) : 0.f) - ag;
             }
             if (DTYPE != NMSA_F32) keep_packed(r);
+            asm volatile("" : "+s"(C3));
 #pragma unroll
             for (int c = 0; c < NP; ++c) {
-                if (c < C) {
+                if (c < C3) {
                     float o[PXT];
                     const float bjg = SMOOTH ? g * (ls / C) * s_w[c] : 0.f;
 #pragma unroll
