@@ -103,27 +103,34 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
         const int p0 = (tile * 64 + l) * PXT;
         return (uint32_t)((p0 < P ? p0 : 0) * ESIZE);
     };
-    auto request_plane = [&](int i, uint32_t off) {
-        const char* pb = pred_b + (size_t)(c0 + i) * P * ESIZE;          // wave-uniform
-        r[i] = __builtin_nontemporal_load((const u32x2_s*)(pb + off));
+    // plane addresses: ONE running scalar offset per walk (`po`, advanced by a plane per step and
+    // made opaque so that it stays a running sum) + the lane offset — NP loop-invariant plane
+    // bases hoisted out of the tile loop were 128 scalar registers, 200-280 of them spilled to lane
+    // registers and read back before every load and store
+    const size_t pstride = (size_t)P * ESIZE;
+    const size_t po0 = (size_t)c0 * pstride;
+    auto request_plane = [&](int i, size_t po, uint32_t off) {
+        r[i] = __builtin_nontemporal_load((const u32x2_s*)(pred_b + po + off));
     };
     // pixels without a target get exactly +0 (the reference gathers the valid rows only): the
     // masks clear their lanes of the packed words, so a non-finite prediction there cannot leak
     // a 0 * inf = NaN into the gradient
-    auto store_plane = [&](int i, uint32_t off, const float o[PXT], uint32_t mx, uint32_t my) {
-        char* gb = grad_b + (size_t)(c0 + i) * P * ESIZE;               // wave-uniform
+    auto store_plane = [&](int i, size_t po, uint32_t off, const float o[PXT], uint32_t mx, uint32_t my) {
         u32x2_s v;
         if (DTYPE == NMSA_F32) { v.x = __float_as_uint(o[0]); v.y = __float_as_uint(o[1]); }
         else { v.x = pack16<DTYPE>(o[0], o[1]); v.y = pack16<DTYPE>(o[2], o[3]); }
         v.x &= mx; v.y &= my;
-        __builtin_nontemporal_store(v, (u32x2_s*)(gb + off));
+        __builtin_nontemporal_store(v, (u32x2_s*)(grad_b + po + off));
     };
     auto request = [&](int tile) {                     // all planes of `tile` into r[]
         const uint32_t off = lane_offset(tile);
+        size_t po = po0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             r[i] = u32x2_s{0u, 0u};
-            if (i < nc) request_plane(i, off);
+            if (i < nc) request_plane(i, po, off);
+            po += pstride;
+            asm volatile("" : "+s"(po));
         }
     };
 #ifndef COSS_PREFETCH
@@ -193,14 +200,17 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
             my = (on[PXT > 2 ? 2 : 0] ? 0xFFFFu : 0u) | (on[PXT > 2 ? 3 : 0] ? 0xFFFF0000u : 0u);
         }
         if (DTYPE != NMSA_F32) keep_packed(r);
+        size_t po = po0;
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
             float o[PXT];
 #pragma unroll
             for (int j = 0; j < PXT; ++j)
                 o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
-            if (store) store_plane(i, off, o, mx, my);
-            if (COSS_PREFETCH) request_plane(i, qoff);         // (the last tile re-reads itself: no branch in the walk)
+            if (store) store_plane(i, po, off, o, mx, my);
+            if (COSS_PREFETCH) request_plane(i, po, qoff);     // (the last tile re-reads itself: no branch in the walk)
+            po += pstride;
+            asm volatile("" : "+s"(po));
         }
     }
     if (LOSS) {
@@ -309,12 +319,14 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
         const int p0 = (tile * 64 + l) * PXT;
         return (uint32_t)((p0 < P ? p0 : 0) * ESIZE);
     };
-    auto request_plane = [&](int i, const char* pred_b, uint32_t off) {
-        const char* pb = pred_b + (size_t)(c0 + i) * P * ESIZE;          // wave-uniform
-        r[i] = __builtin_nontemporal_load((const u32x2_s*)(pb + off));
+    // (plane addresses as in k_cos_split: one running scalar offset per walk + the lane offset)
+    const size_t pstride = (size_t)P * ESIZE;
+    const size_t po0 = (size_t)c0 * pstride;
+    auto request_plane = [&](int i, const char* pred_b, size_t po, uint32_t off) {
+        r[i] = __builtin_nontemporal_load((const u32x2_s*)(pred_b + po + off));
     };
-    auto store_plane = [&](int i, char* grad_b, uint32_t off, const float o[PXT], uint32_t mx, uint32_t my) {
-        char* gb = grad_b + (size_t)(c0 + i) * P * ESIZE;               // wave-uniform
+    auto store_plane = [&](int i, char* grad_b, size_t po, uint32_t off, const float o[PXT], uint32_t mx, uint32_t my) {
+        char* gb = grad_b + po;
         u32x2_s v;
         if (DTYPE == NMSA_F32) { v.x = __float_as_uint(o[0]); v.y = __float_as_uint(o[1]); }
         else { v.x = pack16<DTYPE>(o[0], o[1]); v.y = pack16<DTYPE>(o[2], o[3]); }
@@ -326,8 +338,13 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     if (active) {
         const int b0 = (int)(t_begin / n_tiles);
         const uint32_t off = lane_offset((int)(t_begin - (long long)b0 * n_tiles));
+        size_t po = po0;
 #pragma unroll
-        for (int i = 0; i < NP; ++i) if (!RAGGED || i < nc) request_plane(i, (const char*)pred + b0 * img_bytes, off);
+        for (int i = 0; i < NP; ++i) {
+            if (!RAGGED || i < nc) request_plane(i, (const char*)pred + b0 * img_bytes, po, off);
+            po += pstride;
+            asm volatile("" : "+s"(po));
+        }
     }
     int b_staged = -1;
     for (long long gt = t_begin; gt < t_end; ++gt) {
@@ -449,6 +466,7 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
                 my = (on[PXT > 2 ? 2 : 0] ? 0xFFFFu : 0u) | (on[PXT > 2 ? 3 : 0] ? 0xFFFF0000u : 0u);
             }
             if (DTYPE != NMSA_F32) keep_packed(r);
+            size_t po = po0;
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
                 if (!RAGGED || i < nc) {                                // wave-uniform
@@ -456,9 +474,11 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
 #pragma unroll
                     for (int j = 0; j < PXT; ++j)
                         o[j] = fmaf(k2[j], plane_px<DTYPE>(r[i], j), k1[j] * s_lut[row[j] + i]);
-                    if (store) store_plane(i, grad_b, off, o, mx, my);
-                    request_plane(i, pred_n, qoff);
+                    if (store) store_plane(i, grad_b, po, off, o, mx, my);
+                    request_plane(i, pred_n, po, qoff);
                 }
+                po += pstride;
+                asm volatile("" : "+s"(po));
             }
         }
     }
