@@ -339,9 +339,11 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
         const int b0 = (int)(t_begin / n_tiles);
         const uint32_t off = lane_offset((int)(t_begin - (long long)b0 * n_tiles));
         size_t po = po0;
+        int ncw = nc;
+        if (RAGGED) asm volatile("" : "+s"(ncw));
 #pragma unroll
         for (int i = 0; i < NP; ++i) {
-            if (!RAGGED || i < nc) request_plane(i, (const char*)pred + b0 * img_bytes, po, off);
+            if (!RAGGED || i < ncw) request_plane(i, (const char*)pred + b0 * img_bytes, po, off);
             po += pstride;
             asm volatile("" : "+s"(po));
         }
@@ -467,9 +469,11 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
             }
             if (DTYPE != NMSA_F32) keep_packed(r);
             size_t po = po0;
+            int ncw = nc;                                               // (compared per plane as a scalar,
+            if (RAGGED) asm volatile("" : "+s"(ncw));                   //  not kept as NP lane masks)
 #pragma unroll
             for (int i = 0; i < NP; ++i) {
-                if (!RAGGED || i < nc) {                                // wave-uniform
+                if (!RAGGED || i < ncw) {                               // wave-uniform
                     float o[PXT];
 #pragma unroll
                     for (int j = 0; j < PXT; ++j)
