@@ -86,7 +86,10 @@ __global__ __launch_bounds__(LOSS_THREADS) __attribute__((amdgpu_waves_per_eu(NG
     const size_t pstride = (size_t)P * ESZ;
     // a workgroup walks a RUN of consecutive pixel tiles: its C class planes are C different pages,
     // and one 512-byte piece per page and workgroup left the address translation as the limit
-    // (4.6 TB/s with every exp removed; runs of tiles: the pages are reused tile after tile)
+    // (4.6 TB/s with every exp removed; runs of tiles: the pages are reused tile after tile).
+    // Runs of 2 since round 4 (NMSA_CE_SPLIT_RUN): 1.47 / 1.545 ms against 1.56 / 1.59 with runs
+    // of 4 and 1.56 with single tiles, six and four processes each on two boxes — the spread
+    // between processes (+-3-5 %, where the tensors land) had hidden it in single runs
     double acc = 0.0, accw = 0.0;
     long long cnt = 0;
     bool bad = false;
@@ -315,7 +318,7 @@ int ce_split_blocks(int P, int dtype)
 {
     const int pxt = (dtype == NMSA_F32) ? 2 : 4;
     const int n_tiles = (P + 64 * pxt - 1) / (64 * pxt);
-    static const int run = loss_env_int("NMSA_CE_SPLIT_RUN", 4);
+    static const int run = loss_env_int("NMSA_CE_SPLIT_RUN", 2);
     const int tpw = run < 1 ? 1 : run;
     return (n_tiles + tpw - 1) / tpw;
 }
@@ -329,7 +332,7 @@ int launch_ce_split(bool loss, const void* logits, int dtype, const uint8_t* tar
     const bool vec = (P % pxt == 0) && ((((uintptr_t)logits | (uintptr_t)grad) & 7) == 0) &&
                      ((((uintptr_t)target) & (uintptr_t)(pxt - 1)) == 0);
     const int n_tiles = (P + 64 * pxt - 1) / (64 * pxt);     // the four waves of a block share 64 x pxt pixels
-    static const int run = loss_env_int("NMSA_CE_SPLIT_RUN", 4);
+    static const int run = loss_env_int("NMSA_CE_SPLIT_RUN", 2);
     const int tpw = run < 1 ? 1 : run;
     const int gx = (n_tiles + tpw - 1) / tpw;
     const bool smooth = ls != 0.0f;
