@@ -528,8 +528,11 @@ int cos_kernel(int dtype, int D, int L)
     const bool parts_ok = parts != 0 && D <= COSP_COLS * COSP_MAX_PARTS && cosp_lds_bytes(L, pxt) <= (size_t)158 * 1024;
     if (parts == 1 && parts_ok) return 2;
     // 512 planes fit one workgroup, but two cooperating half-columns with two workgroups per CU
-    // stream 7 % faster (one's exchange wait is the other's streaming time): measured at B = 16
-    if (split_ok && parts_ok && parts == -1 && D > COSP_COLS && 2 * cosp_lds_bytes(L, pxt) <= (size_t)160 * 1024)
+    // stream 7 % faster (one's exchange wait is the other's streaming time): measured at B = 16,
+    // same process, both kernels alternating: 4.61-4.72 vs 4.97-5.17 ms.  Narrower columns are as
+    // fast or faster in one workgroup (D = 448: 4.28-4.36 vs 4.30-4.41, 384: 3.74 vs 3.94,
+    // 256: 2.79 vs 2.82 ms)
+    if (split_ok && parts_ok && parts == -1 && D >= 2 * COSP_COLS && 2 * cosp_lds_bytes(L, pxt) <= (size_t)160 * 1024)
         return 2;
     if (split_ok) return 1;
     return parts_ok ? 2 : 0;
