@@ -56,7 +56,7 @@ __global__ __launch_bounds__(LOSS_THREADS) __attribute__((amdgpu_waves_per_eu(NG
 #define NMSA_CE_SPLIT_SUM1 1
 #endif
 #ifndef NMSA_CE_SPLIT_GS
-#define NMSA_CE_SPLIT_GS 4
+#define NMSA_CE_SPLIT_GS 1          // (with runs of two tiles per workgroup 1, 4 and 8 time the same: 1 is the least code)
 #endif
     constexpr int GS = NMSA_CE_SPLIT_GS;               // planes per straight-line group
     constexpr int NWV = LOSS_THREADS / 64;             // 4
