@@ -49,6 +49,11 @@ enum { NMSA_U8 = 0, NMSA_I16 = 1, NMSA_I32 = 2, NMSA_I64 = 3 };
 int nmsa_version(void);
 const char* nmsa_strerror(int code);
 int nmsa_last_hip_error(void); /* last hipError_t seen by this library (thread-local) */
+/* What the library sizes its grids from: compute units, XCDs and LDS bytes per CU of the CURRENT
+ * device, queried once per device from the HIP runtime (no literal 256 / 8: a partitioned MI355X
+ * shows fewer).  The environment variables NMSA_ASSUME_CUS / NMSA_ASSUME_XCDS override the
+ * queried numbers (tests).  Any pointer may be NULL.  Host pointers. */
+int nmsa_device_geometry(int* cus_host, int* xcds_host, size_t* lds_per_cu_host);
 
 /* ---------------------------------------------------------------------------
  * a2  InstancePostprocessing._get_instance_centers

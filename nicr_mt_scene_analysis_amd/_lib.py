@@ -51,6 +51,7 @@ _SIGNATURES = {
     'nmsa_version': (C.c_int, []),
     'nmsa_strerror': (C.c_char_p, [_i]),
     'nmsa_last_hip_error': (C.c_int, []),
+    'nmsa_device_geometry': (_i, [_vp, _vp, _vp]),
     'nmsa_center_nms_workspace_bytes': (_sz, [_i, _i, _i]),
     'nmsa_center_nms_topk': (_i, [_vp, _vp, _i, _i, _i, _f, _i, _i, _i, _i,
                                   _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -156,6 +157,13 @@ def check(rc: int, what: str) -> None:
         msg = l_.nmsa_strerror(rc).decode()
         hip = l_.nmsa_last_hip_error()
         raise NmsaError(f'{what}: {msg} (code {rc}, hipError {hip})')
+
+
+def device_geometry():
+    """(compute units, XCDs, LDS bytes per CU) the library sizes its grids from on the current device"""
+    cus, xcds, lds = C.c_int(0), C.c_int(0), C.c_size_t(0)
+    check(lib().nmsa_device_geometry(C.byref(cus), C.byref(xcds), C.byref(lds)), 'nmsa_device_geometry')
+    return cus.value, xcds.value, lds.value
 
 
 def ptr(t: Optional[torch.Tensor]):

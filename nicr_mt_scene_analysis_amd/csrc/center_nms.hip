@@ -203,16 +203,17 @@ __global__ __launch_bounds__(1024) void k_nms_strip(
 template <int NR_ROWS, bool HALF>
 __global__ __launch_bounds__(256) void k_nms_rows3(
     const float* __restrict__ center, uint32_t* __restrict__ cand_bits,
-    int H, int W, int words_per_image, float thr, int blocks_per_image, int n_blocks)
+    int H, int W, int words_per_image, float thr, int blocks_per_image, int n_blocks, int n_xcd)
 {
     constexpr int LPB = HALF ? 32 : 64;                    // lanes per band
     constexpr int BW = LPB * 4;                            // band width in pixels
-    // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its
-    // own L2); every XCD gets one contiguous range of row groups, so that the halo rows a wave
-    // shares with the row groups above and below are L2 hits instead of second fetches through
-    // the fabric (FETCH_SIZE 1.42x -> see profiles/r04*)
-    const int per_xcd = (n_blocks + 7) >> 3;
-    const int logical = n_blocks > 0 ? (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    // XCD-aware order: consecutive workgroup ids go round-robin over the device's XCDs (each with
+    // its own L2; `n_xcd` as the runtime reports it: 8 on an unpartitioned MI355X); every XCD gets
+    // one contiguous range of row groups, so that the halo rows a wave shares with the row groups
+    // above and below are L2 hits instead of second fetches through the fabric (FETCH_SIZE 1.42x ->
+    // see profiles/r04*).  Speed only: any n_xcd gives the same bits.
+    const int per_xcd = n_blocks > 0 ? (n_blocks + n_xcd - 1) / n_xcd : 0;
+    const int logical = n_blocks > 0 ? (int)(blockIdx.x % n_xcd) * per_xcd + (int)(blockIdx.x / n_xcd) : (int)blockIdx.x;
     if (n_blocks > 0 && logical >= n_blocks) return;
     const int b = n_blocks > 0 ? logical / blocks_per_image : (int)blockIdx.y;
     const int bx = n_blocks > 0 ? logical - b * blocks_per_image : (int)blockIdx.x;
@@ -610,16 +611,17 @@ extern "C" int nmsa_center_nms_topk(const float* center, const uint8_t* fg,
         static const int half_env = getenv("NMSA_NMS_HALF") ? atoi(getenv("NMSA_NMS_HALF")) : -1;
         const bool half = half_env >= 0 ? (half_env != 0 && W % 128 == 0) : (W % 256 != 0 && W % 128 == 0);
         static const int xcd = getenv("NMSA_NMS_XCD") ? atoi(getenv("NMSA_NMS_XCD")) : 1;
+        const int nx = device_geometry().xcds;
 #define NMSA_ROWS3(NR) do {                                                                                 \
         const int waves = half ? (W / 128) * ((H + 2 * NR - 1) / (2 * NR)) : ((W + 255) / 256) * ((H + NR - 1) / NR); \
         const int bpi = (waves + 3) / 4;                                                                    \
         const long long nb = (long long)bpi * B;                                                            \
-        const bool remap = xcd && nb < (1ll << 30);                                                         \
-        const dim3 grid_ = remap ? dim3((unsigned)(((nb + 7) / 8) * 8)) : dim3(bpi, B);                     \
+        const bool remap = xcd && nx > 1 && nb < (1ll << 30);                                               \
+        const dim3 grid_ = remap ? dim3((unsigned)(((nb + nx - 1) / nx) * nx)) : dim3(bpi, B);              \
         if (half) hipLaunchKernelGGL((k_nms_rows3<NR, true>), grid_, dim3(256), 0, stream, center, bits, H, W, \
-                                     words, threshold, bpi, remap ? (int)nb : 0);                            \
+                                     words, threshold, bpi, remap ? (int)nb : 0, nx);                        \
         else hipLaunchKernelGGL((k_nms_rows3<NR, false>), grid_, dim3(256), 0, stream, center, bits, H, W,   \
-                                words, threshold, bpi, remap ? (int)nb : 0); } while (0)
+                                words, threshold, bpi, remap ? (int)nb : 0, nx); } while (0)
         if (nr == 8) NMSA_ROWS3(8); else NMSA_ROWS3(4);
 #undef NMSA_ROWS3
     } else if ((W % 32) == 0 && pad <= NMS_PAD_MAX && strip_lds <= 64 * 1024) {

@@ -98,6 +98,15 @@ int launch_cos_split(bool loss, const void* pred, int dtype, const int32_t* indi
                      int B, int D, int P, int L, const float* gscale, const float* computed_for,
                      int32_t* counters, void* grad, LossPartial* partials, int32_t* status,
                      void* xch, size_t xch_bytes, hipStream_t stream);
+// losses.hip: the two-walk cosine kernels — shapes no one-pass kernel takes, and the device-gated
+// fallback of k_cos_parts (`gate` non-null: the kernels return at once unless *gate != 0)
+int cos_two_walk_blocks(int dtype, int B, int D, int P, int L);
+int launch_cos_two_walk_fwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                            int B, int D, int P, int L, LossPartial* partials, int32_t* status,
+                            float* dots_out, const int* gate, hipStream_t stream);
+int launch_cos_two_walk_bwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                            int B, int D, int P, int L, const float* grad_scale, const float* dots,
+                            void* grad_pred, const int* gate, int skip_nan_scale, hipStream_t stream);
 int loss_finalize(const LossPartial* partials, int n, double* sum, double* aux, int64_t* count,
                   hipStream_t stream);
 int loss_env_int(const char* name, int dflt);

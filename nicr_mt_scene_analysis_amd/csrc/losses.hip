@@ -444,13 +444,16 @@ template <int DTYPE, bool BWD>
 __global__ __launch_bounds__(LOSS_THREADS) void k_cos_emb(
     const void* __restrict__ pred, const int32_t* __restrict__ indices, const float* __restrict__ lut,
     int D, int P, int L, const float* __restrict__ gscale, void* __restrict__ grad,
-    LossPartial* __restrict__ partials, int* __restrict__ status)
+    LossPartial* __restrict__ partials, int* __restrict__ status, const int* __restrict__ gate,
+    int skip_nan_scale)
 {
+    if (gate && *gate == 0) return;                    // the fallback of k_cos_parts: only when it gave up
     const int b = blockIdx.y;
     const float EPS = 1e-12f;
     double acc = 0.0; long long cnt = 0;
     bool bad = false;
     const float g = BWD ? *gscale : 0.f;
+    if (BWD && skip_nan_scale && g != g) return;       // "no expectation": the forward call writes no gradient
     for (int p = blockIdx.x * LOSS_THREADS + threadIdx.x; p < P; p += gridDim.x * LOSS_THREADS) {
         const int ix = indices[(size_t)b * P + p];
         const bool on = ix > 0 && ix <= L;
@@ -503,9 +506,13 @@ __global__ __launch_bounds__(COS_THREADS) void k_cos_emb_lds(
     int D, int P, int L, int DC, int px_per_block, int vec,
     const float* __restrict__ gscale, void* __restrict__ grad,
     LossPartial* __restrict__ partials, int* __restrict__ status,
-    float* __restrict__ dots /* [B,2,P]: x.y and |x|^2 per pixel; fwd writes, bwd reads; or null */)
+    float* __restrict__ dots /* [B,2,P]: x.y and |x|^2 per pixel; fwd writes, bwd reads; or null */,
+    const int* __restrict__ gate /* non-null: return at once unless *gate != 0 (fallback of k_cos_parts) */,
+    int skip_nan_scale /* backward: write nothing when *gscale is a NaN (a forward call without expectation) */)
 {
     extern __shared__ float s_lut[];                   // [L][DC + 1], then yy[L]
+    if (gate && *gate == 0) return;
+    if (BWD && skip_nan_scale && *gscale != *gscale) return;
     const int b = blockIdx.y;
     const int ld = DC + 1;
     const int nchunks = (D + DC - 1) / DC;
@@ -1172,7 +1179,7 @@ namespace {
 // workgroups per image for the LDS-LUT kernels: ~2 per CU over the whole batch
 int cos_blocks_per_image(int B, int P, int pxt)
 {
-    int per_img = (512 + B - 1) / B;
+    int per_img = (2 * device_geometry().cus + B - 1) / B;
     const int max_useful = (P + COS_THREADS * pxt - 1) / (COS_THREADS * pxt);
     if (per_img > max_useful) per_img = max_useful;
     if (per_img < 1) per_img = 1;
@@ -1196,7 +1203,100 @@ int cos_chunk(int L, int D)
 }
 size_t cos_lds_bytes(int L, int DC) { return ((size_t)L * (DC + 1) + L) * sizeof(float); }
 
+struct CosWalkGeometry { int DC, pxt, ppb, gx; size_t lds; };
+
+CosWalkGeometry cos_walk_geometry(int dtype, int B, int D, int P, int L)
+{
+    CosWalkGeometry g;
+    g.DC = cos_chunk(L, D);
+    if (g.DC > 0) {
+        g.lds = cos_lds_bytes(L, g.DC);
+        g.pxt = (dtype == NMSA_F32) ? 4 : 8;
+        const int per_img = cos_blocks_per_image(B, P, g.pxt);
+        int ppb = (P + per_img - 1) / per_img;
+        g.ppb = ((ppb + g.pxt - 1) / g.pxt) * g.pxt;                // keep 16-B alignment of block starts
+        g.gx = (P + g.ppb - 1) / g.ppb;
+    } else {
+        g.lds = 0; g.pxt = 1; g.ppb = 0;
+        g.gx = grid_x(P, 1);
+    }
+    return g;
+}
+
 }  // namespace
+
+namespace nmsa {
+
+// The two-walk cosine kernels (forward: sums; backward: a second read for the gradient).  They
+// are the path of shapes no one-pass kernel takes AND the device-gated fallback of k_cos_parts
+// (`gate` non-null: every workgroup returns at once unless *gate != 0).
+int cos_two_walk_blocks(int dtype, int B, int D, int P, int L)       // partial slots (whole batch)
+{
+    return cos_walk_geometry(dtype, B, D, P, L).gx * B;
+}
+
+int launch_cos_two_walk_fwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                            int B, int D, int P, int L, LossPartial* partials, int32_t* status,
+                            float* dots_out, const int* gate, hipStream_t stream)
+{
+    const CosWalkGeometry g = cos_walk_geometry(dtype, B, D, P, L);
+    if (g.DC > 0) {
+        const int vec = (P % g.pxt == 0) && ((((uintptr_t)pred) & 15) == 0);
+        // the per-pixel dot products are only kept on the aligned path (16-B float stores)
+        const bool dots_vec = dots_out && vec && ((((uintptr_t)dots_out) & 15) == 0);
+        if (dots_out && !dots_vec) return NMSA_ERR_ARG;
+#define COS_FWD(DT, PX) do { if (allow_dynamic_lds(k_cos_emb_lds<DT, PX, false>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
+        hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, false>), dim3(g.gx, B), dim3(COS_THREADS), g.lds, \
+        stream, pred, indices, lut, D, P, L, g.DC, g.ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status, \
+        dots_vec ? dots_out : (float*)nullptr, gate, 0); } while (0)
+        switch (dtype) {
+            case NMSA_F32: COS_FWD(NMSA_F32, 4); break;
+            case NMSA_BF16: COS_FWD(NMSA_BF16, 8); break;
+            case NMSA_F16: COS_FWD(NMSA_F16, 8); break;
+            default: return NMSA_ERR_ARG;
+        }
+#undef COS_FWD
+        return check_launch();
+    }
+    if (dots_out) return NMSA_ERR_ARG;
+#define CALL(DT) hipLaunchKernelGGL((k_cos_emb<DT, false>), dim3(g.gx, B), dim3(LOSS_THREADS), 0, stream, \
+                                    pred, indices, lut, D, P, L, (const float*)nullptr, (void*)nullptr, partials, status, gate, 0)
+    NMSA_DISPATCH_DTYPE(dtype, CALL)
+#undef CALL
+    return check_launch();
+}
+
+int launch_cos_two_walk_bwd(const void* pred, int dtype, const int32_t* indices, const float* lut,
+                            int B, int D, int P, int L, const float* grad_scale, const float* dots,
+                            void* grad_pred, const int* gate, int skip_nan_scale, hipStream_t stream)
+{
+    const CosWalkGeometry g = cos_walk_geometry(dtype, B, D, P, L);
+    if (dots && (g.DC <= 0 || ((uintptr_t)dots & 15) != 0)) return NMSA_ERR_ARG;
+    if (g.DC > 0) {
+        const int vec = (P % g.pxt == 0) && ((((uintptr_t)pred | (uintptr_t)grad_pred) & 15) == 0);
+        if (dots && !vec) return NMSA_ERR_ARG;
+#define COS_BWD(DT, PX) do { if (allow_dynamic_lds(k_cos_emb_lds<DT, PX, true>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
+        hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, true>), dim3(g.gx, B), dim3(COS_THREADS), g.lds, \
+        stream, pred, indices, lut, D, P, L, g.DC, g.ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr, \
+        (float*)dots, gate, skip_nan_scale); } while (0)
+        switch (dtype) {
+            case NMSA_F32: COS_BWD(NMSA_F32, 4); break;
+            case NMSA_BF16: COS_BWD(NMSA_BF16, 8); break;
+            case NMSA_F16: COS_BWD(NMSA_F16, 8); break;
+            default: return NMSA_ERR_ARG;
+        }
+#undef COS_BWD
+        return check_launch();
+    }
+#define CALL(DT) hipLaunchKernelGGL((k_cos_emb<DT, true>), dim3(g.gx, B), dim3(LOSS_THREADS), 0, stream, \
+                                    pred, indices, lut, D, P, L, grad_scale, grad_pred,                  \
+                                    (LossPartial*)nullptr, (int*)nullptr, gate, skip_nan_scale)
+    NMSA_DISPATCH_DTYPE(dtype, CALL)
+#undef CALL
+    return check_launch();
+}
+
+}  // namespace nmsa
 
 extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t* indices,
                                      const float* lut, int B, int D, int H, int W, int L,
@@ -1207,44 +1307,16 @@ extern "C" int nmsa_loss_cos_emb_fwd(const void* pred, int dtype, const int32_t*
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !indices || !lut || !loss_sum || !n_rows || !status || !workspace) return NMSA_ERR_ARG;
     if (bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
+    if (dtype != NMSA_F32 && dtype != NMSA_BF16 && dtype != NMSA_F16) return NMSA_ERR_ARG;
     if (workspace_bytes < nmsa_loss_workspace_bytes(B, H, W)) return NMSA_ERR_WORKSPACE;
     const int P = H * W;
     LossPartial* partials = (LossPartial*)workspace;
-    const int DC = cos_chunk(L, D);
-    if (DC > 0) {
-        const size_t lds = cos_lds_bytes(L, DC);
-        const int pxt = (dtype == NMSA_F32) ? 4 : 8;
-        const int per_img = cos_blocks_per_image(B, P, pxt);
-        int ppb = (P + per_img - 1) / per_img;
-        ppb = ((ppb + pxt - 1) / pxt) * pxt;                      // keep 16-B alignment of block starts
-        const int gx = (P + ppb - 1) / ppb;
-        const int vec = (P % pxt == 0) && ((((uintptr_t)pred) & 15) == 0);
-        // the per-pixel dot products are only kept on the aligned path (16-B float stores)
-        const bool dots_vec = dots_out && vec && ((((uintptr_t)dots_out) & 15) == 0);
-        if (dots_out && !dots_vec) return NMSA_ERR_ARG;
-#define COS_FWD(DT, PX) do { if (allow_dynamic_lds(k_cos_emb_lds<DT, PX, false>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
-        hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, false>), dim3(gx, B), dim3(COS_THREADS), lds, \
-        stream, pred, indices, lut, D, P, L, DC, ppb, vec, (const float*)nullptr, (void*)nullptr, partials, status, \
-        dots_vec ? dots_out : (float*)nullptr); } while (0)
-        switch (dtype) {
-            case NMSA_F32: COS_FWD(NMSA_F32, 4); break;
-            case NMSA_BF16: COS_FWD(NMSA_BF16, 8); break;
-            case NMSA_F16: COS_FWD(NMSA_F16, 8); break;
-            default: return NMSA_ERR_ARG;
-        }
-#undef COS_FWD
-        int rc = check_launch();
-        if (rc) return rc;
-        return finalize(partials, gx * B, loss_sum, nullptr, n_rows, stream);
-    }
-    const int gx = grid_x(P, 1);
-#define CALL(DT) hipLaunchKernelGGL((k_cos_emb<DT, false>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, \
-                                    pred, indices, lut, D, P, L, (const float*)nullptr, (void*)nullptr, partials, status)
-    NMSA_DISPATCH_DTYPE(dtype, CALL)
-#undef CALL
-    int rc = check_launch();
+    const int n = cos_two_walk_blocks(dtype, B, D, P, L);
+    if ((size_t)n * sizeof(LossPartial) > workspace_bytes) return NMSA_ERR_WORKSPACE;
+    int rc = launch_cos_two_walk_fwd(pred, dtype, indices, lut, B, D, P, L, partials, status, dots_out, nullptr,
+                                     stream);
     if (rc) return rc;
-    return finalize(partials, gx * B, loss_sum, nullptr, n_rows, stream);
+    return finalize(partials, n, loss_sum, nullptr, n_rows, stream);
 }
 
 extern "C" int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L)
@@ -1261,37 +1333,7 @@ extern "C" int nmsa_loss_cos_emb_bwd(const void* pred, int dtype, const int32_t*
     hipStream_t stream = (hipStream_t)stream_;
     if (!pred || !indices || !lut || !grad_scale || !grad_pred) return NMSA_ERR_ARG;
     if (bad_shape(B, H, W) || D <= 0 || L <= 0) return NMSA_ERR_ARG;
-    const int P = H * W;
-    const int DC = cos_chunk(L, D);
-    if (dots && (DC <= 0 || ((uintptr_t)dots & 15) != 0)) return NMSA_ERR_ARG;
-    if (DC > 0) {
-        const size_t lds = cos_lds_bytes(L, DC);
-        const int pxt = (dtype == NMSA_F32) ? 4 : 8;
-        const int per_img = cos_blocks_per_image(B, P, pxt);
-        int ppb = (P + per_img - 1) / per_img;
-        ppb = ((ppb + pxt - 1) / pxt) * pxt;
-        const int gx = (P + ppb - 1) / ppb;
-        const int vec = (P % pxt == 0) && ((((uintptr_t)pred | (uintptr_t)grad_pred) & 15) == 0);
-        if (dots && !vec) return NMSA_ERR_ARG;
-#define COS_BWD(DT, PX) do { if (allow_dynamic_lds(k_cos_emb_lds<DT, PX, true>, COS_LDS_BUDGET + 1024)) return NMSA_ERR_LAUNCH; \
-        hipLaunchKernelGGL((k_cos_emb_lds<DT, PX, true>), dim3(gx, B), dim3(COS_THREADS), lds, \
-        stream, pred, indices, lut, D, P, L, DC, ppb, vec, grad_scale, grad_pred, (LossPartial*)nullptr, (int*)nullptr, \
-        (float*)dots); } while (0)
-        switch (dtype) {
-            case NMSA_F32: COS_BWD(NMSA_F32, 4); break;
-            case NMSA_BF16: COS_BWD(NMSA_BF16, 8); break;
-            case NMSA_F16: COS_BWD(NMSA_F16, 8); break;
-            default: return NMSA_ERR_ARG;
-        }
-#undef COS_BWD
-        return check_launch();
-    }
-    const int gx = grid_x(P, 1);
-#define CALL(DT) hipLaunchKernelGGL((k_cos_emb<DT, true>), dim3(gx, B), dim3(LOSS_THREADS), 0, stream, \
-                                    pred, indices, lut, D, P, L, grad_scale, grad_pred,                \
-                                    (LossPartial*)nullptr, (int*)nullptr)
-    NMSA_DISPATCH_DTYPE(dtype, CALL)
-#undef CALL
-    return check_launch();
+    return launch_cos_two_walk_bwd(pred, dtype, indices, lut, B, D, H * W, L, grad_scale, dots, grad_pred,
+                                   nullptr, 0, stream);
 }
 

@@ -234,16 +234,27 @@ __global__ __launch_bounds__(64 * COSS_MAX_WAVES) void k_cos_split(
 // part publishes tile t + 1 only after it has read its partners' tile t, which they published
 // after reading tile t - 1 of everybody.
 // Forward progress: the launch geometry (coss_geometry) never asks for more workgroups than the
-// chip holds at once (256 CUs x the workgroups per CU the LDS footprint allows), so whatever the
-// dispatch order, once foreign kernels have drained every workgroup of the grid is resident and
-// every partner answers.  (Only the test override NMSA_COS_SPLIT_RUN makes larger grids; those
-// rely on partners being neighbours in the linear workgroup id and on dispatch in id order.)
-// Should a partner still not answer within ~2 s the wait gives up for good and poisons sums and
-// gradients with NaN, status bit 32 (every wave reaches the end; the failure is loud).
+// DEVICE holds at once — compute units as the HIP runtime reports them for this device (a
+// partitioned MI355X or a CU mask shows fewer than 256: api.hip device_geometry) x the workgroups
+// per CU that the LDS footprint, the launch bounds (2 waves per SIMD) and the occupancy query
+// admit — so once foreign kernels have drained every workgroup of the grid is resident and every
+// partner answers, whatever the dispatch order.  That is an argument about an otherwise idle
+// device, not a guarantee: another stream's long kernel, or a device that shows the runtime more
+// CUs than it schedules on, leaves partners un-dispatched.  So every wait is bounded (`timeout`
+// ticks of the 100 MHz wall clock, 0.5 s by default, NMSA_COS_PARTS_TIMEOUT_MS): a wave 0 that
+// gives up stops waiting for good, poisons its sums with NaN so that every wave still reaches the
+// end, and raises the call's `gave_up` word (+ status bit 32, also from the gradient-only
+// launch).  The launch function queues the two-walk kernels of losses.hip behind it, gated ON THE
+// DEVICE by that word: they return at once after a healthy run (three empty launches, ~6 us behind
+// a 4-8 ms kernel) and otherwise recompute the call's sums and gradient — a call never returns
+// the poison.  (The test hooks NMSA_ASSUME_CUS — an overstated chip — and NMSA_COS_PARTS_ORDER=1
+// — the parts of a group far apart in the workgroup order instead of neighbours — together strand
+// every resident workgroup and drive exactly that path.)
 constexpr int COSP_WAVES = 4;
 constexpr int COSP_COLS = COSP_WAVES * COSS_NP;        // 256 planes per part
 constexpr int COSP_MAX_PARTS = 4;                      // D <= 1024
 constexpr int COSP_GRAN = 2 * 4 * 64;                  // granules per (slot, part): 2 sums x 4 px x 64 lanes
+constexpr size_t COSP_HEAD = 64;                       // the call's gave_up word in front of the granules
 
 // RAGGED: D is no multiple of 64 — the last wave that holds planes holds fewer than 64; its walks
 // test every plane against the wave's plane count (wave-uniform branches).  Compiled apart so that
@@ -255,7 +266,7 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     const float* __restrict__ expected_gscale, void* __restrict__ grad,
     LossPartial* __restrict__ partials, int* __restrict__ status,
     const float* __restrict__ computed_for, int* __restrict__ counters,
-    unsigned long long* __restrict__ xch)
+    unsigned long long* __restrict__ xch, int* __restrict__ gave_up, int part_major, long long timeout)
 {
     constexpr int PXT = (DTYPE == NMSA_F32) ? 2 : 4;
     constexpr int NP = COSS_NP;
@@ -267,8 +278,11 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
     // the tiles of the whole batch form ONE sequence (image after image) cut into equal runs, one
     // per group: every workgroup slot of the chip gets the same amount of work whatever B is; a
     // run that crosses into the next image restages that image's LUT columns (from L2)
+    // the NS parts of a group are neighbours in the workgroup order (dispatched together); the
+    // test hook `part_major` puts them a whole grid / NS apart instead
     const int wg = blockIdx.y * gridDim.x + blockIdx.x;
-    const int part = wg % NS, group = wg / NS;
+    const int n_groups = (int)(gridDim.x * gridDim.y) / NS;
+    const int part = part_major ? wg / n_groups : wg % NS, group = part_major ? wg % n_groups : wg / NS;
     const int d0 = part * COSP_COLS;
     const int DP = min(COSP_COLS, D - d0);             // my columns (a multiple of 64 unless RAGGED)
     constexpr int ld = COSP_COLS + 1;
@@ -432,7 +446,7 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
                     }
                     if (dead) break;                                                  // (wave-uniform)
                     __builtin_amdgcn_s_sleep(8);
-                    if (__any((long long)wall_clock64() - t0 > 200000000LL)) dead = true;     // ~2 s at 100 MHz
+                    if (__any((long long)wall_clock64() - t0 > timeout)) dead = true;         // 100 MHz ticks
                 }
 #pragma unroll
                 for (int k = 0; k < 2 * PXT; ++k)
@@ -486,10 +500,38 @@ __global__ __launch_bounds__(64 * COSP_WAVES, 2) void k_cos_parts(
             }
         }
     }
+    if (dead && l == 0) {                               // (wave 0 only; both launch modes)
+        atomicOr(gave_up, 1);
+        if (status) atomicOr(status, 32);
+    }
     if (LOSS) {
         if (bad) atomicOr(status, 8);
-        if (dead) atomicOr(status, 32);
         block_partial_wide(acc, cnt, partials);
+    }
+}
+
+// After a k_cos_parts that gave up, the two-walk forward kernel has left the call's sums in
+// `fb[0 .. n_fb)`: they replace the poisoned partials (slot 0 = their sum in a fixed order, the
+// other slots 0), so whoever finalizes the partials — this file or the multi-loss call — sees the
+// fallback's result.  One workgroup; returns at once when nobody gave up.
+__global__ __launch_bounds__(256) void k_cos_adopt(const int* __restrict__ gave_up, const LossPartial* __restrict__ fb,
+                                                   int n_fb, LossPartial* __restrict__ partials, int n)
+{
+    if (*gave_up == 0) return;
+    __shared__ double s_sum[256];
+    __shared__ long long s_cnt[256];
+    double a = 0.0; long long c = 0;
+    for (int i = threadIdx.x; i < n_fb; i += 256) { a += fb[i].sum; c += fb[i].count; }
+    s_sum[threadIdx.x] = a; s_cnt[threadIdx.x] = c;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if ((int)threadIdx.x < o) { s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; s_cnt[threadIdx.x] += s_cnt[threadIdx.x + o]; }
+        __syncthreads();
+    }
+    for (int i = threadIdx.x; i < n; i += 256) {
+        LossPartial pr; pr.sum = 0; pr.aux = 0; pr.count = 0; pr.pad = 0;
+        if (i == 0) { pr.sum = s_sum[0]; pr.count = s_cnt[0]; }
+        partials[i] = pr;
     }
 }
 }  // namespace nmsa
@@ -524,21 +566,49 @@ int cos_kernel(int dtype, int D, int L)
     if (!on) return 0;
     const int pxt = dtype == NMSA_F32 ? 2 : 4;
     const int nw = D / COSS_NP;
-    const bool split_ok = !ragged && nw <= COSS_MAX_WAVES && coss_lds_bytes(D, L, nw, pxt) <= (size_t)158 * 1024;
-    const bool parts_ok = parts != 0 && D <= COSP_COLS * COSP_MAX_PARTS && cosp_lds_bytes(L, pxt) <= (size_t)158 * 1024;
+    const DeviceGeometry dg = device_geometry();
+    const size_t wg_lds = dg.lds_per_block > 2048 ? dg.lds_per_block - 2048 : 0;    // (static LDS of the reductions)
+    const bool split_ok = !ragged && nw <= COSS_MAX_WAVES && coss_lds_bytes(D, L, nw, pxt) <= wg_lds;
+    const bool parts_ok = parts != 0 && D <= COSP_COLS * COSP_MAX_PARTS && cosp_lds_bytes(L, pxt) <= wg_lds;
     if (parts == 1 && parts_ok) return 2;
     // 512 planes fit one workgroup, but two cooperating half-columns with two workgroups per CU
     // stream 7 % faster (one's exchange wait is the other's streaming time): measured at B = 16,
     // same process, both kernels alternating: 4.61-4.72 vs 4.97-5.17 ms.  Narrower columns are as
     // fast or faster in one workgroup (D = 448: 4.28-4.36 vs 4.30-4.41, 384: 3.74 vs 3.94,
     // 256: 2.79 vs 2.82 ms)
-    if (split_ok && parts_ok && parts == -1 && D >= 2 * COSP_COLS && 2 * cosp_lds_bytes(L, pxt) <= (size_t)160 * 1024)
+    if (split_ok && parts_ok && parts == -1 && D >= 2 * COSP_COLS && 2 * cosp_lds_bytes(L, pxt) <= dg.lds_per_cu)
         return 2;
     if (split_ok) return 1;
     return parts_ok ? 2 : 0;
 }
 
 int cosp_parts(int D) { return (D + COSP_COLS - 1) / COSP_COLS; }
+
+// workgroups of k_cos_parts that are resident per CU: 2 at most (its launch bounds keep the
+// registers of 2 x 4 waves per SIMD pair free), fewer when the LDS of the device or the runtime's
+// occupancy answer for this instantiation says so.  (The API over-reports only near 8 per CU —
+// MI355X_MICROARCH.md, Residency — far from the 2 asked for here.)
+int cosp_resident_per_cu(int dtype, bool ragged, int L)
+{
+    const int pxt = (dtype == NMSA_F32) ? 2 : 4;
+    const size_t lds = cosp_lds_bytes(L, pxt);
+    const DeviceGeometry dg = device_geometry();
+    int per_cu = (int)(dg.lds_per_cu / lds) >= 2 ? 2 : 1;
+    int api = 0;
+    hipError_t e = hipErrorUnknown;
+#define OCC_(DT, RG) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&api, k_cos_parts<DT, 0, RG>, 64 * COSP_WAVES, lds)
+#define OCC(DT) do { if (ragged) OCC_(DT, true); else OCC_(DT, false); } while (0)
+    switch (dtype) {
+        case NMSA_F32: OCC(NMSA_F32); break;
+        case NMSA_BF16: OCC(NMSA_BF16); break;
+        default: OCC(NMSA_F16); break;
+    }
+#undef OCC
+#undef OCC_
+    if (e == hipSuccess && api >= 1 && api < per_cu) per_cu = api;
+    if (e != hipSuccess) (void)hipGetLastError();      // (no device: the LDS bound alone)
+    return per_cu;
+}
 
 // workgroups per image and tiles per workgroup.  k_cos_split: one workgroup per CU is resident
 // (the LUT fills the LDS), a few workgroups per CU over the whole batch, each walking a run of
@@ -558,8 +628,8 @@ void coss_geometry(int B, int D, int P, int L, int dtype, int* gx, int* tpw, int
         *ns = cosp_parts(D);
         const char* re = getenv("NMSA_COS_PARTS_ROUNDS");              // (per call: same-process A/B)
         const int rounds = (re && *re) ? atoi(re) : 1;
-        const int per_cu = (int)((size_t)160 * 1024 / cosp_lds_bytes(L, pxt)) >= 2 ? 2 : 1;
-        long long G = 256 * per_cu * (rounds < 1 ? 1 : rounds) / *ns;
+        const int per_cu = cosp_resident_per_cu(dtype, D % COSS_NP != 0, L);
+        long long G = (long long)device_geometry().cus * per_cu * (rounds < 1 ? 1 : rounds) / *ns;
         const long long t_total = (long long)B * n_tiles;
         if (G > t_total) G = t_total;
         if (G < 1) G = 1;
@@ -573,7 +643,7 @@ void coss_geometry(int B, int D, int P, int L, int dtype, int* gx, int* tpw, int
         return;
     } else {
         static const int per_cu = loss_env_int("NMSA_COS_SPLIT_WGS_PER_CU", 2);
-        per_img = (256 * (per_cu < 1 ? 1 : per_cu) + B - 1) / B;
+        per_img = (device_geometry().cus * (per_cu < 1 ? 1 : per_cu) + B - 1) / B;
     }
     if (per_img > n_tiles) per_img = n_tiles;
     if (per_img > 4096) per_img = 4096;
@@ -603,20 +673,42 @@ int coss_launch(const void* pred, int dtype, const int32_t* indices, const float
     int gx, tpw, ns;
     coss_geometry(B, D, P, L, dtype, &gx, &tpw, &ns);
     if (which == 2) {
+        // [ gave_up word (64 B) | granules | partials of the fallback's forward walk ]
         const size_t need = (size_t)B * gx * 2 * ns * COSP_GRAN * sizeof(unsigned long long);
-        if (!xch || xch_bytes < need || (((uintptr_t)xch) & 7)) return NMSA_ERR_WORKSPACE;
+        const int n_fb = cos_two_walk_blocks(dtype, B, D, P, L);
+        if (!xch || xch_bytes < COSP_HEAD + need + (MODE == 0 ? (size_t)n_fb * sizeof(LossPartial) : 0) ||
+            (((uintptr_t)xch) & 15)) return NMSA_ERR_WORKSPACE;
+        int* gave_up = (int*)xch;
+        unsigned long long* granules = (unsigned long long*)((char*)xch + COSP_HEAD);
+        LossPartial* fb = (LossPartial*)((char*)xch + COSP_HEAD + need);
         // tags start at 1: a zeroed buffer holds no valid granule
-        if (check_hip(hipMemsetAsync(xch, 0, need, stream))) return NMSA_ERR_LAUNCH;
+        if (check_hip(hipMemsetAsync(xch, 0, COSP_HEAD + need, stream))) return NMSA_ERR_LAUNCH;
         const size_t lds = cosp_lds_bytes(L, pxt);
+        const char* oe = getenv("NMSA_COS_PARTS_ORDER");               // (per call: a test hook)
+        const int part_major = (oe && atoi(oe) == 1) ? 1 : 0;
+        const char* te = getenv("NMSA_COS_PARTS_TIMEOUT_MS");
+        const long long timeout = 100000ll * ((te && atoi(te) > 0) ? atoi(te) : 500);   // 100 MHz ticks
 #define COSP_(DT, RG) do { int rc_ = allow_dynamic_lds(k_cos_parts<DT, MODE, RG>, lds); if (rc_) return rc_;       \
         hipLaunchKernelGGL((k_cos_parts<DT, MODE, RG>), dim3(gx * ns, B), dim3(64 * COSP_WAVES), lds, stream, pred, \
                            indices, lut, B, D, P, L, ns, tpw, gscale, grad, partials, status, computed_for,     \
-                           counters, (unsigned long long*)xch); } while (0)
+                           counters, granules, gave_up, part_major, timeout); } while (0)
 #define COSP(DT) do { if (D % COSS_NP != 0) COSP_(DT, true); else COSP_(DT, false); } while (0)
         NMSA_DISPATCH_DTYPE(dtype, COSP)
 #undef COSP
 #undef COSP_
-        return check_launch();
+        int rc = check_launch();
+        if (rc) return rc;
+        // the fallback, gated on the device by `gave_up` (see the kernel's header comment)
+        if (MODE == 0) {
+            rc = launch_cos_two_walk_fwd(pred, dtype, indices, lut, B, D, P, L, fb, status, nullptr, gave_up, stream);
+            if (rc) return rc;
+            hipLaunchKernelGGL(k_cos_adopt, dim3(1), dim3(256), 0, stream, gave_up, fb, n_fb, partials, B * gx * ns);
+            rc = check_launch();
+            if (rc) return rc;
+        }
+        if (grad) rc = launch_cos_two_walk_bwd(pred, dtype, indices, lut, B, D, P, L, gscale, nullptr, grad, gave_up,
+                                               MODE == 0 ? 1 : 0, stream);
+        return rc;
     }
     const int nw = D / COSS_NP;
     const size_t lds = coss_lds_bytes(D, L, nw, pxt);
@@ -648,13 +740,15 @@ int cos_split_blocks(int B, int D, int P, int L, int dtype)     // partial slots
     return gx * ns;
 }
 
-// bytes of the granule exchange buffer of k_cos_parts (0: the shape runs in one workgroup)
+// bytes of the exchange buffer of k_cos_parts (0: the shape runs in one workgroup)
 size_t cos_split_xch_bytes(int B, int D, int P, int L, int dtype)
 {
     if (cos_kernel(dtype, D, L) != 2) return 0;
     int gx, tpw, ns;
     coss_geometry(B, D, P, L, dtype, &gx, &tpw, &ns);
-    return (size_t)B * gx * 2 * ns * COSP_GRAN * sizeof(unsigned long long);
+    // [ gave_up word | granules | partials of the fallback's forward walk ] (coss_launch)
+    const size_t fb = ((size_t)cos_two_walk_blocks(dtype, B, D, P, L) * sizeof(LossPartial) + 63) & ~(size_t)63;
+    return COSP_HEAD + (size_t)B * gx * 2 * ns * COSP_GRAN * sizeof(unsigned long long) + fb;
 }
 
 int launch_cos_split(bool loss, const void* pred, int dtype, const int32_t* indices, const float* lut,

@@ -821,7 +821,8 @@ extern "C" int nmsa_confmat_update(const void* preds, int pred_dtype, int64_t pr
     const int64_t n_chunks = (n_px + 2 * CM_UNROLL - 1) / (2 * CM_UNROLL);     // per-thread work items
     // >= 4 workgroups per CU for latency hiding; a big LDS histogram allows only one
     static const int blocks_env = getenv("NMSA_CM_BLOCKS") ? atoi(getenv("NMSA_CM_BLOCKS")) : 0;
-    int64_t blocks = (lds > 40 * 1024) ? 256 : (blocks_env > 0 && blocks_env <= CM_MAX_BLOCKS ? blocks_env : CM_MAX_BLOCKS);
+    const int one_per_cu = device_geometry().cus < CM_MAX_BLOCKS ? device_geometry().cus : CM_MAX_BLOCKS;
+    int64_t blocks = (lds > 40 * 1024) ? one_per_cu : (blocks_env > 0 && blocks_env <= CM_MAX_BLOCKS ? blocks_env : CM_MAX_BLOCKS);
     const int64_t need = (n_chunks + 256 - 1) / 256;
     if (blocks > need) blocks = need;
     if (blocks < 1) blocks = 1;

@@ -34,6 +34,21 @@ int allow_dynamic_lds(K kernel, size_t bytes)
     return allow_dynamic_lds_impl(reinterpret_cast<const void*>(kernel), bytes);
 }
 
+// What the launch geometry is sized from: read ONCE per device from the HIP runtime (api.hip) —
+// never a literal 256 / 8: a partitioned MI355X (DPX / QPX / CPX modes) or a CU mask shows fewer
+// CUs and XCDs, and the cooperating-workgroup cosine kernel's forward progress depends on the grid
+// fitting the chip.  NMSA_ASSUME_CUS / NMSA_ASSUME_XCDS (read at every call) override the queried
+// values: tests shrink the chip (results must not change) or overstate it (the cosine kernel's
+// partners then time out and the call takes its fallback).  Without a device (CPU-only symbol
+// checks, workspace queries) the MI355X's numbers are returned.
+struct DeviceGeometry {
+    int cus;                // compute units of the current device
+    int xcds;               // XCDs (each with its own L2)
+    size_t lds_per_cu;      // bytes
+    size_t lds_per_block;   // largest dynamic + static LDS one workgroup may ask for
+};
+DeviceGeometry device_geometry();
+
 __device__ __forceinline__ int lane_id() { return (int)(threadIdx.x & 63); }
 
 __device__ __forceinline__ float bf16_to_f32(uint16_t v)

@@ -26,6 +26,26 @@ def test_version_and_error_strings():
     assert b'argument' in lib.nmsa_strerror(-1)
 
 
+def test_device_geometry_query_and_override(monkeypatch):
+    """grids are sized from what the HIP runtime reports for the device (csrc/api.hip); without a
+    device the MI355X's numbers; NMSA_ASSUME_CUS / NMSA_ASSUME_XCDS override per call — and the
+    workspace of the cooperating-workgroup cosine kernel follows (fewer CUs: fewer groups)"""
+    monkeypatch.delenv('NMSA_ASSUME_CUS', raising=False)
+    monkeypatch.delenv('NMSA_ASSUME_XCDS', raising=False)
+    cus, xcds, lds = L.device_geometry()
+    assert cus >= 1 and 1 <= xcds <= cus and lds >= 64 * 1024
+    if not torch.cuda.is_available():
+        assert (cus, xcds, lds) == (256, 8, 160 * 1024)
+    full = L.lib().nmsa_loss_cos_emb_fwd_grad_workspace_bytes(2, 768, 256, 512, 64)
+    monkeypatch.setenv('NMSA_ASSUME_CUS', '64')
+    monkeypatch.setenv('NMSA_ASSUME_XCDS', '2')
+    assert L.device_geometry()[:2] == (64, 2)
+    quarter = L.lib().nmsa_loss_cos_emb_fwd_grad_workspace_bytes(2, 768, 256, 512, 64)
+    assert 0 < quarter < full
+    monkeypatch.setenv('NMSA_ASSUME_XCDS', '4096')             # never more XCDs than CUs
+    assert L.device_geometry()[:2] == (64, 64)
+
+
 def test_cpu_tensors_are_rejected_loudly():
     from nicr_mt_scene_analysis_amd import ops
     with pytest.raises(L.NmsaError):

@@ -553,3 +553,125 @@ def test_ce_bf16_far_classes_keep_their_gradient():
     np.testing.assert_allclose(got.cpu().numpy(), want.cpu().numpy(), rtol=2 ** -7, atol=1e-9 / int(n) * 0.1)
     small = (xr.grad.abs() < 1e-5 / int(n)) & (xr.grad != 0)
     assert int(small.sum()) > 1000 and bool((got[small] != 0).all())
+
+
+@pytest.fixture
+def lib_env():
+    """environment variables the library reads at every call; restored afterwards"""
+    import os
+    saved = {}
+
+    def set_env(**kw):
+        for k, v in kw.items():
+            if k not in saved:
+                saved[k] = os.environ.get(k)
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = str(v)
+    yield set_env
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
+
+
+def _cos_parts_case(B, D, H, W, L, seed):
+    g = _gen(seed)
+    x = torch.randn((B, D, H, W), device='cuda', generator=g).to(torch.bfloat16)
+    lut = torch.nn.functional.normalize(torch.randn((B, L, D), device='cuda', generator=g), dim=-1)
+    idx = _segment_indices(B, H, W, L, g)
+    return x, lut, idx
+
+
+def test_cos_parts_grid_follows_the_device_geometry(lib_env):
+    """the cooperating-workgroup cosine kernel sizes its grid from the compute units the HIP
+    runtime reports (csrc/api.hip device_geometry), not from a literal 256: with a quarter of the
+    device assumed (NMSA_ASSUME_CUS, e.g. a partition or a CU mask) the grid shrinks — fewer,
+    longer runs of tiles — and loss, count and every gradient bit stay the same"""
+    from nicr_mt_scene_analysis_amd import _lib as L_
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi, check_loss_status
+    from nicr_mt_scene_analysis_amd.loss import _functional as _F
+    if not _F.speculation_enabled():
+        pytest.skip('NMSA_SPECULATIVE_GRAD=0')
+    lib_env(NMSA_ASSUME_CUS=None, NMSA_ASSUME_XCDS=None)
+    cus, xcds, lds = L_.device_geometry()
+    props = torch.cuda.get_device_properties(0)
+    assert cus == props.multi_processor_count and xcds >= 1 and lds >= 64 * 1024
+    B, D, H, W, L = 2, 768, 128, 512, 64
+    x, lut, idx = _cos_parts_case(B, D, H, W, L, 11)
+    assert _multi.cos_supported(x, lut)
+    ws_bytes = lambda: L_.lib().nmsa_loss_cos_emb_fwd_grad_workspace_bytes(B, D, H, W, L)
+    ref_loss, ref_n, ref_grad = _cos_reference(x, idx, lut)
+    out = []
+    for assumed in (None, max(1, cus // 4)):
+        lib_env(NMSA_ASSUME_CUS=assumed)
+        assert L_.device_geometry()[0] == (assumed or cus)
+        out.append([ws_bytes()])
+        for scale in (1.0, 0.5):               # confirmed forward-written gradient / the recomputing launch
+            xs = x.clone().requires_grad_(True)
+            loss, n = CosineEmbeddingLoss().lut_sum(xs, idx, lut)
+            (scale * (loss / n.clamp(min=1))).backward()
+            assert int(n) == ref_n
+            np.testing.assert_allclose(float(loss), ref_loss, rtol=RTOL)
+            out[-1] += [float(loss), xs.grad.clone()]
+    check_loss_status()                         # nothing gave up, nothing out of range
+    (ws_a, loss_a, g_a, _, gh_a), (ws_b, loss_b, g_b, _, gh_b) = out
+    assert ws_b < ws_a, 'a smaller device must get a smaller grid (fewer exchange slots)'
+    assert abs(loss_a - loss_b) <= 1e-9 * abs(loss_a)        # (f64 sums of the same f32 tile sums, other grouping)
+    assert torch.equal(g_a, g_b) and torch.equal(gh_a, gh_b)
+    tol = _grad_tol(torch.bfloat16)
+    np.testing.assert_allclose(g_b.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol,
+                               atol=tol * float(ref_grad.abs().max()) * 0.05 + 1e-12)
+
+
+def test_cos_parts_stranded_partners_take_the_fallback(lib_env):
+    """a grid that is NOT resident as a whole: four times the device's compute units assumed and
+    the parts of a group a third of the grid apart in the workgroup order (NMSA_COS_PARTS_ORDER=1)
+    instead of neighbours — the first workgroups fill the device and wait for partners that cannot
+    be dispatched.  Their waits time out (20 ms here), the call's gave-up word gates the two-walk
+    kernels in ON THE DEVICE, and the call returns the right loss, count and gradient (forward-
+    written and recomputed); the status word reports it as a warning"""
+    from nicr_mt_scene_analysis_amd import _lib as L_
+    from nicr_mt_scene_analysis_amd.loss import CosineEmbeddingLoss, _multi, check_loss_status
+    from nicr_mt_scene_analysis_amd.loss import _functional as _F
+    if not _F.speculation_enabled():
+        pytest.skip('NMSA_SPECULATIVE_GRAD=0')
+    import warnings
+    lib_env(NMSA_ASSUME_CUS=None)
+    cus = L_.device_geometry()[0]
+    B, D, L = 2, 768, 64
+    H, W = 192, 512 * max(1, cus // 256)        # 768 tiles on a whole MI355X: more than the 682 groups asked for
+    x, lut, idx = _cos_parts_case(B, D, H, W, L, 23)
+    assert _multi.cos_supported(x, lut)
+    ref_loss, ref_n, ref_grad = _cos_reference(x, idx, lut)
+    tol = _grad_tol(torch.bfloat16)
+    atol = tol * float(ref_grad.abs().max()) * 0.05 + 1e-12
+    with warnings.catch_warnings():
+        warnings.simplefilter('error')
+        check_loss_status()                     # clean before
+    lib_env(NMSA_ASSUME_CUS=4 * cus, NMSA_COS_PARTS_ORDER=1, NMSA_COS_PARTS_TIMEOUT_MS=20)
+    for scale in (1.0, 0.5):
+        xs = x.clone().requires_grad_(True)
+        loss, n = CosineEmbeddingLoss().lut_sum(xs, idx, lut)
+        (scale * (loss / n.clamp(min=1))).backward()
+        torch.cuda.synchronize()
+        assert int(n) == ref_n
+        assert np.isfinite(float(loss))
+        np.testing.assert_allclose(float(loss), ref_loss, rtol=RTOL)
+        assert torch.isfinite(xs.grad).all()
+        np.testing.assert_allclose(xs.grad.double().cpu().numpy(), scale * ref_grad.cpu().numpy(), rtol=tol, atol=atol)
+        with pytest.warns(RuntimeWarning, match='k_cos_parts'):
+            check_loss_status()
+    # the neighbours order survives the same over-subscription (partners are dispatched together) —
+    # and whatever happens, the result is right
+    lib_env(NMSA_COS_PARTS_ORDER=None)
+    xs = x.clone().requires_grad_(True)
+    loss, n = CosineEmbeddingLoss().lut_sum(xs, idx, lut)
+    (loss / n.clamp(min=1)).backward()
+    np.testing.assert_allclose(float(loss), ref_loss, rtol=RTOL)
+    np.testing.assert_allclose(xs.grad.double().cpu().numpy(), ref_grad.cpu().numpy(), rtol=tol, atol=atol)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')
+        check_loss_status()
