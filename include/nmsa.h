@@ -575,21 +575,22 @@ int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
  *      TaskHelperBase.accumulate_losses    task_helper/base.py:161-182
  * Every (loss, supervision scale) pair is an ITEM; the items whose sums the caller adds and
  * divides by their summed element counts (accumulate_losses) form a TOTAL.  One call
- *   counts the labels / mask bytes of all items                          (launch 1, 1 B/px)
- *   forms per total the divisor n and the EXPECTED upstream gradient w / n of its loss sums
- *     (launch 2; w lives in the total's spec record and is learned from the backward passes:
- *     loss weights, AMP scale, ... need no hint from the caller)
- *   computes all forward sums and writes all gradients for that expectation (launch 3: block
+ *   counts the labels / mask bytes of all items (launch 1, 1 B/px); the launch's last workgroup
+ *     forms per total the divisor n and the EXPECTED upstream gradient w / n of its loss sums
+ *     (w lives in the total's spec record and is learned from the backward passes: loss
+ *     weights, AMP scale, ... need no hint from the caller)
+ *   computes all forward sums and writes all gradients for that expectation (launch 2: block
  *     ranges per item; cross entropies above 48 classes run k_ce_split as launches of their own)
  *   reduces the block partials per item in a fixed order and forms per item loss_sum / count
- *     and per total sum(loss sums) / divisor (launch 4; the reductions of accumulate_losses, in
+ *     and per total sum(loss sums) / divisor (launch 3; the reductions of accumulate_losses, in
  *     item order, float32)
  * A call without any gradient buffer (validation) skips the count and takes the divisors from
- * the finalized counts (3 launches).
- * nmsa_multitask_loss_bwd_unless turns the upstream gradients of the three outputs into one
- * upstream scale per item, compares it with the expectation on the device (launch 1: also
- * updates w) and recomputes only the items that differ (launch 2: a small grid that walks the
- * block list and is gone at once when every gradient stands).  A NaN expectation ("the forward
+ * the finalized counts (2 launches).
+ * nmsa_multitask_loss_bwd_unless is ONE launch (+ one per wide cross entropy / cosine item): a
+ * small grid that walks the block list; every workgroup turns the upstream gradients of the
+ * three outputs into one upstream scale per item and compares it with the expectation,
+ * workgroup 0 also updates w; only the items that differ are recomputed and the grid is gone at
+ * once when every gradient stands.  A NaN expectation ("the forward
  * pass wrote no gradient") is never confirmed — not even by an upstream gradient that is the same
  * NaN: gradient-only launches always write, so a NaN upstream comes out as NaN gradients.
  * `spec` (and `counters`) may be NULL there: a recompute nobody predicted (a second backward
@@ -607,9 +608,12 @@ int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
  *                grad = gradient buffer shaped like pred, or NULL (forward only).
  *                clamp_count: the item's count enters its loss and its total as max(count, 1)
  *                (task_helper/instance.py:206-211)
- *   spec         i32 [n_totals][8] device, persistent, owned by the caller (zero it, then store
- *                the fp32 bits of the initial upstream weight, usually 1.0f, at [t][2]):
- *                [0] backward passes that found their gradient written [1] ... that recomputed
+ *   spec         i32 [n_totals + 1][8] device, persistent, owned by the caller (zero it, then store
+ *                the fp32 bits of the initial upstream weight, usually 1.0f, at [t][2], t < n_totals):
+ *                [0] backward passes that found their gradient written [1] ... that recomputed;
+ *                the LAST row is scratch of the calls (the tickets their launches draw to find
+ *                their last workgroup): zero it once, every call leaves it zero again.  One
+ *                record set serves one stream at a time.
  *   expect       f32 [n_totals][2] device, out: expected upstream gradient (NaN: none) and the
  *                divisor as float; must be handed to nmsa_multitask_loss_bwd_unless unchanged
  *   loss_sums    f64 [n_items], counts i64 [n_items], aux f64 [n_items] or NULL (CE: sum of the

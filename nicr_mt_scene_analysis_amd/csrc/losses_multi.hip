@@ -8,14 +8,22 @@ namespace nmsa {
 // a10: the losses of a task helper in ONE forward launch (task_helper/instance.py:92-269,
 // task_helper/semantic.py:57-90, task_helper/base.py:161-182): every (loss, scale) pair is an
 // ITEM, items whose sums the caller adds before dividing by the summed counts form a TOTAL.
-//   k_multi_count    counts the labels / mask bytes of every item                 (1 B/px)
-//   k_multi_expect   counts per item, divisor per total, and the EXPECTED upstream gradient of
-//                    the total's loss sums: w / n with w from the total's spec record
+//   k_multi_count    counts the labels / mask bytes of every item (1 B/px); its LAST workgroup
+//                    (a ticket) forms the counts per item, the divisor per total and the EXPECTED
+//                    upstream gradient of the total's loss sums: w / n with w from the total's
+//                    spec record (multi_expect_body: a launch of its own until round 4)
 //   k_multi_loss     all items in one launch (block ranges): forward sums + gradients
 //   k_multi_finalize block partials -> sums / counts per item, fixed order
-// backward: k_multi_spec (one thread per total) compares the real upstream gradient with the
-// expectation and keeps the record's `w` up to date; k_multi_loss<..., LOSS = false> recomputes
-// only the items whose upstream gradient differs bit-wise from the expectation.
+// = 3 launches with gradients, 2 without (no count: the divisors come out of the finalized counts).
+// backward: ONE launch — every workgroup of k_multi_loss<..., MODE 2> turns the upstream gradients
+// of the three outputs into the upstream scale per item (a handful of loads), workgroup 0 also
+// compares them with the expectation, keeps the record's `w` up to date and stores the scales
+// (multi_spec_update: the kernel k_multi_spec until round 4, still launched when no item is part
+// of the joint launch); the walk recomputes only the items whose upstream gradient differs
+// bit-wise from the expectation.
+// The two tickets (count, finalize) live behind the caller's spec records — spec[8 T + 0 / 1] —
+// zero between calls: the last workgroup of each launch resets its ticket, so no launch is spent
+// on zeroing them.
 //
 // Spec record (int32[8], device): [0] confirmed [1] recomputed [2] w (fp32 bits): the factor the
 // caller multiplies the total with before backward (loss weights, AMP scale: learned, see
@@ -40,17 +48,53 @@ struct MultiItem {
 };
 struct MultiArgs { MultiItem it[MULTI_MAX_ITEMS]; int n_items, n_totals, n_blocks; };
 
-__global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long long* __restrict__ partials)
+// divisor of total t from per-item counts (accumulate_losses: max(sum of counts, 1) as float32;
+// an item with clamp enters as max(count, 1), task_helper/instance.py:206-211)
+__device__ inline float multi_divisor(const MultiArgs& a, const long long* counts, int t)
 {
-    __shared__ long long s_cnt[LOSS_THREADS / 64];
-    int i = 0;
-    while (i + 1 < a.n_items && (int)blockIdx.x >= a.it[i].cblock0 + a.it[i].cnblocks) ++i;
-    const MultiItem& it = a.it[i];
-    if ((it.count_mode != 1 && it.count_mode != 3) || (int)blockIdx.x < it.cblock0) {
-        if (threadIdx.x == 0) partials[blockIdx.x] = 0;
-        return;
+    long long n = 0;
+    for (int i = 0; i < a.n_items; ++i)
+        if (a.it[i].total == t) n += a.it[i].clamp == 1 ? max(counts[i], 1LL) : counts[i];
+    return (float)max(n, 1LL);
+}
+
+// counts per item from the count partials, divisor + expected upstream gradient per total; one
+// workgroup of LOSS_THREADS (the last one of k_multi_count: `partials` were written by other
+// workgroups, read them past the L1)
+__device__ inline void multi_expect_body(const MultiArgs& a, long long* partials,
+                                         const int32_t* __restrict__ spec, float* __restrict__ expect)
+{
+    __shared__ long long s_count[MULTI_MAX_ITEMS];
+    const int w = threadIdx.x >> 6, l = lane_id();
+    for (int i = w; i < a.n_items; i += LOSS_THREADS / 64) {
+        const MultiItem& it = a.it[i];
+        const bool counted = it.count_mode == 1 || it.count_mode == 3;
+        long long c = 0;
+        if (counted) {
+            for (int k = l; k < it.cnblocks; k += 64)
+                c += __hip_atomic_load(&partials[it.cblock0 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
+        if (l == 0) s_count[i] = counted ? c : (long long)it.B * it.P;
     }
-    const int bi = blockIdx.x - it.cblock0;
+    __syncthreads();
+    if ((int)threadIdx.x < a.n_totals) {
+        const int t = threadIdx.x;
+        bool known = true;
+        for (int i = 0; i < a.n_items; ++i)
+            if (a.it[i].total == t && a.it[i].count_mode == 2) known = false;   // the divisor is no count of mask bytes
+        const float nf = multi_divisor(a, s_count, t);
+        const float wv = __int_as_float(spec[8 * t + 2]);
+        const bool off = (spec[8 * t + 5] & 1) || !known;
+        expect[2 * t] = off ? __int_as_float(0x7fc00000) : wv / nf;     // NaN: the forward writes no gradient
+        expect[2 * t + 1] = nf;                                         // (!known: k_multi_finalize corrects it)
+    }
+}
+
+// number of bytes / int32 words of the item's mask inside [lo, hi] that fall to this workgroup
+__device__ inline long long multi_count_block(const MultiItem& it, int bi)
+{
     const long long n = (long long)it.B * it.P;
     if (it.count_mode == 3) {
         // int32 indices (cosine embedding: 0 = no target): 4 words per 16-byte load
@@ -68,16 +112,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long 
         }
         for (; q < e4; q += LOSS_THREADS * 4)
             for (long long j = q; j < min(e4, q + 4); ++j) c3 += (((unsigned)v32[j] - lo3) <= span3);
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c3 += __shfl_down(c3, o);
-        if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = c3;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            long long c = 0;
-            for (int k = 0; k < LOSS_THREADS / 64; ++k) c += s_cnt[k];
-            partials[blockIdx.x] = c;
-        }
-        return;
+        return c3;
     }
     const long long per = ((n + it.cnblocks - 1) / it.cnblocks + 15) / 16 * 16;
     const long long begin = min(n, per * bi), end = min(n, begin + per);
@@ -108,6 +143,24 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long 
     }
     for (; k < end; k += LOSS_THREADS * 16)
         for (long long j = k; j < min(end, k + 16); ++j) cnt += (((unsigned)v[j] - lo) <= span);
+    return cnt;
+}
+
+// the first launch of a call that writes gradients.  `tickets` = spec + 8 n_totals: [0] this
+// launch's, [1] k_multi_finalize's; both are zero between calls (the last workgroup resets its own)
+__global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long long* __restrict__ partials,
+                                                              const int32_t* __restrict__ spec,
+                                                              float* __restrict__ expect,
+                                                              unsigned int* __restrict__ tickets)
+{
+    __shared__ long long s_cnt[LOSS_THREADS / 64];
+    __shared__ bool s_last;
+    int i = 0;
+    while (i + 1 < a.n_items && (int)blockIdx.x >= a.it[i].cblock0 + a.it[i].cnblocks) ++i;
+    const MultiItem& it = a.it[i];
+    long long cnt = 0;
+    if ((it.count_mode == 1 || it.count_mode == 3) && (int)blockIdx.x >= it.cblock0)
+        cnt = multi_count_block(it, blockIdx.x - it.cblock0);
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
     if (lane_id() == 0) s_cnt[threadIdx.x >> 6] = cnt;
@@ -115,52 +168,20 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_multi_count(MultiArgs a, long 
     if (threadIdx.x == 0) {
         long long c = 0;
         for (int q = 0; q < LOSS_THREADS / 64; ++q) c += s_cnt[q];
-        partials[blockIdx.x] = c;
-    }
-}
-
-// divisor of total t from per-item counts (accumulate_losses: max(sum of counts, 1) as float32;
-// an item with clamp enters as max(count, 1), task_helper/instance.py:206-211)
-__device__ inline float multi_divisor(const MultiArgs& a, const long long* counts, int t)
-{
-    long long n = 0;
-    for (int i = 0; i < a.n_items; ++i)
-        if (a.it[i].total == t) n += a.it[i].clamp == 1 ? max(counts[i], 1LL) : counts[i];
-    return (float)max(n, 1LL);
-}
-
-// always the first launch of a call.  With count partials: divisor + expected upstream gradient
-// per total.  Without (forward-only call, nobody needs them before the sums): no expectation,
-// the divisors are filled in by k_multi_finalize from the finalized counts.  Also zeroes the
-// ticket k_multi_finalize's workgroups draw to find out which of them is the last.
-__global__ __launch_bounds__(LOSS_THREADS) void k_multi_expect(MultiArgs a, const long long* __restrict__ partials,
-                                                               const int32_t* __restrict__ spec,
-                                                               float* __restrict__ expect,
-                                                               unsigned int* __restrict__ ticket)
-{
-    __shared__ long long s_count[MULTI_MAX_ITEMS];
-    if (threadIdx.x == 0) *ticket = 0u;
-    const int w = threadIdx.x >> 6, l = lane_id();
-    for (int i = w; i < a.n_items; i += LOSS_THREADS / 64) {
-        const MultiItem& it = a.it[i];
-        long long c = 0;
-        if ((it.count_mode == 1 || it.count_mode == 3) && partials) { for (int k = l; k < it.cnblocks; k += 64) c += partials[it.cblock0 + k]; }
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) c += __shfl_down(c, o);
-        if (l == 0) s_count[i] = (it.count_mode == 1 || it.count_mode == 3) ? c : (long long)it.B * it.P;
+        // my partial before my ticket: ONE write-through (sc1) 8-byte store, drained — not a release
+        // fence: a thousand workgroups writing back their XCD's L2 at once cost 26 us here
+        __hip_atomic_store(&partials[blockIdx.x], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        s_last = atomicAdd(&tickets[0], 1u) == gridDim.x - 1;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' partials after it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
-    if ((int)threadIdx.x < a.n_totals) {
-        const int t = threadIdx.x;
-        bool known = partials != nullptr;
-        for (int i = 0; i < a.n_items; ++i)
-            if (a.it[i].total == t && a.it[i].count_mode == 2) known = false;   // the divisor is no count of mask bytes
-        const float nf = multi_divisor(a, s_count, t);
-        const float wv = __int_as_float(spec[8 * t + 2]);
-        const bool off = (spec[8 * t + 5] & 1) || !known;
-        expect[2 * t] = off ? __int_as_float(0x7fc00000) : wv / nf;     // NaN: the forward writes no gradient
-        expect[2 * t + 1] = nf;                                         // (!known: k_multi_finalize corrects it)
-    }
+    if (!s_last) return;
+    multi_expect_body(a, partials, spec, expect);
+    if (threadIdx.x == 0) tickets[0] = 0u;                 // zero again for the next call
 }
 
 // upstream weight behind an observed gradient g = fl(w / n): candidates around fl(g n) that
@@ -180,31 +201,36 @@ __device__ inline float spec_estimate_w(float g, float n, float g_prev, float n_
     return best;
 }
 
-__global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, const float* __restrict__ grad_items,
-                             const float* __restrict__ grad_totals, const long long* __restrict__ counts,
-                             const float* __restrict__ expect, int32_t* __restrict__ spec,
-                             float* __restrict__ gs, int32_t* __restrict__ counters)
+struct MultiBwd {                                      // what the backward launch turns into upstream scales
+    const float* grad_sums; const float* grad_items; const float* grad_totals;
+    const long long* counts;
+    int32_t* spec; int32_t* counters;
+    float* gs;                                         // out: upstream scale per item
+};
+
+// upstream scale of item i's raw loss sum from the gradients of the three outputs (what
+// autograd's division backward gives: grad / divisor, float32)
+__device__ inline float multi_upstream(const MultiArgs& a, const MultiBwd& bw, const float* __restrict__ expect, int i)
 {
-    // upstream scale of item i's raw loss sum from the gradients of the three outputs (what
-    // autograd's division backward gives: grad / divisor, float32)
-    const int n = a.n_items;
-    if ((int)threadIdx.x < n) {
-        const int i = threadIdx.x;
-        const MultiItem& it = a.it[i];
-        float g = grad_sums ? grad_sums[i] : 0.f;
-        const float gi = grad_items ? grad_items[i] : 0.f, gt = grad_totals ? grad_totals[it.total] : 0.f;
-        if (gi != 0.f) g += gi / (float)(it.clamp ? max(counts[i], 1LL) : counts[i]);
-        if (gt != 0.f) g += gt / expect[2 * it.total + 1];
-        gs[i] = g;
-    }
-    __syncthreads();
-    const int t = threadIdx.x;
-    if (t >= a.n_totals) return;
+    const MultiItem& it = a.it[i];
+    float g = bw.grad_sums ? bw.grad_sums[i] : 0.f;
+    const float gi = bw.grad_items ? bw.grad_items[i] : 0.f, gt = bw.grad_totals ? bw.grad_totals[it.total] : 0.f;
+    if (gi != 0.f) g += gi / (float)(it.clamp ? max(bw.counts[i], 1LL) : bw.counts[i]);
+    if (gt != 0.f) g += gt / expect[2 * it.total + 1];
+    return g;
+}
+
+// thread t < n_totals of ONE workgroup: judge the expectation of total t against the upstream
+// scale of its first item with a gradient and keep the record up to date
+__device__ inline void multi_spec_update(const MultiArgs& a, const MultiBwd& bw, const float* __restrict__ expect, int t)
+{
+    int32_t* spec = bw.spec;
+    int32_t* counters = bw.counters;
     int first = -1;
     for (int i = 0; i < a.n_items; ++i) if (a.it[i].total == t && a.it[i].grad && first < 0) first = i;
     if (first < 0 || !spec) return;          // no record: a recompute nobody predicted (retained graph)
     int32_t* r = spec + 8 * t;
-    const float g = gs[first], e = expect[2 * t], nf = expect[2 * t + 1];
+    const float g = multi_upstream(a, bw, expect, first), e = expect[2 * t], nf = expect[2 * t + 1];
     const float g_prev = __int_as_float(r[3]), n_prev = __int_as_float(r[4]);
     const bool same = e == e && __float_as_int(g) == __float_as_int(e);     // NaN: no expectation
     if (counters) atomicAdd(&counters[same ? 0 : 1], 1);       // per-device tally (statistics only)
@@ -227,6 +253,13 @@ __global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, c
     r[4] = __float_as_int(nf);
 }
 
+// calls whose items all run as launches of their own (no joint launch to ride in)
+__global__ void k_multi_spec(MultiArgs a, MultiBwd bw, const float* __restrict__ expect)
+{
+    if ((int)threadIdx.x < a.n_items) bw.gs[threadIdx.x] = multi_upstream(a, bw, expect, threadIdx.x);
+    if ((int)threadIdx.x < a.n_totals) multi_spec_update(a, bw, expect, threadIdx.x);
+}
+
 // all items of one call: block ranges [block0, block0 + nbx * B) per item.  CE_* select the ONE
 // cross-entropy variant compiled into this instantiation (CE_NG = 0: no CE item in the launch);
 // the element-wise and von Mises bodies are selected at run time (they are small).
@@ -242,22 +275,35 @@ __global__ void k_multi_spec(MultiArgs a, const float* __restrict__ grad_sums, c
 template <int CE_DT, int CE_NG, bool CE_SM, int MODE>        // MODE as in ce_fused_body
 __global__ __launch_bounds__(LOSS_THREADS)
 __attribute__((amdgpu_waves_per_eu((MODE == 1) ? (CE_SM ? 4 : NMSA_MULTI_FWD_WAVES) : (CE_NG <= 5) ? 4 : 3, (MODE != 1 && CE_NG > 5) ? 3 : 8))) void k_multi_loss(
-    MultiArgs a, const float* __restrict__ expect, const float* __restrict__ gs,
+    MultiArgs a, const float* __restrict__ expect, MultiBwd bw,
     LossPartial* __restrict__ partials, int* __restrict__ status)
 {
     extern __shared__ float s_w[];
     constexpr bool LOSS = MODE != 2;
     if (!LOSS) {
+        // every workgroup forms the upstream scales itself (n_items <= 16: a handful of scalar
+        // loads per item); workgroup 0 also judges the expectations, updates the records and stores
+        // the scales for the launches that follow (wide cross entropies, cosine items)
+        if (blockIdx.x == 0) {
+            if ((int)threadIdx.x < a.n_items) bw.gs[threadIdx.x] = multi_upstream(a, bw, expect, threadIdx.x);
+            if ((int)threadIdx.x < a.n_totals) multi_spec_update(a, bw, expect, threadIdx.x);
+        }
         // the recomputing launch is a small grid walking the block list: when every item's
         // gradient stands (the usual case) its workgroups are gone after this check
-        bool any = false;
-        for (int i = 0; i < a.n_items; ++i) {
+    }
+    // (lane i of every wave holds item i's upstream scale and whether its gradient stands: the
+    // loads of all items in flight at once, then lane reads with wave-uniform indices)
+    float g_lane = 0.f;
+    bool redo_lane = false;
+    if (!LOSS) {
+        const int i = lane_id();
+        if (i < a.n_items) {
             const MultiItem& it = a.it[i];
             const float e = expect[2 * it.total];
-            any = any || (it.in_launch && it.grad &&
-                          (!(e == e) || __float_as_int(gs[i]) != __float_as_int(e)));
+            g_lane = multi_upstream(a, bw, expect, i);
+            redo_lane = it.in_launch && it.grad && (!(e == e) || __float_as_int(g_lane) != __float_as_int(e));
         }
-        if (!any) return;
+        if (!__any(redo_lane)) return;
     }
     for (int blk = blockIdx.x; blk < a.n_blocks; blk += gridDim.x) {     // LOSS: exactly one pass
         int i = 0;
@@ -270,7 +316,7 @@ __attribute__((amdgpu_waves_per_eu((MODE == 1) ? (CE_SM ? 4 : NMSA_MULTI_FWD_WAV
         if (MODE != 1 && it.grad && expect) g = expect[2 * it.total];
         if (!LOSS) {
             if (!it.grad) continue;
-            const float gr = gs[i];
+            const float gr = __shfl(g_lane, i);                                // (i is wave-uniform)
             if (g == g && __float_as_int(gr) == __float_as_int(g)) continue;   // the forward's gradient stands
             g = gr;
         }
@@ -367,20 +413,28 @@ __global__ __launch_bounds__(MULTI_FIN_THREADS) void k_multi_finalize(
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        LossPartial r; r.sum = s_sum[0]; r.aux = s_aux[0]; r.count = s_cnt[0]; r.pad = 0;
-        slices[blockIdx.x] = r;
-        __threadfence();                                   // the slice before the ticket
+        // the slice before the ticket: write-through 8-byte stores, drained (see k_multi_count)
+        unsigned long long* q = (unsigned long long*)(slices + blockIdx.x);
+        __hip_atomic_store(q + 0, (unsigned long long)__double_as_longlong(s_sum[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 1, (unsigned long long)__double_as_longlong(s_aux[0]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(q + 2, (unsigned long long)s_cnt[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         s_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+        if (s_last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the other workgroups' slices after it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
     }
     __syncthreads();
     if (!s_last) return;
-    __threadfence();                                       // the other workgroups' slices after the ticket
     __shared__ long long s_count[MULTI_MAX_ITEMS];
     __shared__ float s_f[MULTI_MAX_ITEMS];
     const int ni = a.n_items, t = threadIdx.x;
     if (t < ni * MULTI_FIN_SPLIT) {                        // every slice by its own thread, then item by item
-        const volatile LossPartial* q = slices + t;
-        s_sum[t] = q->sum; s_aux[t] = q->aux; s_cnt[t] = q->count;
+        unsigned long long* q = (unsigned long long*)(slices + t);
+        s_sum[t] = __longlong_as_double((long long)__hip_atomic_load(q + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        s_aux[t] = __longlong_as_double((long long)__hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        s_cnt[t] = (long long)__hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     __syncthreads();
     if (t < ni) {
@@ -404,12 +458,14 @@ __global__ __launch_bounds__(MULTI_FIN_THREADS) void k_multi_finalize(
         for (int i = 0; i < ni; ++i) if (a.it[i].total == t && a.it[i].count_mode == 2) known = false;
         float nf = expect[2 * t + 1];
         if (!known) { nf = multi_divisor(a, s_count, t); expect[2 * t + 1] = nf; }
+        if (late_divisors) expect[2 * t] = __int_as_float(0x7fc00000);      // a call without gradients: no expectation
         if (out) {
             float acc = 0.f;
             for (int i = 0; i < ni; ++i) if (a.it[i].total == t) acc += s_f[i];
             out[2 * ni + t] = acc / nf;
         }
     }
+    if (t == 0) *ticket = 0u;                              // zero again for the next call
 }
 
 }  // namespace nmsa
@@ -523,7 +579,7 @@ size_t multi_partial_blocks(const MultiPlan& pl)
 }
 
 template <int MODE>
-int multi_launch_joint(const MultiPlan& pl, const float* expect, const float* gs, LossPartial* partials,
+int multi_launch_joint(const MultiPlan& pl, const float* expect, const MultiBwd& bw, LossPartial* partials,
                        int* status, hipStream_t stream)
 {
     const MultiArgs& a = pl.args;
@@ -531,7 +587,7 @@ int multi_launch_joint(const MultiPlan& pl, const float* expect, const float* gs
     // (the recomputing launch: a small grid that walks the block list, see k_multi_loss)
     const int grid = MODE != 2 ? a.n_blocks : (a.n_blocks < 4096 ? a.n_blocks : 4096);
 #define ML(DT, NG, SM) hipLaunchKernelGGL((k_multi_loss<DT, NG, SM, MODE>), dim3(grid), dim3(LOSS_THREADS), \
-        pl.lds, stream, a, expect, gs, partials, status)
+        pl.lds, stream, a, expect, bw, partials, status)
 #define ML_NG(DT, SM) do { if (pl.ce_ng == 3) ML(DT, 3, SM); else if (pl.ce_ng == 5) ML(DT, 5, SM); else ML(DT, 6, SM); } while (0)
 #define ML_DT(DT) do { if (pl.ce_sm) ML_NG(DT, true); else ML_NG(DT, false); } while (0)
     if (pl.ce_ng == 0) ML(NMSA_F32, 0, false);
@@ -598,25 +654,23 @@ extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_i
     LossPartial* partials = (LossPartial*)workspace;
     LossPartial* slices = partials + nb;
     long long* cpart = (long long*)(slices + (size_t)MULTI_MAX_ITEMS * MULTI_FIN_SPLIT);
-    unsigned int* ticket = (unsigned int*)(cpart + pl.n_count_blocks);
+    unsigned int* tickets = (unsigned int*)(spec + 8 * n_totals);     // [0] count, [1] finalize: zero between calls
     void* xch = (char*)workspace + multi_main_bytes(pl);
     const size_t xch_bytes = multi_xch_bytes(pl);
     const MultiArgs& a = pl.args;
     bool any_grad = false;
     for (int i = 0; i < n_items; ++i) any_grad = any_grad || a.it[i].grad != nullptr;
-    // (forward only: nobody needs a count before the sums; k_multi_expect then only marks "no
-    // expectation" and the divisors come out of the finalized counts)
+    // (forward only: nobody needs a count before the sums; k_multi_finalize then marks "no
+    // expectation" and forms the divisors from the finalized counts)
+    const MultiBwd none{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     if (any_grad) {
-        hipLaunchKernelGGL(k_multi_count, dim3(pl.n_count_blocks), dim3(LOSS_THREADS), 0, stream, a, cpart);
+        hipLaunchKernelGGL(k_multi_count, dim3(pl.n_count_blocks), dim3(LOSS_THREADS), 0, stream, a, cpart,
+                           (const int32_t*)spec, expect, tickets);
         rc = check_launch();
         if (rc) return rc;
     }
-    hipLaunchKernelGGL(k_multi_expect, dim3(1), dim3(LOSS_THREADS), 0, stream, a,
-                       any_grad ? (const long long*)cpart : (const long long*)nullptr, spec, expect, ticket);
-    rc = check_launch();
-    if (rc) return rc;
-    rc = any_grad ? multi_launch_joint<0>(pl, expect, nullptr, partials, status, stream)
-                  : multi_launch_joint<1>(pl, expect, nullptr, partials, status, stream);
+    rc = any_grad ? multi_launch_joint<0>(pl, expect, none, partials, status, stream)
+                  : multi_launch_joint<1>(pl, expect, none, partials, status, stream);
     if (rc) return rc;
     for (int i = 0; i < n_items; ++i) {                 // cross entropies outside the joint launch
         const MultiItem& it = a.it[i];
@@ -638,7 +692,7 @@ extern "C" int nmsa_multitask_loss_fwd_grad(const nmsa_loss_item* items, int n_i
         if (rc) return rc;
     }
     hipLaunchKernelGGL(k_multi_finalize, dim3(n_items * MULTI_FIN_SPLIT), dim3(MULTI_FIN_THREADS), 0, stream, a,
-                       partials, slices, ticket, any_grad ? 0 : 1, loss_sums, (long long*)counts, aux, expect,
+                       partials, slices, tickets + 1, any_grad ? 0 : 1, loss_sums, (long long*)counts, aux, expect,
                        out_f32);
     return check_launch();
 }
@@ -659,11 +713,14 @@ extern "C" int nmsa_multitask_loss_bwd_unless(const nmsa_loss_item* items, int n
     // spans several workgroups use it, as their granule exchange buffer
     if (multi_xch_bytes(pl) > 0 && (!workspace || workspace_bytes < multi_xch_bytes(pl))) return NMSA_ERR_WORKSPACE;
     const MultiArgs& a = pl.args;
-    hipLaunchKernelGGL(k_multi_spec, dim3(1), dim3(64), 0, stream, a, grad_sums, grad_item_losses,
-                       grad_total_losses, (const long long*)counts, expect, spec, grad_scales, counters);
-    rc = check_launch();
-    if (rc) return rc;
-    rc = multi_launch_joint<2>(pl, expect, grad_scales, nullptr, nullptr, stream);
+    const MultiBwd bw{grad_sums, grad_item_losses, grad_total_losses, (const long long*)counts, spec, counters,
+                      grad_scales};
+    if (a.n_blocks > 0) {
+        rc = multi_launch_joint<2>(pl, expect, bw, nullptr, nullptr, stream);
+    } else {
+        hipLaunchKernelGGL(k_multi_spec, dim3(1), dim3(64), 0, stream, a, bw, expect);
+        rc = check_launch();
+    }
     if (rc) return rc;
     for (int i = 0; i < n_items; ++i) {
         const MultiItem& it = a.it[i];

@@ -5,9 +5,10 @@ base.py:161-182).
 Every (loss, supervision scale) pair is an ITEM, the items whose sums the caller adds and divides
 by their summed element counts form a TOTAL.  The forward call counts the labels / mask bytes,
 forms per total the divisor and the EXPECTED upstream gradient `w / n` of its loss sums, computes
-all sums and writes all gradients for that expectation (4 launches whatever the number of items);
+all sums and writes all gradients for that expectation (3 launches whatever the number of items:
+the count's last workgroup forms the expectation; 2 without gradients);
 backward compares the real upstream gradients with the expectation ON THE DEVICE and recomputes
-only what differs (2 launches).  `w` — the factor the trainer multiplies the total with before
+only what differs (1 launch: workgroup 0 of the recomputing walk keeps the records).  `w` — the factor the trainer multiplies the total with before
 `backward()`: loss weights (reference loss_weighting/fixed.py:28-37), an AMP scale — lives in a
 `SpecState` owned by the caller (a task helper, a loss instance) and is LEARNED on the device from
 the upstream gradients it sees: constant factors are confirmed from the second step on without any
@@ -39,8 +40,9 @@ _STATES: 'weakref.WeakSet[SpecState]' = weakref.WeakSet()
 
 
 class SpecState:
-    """device-resident spec records of the totals of one caller: int32 [n_totals, 8]
-    ([0] confirmed, [1] recomputed, [2] w as fp32 bits, [5] flags; see csrc/losses.hip)"""
+    """device-resident spec records of the totals of one caller: int32 [n_totals + 1, 8]
+    ([0] confirmed, [1] recomputed, [2] w as fp32 bits, [5] flags; see csrc/losses_multi.hip);
+    the last row is scratch of the calls (the tickets of their launches), zero between calls"""
 
     def __init__(self, n_totals: int, initial_weight=1.0) -> None:
         assert 1 <= n_totals <= MAX_TOTALS
@@ -56,8 +58,8 @@ class SpecState:
             dev = torch.device('cuda', torch.cuda.current_device())
         r = self._rec.get(dev)
         if r is None:
-            host = torch.zeros((self.n_totals, 8), dtype=torch.int32)
-            host.view(torch.float32)[:, 2] = torch.tensor(self._w0, dtype=torch.float32)
+            host = torch.zeros((self.n_totals + 1, 8), dtype=torch.int32)
+            host.view(torch.float32)[:self.n_totals, 2] = torch.tensor(self._w0, dtype=torch.float32)
             r = self._rec[dev] = host.to(dev)
         return r
 
@@ -69,14 +71,14 @@ class SpecState:
         """host sync"""
         out = {'confirmed': 0, 'recomputed': 0}
         for r in self._rec.values():
-            v = r[:, :2].sum(dim=0).tolist()
+            v = r[:self.n_totals, :2].sum(dim=0).tolist()
             out['confirmed'] += int(v[0])
             out['recomputed'] += int(v[1])
         return out
 
     def weights(self, dev) -> List[float]:
         """the learned upstream factors (host sync; tests, diagnostics)"""
-        return self.records(dev).view(torch.float32)[:, 2].tolist()
+        return self.records(dev).view(torch.float32)[:self.n_totals, 2].tolist()
 
 
 def reset_all() -> None:

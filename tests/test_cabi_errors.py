@@ -208,8 +208,8 @@ def test_multitask_loss_bad_arguments(env):
     p, st = L.ptr, L.stream_ptr(dev)
     labels = torch.randint(0, C + 1, (B, H, W), device=dev).to(torch.uint8)
     grad = torch.empty_like(t['logits'])
-    spec = torch.zeros((2, 8), dtype=torch.int32, device=dev)
-    spec.view(torch.float32)[:, 2] = 1.0
+    spec = torch.zeros((2 + 1, 8), dtype=torch.int32, device=dev)        # (last row: the calls' tickets)
+    spec.view(torch.float32)[:2, 2] = 1.0
     expect = torch.empty((2, 2), dtype=torch.float32, device=dev)
     small = torch.empty((6,), dtype=torch.float64, device=dev)
     out = torch.empty((5,), dtype=torch.float32, device=dev)
@@ -257,3 +257,4 @@ def test_multitask_loss_bad_arguments(env):
     assert bwd(good, gs_=None) == ERR_ARG
     torch.cuda.synchronize()
     assert int(spec[0, 0]) + int(spec[0, 1]) == 1                   # exactly one backward pass was judged
+    assert not spec[2].any()                                        # the tickets are zero again after every call
