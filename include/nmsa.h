@@ -286,7 +286,14 @@ int nmsa_instance_orientation_wide(const float* orientation, const void* instanc
  *     `max_instances` (<= 4096) distinct ids per image.
  *  status bits (OR-ed into *status): 1 too many distinct ids, 32 id out of range,
  *     64 semantic label outside [0, n_classes), 128 id table (max_segments) overflow.
- *  workspace: nmsa_targets_workspace_bytes(B, n_classes, max_instances), 8-byte aligned.
+ *  workspace: nmsa_targets_workspace_bytes(B, n_classes, max_instances), 8-byte aligned (16-byte
+ *     aligned for the one-launch front end of the on-wire layout, see below).  A caller that
+ *     allocates 16 bytes more and passes `status` = workspace + nmsa_targets_workspace_bytes(..)
+ *     gets the status word zeroed by nmsa_instance_targets / nmsa_panoptic_targets themselves
+ *     (one launch less); any other status word is the caller's to zero (bits are OR-ed).
+ *  launches: the on-wire layout (semantic uint8, instance int32, 16-byte aligned rows of 4 pixels,
+ *     W % 4 == 0, n_classes <= 16384) runs as memset + ONE scan launch (presence, statistics, rank,
+ *     decide / naive ranks: k_tg_scan) + the paint launch; any other layout as memset + 5.
  *
  *  nmsa_instance_clear_stuff   InstanceClearStuffIDs._preprocess   data/preprocessing/instance.py:46-93
  *     instance[is_stuff_class[semantic]] = 0, in place (is_stuff_class includes void)

@@ -393,6 +393,467 @@ __global__ __launch_bounds__(1024) void k_tg_decide(
     }
 }
 
+// ---- ONE launch for presence + rank + statistics + decide (round 5) -------------------------------
+// Rounds 2-4 ran presence -> rank -> statistics -> decide (-> naive ranks) as four launches behind
+// a memset: each waits for the one before and each is a chain of latencies, not bytes (48 us of
+// kernels + gaps for 49 MB of labels at B = 32, 640 x 480), and the one-workgroup-per-image steps
+// leave 7/8 of the chip idle.  k_tg_scan is ONE launch in front of the paint kernel:
+//   scan   `wpi` workgroups per image, as many as the device holds at once (ONE round of resident
+//          workgroups: a workgroup's life is a chain of memory latencies, so rounds are what cost):
+//          each walks a contiguous range of its image — the next round's labels are requested
+//          before the current one is worked on — and counts votes and coordinate sums per
+//          (instance id, class) in ONE LDS table keyed by the RAW id (no dense rank needed while
+//          scanning: the two dependent bitmap / prefix loads per lane of k_tg_stats are gone, one
+//          table probe serves the vote and both sums), flushed ONCE into per-image accumulators
+//          indexed by the slot the id gets in a per-image open-addressing table in global memory
+//          (`hkeys`, key 0 = empty, atomicCAS insert).  Everything handed to the image's last
+//          workgroup goes through device-scope atomics (performed at the memory side: no release
+//          fence — a fence per workgroup cost 26 us in k_multi_count — only a drain of the
+//          workgroup's own atomics before its ticket).
+//   tail   the workgroup that draws an image's LAST ticket does what k_tg_rank + k_tg_decide
+//          (+ k_tg_naive_ranks) did: presence bitmap and prefix from the table's keys (in LDS),
+//          dense ranks in ascending id order (= np.unique order), majority class / thing filter /
+//          center, the ordered lists — or the per-class running ranks of the naive merge.
+// The paint kernels are unchanged.  (Measured on the way, docs/measurement_log.md: the same scan
+// with 150 small workgroups per image 64 us — 23 us of it the two-table LDS work, 16 us flush
+// chains, 10 us tail; a persistent launch that also paints, work pulled from queues: 159 us — every
+// pull, flush, ticket and sc1 table load is a ~2 us round trip to the memory side, in series per
+// workgroup, with 4 workgroups per CU to hide them.)
+constexpr int TGF_MAX_NC = 16384;                        // (id, class) as one 30-bit key
+struct TgHash {
+    int32_t* hkeys;              // [HT] raw instance id, 0 = empty
+    unsigned long long* hsum_y;  // [HT]
+    unsigned long long* hsum_x;  // [HT]
+    uint32_t* hvotes;            // [HT * NC]
+    uint32_t* ticket;            // [0] workgroups of the image that are done
+};
+
+__host__ __device__ inline int tg_hash_slots(int cap)
+{
+    int ht = 1024;
+    while (ht < cap) ht <<= 1;
+    return ht;
+}
+
+__host__ __device__ inline size_t tg_hash_bytes(int cap, int NC)
+{
+    const size_t ht = (size_t)tg_hash_slots(cap);
+    return (ht * 4 + ht * 8 * 2 + ht * NC * 4 + 256 + 255) & ~(size_t)255;       // (the ticket: a line of its own)
+}
+
+
+__device__ __forceinline__ TgHash tg_hash_view(unsigned char* hs, int b, int cap, int NC)
+{
+    const size_t ht = (size_t)tg_hash_slots(cap);
+    unsigned char* base = hs + (size_t)b * tg_hash_bytes(cap, NC);
+    TgHash h;
+    h.hsum_y = (unsigned long long*)base;
+    h.hsum_x = h.hsum_y + ht;
+    h.hkeys = (int32_t*)(h.hsum_x + ht);
+    h.hvotes = (uint32_t*)(h.hkeys + ht);
+    h.ticket = h.hvotes + ht * NC;
+    return h;
+}
+
+// slot of `id` (> 0) in the image's table, inserting it when new; -1: the table is full
+__device__ __forceinline__ int tg_hash_insert(int32_t* hkeys, int HT, int id)
+{
+    int slot = (int)(((uint32_t)id * 2654435761u) >> 12) & (HT - 1);
+    for (int t = 0; t < HT; ++t) {
+        const int old = atomicCAS(&hkeys[slot], 0, id);
+        if (old == 0 || old == id) return slot;
+        slot = (slot + 1) & (HT - 1);
+    }
+    return -1;
+}
+
+// bytes another workgroup of the same launch wrote / will read: write-through stores, L1-bypassing loads
+template <typename T>
+__device__ __forceinline__ void st_shared(T* p, T v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T ld_shared(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// ---- the scan -------------------------------------------------------------------------------------
+struct TgScanTab { int key[TG_H2]; uint32_t cnt[TG_H2], sy[TG_H2], sx[TG_H2]; };
+constexpr int TGS_AHEAD = 2;                             // rounds of labels in flight per thread
+
+// ---- tail: what k_tg_rank + k_tg_decide (WITH_MOMENTS) or k_tg_rank + k_tg_naive_ranks did, by
+// the workgroup (256 threads) that drew the image's last ticket.  What the NEXT launch reads goes
+// out as plain stores (write-through sc1 stores left no copy behind and the paint kernels took
+// 9 us longer to find their tables); what this workgroup needs again stays in LDS:
+// scratch [32] | bitmap [2048] | prefix [2048] | slot of dense u16 [cap] | enc u8 [cap] (or, naive
+// merge: the dict base of every instance i32 [cap]); once the
+// ranks are known, bitmap + prefix are dead and hold the packed centers (WITH_MOMENTS) or the
+// u16 rank cells of the naive merge (up to 8192 cells; beyond: the rows in global memory).
+constexpr int TGS_CELLS_LDS = 2 * MW_WORDS * 2;          // u16 cells in the bitmap + prefix region
+
+template <bool WITH_MOMENTS>
+__device__ __forceinline__ void tg_rank_decide_tail(
+    TgView v, TgHash h, int b, int cap, int HT, int NC, uint32_t* __restrict__ lds,
+    const uint8_t* __restrict__ is_thing_class, int32_t* __restrict__ encoded_ids,
+    int32_t* __restrict__ n_encoded, int32_t* __restrict__ skipped_ids, int32_t* __restrict__ n_skipped,
+    int pair_cap, int64_t max_inst, int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins,
+    int32_t* __restrict__ n_ids, int* __restrict__ status)
+{
+    int* scratch = (int*)lds;                            // [32]
+    uint32_t* s_bitmap = lds + 32;
+    uint32_t* s_prefix = s_bitmap + MW_WORDS;
+    uint16_t* s_slot = (uint16_t*)(s_prefix + MW_WORDS);
+    uint8_t* s_enc = (uint8_t*)(s_slot + cap);
+    const int t = threadIdx.x;
+    for (int i = t; i < MW_WORDS; i += 256) s_bitmap[i] = 0u;
+    __syncthreads();
+    // the keys of the table: every thread keeps its share in registers (HT / 256 <= 16)
+    constexpr int KPT = 16;
+    int key[KPT];
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        const int sl = t + k * 256;
+        key[k] = sl < HT ? ld_shared(&h.hkeys[sl]) : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) if (key[k] > 0) atomicOr(&s_bitmap[key[k] >> 5], 1u << (key[k] & 31));
+    __syncthreads();
+    // exclusive popcount prefix over the 2048 words (8 consecutive words per thread)
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    uint32_t w8[8], p8[8];
+    int c = 0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { w8[k] = s_bitmap[8 * t + k]; c += __popc(w8[k]); }
+    int total;
+    int run = mw_block_scan(c, scratch, &total) - c;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { p8[k] = (uint32_t)run; s_prefix[8 * t + k] = p8[k]; run += __popc(w8[k]); }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        u32x4_t wv, pv;
+        wv.x = w8[4 * q]; wv.y = w8[4 * q + 1]; wv.z = w8[4 * q + 2]; wv.w = w8[4 * q + 3];
+        pv.x = p8[4 * q]; pv.y = p8[4 * q + 1]; pv.z = p8[4 * q + 2]; pv.w = p8[4 * q + 3];
+        *(u32x4_t*)(v.bitmap + 8 * t + 4 * q) = wv;
+        *(u32x4_t*)(v.prefix + 8 * t + 4 * q) = pv;
+    }
+    __syncthreads();
+    const int n_dense = min(total, cap);
+    if (t == 0) {
+        v.counters[0] = n_dense;
+        if (total > cap) atomicOr(status, TG_ST_OVERFLOW);
+    }
+    // dense rank of every key: ascending id order = np.unique order
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        if (key[k] <= 0) continue;
+        const int d = (int)s_prefix[key[k] >> 5] + __popc(s_bitmap[key[k] >> 5] & ((1u << (key[k] & 31)) - 1u));
+        if (d < cap) { s_slot[d] = (uint16_t)(t + k * 256); v.id_of_dense[d] = key[k]; }
+    }
+    __syncthreads();                                     // (bitmap + prefix in LDS are dead from here)
+    if (WITH_MOMENTS) {
+        uint32_t* s_center = s_bitmap;                   // [cap <= 4096]: (cy << 16) | cx
+        // per instance: a group of 16 lanes per dense slot (lane = class, strided), four slots per
+        // group in flight: with up to 64 instances every histogram load of the image is issued at
+        // once (the loop is a chain of memory latencies, not work)
+        const int grp = t >> 4, l16 = t & 15;
+        for (int d0 = grp; d0 < n_dense; d0 += 64) {
+            int slot[4];
+            uint32_t tot[4] = {0u, 0u, 0u, 0u};
+            long long best[4] = {-1, -1, -1, -1};     // (count << 32) | ~class: max = larger count, lower class
+#pragma unroll
+            for (int u = 0; u < 4; ++u) slot[u] = (d0 + 16 * u < n_dense) ? (int)s_slot[d0 + 16 * u] : -1;
+            for (int cc = l16; cc < NC; cc += 16) {
+                uint32_t x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    x[u] = slot[u] >= 0 ? ld_shared(&h.hvotes[(size_t)slot[u] * NC + cc]) : 0u;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    if (slot[u] < 0) continue;
+                    tot[u] += x[u];
+                    const long long kk = ((long long)x[u] << 32) | (uint32_t)(0x7fffffff - cc);
+                    best[u] = kk > best[u] ? kk : best[u];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                for (int o = 8; o > 0; o >>= 1) {
+                    tot[u] += __shfl_down(tot[u], o, 16);
+                    const long long other = __shfl_down(best[u], o, 16);
+                    best[u] = other > best[u] ? other : best[u];
+                }
+            }
+            // lane 0 of the group holds the four results; lanes 0..3 take one each
+            uint32_t tu = 0; long long bu = -1; int su = -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const uint32_t t0 = __shfl(tot[u], 0, 16);
+                const long long b0 = __shfl(best[u], 0, 16);
+                if (l16 == u) { tu = t0; bu = b0; su = slot[u]; }
+            }
+            if (l16 < 4 && su >= 0) {
+                const int d = d0 + 16 * l16;
+                const int c_best = 0x7fffffff - (int)(uint32_t)(bu & 0xffffffffll);   // np.bincount(..).argmax()
+                const bool thing = is_thing_class ? (is_thing_class[c_best] != 0) : true;
+                const int e = thing && tu > 0;
+                s_enc[d] = (uint8_t)e;
+                v.enc[d] = e;
+                if (e) {
+                    // int(np.mean(rows)), int(np.mean(cols)): exact integer floor (instance.py:210-211)
+                    const int cy = (int)(ld_shared(&h.hsum_y[su]) / tu), cx = (int)(ld_shared(&h.hsum_x[su]) / tu);
+                    v.center_yx[2 * d] = cy;
+                    v.center_yx[2 * d + 1] = cx;
+                    s_center[d] = ((uint32_t)cy << 16) | (uint32_t)cx;       // H, W < 32768
+                }
+            }
+        }
+        __syncthreads();
+        // the ordered lists: encoded / skipped ids ascending, the encoded centers compacted
+        const int per = cap / 256;                       // cap is a multiple of 1024
+        int n_enc = 0, n_skip = 0;
+        for (int j = 0; j < per; ++j) {
+            const int d = t * per + j;
+            if (d >= n_dense) break;
+            n_enc += s_enc[d];
+            n_skip += !s_enc[d];
+        }
+        int tot_enc, tot_skip;
+        int pe = mw_block_scan(n_enc, scratch, &tot_enc) - n_enc;
+        int ps = mw_block_scan(n_skip, scratch, &tot_skip) - n_skip;
+        for (int j = 0; j < per; ++j) {
+            const int d = t * per + j;
+            if (d >= n_dense) break;
+            const int id = ld_shared(&h.hkeys[s_slot[d]]);
+            if (s_enc[d]) {
+                v.enc_list[2 * pe] = (int)(s_center[d] >> 16);
+                v.enc_list[2 * pe + 1] = (int)(s_center[d] & 0xffffu);
+                if (encoded_ids) encoded_ids[(size_t)b * cap + pe] = id;
+                ++pe;
+            } else {
+                if (skipped_ids) skipped_ids[(size_t)b * cap + ps] = id;
+                ++ps;
+            }
+        }
+        if (t == 0) {
+            v.counters[1] = tot_enc;
+            if (n_encoded) n_encoded[b] = tot_enc;
+            if (n_skipped) n_skipped[b] = tot_skip;
+        }
+    } else {
+        // naive merge (k_tg_naive_ranks): class c's running counter over the instances in ascending
+        // id order replaces every non-zero histogram entry (class_id_tracker, panoptic_merge.py:
+        // 76-79); the ranks go to the DENSE rows the paint reads.  The cells (present or not, then
+        // the rank) live in LDS as u16 when the image's rows fit
+        const int n_cells = n_dense * NC;
+        const bool in_lds = n_cells <= TGS_CELLS_LDS;
+        uint16_t* s_cell = (uint16_t*)s_bitmap;
+        if (in_lds) {
+            for (int i0 = t; i0 < n_cells; i0 += 4 * 256) {
+                uint32_t x[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int i = i0 + u * 256;
+                    const int d = i / NC, cc = i - d * NC;
+                    x[u] = i < n_cells ? ld_shared(&h.hvotes[(size_t)s_slot[d] * NC + cc]) : 0u;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) if (i0 + u * 256 < n_cells) s_cell[i0 + u * 256] = x[u] != 0;
+            }
+            __syncthreads();
+            // a WAVE per class, lanes = instances in ascending order: the running counter of a
+            // class is a prefix count of its non-zero cells (ballot + popcount, 64 instances a step)
+            for (int cc = t >> 6; cc < NC; cc += 4) {
+                uint32_t carry = 0;
+                for (int d0 = 0; d0 < n_dense; d0 += 64) {
+                    const int d = d0 + lane_id();
+                    const bool nz = cc != 0 && d < n_dense && s_cell[d * NC + cc] != 0;   // void is ignored (:73-74)
+                    const unsigned long long m = __ballot(nz);
+                    if (d < n_dense) s_cell[d * NC + cc] = nz ? (uint16_t)(carry + __popcll(m & ((2ull << lane_id()) - 1ull))) : 0;
+                    carry += (uint32_t)__popcll(m);
+                }
+            }
+            __syncthreads();
+            for (int i = t; i < n_cells; i += 256) v.votes[i] = s_cell[i];
+        } else {
+            for (int cc = t; cc < NC; cc += 256) {
+                uint32_t runc = 0;
+                for (int d = 0; d < n_dense; ++d) {
+                    const uint32_t x = ld_shared(&h.hvotes[(size_t)s_slot[d] * NC + cc]);
+                    const uint32_t r = (cc != 0 && x) ? ++runc : 0u;
+                    v.votes[(size_t)d * NC + cc] = r;
+                    st_shared(&h.hvotes[(size_t)s_slot[d] * NC + cc], r);   // (read back below, past the L1)
+                }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        auto rank_of = [&](int d, int cc) -> uint32_t {
+            return in_lds ? (uint32_t)s_cell[d * NC + cc] : ld_shared(&h.hvotes[(size_t)s_slot[d] * NC + cc]);
+        };
+        // the id dict in the reference's insertion order (instance ascending, class ascending): the
+        // segments of an instance are counted by a WAVE (lanes = classes), an exclusive scan over
+        // the instances gives every row its base, then every non-zero cell knows its place
+        int* s_base = (int*)(s_slot + cap);              // [cap] (the naive merge has no enc bytes)
+        for (int d = t >> 6; d < n_dense; d += 4) {
+            int n = 0;
+            for (int c0 = 0; c0 < NC; c0 += 64) {
+                const int cc = c0 + lane_id();
+                n += __popcll(__ballot(cc >= 1 && cc < NC && rank_of(d, cc) != 0));
+            }
+            if (lane_id() == 0) s_base[d] = n;
+        }
+        __syncthreads();
+        const int per = cap / 256;
+        int cnt = 0;
+        for (int j = 0; j < per; ++j) {
+            const int d = t * per + j;
+            if (d >= n_dense) break;
+            cnt += s_base[d];
+        }
+        int totp;
+        int pos = mw_block_scan(cnt, scratch, &totp) - cnt;
+        for (int j = 0; j < per; ++j) {
+            const int d = t * per + j;
+            if (d >= n_dense) break;
+            const int n = s_base[d];
+            s_base[d] = pos;
+            pos += n;
+        }
+        __syncthreads();
+        for (int d = t >> 6; d < n_dense; d += 4) {
+            const int id = ld_shared(&h.hkeys[s_slot[d]]);
+            int at = s_base[d];
+            for (int c0 = 0; c0 < NC; c0 += 64) {
+                const int cc = c0 + lane_id();
+                const uint32_t r = (cc >= 1 && cc < NC) ? rank_of(d, cc) : 0u;
+                const unsigned long long m = __ballot(r != 0);
+                const int mine = at + __popcll(m & ((1ull << lane_id()) - 1ull));
+                if (r && mine < pair_cap) {
+                    ids_pan[(size_t)b * pair_cap + mine] = (int64_t)cc * max_inst + r;
+                    ids_ins[(size_t)b * pair_cap + mine] = id;
+                }
+                at += __popcll(m);
+            }
+        }
+        if (t == 0) {
+            n_ids[b] = min(totp, pair_cap);
+            if (totp > pair_cap) atomicOr(status, TG_ST_PAIR_OVERFLOW);
+        }
+    }
+}
+
+// The on-wire layout only (uint8 semantic, int32 ids, 16-byte aligned rows of 4 pixels, W % 4 == 0,
+// NC <= 16384): everything else keeps the launches of rounds 2-4.
+template <bool WITH_MOMENTS>
+__global__ __launch_bounds__(256) void k_tg_scan(
+    const uint8_t* __restrict__ sem, const int32_t* __restrict__ ins, int P, int W, int cap, int NC,
+    int px_per_wg, unsigned char* __restrict__ ws, unsigned char* __restrict__ hs,
+    const uint8_t* __restrict__ is_thing_class, int32_t* __restrict__ encoded_ids,
+    int32_t* __restrict__ n_encoded, int32_t* __restrict__ skipped_ids, int32_t* __restrict__ n_skipped,
+    int pair_cap, int64_t max_inst, int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins,
+    int32_t* __restrict__ n_ids, int* __restrict__ status)
+{
+    // all LDS is dynamic (no static variable in front of it: the base stays 16-byte aligned):
+    // [ control word (16 B) | the scan table, then the tail's arrays ]
+    extern __shared__ __attribute__((aligned(16))) uint32_t tgs_lds[];
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned char u8x4_t __attribute__((ext_vector_type(4)));
+    volatile uint32_t* ctl = tgs_lds;
+    TgScanTab& T = *(TgScanTab*)(tgs_lds + 4);
+    const int b = blockIdx.y;
+    const int HT = tg_hash_slots(cap);
+    TgHash h = tg_hash_view(hs, b, cap, NC);
+    const int p_begin = blockIdx.x * px_per_wg, p_end = min(P, p_begin + px_per_wg);   // px_per_wg % 1024 == 0
+    const int n_rounds = (p_end - p_begin + 1023) / 1024;
+    // the labels of the next TGS_AHEAD rounds are on their way while a round is worked on
+    i32x4_t id4[TGS_AHEAD];
+    u8x4_t sm4[TGS_AHEAD];
+    auto request = [&](int r, i32x4_t& idv, u8x4_t& smv) {
+        const int p = p_begin + (r * 256 + (int)threadIdx.x) * 4;      // P % 4 == 0: whole groups
+        idv = i32x4_t{0, 0, 0, 0};
+        smv = u8x4_t{0, 0, 0, 0};
+        if (r < n_rounds && p < p_end) {
+            // (plain loads: the paint kernel reads the labels again — with non-temporal loads here it
+            // found none of them in the Infinity Cache and took 9 us longer)
+            idv = *(const i32x4_t*)(ins + (size_t)b * P + p);
+            smv = *(const u8x4_t*)(sem + (size_t)b * P + p);
+        }
+    };
+#pragma unroll
+    for (int k = 0; k < TGS_AHEAD; ++k) request(k, id4[k], sm4[k]);
+    T.key[threadIdx.x] = -1; T.cnt[threadIdx.x] = 0; T.sy[threadIdx.x] = 0; T.sx[threadIdx.x] = 0;
+    __syncthreads();
+    int st = 0;
+    auto global_add = [&](int key, uint32_t n, unsigned long long ay, unsigned long long ax) {
+        const int g = tg_hash_insert(h.hkeys, HT, key >> 14);
+        if (g < 0) { st |= TG_ST_OVERFLOW; return; }
+        if (n) atomicAdd(&h.hvotes[(size_t)g * NC + (key & (TGF_MAX_NC - 1))], n);
+        if (WITH_MOMENTS && n) { atomicAdd(&h.hsum_y[g], ay); atomicAdd(&h.hsum_x[g], ax); }
+    };
+    auto add = [&](int key, uint32_t n, uint32_t ay, uint32_t ax) {
+        const int slot = lds_hash_slot(T.key, TG_H2, key);
+        if (slot < 0) { global_add(key, n, ay, ax); return; }
+        atomicAdd(&T.cnt[slot], n);
+        if (WITH_MOMENTS) { atomicAdd(&T.sy[slot], ay); atomicAdd(&T.sx[slot], ax); }
+    };
+    // (32-bit sums in LDS: a workgroup's range is at most 2^17 px (the host caps it), x and y < 2^15)
+    for (int r0 = 0; r0 < n_rounds; r0 += TGS_AHEAD) {
+#pragma unroll
+        for (int k = 0; k < TGS_AHEAD; ++k) {
+            const int r = r0 + k;
+            const i32x4_t idv = id4[k];
+            const u8x4_t smv = sm4[k];
+            request(r + TGS_AHEAD, id4[k], sm4[k]);
+            if (r >= n_rounds) continue;                          // (uniform)
+            const int p = p_begin + (r * 256 + (int)threadIdx.x) * 4;
+            const int id[4] = {idv.x, idv.y, idv.z, idv.w};
+            const int cl[4] = {smv.x, smv.y, smv.z, smv.w};
+            int key[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                key[j] = -1;
+                if ((unsigned)id[j] > (unsigned)MW_MAX_ID) st |= TG_ST_ID_RANGE;
+                else if (id[j] > 0) {
+                    if (cl[j] < NC) key[j] = (id[j] << 14) | cl[j];
+                    else { st |= TG_ST_CLASS_RANGE; global_add(id[j] << 14, 0u, 0u, 0u); }   // present, no vote
+                }
+            }
+            if (!__any(key[0] >= 0 || key[1] >= 0 || key[2] >= 0 || key[3] >= 0)) continue;   // a wave of background
+            const int y0 = p / W, x0 = p - y0 * W;            // W % 4 == 0: a group never leaves its row
+            // lanes whose 4 pixels agree (the usual case) are cut into runs of lanes — at row changes
+            // too: the run key carries the row's parity — and the run head adds the closed forms for
+            // its 4 n pixels: n lanes from x0 in row y0 sum to y = 4 n y0, x = n (4 x0 + 6) + 8 n (n - 1)
+            const bool same = key[0] == key[1] && key[1] == key[2] && key[2] == key[3];
+            const int rk = (same && key[0] >= 0) ? ((key[0] << 1) | (y0 & 1)) : -1;
+            int rl, rlast;
+            if (wave_run_head(rk, rl, rlast)) {
+                const uint32_t n = (uint32_t)rl;
+                add(key[0], 4u * n, 4u * n * (uint32_t)y0, n * (uint32_t)(4 * x0 + 6) + 8u * n * (n - 1u));
+            }
+            if (!same) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (key[j] >= 0) add(key[j], 1u, (uint32_t)y0, (uint32_t)(x0 + j));
+            }
+        }
+    }
+    __syncthreads();
+    if (T.key[threadIdx.x] >= 0)
+        global_add(T.key[threadIdx.x], T.cnt[threadIdx.x], T.sy[threadIdx.x], T.sx[threadIdx.x]);
+    if (st) atomicOr(status, st);
+    // every atomic of this workgroup has been performed before its ticket is drawn
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const bool last = atomicAdd(&h.ticket[0], 1u) == gridDim.x - 1;
+        ctl[0] = last ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+    }
+    __syncthreads();
+    if (!ctl[0]) return;
+    tg_rank_decide_tail<WITH_MOMENTS>(tg_view(ws, b, cap, NC), h, b, cap, HT, NC, tgs_lds + 4, is_thing_class,
+                                      encoded_ids, n_encoded, skipped_ids, n_skipped, pair_cap, max_inst,
+                                      ids_pan, ids_ins, n_ids, status);
+}
+
 // ---- paint: heat-map, offsets, foreground, center mask -------------------------------------------
 constexpr int TGP_THREADS = 256;
 constexpr int TGP_PX = 1024;                 // consecutive pixels per workgroup
@@ -1017,11 +1478,69 @@ int tg_grid_x(int P)
     return gx > 1024 ? 1024 : gx;
 }
 
+// the one-launch front end takes the on-wire layout; NMSA_TG_FUSED=0 (read per call: same-process
+// A/B): never
+bool tg_scan_ok(const void* sem, int sem_dtype, const void* ins, int ins_dtype, int P, int W, int NC)
+{
+    const char* e = getenv("NMSA_TG_FUSED");
+    if (e && atoi(e) == 0) return false;
+    return tg_fast(sem, sem_dtype, ins, ins_dtype, P) && W % 4 == 0 && NC <= TGF_MAX_NC;
+}
+
+size_t tg_scan_lds_bytes(int cap, bool moments)
+{
+    // scratch | bitmap + prefix | slot u16 [cap] | enc u8 [cap] (instance targets) or base i32 [cap] (naive merge)
+    const size_t tail = 32 * 4 + (size_t)2 * MW_WORDS * 4 + (size_t)cap * 2 + (size_t)cap * (moments ? 1 : 4);
+    return 16 + (((tail > sizeof(TgScanTab) ? tail : sizeof(TgScanTab)) + 15) & ~(size_t)15);
+}
+
+// pixels per workgroup: ONE round of resident workgroups over the batch (8 workgroups of 256
+// threads per CU, fewer when the LDS footprint says so), whole rounds of 1024 px, at most 2^17 px
+int tg_scan_px_per_wg(int B, int P, size_t lds)
+{
+    const DeviceGeometry g = device_geometry();
+    long long per_cu = (long long)(g.lds_per_cu / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const char* e = getenv("NMSA_TG_WGS_PER_CU");       // (per call: tuning)
+    if (e && atoi(e) > 0) per_cu = atoi(e);
+    long long wpi = (long long)g.cus * per_cu / B;     // workgroups per image
+    if (wpi < 1) wpi = 1;
+    long long px = ((P + wpi - 1) / wpi + 1023) / 1024 * 1024;
+    if (px > (1 << 17)) px = 1 << 17;
+    if (px < 1024) px = 1024;
+    return (int)px;
+}
+
 int tg_common(const void* sem, int sem_dtype, const void* ins, int ins_dtype, int B, int NC, int P,
               int W, int cap, bool moments, unsigned char* ws, size_t need, int32_t* status,
-              hipStream_t stream)
+              hipStream_t stream, const uint8_t* is_thing_class = nullptr, int32_t* encoded_ids = nullptr,
+              int32_t* n_encoded = nullptr, int32_t* skipped_ids = nullptr, int32_t* n_skipped = nullptr,
+              int pair_cap = 0, int64_t max_inst = 0, int64_t* ids_pan = nullptr, int64_t* ids_ins = nullptr,
+              int32_t* n_ids = nullptr, bool* did_tail = nullptr)
 {
-    int rc = check_hip(hipMemsetAsync(ws, 0, need, stream));
+    if (did_tail) *did_tail = false;
+    if (tg_scan_ok(sem, sem_dtype, ins, ins_dtype, P, W, NC) && (uintptr_t)ws % 16 == 0) {
+        // ONE launch behind a memset of the hash tables (k_tg_scan: scan + rank + decide / naive ranks)
+        unsigned char* hs = ws + (size_t)B * tg_image_bytes(cap, NC);
+        // (a status word that sits right behind the workspace is zeroed by the same memset: the
+        // caller saves the launch that would zero it)
+        const size_t hbytes = (size_t)B * tg_hash_bytes(cap, NC);
+        int rc = check_hip(hipMemsetAsync(hs, 0, hbytes + ((unsigned char*)status == hs + hbytes ? 16 : 0), stream));
+        if (rc) return rc;
+        const size_t lds = tg_scan_lds_bytes(cap, moments);
+        const int px = tg_scan_px_per_wg(B, P, lds);
+        const dim3 grid((P + px - 1) / px, B);
+#define NMSA_LAUNCH_SCAN(M) do { rc = allow_dynamic_lds(k_tg_scan<M>, lds); if (rc) return rc;                  \
+        hipLaunchKernelGGL((k_tg_scan<M>), grid, dim3(256), lds, stream, (const uint8_t*)sem, (const int32_t*)ins, \
+                           P, W, cap, NC, px, ws, hs, is_thing_class, encoded_ids, n_encoded, skipped_ids,       \
+                           n_skipped, pair_cap, max_inst, ids_pan, ids_ins, n_ids, status); } while (0)
+        if (moments) NMSA_LAUNCH_SCAN(true); else NMSA_LAUNCH_SCAN(false);
+#undef NMSA_LAUNCH_SCAN
+        if (did_tail) *did_tail = true;
+        return check_launch();
+    }
+    int rc = check_hip(hipMemsetAsync(ws, 0, (size_t)B * tg_image_bytes(cap, NC), stream));
     if (rc) return rc;
     const int gx = tg_grid_x(P);
     const bool fast = tg_fast(sem, sem_dtype, ins, ins_dtype, P);
@@ -1053,7 +1572,9 @@ using namespace nmsa;
 extern "C" size_t nmsa_targets_workspace_bytes(int B, int n_classes, int max_instances)
 {
     if (B <= 0 || n_classes <= 0 || max_instances <= 0 || max_instances > 4096) return 0;
-    return (size_t)B * tg_image_bytes(tg_cap(max_instances), n_classes);
+    // [ dense per-image tables (TgView) | per-image hash tables of the one-launch front end (TgHash) ]
+    const int cap = tg_cap(max_instances);
+    return (size_t)B * (tg_image_bytes(cap, n_classes) + tg_hash_bytes(cap, n_classes));
 }
 
 extern "C" int nmsa_instance_targets(const void* semantic, int sem_dtype, const void* instance,
@@ -1083,12 +1604,16 @@ extern "C" int nmsa_instance_targets(const void* semantic, int sem_dtype, const 
     if ((uintptr_t)workspace % 8) return NMSA_ERR_ARG;
     unsigned char* ws = (unsigned char*)workspace;
     const int P = H * W;
+    bool decided = false;
     int rc = tg_common(semantic, sem_dtype, instance, ins_dtype, B, n_classes, P, W, cap, true, ws, need,
-                       status, stream);
+                       status, stream, is_thing_class, encoded_ids, n_encoded, skipped_ids, n_skipped, 0, 0,
+                       nullptr, nullptr, nullptr, &decided);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tg_decide, dim3(B), dim3(1024), 0, stream, ws, cap, n_classes, is_thing_class,
-                       encoded_ids, n_encoded, skipped_ids, n_skipped);
-    if ((rc = check_launch())) return rc;
+    if (!decided) {
+        hipLaunchKernelGGL(k_tg_decide, dim3(B), dim3(1024), 0, stream, ws, cap, n_classes, is_thing_class,
+                           encoded_ids, n_encoded, skipped_ids, n_skipped);
+        if ((rc = check_launch())) return rc;
+    }
     const int radius = 3 * sigma + 1;
     const int lut_n = 2 * radius * radius + 1;
     const size_t lds = (size_t)cap * 2 * sizeof(int) + (lut_n <= TGP_LUT_LDS ? (size_t)lut_n * 4 : 0);
@@ -1146,12 +1671,16 @@ extern "C" int nmsa_panoptic_targets(const void* semantic, int sem_dtype, const 
     if ((uintptr_t)workspace % 8) return NMSA_ERR_ARG;
     unsigned char* ws = (unsigned char*)workspace;
     const int P = H * W;
+    bool ranked = false;
     int rc = tg_common(semantic, sem_dtype, instance, ins_dtype, B, n_classes, P, W, cap, false, ws, need,
-                       status, stream);
+                       status, stream, nullptr, nullptr, nullptr, nullptr, nullptr, max_segments,
+                       max_instances_per_category, ids_pan, ids_ins, n_ids, &ranked);
     if (rc) return rc;
-    hipLaunchKernelGGL(k_tg_naive_ranks, dim3(B), dim3(1024), 0, stream, ws, cap, n_classes, max_segments,
-                       max_instances_per_category, ids_pan, ids_ins, n_ids, status);
-    if ((rc = check_launch())) return rc;
+    if (!ranked) {
+        hipLaunchKernelGGL(k_tg_naive_ranks, dim3(B), dim3(1024), 0, stream, ws, cap, n_classes, max_segments,
+                           max_instances_per_category, ids_pan, ids_ins, n_ids, status);
+        if ((rc = check_launch())) return rc;
+    }
     const int gx = tg_grid_x(P);
     if (tg_fast(semantic, sem_dtype, instance, ins_dtype, P) && (uintptr_t)panoptic % 32 == 0)
         hipLaunchKernelGGL(k_tg_naive_paint<true>, dim3(gx, B), dim3(256), 0, stream, semantic, sem_dtype,

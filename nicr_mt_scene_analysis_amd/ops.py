@@ -372,11 +372,28 @@ def _gauss_lut(sigma: int, dev: torch.device) -> torch.Tensor:
     return _GAUSS_LUTS[key]
 
 
-def _targets_workspace(B: int, n_classes: int, max_instances: int, dev) -> Tuple[torch.Tensor, int]:
+def _targets_workspace(B: int, n_classes: int, max_instances: int, dev, with_status: bool = False):
+    """(workspace, bytes) — with_status: (workspace, bytes, status): the int32 status word sits
+    right behind the workspace, where the target generators zero it with their own memset (no
+    launch of ours to zero it)"""
     nbytes = L.lib().nmsa_targets_workspace_bytes(B, n_classes, max_instances)
     if nbytes == 0:
         raise ValueError('max_instances must be in [1, 4096]')
-    return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev), nbytes
+    if not with_status:
+        return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev), nbytes
+    assert nbytes % 16 == 0
+    buf = torch.empty((nbytes // 8 + 2,), dtype=torch.int64, device=dev)
+    status = buf[nbytes // 8:].view(torch.int32)[:1]
+    return buf, nbytes, status
+
+
+def _targets_zero_their_status(sem: torch.Tensor, ins: torch.Tensor, H: int, W: int, n_classes: int) -> bool:
+    """the layouts the one-launch front end of csrc/targets.hip takes (it zeroes a status word that
+    sits behind its workspace): the on-wire dtypes, rows of 4 pixels"""
+    import os
+    return (os.environ.get('NMSA_TG_FUSED', '1') != '0' and sem.dtype == torch.uint8 and
+            ins.dtype == torch.int32 and W % 4 == 0 and n_classes <= 16384 and
+            sem.data_ptr() % 4 == 0 and ins.data_ptr() % 16 == 0)
 
 
 def instance_clear_stuff(semantic: torch.Tensor, instance: torch.Tensor,
@@ -421,8 +438,9 @@ def instance_targets(
     skp = torch.empty((B, cap), dtype=torch.int32, device=dev)
     n_enc = torch.empty((B,), dtype=torch.int32, device=dev)
     n_skp = torch.empty((B,), dtype=torch.int32, device=dev)
-    status = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ws, ws_bytes = _targets_workspace(B, int(n_classes), int(max_instances), dev)
+    ws, ws_bytes, status = _targets_workspace(B, int(n_classes), int(max_instances), dev, with_status=True)
+    if not _targets_zero_their_status(sem, ins, H, W, int(n_classes)):
+        status.zero_()
     L.check(L.lib().nmsa_instance_targets(
         L.ptr(sem), L.int_dtype_code(sem), L.ptr(ins), L.int_dtype_code(ins), L.ptr(th), L.ptr(st),
         B, int(n_classes), H, W, int(sigma), L.ptr(_gauss_lut(sigma, dev)),
@@ -456,8 +474,9 @@ def panoptic_targets(
     ids_pan = torch.empty((B, int(max_segments)), dtype=torch.int64, device=dev)
     ids_ins = torch.empty((B, int(max_segments)), dtype=torch.int64, device=dev)
     n_ids = torch.empty((B,), dtype=torch.int32, device=dev)
-    status = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ws, ws_bytes = _targets_workspace(B, int(n_classes), int(max_instances), dev)
+    ws, ws_bytes, status = _targets_workspace(B, int(n_classes), int(max_instances), dev, with_status=True)
+    if not _targets_zero_their_status(sem, ins, H, W, int(n_classes)):
+        status.zero_()
     L.check(L.lib().nmsa_panoptic_targets(
         L.ptr(sem), L.int_dtype_code(sem), L.ptr(ins), L.int_dtype_code(ins), L.ptr(th),
         B, int(n_classes), H, W, int(max_instances_per_category), int(void_label),
