@@ -221,7 +221,7 @@ def secondary_pipeline(ops, syn, dev, B, C, H, W, K, dtype, with_metrics=True, o
     def step():
         r = ops.panoptic_pipeline(*a, want_foreground=False, fused_kernel_events=ev)
         if m is not None:
-            m.update_and_reduce(r['panoptic'])
+            m.update_and_reduce(r)
     ms = hip_timed(step, reps=20, warm=5)
     # the headline's schedule: consecutive batches alternate over two streams, metric kernels
     # on a side stream (the one-workgroup-per-image kernels hide behind the other batch)
@@ -233,7 +233,7 @@ def secondary_pipeline(ops, syn, dev, B, C, H, W, K, dtype, with_metrics=True, o
         with torch.cuda.stream(streams[i % 2]):
             r = ops.panoptic_pipeline(*a, want_foreground=False)
             if m2 is not None:
-                m2.update_and_reduce(r['panoptic'])
+                m2.update_and_reduce(r)
     ms2 = float('nan')
     if overlap:                                 # (rocprofv3 leg profiles skip it: clean per-kernel averages)
         for i in range(6):
@@ -514,7 +514,7 @@ def secondary_cfg5_full(ops, syn, dev, B=16, C=150, H=768, W=1024, K=48, D=512, 
 
     def step():
         r = ops.panoptic_pipeline(*a, want_foreground=False)
-        metrics.update_and_reduce(r['panoptic'])
+        metrics.update_and_reduce(r)
         for t in leaves:
             t.grad = None
         total = _multi.multi_loss(items, 4, spec).total_losses.sum()
@@ -823,7 +823,7 @@ def main():
             r = ops.panoptic_pipeline(logits, center, offset, is_thing, want_foreground=False,
                                       fused_kernel_events=events if record else None)
             if metrics is not None:
-                metrics.update_and_reduce(r['panoptic'], dist)
+                metrics.update_and_reduce(r, dist)
         return r
 
     for i in range(args.warmup):
@@ -853,7 +853,7 @@ def main():
                     torch.cuda.synchronize()
                     gm = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gm, stream=metrics.stream, capture_error_mode='thread_local'):
-                        metrics.enqueue(out['panoptic'])
+                        metrics.enqueue(out)
                 graphs.append((gp, gm, out, torch.cuda.Event()))
             torch.cuda.synchronize()
         except Exception as e:                  # noqa: BLE001 — any capture problem: measure eagerly

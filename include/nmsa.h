@@ -428,6 +428,25 @@ int nmsa_pq_update_with_confmat(
     int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
     int confmat_classes, int64_t pred_div, int64_t* confmat, int32_t* confmat_status,
     void* confmat_workspace, size_t confmat_workspace_bytes, nmsa_stream_t stream);
+/* The same update with the prediction given as the PARTS nmsa_panoptic_paint paints the map from
+ * (the fused pipeline's outputs) instead of the painted int64 map: the predicted panoptic id of
+ * a pixel is pan_of_inst[b][pred_instance] where pred_instance != 0, else (pred_semantic + 1) *
+ * max_instances_per_category when that class is stuff, else void_label — 2 B/px read instead of
+ * 8 B/px; results are bit-identical to nmsa_pq_update_with_confmat on the painted map
+ * (task_helper/panoptic.py:104-126 at network resolution; no match list).
+ *   pred_semantic u8 [B,H,W] class index 0..n_sem_classes-1 (<= 255), pred_instance u8 [B,H,W],
+ *   pan_of_inst i64 [B,256], is_thing_class u8 [n_sem_classes] */
+int nmsa_pq_update_with_confmat_parts(
+    const uint8_t* pred_semantic, const uint8_t* pred_instance, const int64_t* pan_of_inst,
+    const uint8_t* is_thing_class, int n_sem_classes, int64_t void_label,
+    const int64_t* target, const uint8_t* target_semantic,
+    int B, int H, int W,
+    int num_categories, int64_t ignored_label, int64_t max_instances_per_category, int64_t offset,
+    int64_t void_segment_id,
+    double* iou_per_class, double* tp_per_class, double* fn_per_class, double* fp_per_class,
+    int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
+    int confmat_classes, int64_t pred_div, int64_t* confmat, int32_t* confmat_status,
+    void* confmat_workspace, size_t confmat_workspace_bytes, nmsa_stream_t stream);
 
 /* ---------------------------------------------------------------------------
  * a6-a10  per-pixel multi-task losses (forward + backward)

@@ -92,6 +92,9 @@ _SIGNATURES = {
     'nmsa_pq_update_with_confmat': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64,
                                          _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _i,
                                          _i, _i64, _vp, _vp, _vp, _sz, _vp]),
+    'nmsa_pq_update_with_confmat_parts': (_i, [_vp, _vp, _vp, _vp, _i, _i64, _vp, _vp, _i, _i, _i,
+                                               _i, _i64, _i64, _i64, _i64, _vp, _vp, _vp, _vp,
+                                               _vp, _vp, _sz, _i, _i, _i64, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_pack_tables': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     'nmsa_loss_workspace_bytes': (_sz, [_i, _i, _i]),
     'nmsa_loss_ce_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz,

@@ -337,19 +337,38 @@ __device__ __forceinline__ longlong2 ld_i64x2_stream(const int64_t* p)
 // task_helper/panoptic.py:57-63): shifts, and every per-pixel range test as branch-free selects —
 // the early returns of the generic form are eight divergent branch diamonds per load, with an
 // inlined 64-bit division in each.
-template <bool WITH_CM, bool POW2>
+// PARTS: the prediction is not read as its painted int64 map (8 B/px) but formed in registers from
+// what the merge painted it from — semantic class u8, instance id u8 and the per-image table
+// pan_of_inst (k_paint2's rule, panoptic.hip): 2 B/px.  The metric chain of a validation step then
+// reads 11 B/px instead of 17; the map itself is still written for the API.
+struct PqPredParts {
+    const uint8_t* sem;                // [B,P] class index 0..C-1
+    const uint8_t* inst;               // [B,P] instance id 0..255
+    const int64_t* pan_of_inst;        // [B,256]
+    const uint8_t* is_thing;           // [C]
+    int C;
+    int64_t max_inst, void_label;
+};
+
+template <bool WITH_CM, bool POW2, bool PARTS>
 __global__ __launch_bounds__(256) void k_pq_count(
     const int64_t* __restrict__ pred, const int64_t* __restrict__ target,
     int P, int64_t offset, int px_per_block,
     unsigned char* __restrict__ ws, int cap, int* __restrict__ status,
     const uint8_t* __restrict__ target_sem, int cm_n, int64_t cm_div, int cm_shift,
     uint32_t* __restrict__ cm_slab, int* __restrict__ cm_status, int ablate,
-    int* __restrict__ list_n_all)
+    int* __restrict__ list_n_all, PqPredParts parts)
 {
     __shared__ int64_t lkI[PQ_LI];
     __shared__ uint32_t lcI[PQ_LI];
+    __shared__ int64_t s_pinst[PARTS ? 256 : 1], s_pstuff[PARTS ? 256 : 1];
     extern __shared__ uint32_t cm_hist_pq[];
     const int b = blockIdx.y;
+    if (PARTS) {
+        const int t = threadIdx.x;
+        s_pinst[t] = parts.pan_of_inst[(size_t)b * 256 + t];
+        s_pstuff[t] = (t < parts.C && !parts.is_thing[t]) ? (int64_t)(t + 1) * parts.max_inst : parts.void_label;
+    }
     const int cm_bins = WITH_CM ? cm_n * cm_n : 0;
     for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) { lkI[i] = KEY_EMPTY; lcI[i] = 0; }
     if (WITH_CM) for (int i = threadIdx.x; i < cm_bins; i += blockDim.x) cm_hist_pq[i] = 0;
@@ -388,7 +407,11 @@ __global__ __launch_bounds__(256) void k_pq_count(
     int* list_n = list_n_all + b * PQ_LIST_STRIDE;     // one counter per image, each on a line of its own
     uint32_t* list_slots = (uint32_t*)(pq_list_keys(ws, b, cap) + cap / 2) + cap / 2;
     const int list_cap = cap / 2;
-    const int64_t* pr = pred + (size_t)b * P;
+    const int64_t* pr = PARTS ? nullptr : pred + (size_t)b * P;
+    const uint8_t* psem = PARTS ? parts.sem + (size_t)b * P : nullptr;
+    const uint8_t* pins = PARTS ? parts.inst + (size_t)b * P : nullptr;
+    // the painted value of a pixel (k_paint2): its instance's panoptic id, else its stuff class's
+    auto painted = [&](uint32_t sm, uint32_t in) -> int64_t { return in ? s_pinst[in] : s_pstuff[sm]; };
     const int64_t* tg = target + (size_t)b * P;
     const int start = blockIdx.x * px_per_block;
     const int end = min(start + px_per_block, P);
@@ -438,6 +461,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
     // the image plane is consumed as 16-B (2 px) loads when the rows allow it
     const bool vec = ((P & 1) == 0) && ((start & 1) == 0) &&
                      ((((uintptr_t)pr | (uintptr_t)tg) & 15) == 0) &&
+                     (!PARTS || ((((uintptr_t)psem | (uintptr_t)pins) & 1) == 0)) &&
                      (!WITH_CM || (((uintptr_t)ts) & 1) == 0);
     if (vec) {
         const int tile = blockDim.x * 2 * PQ_UNROLL;            // px per block iteration
@@ -452,8 +476,23 @@ __global__ __launch_bounds__(256) void k_pq_count(
                 const int i = base + (u * blockDim.x + threadIdx.x) * 2;
                 ok[u] = i < end;                                // end is even on this path
                 tv[u] = ok[u] ? ld_i64x2_stream(tg + i) : make_longlong2(0, 0);
-                pv[u] = ok[u] ? ld_i64x2_stream(pr + i) : make_longlong2(0, 0);
+                if (!PARTS) pv[u] = ok[u] ? ld_i64x2_stream(pr + i) : make_longlong2(0, 0);
+                else {
+                    // (the two label bytes of both pixels travel in the prediction's registers
+                    // until all loads of the tile are issued)
+                    pv[u].x = ok[u] ? (long long)(((uint32_t)*(const uint16_t*)(psem + i) << 16) | *(const uint16_t*)(pins + i)) : 0;
+                    pv[u].y = 0;
+                }
                 sv[u] = (WITH_CM && ok[u]) ? (uint32_t)*(const uint16_t*)(ts + i) : 0u;
+            }
+            if (PARTS) {
+#pragma unroll
+                for (int u = 0; u < PQ_UNROLL; ++u) {
+                    const uint32_t w = (uint32_t)pv[u].x;
+                    const uint32_t sm = w >> 16, in = w & 0xFFFFu;
+                    pv[u].x = ok[u] ? painted(sm & 0xFFu, in & 0xFFu) : 0;
+                    pv[u].y = ok[u] ? painted(sm >> 8, in >> 8) : 0;
+                }
             }
             if (WITH_CM) {
 #pragma unroll
@@ -499,8 +538,9 @@ __global__ __launch_bounds__(256) void k_pq_count(
         for (int k = 0; k < trips; ++k) {
             const int i = start + k * blockDim.x + threadIdx.x;
             const bool valid = i < end;
-            wave_runs(valid, iid_of(valid ? tg[i] : 0, valid ? pr[i] : 0, valid), 1u);
-            if (WITH_CM) cm_runs(cm_key(valid ? ts[i] : 0, valid ? pr[i] : 0, valid), 1u);
+            const int64_t pi = !valid ? 0 : PARTS ? painted(psem[i], pins[i]) : pr[i];
+            wave_runs(valid, iid_of(valid ? tg[i] : 0, pi, valid), 1u);
+            if (WITH_CM) cm_runs(cm_key(valid ? ts[i] : 0, pi, valid), 1u);
         }
     }
     __syncthreads();
@@ -888,9 +928,10 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
                    double* fp_per_class, int64_t* matches, int match_capacity, int32_t* n_matches,
                    int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
                    const uint8_t* target_sem, int cm_n, int64_t cm_div, int64_t* confmat,
-                   int32_t* cm_status, void* cm_workspace, hipStream_t stream)
+                   int32_t* cm_status, void* cm_workspace, hipStream_t stream,
+                   const PqPredParts* parts = nullptr)
 {
-    if (!pred || !target || !iou_per_class || !tp_per_class || !fn_per_class || !fp_per_class ||
+    if ((!pred && !parts) || !target || !iou_per_class || !tp_per_class || !fn_per_class || !fp_per_class ||
         !status || !workspace)
         return NMSA_ERR_ARG;
     if (B <= 0 || H <= 0 || W <= 0 || (int64_t)H * W > ((int64_t)1 << 30) || B > 65535) return NMSA_ERR_ARG;
@@ -916,17 +957,21 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
     if (target_sem) {
         int shift = -1;
         if ((cm_div & (cm_div - 1)) == 0) shift = __builtin_ctzll((unsigned long long)cm_div);
-        auto kern = (off_pow2 && shift >= 0) ? k_pq_count<true, true> : k_pq_count<true, false>;
+        const bool p2 = off_pow2 && shift >= 0;
+        auto kern = parts ? (p2 ? k_pq_count<true, true, true> : k_pq_count<true, false, true>)
+                          : (p2 ? k_pq_count<true, true, false> : k_pq_count<true, false, false>);
         hipLaunchKernelGGL(kern, grid, dim3(256),
                            (size_t)cm_n * cm_n * sizeof(uint32_t),
                            stream, pred, target, P, offset, px_per_block, ws, cap, status, target_sem, cm_n,
-                           cm_div, shift, (uint32_t*)cm_workspace, cm_status, ablate, list_n);
+                           cm_div, shift, (uint32_t*)cm_workspace, cm_status, ablate, list_n,
+                           parts ? *parts : PqPredParts{});
     } else {
-        auto kern = off_pow2 ? k_pq_count<false, true> : k_pq_count<false, false>;
+        auto kern = parts ? (off_pow2 ? k_pq_count<false, true, true> : k_pq_count<false, false, true>)
+                          : (off_pow2 ? k_pq_count<false, true, false> : k_pq_count<false, false, false>);
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream,
                            pred, target, P, offset,
                            px_per_block, ws, cap, status, (const uint8_t*)nullptr, 0, (int64_t)1, -1,
-                           (uint32_t*)nullptr, (int*)nullptr, ablate, list_n);
+                           (uint32_t*)nullptr, (int*)nullptr, ablate, list_n, parts ? *parts : PqPredParts{});
     }
     rc = check_launch();
     if (rc) return rc;
@@ -993,4 +1038,37 @@ extern "C" int nmsa_pq_update_with_confmat(
                           status, workspace, workspace_bytes, workspace_is_clean,
                           target_semantic, confmat_classes, pred_div, confmat, confmat_status,
                           confmat_workspace, (hipStream_t)stream_);
+}
+
+// the same with the prediction given as the PARTS the merge painted it from (PqPredParts): the
+// pixel's predicted panoptic id is pan_of_inst[b][inst] where inst != 0, else (sem + 1) *
+// max_instances_per_category for a stuff class, else void_label — nmsa_panoptic_paint's rule — so
+// the result is bit-identical to nmsa_pq_update_with_confmat on the painted map, which is not read
+extern "C" int nmsa_pq_update_with_confmat_parts(
+    const uint8_t* pred_semantic, const uint8_t* pred_instance, const int64_t* pan_of_inst,
+    const uint8_t* is_thing_class, int n_sem_classes, int64_t void_label,
+    const int64_t* target, const uint8_t* target_semantic,
+    int B, int H, int W,
+    int num_categories, int64_t ignored_label, int64_t max_instances_per_category, int64_t offset,
+    int64_t void_segment_id,
+    double* iou_per_class, double* tp_per_class, double* fn_per_class, double* fp_per_class,
+    int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
+    int confmat_classes, int64_t pred_div, int64_t* confmat, int32_t* confmat_status,
+    void* confmat_workspace, size_t confmat_workspace_bytes, nmsa_stream_t stream_)
+{
+    if (!pred_semantic || !pred_instance || !pan_of_inst || !is_thing_class) return NMSA_ERR_ARG;
+    if (n_sem_classes <= 0 || n_sem_classes > 255 || void_label < 0) return NMSA_ERR_ARG;
+    if (!target_semantic || !confmat || !confmat_status || !confmat_workspace) return NMSA_ERR_ARG;
+    if (confmat_classes <= 0 || confmat_classes > PQ_CM_MAX_CLASSES || pred_div <= 0) return NMSA_ERR_ARG;
+    const size_t need = nmsa_pq_confmat_workspace_bytes(B, H, W, confmat_classes);
+    if (need == 0) return NMSA_ERR_ARG;
+    if (confmat_workspace_bytes < need) return NMSA_ERR_WORKSPACE;
+    const PqPredParts parts{pred_semantic, pred_instance, pan_of_inst, is_thing_class, n_sem_classes,
+                            max_instances_per_category, void_label};
+    return pq_update_impl(nullptr, target, B, H, W, num_categories, ignored_label,
+                          max_instances_per_category, offset, void_segment_id, iou_per_class,
+                          tp_per_class, fn_per_class, fp_per_class, nullptr, 0, nullptr,
+                          status, workspace, workspace_bytes, workspace_is_clean,
+                          target_semantic, confmat_classes, pred_div, confmat, confmat_status,
+                          confmat_workspace, (hipStream_t)stream_, &parts);
 }

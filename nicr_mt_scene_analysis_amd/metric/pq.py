@@ -72,16 +72,17 @@ class PanopticQuality(Metric):
     # ------------------------------------------------------------------ update
     def _device_update(self, preds: torch.Tensor, targets: torch.Tensor, want_matches: bool,
                        miou=None, target_semantic: Optional[torch.Tensor] = None,
-                       pred_div: int = 1) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
+                       pred_div: int = 1, parts: Optional[dict] = None
+                       ) -> Optional[Tuple[torch.Tensor, torch.Tensor]]:
         if self.device.type != 'cuda':
             raise L.NmsaError('PanopticQuality.update needs the MI355X '
                               '(states live on the GPU; no CPU fallback)')
         assert preds.ndim == 3
         assert targets.shape == preds.shape
         dev = self.device
-        p = preds.to(dev, dtype=torch.int64).contiguous()
+        p = None if parts is not None else preds.to(dev, dtype=torch.int64).contiguous()
         t = targets.to(dev, dtype=torch.int64).contiguous()
-        B, H, W = p.shape
+        B, H, W = t.shape
         lib = L.lib()
         ws_bytes = lib.nmsa_pq_workspace_bytes(B, H, W, self.num_categories)
         # persistent workspace per (batch size, stream): a completed update leaves the hash
@@ -109,6 +110,19 @@ class PanopticQuality(Metric):
             n_cm = miou._n_classes
             cm_bytes = lib.nmsa_pq_confmat_workspace_bytes(B, H, W, n_cm)
             cm_ws = torch.empty((cm_bytes,), dtype=torch.uint8, device=dev)
+            if parts is not None:
+                # the prediction as the parts it was painted from (2 B/px instead of 8 B/px)
+                th = parts['is_thing']
+                L.check(lib.nmsa_pq_update_with_confmat_parts(
+                    L.ptr(parts['semantic_idx_u8']), L.ptr(parts['instance']), L.ptr(parts['pan_of_inst']),
+                    L.ptr(th), int(th.numel()), int(parts.get('void_label', 0)), L.ptr(t), L.ptr(ts),
+                    B, H, W, self.num_categories, int(self.ignored_label),
+                    int(self.max_instances_per_category), int(self.offset), int(self.void_segment_id),
+                    L.ptr(self.iou_per_class), L.ptr(self.tp_per_class), L.ptr(self.fn_per_class),
+                    L.ptr(self.fp_per_class), L.ptr(self._status), L.ptr(ws), ws_bytes, int(clean),
+                    n_cm, int(pred_div), L.ptr(miou.confmat), L.ptr(miou._status), L.ptr(cm_ws), cm_bytes,
+                    L.stream_ptr(dev)), 'nmsa_pq_update_with_confmat_parts')
+                return None
             L.check(lib.nmsa_pq_update_with_confmat(
                 L.ptr(p), L.ptr(t), L.ptr(ts), *common, n_cm, int(pred_div), L.ptr(miou.confmat),
                 L.ptr(miou._status), L.ptr(cm_ws), cm_bytes, L.stream_ptr(dev)),
@@ -135,6 +149,35 @@ class PanopticQuality(Metric):
         miou._require_gpu()
         self._device_update(preds, targets, want_matches=False, miou=miou,
                             target_semantic=target_semantic, pred_div=pred_div)
+
+    @staticmethod
+    def parts_usable(parts: Optional[dict], preds: torch.Tensor, max_instances_per_category: int) -> bool:
+        """`parts` (ops.panoptic_pipeline's semantic_idx_u8 / instance / pan_of_inst + the thing
+        LUT, what the map `preds` was painted from) can stand in for `preds` in
+        `update_with_miou`: `preds` IS the painted map of these parts"""
+        if not parts or parts.get('panoptic') is not preds:
+            return False
+        s, i, t, th = (parts.get(k) for k in ('semantic_idx_u8', 'instance', 'pan_of_inst', 'is_thing'))
+        return (all(isinstance(x, torch.Tensor) and x.is_cuda and x.is_contiguous() for x in (s, i, t, th))
+                and s.dtype == torch.uint8 and i.dtype == torch.uint8 and t.dtype == torch.int64
+                and th.dtype == torch.uint8 and s.shape == preds.shape and i.shape == preds.shape
+                and t.shape == (preds.shape[0], 256) and th.numel() <= 255
+                and int(parts.get('max_instances_per_category', -1)) == int(max_instances_per_category))
+
+    def update_with_miou_parts(self, parts: dict, targets: torch.Tensor, miou,
+                               target_semantic: torch.Tensor, pred_div: int) -> None:
+        """`update_with_miou(parts['panoptic'], ...)` without reading the painted int64 map: the
+        predicted id of every pixel is formed in registers from the parts the merge painted it
+        from (csrc/metrics.hip k_pq_count<.., PARTS>): bit-identical states, 11 instead of 17
+        bytes per pixel.  Falls back to `update_with_miou` when the parts do not apply."""
+        preds = parts['panoptic']
+        if not (self.parts_usable(parts, preds, self.max_instances_per_category)
+                and self._can_fuse(preds, miou, target_semantic)):
+            self.update_with_miou(preds, targets, miou, target_semantic, pred_div)
+            return
+        miou._require_gpu()
+        self._device_update(preds, targets, want_matches=False, miou=miou,
+                            target_semantic=target_semantic, pred_div=pred_div, parts=parts)
 
     def update(self, preds: torch.Tensor, targets: torch.Tensor) -> None:
         self._device_update(preds, targets, want_matches=False)

@@ -174,6 +174,12 @@ class PanopticPostprocessing(DensePostprocessingBase):
         # (small stores are what a read-dominated stream pays most for: DESIGN.md 5)
         r.set_lazy('panoptic_foreground_mask', lambda: thing_lut[sem_u8.long()].to(torch.bool))
         r['panoptic_segmentation_deeplab'] = panoptic_seg
+        # what the map was painted from: the metric update reads these 2 B/px instead of the
+        # 8 B/px map when the map it is handed IS this one (task_helper/panoptic.py)
+        r.aux['panoptic_parts'] = {
+            'panoptic': panoptic_seg, 'semantic_idx_u8': sem_u8, 'instance': instance_seg,
+            'pan_of_inst': p['pan_of_inst'], 'is_thing': thing_lut, 'void_label': 0,
+            'max_instances_per_category': self._max_instances_per_category}
         # id dicts / instance meta: Python objects built from the host tables when first read
         r.set_lazy('panoptic_segmentation_deeplab_ids',
                    lambda: self._id_dicts_from_host(tables.get()))

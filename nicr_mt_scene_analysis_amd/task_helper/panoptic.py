@@ -72,7 +72,10 @@ class PanopticTaskHelper(TaskHelperBase):
             # merging may change classes: mIoU of panoptic // max_instances (panoptic.py:120-126)
             # rides on the PQ pass over the prediction (one read of the i64 map for both metrics)
             miou=self._metric_iou, semantic_target=get_fullres(batch, 'semantic'),
-            pred_div=self._max_instances_per_category)
+            pred_div=self._max_instances_per_category,
+            # (used only when `panoptic_preds` is the very map these parts were painted into:
+            # network resolution = dataset resolution)
+            panoptic_pred_parts=getattr(predictions_post, 'aux', {}).get('panoptic_parts'))
         return {}, {}
 
     @append_profile_to_logs('panoptic_epoch_end_time')

@@ -494,6 +494,58 @@ def test_fused_pq_confmat_equals_separate_updates(shape, max_inst, offset):
 
 
 @gpu
+@pytest.mark.parametrize('max_inst,offset', [(1 << 16, 256 ** 3), (1000, 10 ** 7)])
+@pytest.mark.parametrize('shape', [(3, 48, 64), (2, 37, 41), (2, 480, 640)])
+def test_pq_confmat_from_the_parts_of_the_prediction(shape, max_inst, offset):
+    """nmsa_pq_update_with_confmat_parts: the predicted panoptic id formed in registers from the
+    parts the merge paints the map from (class u8, instance u8, pan_of_inst; nmsa_panoptic_paint's
+    rule) == nmsa_pq_update_with_confmat on the painted map, bit for bit (both states, repeated
+    updates, odd sizes on the scalar path), and the fall back when the parts are not the map's"""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
+    B, H, W = shape
+    C = 8
+    n = C + 1
+    g = torch.Generator(device='cuda').manual_seed(B * 77 + W)
+    is_thing_c = torch.tensor([False, True, True, False, True, True, False, True], device='cuda')
+
+    def blocky(hi, cell=8):
+        c = torch.randint(0, hi, (B, (H + cell - 1) // cell, (W + cell - 1) // cell), device='cuda', generator=g)
+        return c.repeat_interleave(cell, 1).repeat_interleave(cell, 2)[:, :H, :W].contiguous()
+    sem = blocky(C).to(torch.uint8)
+    inst = (blocky(6, 16) * is_thing_c[sem.long()]).to(torch.uint8)       # instances on thing classes only
+    pan_of_inst = torch.zeros((B, 256), dtype=torch.int64, device='cuda')
+    for b in range(B):
+        for i in range(1, 6):
+            pan_of_inst[b, i] = int(torch.randint(1, n, (1,), generator=g, device='cuda')) * max_inst + i
+    thing_u8 = is_thing_c.to(torch.uint8)
+    pred = torch.empty((B, H, W), dtype=torch.int64, device='cuda')
+    L_ = ops.L
+    L_.check(L_.lib().nmsa_panoptic_paint(L_.ptr(sem), L_.ptr(inst), L_.ptr(pan_of_inst), L_.ptr(thing_u8), B, C, H, W,
+                                          max_inst, 0, L_.ptr(pred), None, L_.stream_ptr(pred.device)),
+             'nmsa_panoptic_paint')
+    tgt = blocky(n) * max_inst + blocky(3)
+    tsem = blocky(n).to(torch.uint8)
+    parts = {'panoptic': pred, 'semantic_idx_u8': sem, 'instance': inst, 'pan_of_inst': pan_of_inst,
+             'is_thing': thing_u8, 'void_label': 0, 'max_instances_per_category': max_inst}
+    is_thing = [False] + is_thing_c.tolist()
+    pq_a, pq_b = (PanopticQuality(n, 0, max_inst, offset, is_thing, device='cuda') for _ in range(2))
+    mi_a, mi_b = (MeanIntersectionOverUnion(n, device='cuda') for _ in range(2))
+    assert PanopticQuality.parts_usable(parts, pred, max_inst)
+    for _ in range(2):
+        pq_a.update_with_miou(pred, tgt, mi_a, tsem, max_inst)
+        pq_b.update_with_miou_parts(parts, tgt, mi_b, tsem, max_inst)
+    torch.cuda.synchronize()
+    assert mi_a.confmat.sum() == 2 * B * H * W and torch.equal(mi_a.confmat, mi_b.confmat)
+    for name in ('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class'):
+        assert torch.equal(getattr(pq_a, name), getattr(pq_b, name)), name
+    assert float(pq_a.tp_per_class.sum()) + float(pq_a.fp_per_class.sum()) > 0
+    # parts of ANOTHER map (a clone is not the painted tensor itself) are not used
+    assert not PanopticQuality.parts_usable(dict(parts, panoptic=pred.clone()), pred, max_inst)
+    assert not PanopticQuality.parts_usable(parts, pred, max_inst + 1)
+
+
+@gpu
 def test_compare_and_accumulate_function(oracle):
     """module-level compare_and_accumulate (reference pq.py:60-179 signature) on the HIP path"""
     from nicr_mt_scene_analysis_amd.metric.pq import compare_and_accumulate

@@ -36,6 +36,7 @@ class MetricAccumulators:
         self.sync_every_step = sync_every_step and dist_.is_available() and dist_.is_initialized()
         n = n_classes_with_void
         is_thing = [False] + [bool(x) for x in inputs['semantic_classes_is_thing'].cpu().tolist()]
+        self._thing_lut = inputs['semantic_classes_is_thing'].to(device=device, dtype=torch.uint8).contiguous()
         # the bench reads the summed states themselves, so the metrics do not sum again in compute()
         self.miou = MeanIntersectionOverUnion(n, ignore_first_class=True, device=device,
                                               sync_on_compute=False)
@@ -102,7 +103,22 @@ class MetricAccumulators:
                 pq.zero_()
         self._merged = True
 
-    def update_and_reduce(self, panoptic_pred: torch.Tensor, dist=None) -> None:
+    def _parts(self, r):
+        """the pipeline's result as the `parts` of PanopticQuality.update_with_miou_parts (the
+        metric pass then reads 2 B/px of labels instead of the 8 B/px painted map);
+        NMSA_BENCH_METRIC_PARTS=0: always the map"""
+        if not isinstance(r, dict) or os.environ.get('NMSA_BENCH_METRIC_PARTS', '1') == '0':
+            return None
+        return {'panoptic': r['panoptic'], 'semantic_idx_u8': r['semantic_idx_u8'], 'instance': r['instance'],
+                'pan_of_inst': r['pan_of_inst'], 'is_thing': self._thing_lut, 'void_label': 0,
+                'max_instances_per_category': self.max_inst}
+
+    def update_and_reduce(self, panoptic_pred, dist=None) -> None:
+        """panoptic_pred: the painted map, or the whole result dict of ops.panoptic_pipeline (the
+        update then reads the parts the map was painted from)"""
+        parts = self._parts(panoptic_pred)
+        if isinstance(panoptic_pred, dict):
+            panoptic_pred = panoptic_pred['panoptic']
         cur, stream = self._side(panoptic_pred.device)
         k = self._turn % len(self._sets)
         self._turn += 1
@@ -114,11 +130,16 @@ class MetricAccumulators:
             self._ready.record(cur)
             stream.wait_event(self._ready)
             panoptic_pred.record_stream(stream)       # caching allocator: used on the side stream
+            if parts is not None:
+                for k in ('semantic_idx_u8', 'instance', 'pan_of_inst'):
+                    parts[k].record_stream(stream)
         with torch.cuda.stream(stream):
             # miou.update(pan // max_inst, semantic target)   (task_helper/panoptic.py:123-126)
             # pq.update(pan, panoptic target)                  (task_helper/panoptic.py:111-118)
             # -> one pass over the prediction for both accumulators
-            if self.fused_metrics:
+            if self.fused_metrics and parts is not None:
+                pq.update_with_miou_parts(parts, self.target_panoptic, miou, self.target_semantic, self.max_inst)
+            elif self.fused_metrics:
                 pq.update_with_miou(panoptic_pred, self.target_panoptic, miou,
                                     self.target_semantic, self.max_inst)
             else:
@@ -132,11 +153,16 @@ class MetricAccumulators:
                 self.miou.reset()                   # next step starts from zero, not synced
                 self.pq.reset()
 
-    def enqueue(self, panoptic_pred: torch.Tensor) -> None:
+    def enqueue(self, panoptic_pred) -> None:
         """the update kernels of the first accumulator set on the CURRENT stream, nothing else
         (what a hipGraph of the metric chain captures)"""
         miou, pq = self._sets[0]
-        if self.fused_metrics:
+        parts = self._parts(panoptic_pred)
+        if isinstance(panoptic_pred, dict):
+            panoptic_pred = panoptic_pred['panoptic']
+        if self.fused_metrics and parts is not None:
+            pq.update_with_miou_parts(parts, self.target_panoptic, miou, self.target_semantic, self.max_inst)
+        elif self.fused_metrics:
             pq.update_with_miou(panoptic_pred, self.target_panoptic, miou, self.target_semantic, self.max_inst)
         else:
             miou.update_from_panoptic(panoptic_pred, self.target_semantic, self.max_inst)
