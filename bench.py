@@ -328,9 +328,9 @@ def secondary_losses(dev, B=64, C=40, H=480, W=640):
         # forward kernels that also write the gradient: per loss the element count
         # (labels / mask, 1 B/px) + inputs once + gradient once; backward launches only confirm
         moved = (1 + 2 * C + 1 + 2 * C) + (1 + 7 + 2) + 2 * (1 + 13 + 4)
-        how = ('ONE multi-loss call: count of labels / masks (1 B/px per loss), expectation, one '
-               'launch for the four forward sums + gradients, finalize; backward compares on the '
-               'device and recomputes nothing when the expectation held')
+        how = ('ONE multi-loss call: count of labels / masks (1 B/px per loss; its last workgroup forms the '
+               'expectation), one launch for the four forward sums + gradients, finalize; backward: one '
+               'launch that compares on the device and recomputes nothing when the expectation held')
     else:
         # two-kernel path: forward inputs (2C+34) + log-sum-exp write 4; CE backward logits 2C +
         # label 1 + lse 4 + gradient 2C; element-wise backward pred + target + mask + gradient
@@ -576,11 +576,13 @@ def secondary_next_rows(ops, syn, dev, B=32, C=40, H=480, W=640):
     ops.instance_clear_stuff(sem, ins, st)
     ms = hip_timed(lambda: ops.instance_targets(sem, ins, C + 1, th, st, 8, True), reps=10, warm=3)
     out['f4_instance_targets'] = _leg(ms, n_px, 1 + 4 + 4 + 8 + 1 + 1,
-                                      what='data/preprocessing/instance.py:97-286 per batch: labels '
-                                           'in, center / offset / masks out; latency-bound passes')
+                                      what='data/preprocessing/instance.py:97-286 per batch: labels in, center / '
+                                           'offset / masks out; memset + one scan launch (presence, statistics, '
+                                           'rank, decide) + the paint launch')
     ms = hip_timed(lambda: ops.panoptic_targets(sem, ins, C + 1, th, 1 << 16), reps=10, warm=3)
     out['f4_panoptic_targets'] = _leg(ms, n_px, 1 + 4 + 8,
-                                      what='data/preprocessing/panoptic.py:16-85 per batch')
+                                      what='data/preprocessing/panoptic.py:16-85 per batch: memset + one scan '
+                                           'launch (presence, class histograms, rank, naive ranks) + the paint launch')
     return out
 
 
@@ -844,7 +846,13 @@ def main():
         try:
             torch.cuda.synchronize()
             graphs = []
-            for st in streams:
+            # TWO graph slots per batch stream (slot k runs on stream k % n): a slot's outputs sit at
+            # fixed addresses and the next replay of that slot rewrites them, so it has to wait for
+            # the metric chain that still reads them (`metric_done`, graph_step) — with two slots per
+            # stream that chain is four steps old and long finished; with one it was the chain of
+            # the step before last, still running next to the other stream's batch
+            for k in range(2 * len(streams)):
+                st = streams[k % len(streams)]
                 gp = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(gp, stream=st, capture_error_mode='thread_local'):
                     out = ops.panoptic_pipeline(logits, center, offset, is_thing, want_foreground=False)
@@ -854,7 +862,7 @@ def main():
                     gm = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gm, stream=metrics.stream, capture_error_mode='thread_local'):
                         metrics.enqueue(out)
-                graphs.append((gp, gm, out, torch.cuda.Event()))
+                graphs.append((gp, gm, out, torch.cuda.Event(), torch.cuda.Event()))
             torch.cuda.synchronize()
         except Exception as e:                  # noqa: BLE001 — any capture problem: measure eagerly
             graphs = None
@@ -862,19 +870,30 @@ def main():
             print(f'bench.py: hipGraph capture failed, eager loop instead: {graph_error}', file=sys.stderr, flush=True)
             torch.cuda.synchronize()
 
+    replayed = [False] * (2 * len(streams))
+
     def graph_step(i):
-        gp, gm, out, ready = graphs[i % len(streams)]
-        st = streams[i % len(streams)]
+        slot = i % (2 * len(streams))
+        gp, gm, out, ready, metric_done = graphs[slot]
+        st = streams[slot % len(streams)]              # (= streams[i % len(streams)])
         with torch.cuda.stream(st):
+            # the pipeline graph rewrites `out` in place (fixed addresses in the graph's pool): the
+            # metric chain of this slot's PREVIOUS step, which reads `out` on the metric stream, must
+            # be through with it (a real pipeline with changing inputs needs this dependency; with
+            # identical inputs every step its absence went unnoticed)
+            if gm is not None and replayed[slot]:
+                st.wait_event(metric_done)
             gp.replay()
             ready.record(st)
         if gm is not None:
             metrics.stream.wait_event(ready)
             with torch.cuda.stream(metrics.stream):
                 gm.replay()
+                metric_done.record(metrics.stream)
+            replayed[slot] = True
         return out
 
-    if graphs is not None:                      # two untimed replays per stream: part of the warm-up
+    if graphs is not None:                      # one untimed replay per slot: part of the warm-up
         for i in range(2 * len(streams)):
             r = graph_step(i)
     if metrics is not None:
@@ -885,11 +904,11 @@ def main():
     torch.cuda.synchronize()
     gc.collect()
     gc.disable()                               # no collector pause inside the (few-ms) timed region
-    # the live duration of the dominant kernel is sampled on every 4th step (+ the last): each pair
+    # the live duration of the dominant kernel is sampled on every 8th step: each pair
     # of event records costs the pipeline ~4 us, 1.2 % of a K = 20 run when every step carries one
     # (neither the first nor the last step: a replayed step reaches the GPU at once, an eager one
     # over the ~0.17 ms its launches take from Python — at the head and in the tail that is idle time)
-    sampled = [i % 4 == 2 and i < args.steps - 1 for i in range(args.steps)]
+    sampled = [i % 8 == 2 and i < args.steps - 1 for i in range(args.steps)]
     if not any(sampled):
         sampled[args.steps // 2] = True
     done = [torch.cuda.Event() for _ in range(len(streams) + 1)]
@@ -959,8 +978,12 @@ def main():
     if metrics is not None:
         pipeline_bytes_px += 8 + 8 + 1                      # + pred pan, target pan, target sem
     # the same kernel without the metric kernels overlapping on the side stream (untimed)
+    # (200 launches: in a `rocprofv3 --kernel-trace --stats` run of this very command they outnumber
+    # the ~45 launches of warm-up and timed region, so the summary's average duration of the kernel
+    # — profiles/<round>_kernel_stats.csv — is this number to within a few percent)
+    n_iso = 200
     iso_events = []
-    for _ in range(20):
+    for _ in range(n_iso + 2):
         ops.panoptic_pipeline(logits, center, offset, is_thing, want_foreground=False,
                               fused_kernel_events=iso_events)
     torch.cuda.synchronize()
@@ -969,20 +992,33 @@ def main():
     # rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE runs, gfx950 wide-stream correction applied by
     # tools/summarize_profile.py); null when the workload differs from the profiled one
     traffic = None
+    traffic_sha = None
     tpath = os.path.join(ROOT, 'profiles', 'latest_traffic.json')
     if os.path.exists(tpath) and (B, C, H, W) == (32, 40, 480, 640) and esize == 4:
-        with open(tpath) as f:
-            traffic = next((v.get('hbm_bytes_per_launch') for k, v in json.load(f).items()
-                            if k.startswith('k_panoptic_fused')), None)
+        import hashlib
+        with open(tpath, 'rb') as f:
+            raw = f.read()
+        traffic_sha = hashlib.sha256(raw).hexdigest()[:16]
+        traffic = next((v.get('hbm_bytes_per_launch') for k, v in json.loads(raw).items()
+                        if k.startswith('k_panoptic_fused')), None)
+    # `frac`: the kernel alone on the chip (the isolated pass above: what a rocprofv3 kernel trace of
+    # this command shows for it); `frac_eager`: HIP events around the launches sampled INSIDE the
+    # timed region — these launches are issued kernel by kernel from Python and queue behind the
+    # other batch in flight, so the figure includes waiting for wave slots and reads lower
     roofline = {
         'bound': 'hbm', 'kernel': 'k_panoptic_fused',
-        'achieved': round(achieved, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-        'frac': round(achieved / HBM_PEAK_GBS, 4), 'traffic': traffic,
-        'traffic_source': 'profiles/latest_traffic.json (rocprofv3 --pmc, per launch)' if traffic else None,
+        'achieved': round(fused_bytes / (iso_ms * 1e-3) / 1e9, 1), 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+        'frac': round(fused_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+        'kernel_ms': round(iso_ms, 4), 'kernel_launches_isolated': n_iso,
+        'frac_eager': round(achieved / HBM_PEAK_GBS, 4), 'achieved_eager': round(achieved, 1),
+        'kernel_ms_eager': round(fused_ms, 4), 'kernel_launches_timed': len(events),
+        # HBM bytes per launch are NOT measured by this run: a constant from the committed PMC passes
+        # of this command (profiles/latest_traffic.json; its content hash says which)
+        'traffic': traffic, 'traffic_profiled': traffic,
+        'traffic_source': ('profiles/latest_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of '
+                           'this command, per launch, gfx950 wide-stream correction)') if traffic else None,
+        'traffic_profile_sha256': traffic_sha,
         'algorithmic_bytes_per_launch': fused_bytes,
-        'kernel_ms_isolated': round(iso_ms, 4),
-        'frac_isolated': round(fused_bytes / (iso_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-        'kernel_ms': round(fused_ms, 4), 'kernel_launches_timed': len(events),
         'algorithmic_bytes_per_px': fused_bytes_px,
         'pipeline_algorithmic_bytes_per_px': pipeline_bytes_px,
         'pipeline_frac': round(pipeline_bytes_px * B * H * W / (ms_per_step * 1e-3) / 1e9
