@@ -164,21 +164,67 @@ def cpu_baseline(inp_dev, n_images, C, H, W, metrics=None, reps=3):
 
 
 def launch_ranks(args) -> int:
-    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) as a
-    CHILD process tree — this process has not touched the GPU and never execs — forward their
-    output (rank 0 prints the JSON line) and return their exit code."""
+    """`python bench.py --gpus N` without a launcher: start N fresh ranks (one per GPU) as CHILD
+    processes — this process has not touched the GPU and never execs — with the environment a
+    launcher gives them (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), forward rank 0's stdout (the
+    JSON line) and return 0 when every rank did.  A rank that fails is named, with the tail of its
+    stderr, before the others are stopped and a non-zero code is returned."""
+    n = args.gpus
     with socket.socket() as sock:
         sock.bind(('127.0.0.1', 0))
         port = sock.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    base = dict(os.environ)
+    # the host driver of this pool only supports dmabuf IPC: without this RCCL's (and torch's)
+    # cross-process sharing of device memory fails with `hipIpcGetMemHandle: invalid argument`
+    # (it is exported on the GPU boxes already; kept in the environment we build for the ranks)
+    base.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     # the ranks share the job's CPU quota (16 cores for the whole GPU box): bound every rank's host
     # thread pools, or 8 ranks x (intra-op pool + RCCL proxy + HSA threads) oversubscribe it
-    env.setdefault('OMP_NUM_THREADS', str(host_threads_per_rank(args.gpus)))
-    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1',
-           f'--nproc-per-node={args.gpus}', '--master-addr', '127.0.0.1',
-           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env)
+    base.setdefault('OMP_NUM_THREADS', str(host_threads_per_rank(n)))
+    base.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n))
+    import tempfile
+    procs = []
+    with tempfile.TemporaryDirectory(prefix='nmsa_bench_ranks_') as logdir:
+        for rank in range(n):
+            env = dict(base, RANK=str(rank), LOCAL_RANK=str(rank))
+            err = open(os.path.join(logdir, f'rank{rank}.stderr'), 'w+')
+            out = None if rank == 0 else subprocess.DEVNULL        # rank 0 prints the one JSON line
+            procs.append((subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:],
+                                           env=env, stdout=out, stderr=err), err))
+        failed = None
+        pending = set(range(n))
+        while pending and failed is None:
+            for rank in sorted(pending):
+                rc = procs[rank][0].poll()
+                if rc is None:
+                    continue
+                pending.discard(rank)
+                if rc != 0:
+                    failed = (rank, rc)
+                    break
+            else:
+                time.sleep(0.05)
+        if failed is not None:
+            for rank in pending:                                   # the others wait in a collective
+                procs[rank][0].terminate()
+            for rank in pending:
+                try:
+                    procs[rank][0].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[rank][0].kill()
+        code = 0
+        for rank, (proc, err) in enumerate(procs):
+            err.seek(0)
+            text = err.read()
+            err.close()
+            if failed is not None and rank == failed[0]:
+                tail = ''.join(text.splitlines(True)[-25:])
+                print(f'bench.py: rank {rank} of {n} exited with code {failed[1]}; the tail of its stderr:\n'
+                      f'{tail}', file=sys.stderr, flush=True)
+                code = failed[1] if 0 < failed[1] < 256 else 1
+            elif rank == 0 and failed is None and text:
+                sys.stderr.write(text)                             # warnings of a healthy run
+        return code
 
 
 def hip_timed(fn, reps, warm):
@@ -796,6 +842,8 @@ def main():
                 raise SystemExit(f'RCCL all-reduce saw {rccl_ranks} ranks, expected {world}')
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+        if os.environ.get('NMSA_BENCH_FAIL_RANK') == str(rank):    # test hook (tests/test_bench_launch.py)
+            raise RuntimeError(f'NMSA_BENCH_FAIL_RANK: rank {rank} fails on request')
 
     B, C, H, W = args.batch_per_gpu, args.classes, args.height, args.width
     logits_dtype = {'f32': None, 'bf16': torch.bfloat16, 'f16': torch.float16}[args.dtype]
@@ -938,6 +986,14 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    host_issue_ranks = None
+    if dist is not None:
+        hi = torch.tensor([host_issue / args.steps * 1e3], dtype=torch.float64,
+                          device=dev if dist.get_backend() == 'nccl' else 'cpu')
+        got = [torch.zeros_like(hi) for _ in range(world)]
+        dist.all_gather(got, hi)
+        host_issue_ranks = [round(float(g.item()), 4) for g in got]
+
     # after the timed region: every rank must hold the same reduced accumulators (checksum of
     # the confusion matrix and the PQ vectors, gathered over the ranks)
     totals_identical = None
@@ -1048,7 +1104,8 @@ def main():
         'collective': {'backend': ('rccl' if backend == 'nccl' else backend), 'rccl_ranks': rccl_ranks,
                        'payload_bytes': metrics.payload_bytes if metrics is not None else 0,
                        'calls': 'Metric.sync(): one all-reduce per state dtype (int64, float64)',
-                       'totals_identical_on_all_ranks': totals_identical}
+                       'totals_identical_on_all_ranks': totals_identical,
+                       'host_issue_ms_per_step_ranks': host_issue_ranks}
         if dist is not None else None,
         'roofline': roofline,
     }

@@ -43,6 +43,20 @@ def test_bench_self_launches_two_ranks():
     assert d['value'] > 0 and d['cpu_baseline'] is None
 
 
+def test_bench_names_the_rank_that_failed():
+    """a rank that dies takes the job down with a non-zero code, and the launcher says WHICH rank
+    and shows the tail of its stderr (NMSA_BENCH_FAIL_RANK: a test hook that makes that rank raise
+    after the process group is up, while the others wait in a collective)"""
+    env = dict(os.environ, NMSA_BENCH_BACKEND='gloo', NMSA_BENCH_FAIL_RANK='1')
+    env.pop('RANK', None)
+    env.pop('WORLD_SIZE', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert 'rank 1 of 2 exited with code' in r.stderr and 'NMSA_BENCH_FAIL_RANK' in r.stderr, r.stderr[-3000:]
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith('{"metric"')]
+
+
 def test_bench_under_launcher_runs_the_rccl_leg():
     env = dict(os.environ)
     env.pop('NMSA_BENCH_BACKEND', None)

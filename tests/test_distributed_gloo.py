@@ -44,8 +44,8 @@ def _accumulate(images, pred, tgt, sem_tgt):
                                                   state=state)
         cm = orc.confmat_update(pred[b] // 65536, sem_tgt[b], N_CAT, cm)
     miou.confmat += torch.from_numpy(cm)
-    for name, s in zip(('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class'), state):
-        getattr(pq, name).add_(torch.from_numpy(s))
+    for name, s in zip(('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class'), state or ()):
+        getattr(pq, name).add_(torch.from_numpy(s))          # (a rank without images: zero states)
     return miou, pq
 
 
@@ -67,16 +67,22 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_metric_sync_world2(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize('world', [2, 8])
+def test_metric_sync_world2(tmp_path, world):
+    """world 2, and the 8 ranks of a whole node (each with one image or none of the four: ranks
+    without any image take part in the all-reduce with zero states)"""
     with socket.socket() as s:
         s.bind(('127.0.0.1', 0))
         port = s.getsockname()[1]
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
     pred, tgt, sem_tgt = _maps(7)
     miou, pq = _accumulate(range(pred.shape[0]), pred, tgt, sem_tgt)
     want_state = np.stack([pq.iou_per_class.numpy(), pq.tp_per_class.numpy(),
                            pq.fn_per_class.numpy(), pq.fp_per_class.numpy()])
-    for rank in range(2):
+    for rank in range(world):
         got = np.load(tmp_path / f'rank{rank}.npz')
         assert (got['confmat'] == miou.confmat.numpy()).all()
         assert (got['state'][1:] == want_state[1:]).all()
