@@ -184,7 +184,7 @@ int nmsa_panoptic_merge(const void* sem, int sem_dtype, const void* ins, int ins
 /* Same merge for instance ids beyond uint8 (ground-truth maps: uint16 ids stored as
  * int32, e.g. > 256 instances per image; task_helper/instance.py:61).  Ids 0..65535
  * are ranked per image first (ascending order preserved), at most max_segments
- * (<= 4096) distinct thing ids per image.
+ * (<= 65536: every id such a map can hold; n_classes <= 65535) distinct thing ids per image.
  *   ids_pan / ids_ins  i64 [B, cap] with cap = max_segments rounded up to 1024
  *   status  i32 [1]: NMSA_ST_TABLE_OVERFLOW (more ids than max_segments),
  *                    32 = instance id outside [0, 65535]

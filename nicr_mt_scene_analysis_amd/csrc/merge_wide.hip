@@ -146,17 +146,18 @@ __global__ __launch_bounds__(256) void k_mw_votes(
         atomicAdd(&v.votes[s_key[threadIdx.x]], s_cnt[threadIdx.x]);
 }
 
-// mode (smallest class on ties) + running per-class counter in ascending id order
+// mode (smallest class on ties) + running per-class counter in ascending id order.  Any cap up
+// to 65536 (every id the maps can hold): the class of every slot is parked in pan_of_dense between
+// the two walks (not in per-thread arrays), the classes of the valid segments sit in LDS as u16.
 __global__ __launch_bounds__(1024) void k_mw_assign(
     unsigned char* __restrict__ ws, int cap, int NC, int64_t max_inst, int64_t void_label,
     int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins, int32_t* __restrict__ n_ids)
 {
-    extern __shared__ int s_vcls[];          // [cap] classes of the valid segments, ascending id
+    extern __shared__ __attribute__((aligned(16))) uint16_t s_vcls[];   // [cap] classes of the valid segments, ascending id
     __shared__ int scratch[32];
     const int b = blockIdx.x, t = threadIdx.x;
     MwView v = mw_view(ws, b, cap, NC);
     const int per = cap / 1024;
-    int cls[4], valid[4];
     int nvalid = 0;
     for (int j = 0; j < per; ++j) {
         const int slot = t * per + j;
@@ -169,23 +170,27 @@ __global__ __launch_bounds__(1024) void k_mw_assign(
             total += x;
             if ((int64_t)x > bestc) { bestc = x; c_best = c; }
         }
-        cls[j] = c_best;
-        valid[j] = (total > 0) && (c_best != 0);       // empty mask / void majority are skipped
-        nvalid += valid[j];
+        const bool valid = (total > 0) && (c_best != 0);     // empty mask / void majority are skipped
+        v.pan_of_dense[slot] = valid ? (int64_t)c_best : -1;  // (this thread reads it back below)
+        nvalid += valid;
     }
     int total_valid;
     int pos = mw_block_scan(nvalid, scratch, &total_valid) - nvalid;
     const int pos0 = pos;
-    for (int j = 0; j < per; ++j) if (valid[j]) s_vcls[pos++] = cls[j];
+    for (int j = 0; j < per; ++j) {
+        const int64_t c = v.pan_of_dense[t * per + j];
+        if (c >= 0) s_vcls[pos++] = (uint16_t)c;
+    }
     __syncthreads();
     pos = pos0;
     for (int j = 0; j < per; ++j) {
         const int slot = t * per + j;
+        const int64_t c = v.pan_of_dense[slot];
         int64_t pid = void_label;
-        if (valid[j]) {
+        if (c >= 0) {
             int rank = 1;
-            for (int k = 0; k < pos; ++k) rank += (s_vcls[k] == cls[j]);
-            pid = (int64_t)cls[j] * max_inst + rank;
+            for (int k = 0; k < pos; ++k) rank += (s_vcls[k] == (uint16_t)c);
+            pid = c * max_inst + rank;
             ids_pan[(size_t)b * cap + pos] = pid;
             ids_ins[(size_t)b * cap + pos] = v.id_of_dense[slot];
             ++pos;
@@ -228,7 +233,7 @@ extern "C" size_t nmsa_panoptic_merge_wide_workspace_bytes(int B, int n_classes,
 {
     if (B <= 0 || n_classes <= 0 || max_segments <= 0) return 0;
     const int cap = ((max_segments + 1023) / 1024) * 1024;
-    if (cap > 4096) return 0;
+    if (cap > 65536 || n_classes > 65535) return 0;
     return (size_t)B * mw_image_bytes(cap, n_classes);
 }
 
@@ -246,7 +251,7 @@ extern "C" int nmsa_panoptic_merge_wide(const void* sem, int sem_dtype, const vo
         !status || !workspace)
         return NMSA_ERR_ARG;
     if (B <= 0 || B > 65535 || H <= 0 || W <= 0 || (int64_t)H * W > ((int64_t)1 << 30)) return NMSA_ERR_ARG;
-    if (n_classes <= 0 || max_segments <= 0 || max_segments > 4096) return NMSA_ERR_ARG;
+    if (n_classes <= 0 || n_classes > 65535 || max_segments <= 0 || max_segments > 65536) return NMSA_ERR_ARG;
     if (sem_dtype < NMSA_U8 || sem_dtype > NMSA_I64 || ins_dtype < NMSA_U8 || ins_dtype > NMSA_I64)
         return NMSA_ERR_ARG;
     const int cap = ((max_segments + 1023) / 1024) * 1024;        // ids_* are [B, cap]
@@ -266,7 +271,8 @@ extern "C" int nmsa_panoptic_merge_wide(const void* sem, int sem_dtype, const vo
     hipLaunchKernelGGL(k_mw_votes, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins, ins_dtype,
                        thing_seg, P, cap, n_classes, ws);
     if ((rc = check_launch())) return rc;
-    hipLaunchKernelGGL(k_mw_assign, dim3(B), dim3(1024), (size_t)cap * sizeof(int), stream, ws, cap,
+    if ((rc = allow_dynamic_lds(k_mw_assign, (size_t)cap * sizeof(uint16_t)))) return rc;    // (128 KB at 65536 ids)
+    hipLaunchKernelGGL(k_mw_assign, dim3(B), dim3(1024), (size_t)cap * sizeof(uint16_t), stream, ws, cap,
                        n_classes, max_instances_per_category, void_label, ids_pan, ids_ins, n_ids);
     if ((rc = check_launch())) return rc;
     hipLaunchKernelGGL(k_mw_paint, dim3(gx, B), dim3(256), 0, stream, sem, sem_dtype, ins, ins_dtype,

@@ -60,7 +60,7 @@ def _merge_on_device(sem, ins, fg, max_instances_per_category, thing_ids, void_l
         return ops.panoptic_merge(sem, ins, fg, lut, int(max_instances_per_category),
                                   int(void_label))
     # ground-truth maps: ids 0..65535, ranked per image on the device
-    for max_segments in (1024, 4096):
+    for max_segments in (1024, 4096, 65536):        # (65536: every id a uint16 map can hold)
         r = ops.panoptic_merge_wide(sem, ins, fg, lut, int(max_instances_per_category),
                                     int(void_label), max_segments=max_segments)
         st = int(r['status'].item())
@@ -69,7 +69,7 @@ def _merge_on_device(sem, ins, fg, max_instances_per_category, thing_ids, void_l
                                       '(dataset instance maps are uint16)')
         if not (st & 1):
             return r
-    raise NotImplementedError('more than 4096 distinct instance ids in one image')
+    raise AssertionError('unreachable: 65536 segments hold every id of [0, 65535]')
 
 
 def deeplab_merge_batch(

@@ -140,9 +140,9 @@ def _merge(fn, sem, ins, thing_seg, max_inst, thing_ids, void_label, cap=1024):
     return pan, dicts
 
 
-def deeplab_merge(sem, ins, thing_seg, max_inst, thing_ids, void_label=0):
+def deeplab_merge(sem, ins, thing_seg, max_inst, thing_ids, void_label=0, cap=1024):
     return _merge(lib().orc_deeplab_merge, sem, ins, thing_seg, max_inst,
-                  thing_ids, void_label)
+                  thing_ids, void_label, cap=cap)
 
 
 def naive_merge(sem, ins, max_inst, thing_ids, void_label=0, cap=1024):

@@ -534,3 +534,28 @@ def test_pipeline_image_side_beyond_16_bits(ops, oracle, dtype):
     assert int(n[0]) == 4 and (r['n_centers'].cpu().numpy() == n).all()
     assert (r['instance'].cpu().numpy() == inst).all()
     assert (r['panoptic'].cpu().numpy() == pan).all()
+
+
+def test_deeplab_merge_more_than_4096_instance_ids(oracle):
+    """a ground-truth style map with more distinct instance ids than the 4096 the ranked merge
+    held until round 4 (reference utils/panoptic_merge.py:172-225 takes any number): 4608 ids on
+    one image, classes and thing mask disagreeing here and there — panoptic map and the id dict in
+    the reference's insertion order, against the C oracle"""
+    from nicr_mt_scene_analysis_amd.utils.panoptic_merge import deeplab_merge_batch
+    rng = np.random.default_rng(65)
+    H = W = 96
+    n_cells = H * (W // 2)
+    ids = rng.permutation(np.arange(1, 65536))[:n_cells]
+    ins = np.repeat(ids.reshape(1, H, W // 2), 2, axis=2).astype(np.int64)          # 1 x 2 px per instance
+    ins[0, rng.random((H, W)) < 0.05] = 0
+    sem = np.repeat(np.repeat(rng.integers(0, 6, (1, H // 4, W // 4)), 4, 1), 4, 2).astype(np.int64)
+    sem[0, rng.random((H, W)) < 0.1] = rng.integers(0, 6)
+    thing_ids = [2, 3, 4]
+    thing_seg = np.isin(sem, thing_ids) ^ (rng.random((1, H, W)) < 0.05)
+    assert len(np.unique(ins)) - 1 > 4096
+    want_pan, want_ids = oracle.deeplab_merge(sem, ins, thing_seg, 1 << 16, thing_ids, 0, cap=8192)
+    pan, dicts = deeplab_merge_batch(torch.from_numpy(sem).cuda(), torch.from_numpy(ins.astype(np.int32)).cuda(),
+                                     torch.from_numpy(thing_seg).cuda(), 1 << 16, thing_ids, 0)
+    assert np.array_equal(pan.cpu().numpy(), want_pan)
+    assert len(want_ids[0]) > 1000
+    assert [list(d.items()) for d in dicts] == [list(d.items()) for d in want_ids]
