@@ -514,6 +514,19 @@ int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* target, const
                      int B, int C, int H, int W, float label_smoothing,
                      const float* grad_scale, const float* lse2, void* grad_logits,
                      nmsa_stream_t stream);
+/* the same two kernels for more than 255 classes (reference ce.py:40-68 takes any number): labels
+ * as int16 (0 = void, 1..C), C <= 4096 */
+int nmsa_loss_ce_fwd_i16(const void* logits, int dtype, const int16_t* target,
+                         const float* weights, int B, int C, int H, int W,
+                         float label_smoothing,
+                         double* loss_sum, int64_t* n_elements, double* weight_sum,
+                         float* lse2_out,
+                         int32_t* status, void* workspace, size_t workspace_bytes,
+                         nmsa_stream_t stream);
+int nmsa_loss_ce_bwd_i16(const void* logits, int dtype, const int16_t* target,
+                         const float* weights, int B, int C, int H, int W,
+                         float label_smoothing, const float* grad_scale, const float* lse2,
+                         void* grad_logits, nmsa_stream_t stream);
 int nmsa_loss_ce_fwd_grad_supported(int dtype, int C);
 int nmsa_loss_ce_fwd_grad(const void* logits, int dtype, const uint8_t* target, const float* weights,
                           int B, int C, int H, int W, float label_smoothing,

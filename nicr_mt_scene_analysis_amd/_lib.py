@@ -100,6 +100,9 @@ _SIGNATURES = {
     'nmsa_loss_ce_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
                               _vp]),
     'nmsa_loss_ce_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    'nmsa_loss_ce_fwd_i16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _sz,
+                                  _vp]),
+    'nmsa_loss_ce_bwd_i16': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'nmsa_loss_masked_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_loss_masked_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'nmsa_loss_vonmises_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp, _vp, _vp, _sz, _vp]),

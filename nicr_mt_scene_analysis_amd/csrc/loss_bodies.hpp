@@ -213,12 +213,18 @@ __device__ __forceinline__ void ce_scan(const void* logits, size_t img, int P, i
 
 // body of workgroup bx (of nbx per image) of image b: shared by k_ce_fwd and the forward-only
 // cross-entropy items of the multi-loss launch (k_multi_loss, MODE 1)
+// label 0..C (0 = void) of pixel i: uint8, or int16 for more than 255 classes (`wide`)
+__device__ __forceinline__ int ce_label(const uint8_t* __restrict__ target, int wide, size_t i)
+{
+    return wide ? (int)((const int16_t*)target)[i] : (int)target[i];
+}
+
 template <int DTYPE, int PXT, bool SMOOTH, int U>
 __device__ __forceinline__ void ce_fwd_body(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
     LossPartial* __restrict__ slot, int* __restrict__ status, float* __restrict__ lse2_out,
-    float* s_w, int bx, int nbx, int b)
+    float* s_w, int bx, int nbx, int b, int wide = 0)
 {
     for (int c = threadIdx.x; c < C; c += LOSS_THREADS) s_w[c] = weights ? weights[c] : 1.0f;
     __syncthreads();
@@ -234,7 +240,7 @@ __device__ __forceinline__ void ce_fwd_body(
         int tt[PXT];
 #pragma unroll
         for (int j = 0; j < PXT; ++j)
-            tt[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;       // ce.py:46
+            tt[j] = (j < nvalid) ? ce_label(target, wide, (size_t)b * P + p0 + j) - 1 : -1;       // ce.py:46
         ce_scan<DTYPE, PXT, U, SMOOTH, true, true>(logits, img, P, p0, nvalid, vec, C, s_w, tt,
                                                    m, s, swx, xts);
         if (lse2_out) {

@@ -62,12 +62,12 @@ template <int DTYPE, int PXT, bool SMOOTH, int U>
 __global__ __launch_bounds__(LOSS_THREADS) void k_ce_fwd(
     const void* __restrict__ logits, const uint8_t* __restrict__ target,
     const float* __restrict__ weights, int C, int P, float ls, int vec,
-    LossPartial* __restrict__ partials, int* __restrict__ status, float* __restrict__ lse2_out)
+    LossPartial* __restrict__ partials, int* __restrict__ status, float* __restrict__ lse2_out, int wide)
 {
     extern __shared__ float s_w[];
     ce_fwd_body<DTYPE, PXT, SMOOTH, U>(logits, target, weights, C, P, ls, vec,
                                        partials + (size_t)blockIdx.y * gridDim.x + blockIdx.x, status,
-                                       lse2_out, s_w, blockIdx.x, gridDim.x, blockIdx.y);
+                                       lse2_out, s_w, blockIdx.x, gridDim.x, blockIdx.y, wide);
 }
 
 // d loss_sum / d logits, times the upstream gradient *gscale  (ce.py via autograd)
@@ -85,7 +85,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
     const float* __restrict__ weights, int C, int P, float ls, int vec,
     const float* __restrict__ gscale, void* __restrict__ grad, const float* __restrict__ lse2,
     const float* __restrict__ computed_for, int* __restrict__ counters,
-    LossPartial* __restrict__ partials = nullptr, int* __restrict__ status = nullptr)
+    LossPartial* __restrict__ partials = nullptr, int* __restrict__ status = nullptr, int wide = 0)
 {
     extern __shared__ float s_w[];
     if (!LOSS && grad_already_computed(gscale, computed_for, counters)) return;
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(LOSS_THREADS) void k_ce_bwd(
         int t[PXT];
 #pragma unroll
         for (int j = 0; j < PXT; ++j)
-            t[j] = (j < nvalid) ? (int)target[(size_t)b * P + p0 + j] - 1 : -1;
+            t[j] = (j < nvalid) ? ce_label(target, wide, (size_t)b * P + p0 + j) - 1 : -1;
         float ag[PXT], abg[PXT], k0[PXT];
         if (lse2) {
             // the forward pass left -log2(sum exp) per pixel: no first pass over the logits
@@ -730,13 +730,13 @@ extern "C" size_t nmsa_loss_workspace_bytes(int B, int H, int W)
 }
 
 
-extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* target,
-                                const float* weights, int B, int C, int H, int W,
-                                float label_smoothing,
-                                double* loss_sum, int64_t* n_elements, double* weight_sum,
-                                float* lse2_out,
-                                int32_t* status, void* workspace, size_t workspace_bytes,
-                                nmsa_stream_t stream_)
+static int ce_fwd_impl(const void* logits, int dtype, const uint8_t* target, int wide,
+                       const float* weights, int B, int C, int H, int W,
+                       float label_smoothing,
+                       double* loss_sum, int64_t* n_elements, double* weight_sum,
+                       float* lse2_out,
+                       int32_t* status, void* workspace, size_t workspace_bytes,
+                       nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!logits || !target || !loss_sum || !n_elements || !status || !workspace) return NMSA_ERR_ARG;
@@ -752,7 +752,7 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
     const int uu = fwd_u ? fwd_u : ((dtype == NMSA_F32) ? 8 : 4);
 #define CE_FWD_U(DT, PX, SM, UU) hipLaunchKernelGGL((k_ce_fwd<DT, PX, SM, UU>), dim3(gx, B), dim3(LOSS_THREADS), \
         C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, partials, status, \
-        lse2_out)
+        lse2_out, wide)
 #define CE_FWD(DT, PX, SM) do { if (uu == 8) CE_FWD_U(DT, PX, SM, 8); else CE_FWD_U(DT, PX, SM, 4); } while (0)
     switch (dtype) {
         case NMSA_F32: if (smooth) CE_FWD(NMSA_F32, 4, true); else CE_FWD(NMSA_F32, 4, false); break;
@@ -767,11 +767,38 @@ extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* ta
     return finalize(partials, gx * B, loss_sum, weight_sum, n_elements, stream);
 }
 
+extern "C" int nmsa_loss_ce_fwd(const void* logits, int dtype, const uint8_t* target,
+                                const float* weights, int B, int C, int H, int W,
+                                float label_smoothing,
+                                double* loss_sum, int64_t* n_elements, double* weight_sum,
+                                float* lse2_out,
+                                int32_t* status, void* workspace, size_t workspace_bytes,
+                                nmsa_stream_t stream_)
+{
+    return ce_fwd_impl(logits, dtype, target, 0, weights, B, C, H, W, label_smoothing, loss_sum, n_elements,
+                       weight_sum, lse2_out, status, workspace, workspace_bytes, stream_);
+}
+
+// more than 255 classes (the reference's CrossEntropyLoss takes any number, ce.py:40-68): the
+// labels travel as int16 (0 = void, 1..C, C <= 4096) through the same two kernels
+extern "C" int nmsa_loss_ce_fwd_i16(const void* logits, int dtype, const int16_t* target,
+                                    const float* weights, int B, int C, int H, int W,
+                                    float label_smoothing,
+                                    double* loss_sum, int64_t* n_elements, double* weight_sum,
+                                    float* lse2_out,
+                                    int32_t* status, void* workspace, size_t workspace_bytes,
+                                    nmsa_stream_t stream_)
+{
+    if (((uintptr_t)target) & 1) return NMSA_ERR_ARG;
+    return ce_fwd_impl(logits, dtype, (const uint8_t*)target, 1, weights, B, C, H, W, label_smoothing, loss_sum,
+                       n_elements, weight_sum, lse2_out, status, workspace, workspace_bytes, stream_);
+}
+
 static int ce_bwd_impl(const void* logits, int dtype, const uint8_t* target,
                        const float* weights, int B, int C, int H, int W,
                        float label_smoothing, const float* grad_scale, const float* lse2,
                        void* grad_logits, const float* computed_for, int32_t* counters,
-                       nmsa_stream_t stream_)
+                       nmsa_stream_t stream_, int wide = 0)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!logits || !target || !grad_scale || !grad_logits) return NMSA_ERR_ARG;
@@ -786,7 +813,7 @@ static int ce_bwd_impl(const void* logits, int dtype, const uint8_t* target,
     const int ub = bwd_u ? bwd_u : 4;
 #define CE_BWD_U(DT, PX, SM, UU) hipLaunchKernelGGL((k_ce_bwd<DT, PX, SM, UU>), dim3(gx, B), dim3(LOSS_THREADS), \
         C * sizeof(float), stream, logits, target, weights, C, P, label_smoothing, vec, grad_scale, \
-        grad_logits, lse2, computed_for, counters)
+        grad_logits, lse2, computed_for, counters, (LossPartial*)nullptr, (int*)nullptr, wide)
 #define CE_BWD(DT, PX, SM) do { if (ub == 8) CE_BWD_U(DT, PX, SM, 8); else if (ub == 1) CE_BWD_U(DT, PX, SM, 1); \
                                 else CE_BWD_U(DT, PX, SM, 4); } while (0)
     switch (dtype) {
@@ -807,6 +834,16 @@ extern "C" int nmsa_loss_ce_bwd(const void* logits, int dtype, const uint8_t* ta
 {
     return ce_bwd_impl(logits, dtype, target, weights, B, C, H, W, label_smoothing, grad_scale, lse2,
                        grad_logits, nullptr, nullptr, stream);
+}
+
+extern "C" int nmsa_loss_ce_bwd_i16(const void* logits, int dtype, const int16_t* target,
+                                    const float* weights, int B, int C, int H, int W,
+                                    float label_smoothing, const float* grad_scale, const float* lse2,
+                                    void* grad_logits, nmsa_stream_t stream)
+{
+    if (((uintptr_t)target) & 1) return NMSA_ERR_ARG;
+    return ce_bwd_impl(logits, dtype, (const uint8_t*)target, weights, B, C, H, W, label_smoothing, grad_scale,
+                       lse2, grad_logits, nullptr, nullptr, stream, 1);
 }
 
 

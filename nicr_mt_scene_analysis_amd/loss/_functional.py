@@ -162,6 +162,16 @@ def labels_u8(target: torch.Tensor, dev) -> torch.Tensor:
     return t.contiguous()
 
 
+def labels_i16(target: torch.Tensor, dev) -> torch.Tensor:
+    """labels 0..C (0 = void) as contiguous int16 on `dev` (more than 255 classes); values that
+    do not fit become 32767 (> C: the kernel skips the pixel and sets the status bit)"""
+    t = target.to(dev)
+    if t.dtype != torch.int16:
+        t = torch.where((t < 0) | (t > 32767), 32767, t).to(torch.int16) \
+            if t.dtype not in (torch.bool, torch.uint8) else t.to(torch.int16)
+    return t.contiguous()
+
+
 def _expected(hint, dev) -> Optional[torch.Tensor]:
     if hint is None or not _SPECULATE:
         return None
@@ -180,11 +190,12 @@ class CrossEntropyFunction(torch.autograd.Function):
         x = L.require_device_tensor(logits, 'input_')
         B, C_, H, W = x.shape
         dev = x.device
-        if C_ > 255:
-            # labels travel as uint8 (0 = void, 1..C; ToTorchTensors keeps semantic uint8):
-            # a wider label would wrap silently
-            raise ValueError(f'{C_} classes: the CE kernel takes uint8 labels (C <= 255)')
-        t = labels_u8(target, dev)
+        wide = C_ > 255
+        if C_ > 4096:
+            raise ValueError(f'{C_} classes: the CE kernels take up to 4096')
+        # labels travel as uint8 (0 = void, 1..C; ToTorchTensors keeps semantic uint8); with more
+        # than 255 classes as int16 through the two-kernel path (nmsa_loss_ce_*_i16)
+        t = labels_i16(target, dev) if wide else labels_u8(target, dev)
         w = None if weights is None else weights.to(dev, torch.float32).contiguous()
         s, n = _scalar_outputs(dev)
         wsum = torch.empty((1,), dtype=torch.float64, device=dev)
@@ -192,7 +203,7 @@ class CrossEntropyFunction(torch.autograd.Function):
         ws, nbytes = _workspace(B, H, W, dev)
         code = L.float_dtype_code(x)
         exp = _expected(expected, dev) if ctx.needs_input_grad[0] else None
-        if exp is not None and not L.lib().nmsa_loss_ce_fwd_grad_supported(code, C_):
+        if exp is not None and (wide or not L.lib().nmsa_loss_ce_fwd_grad_supported(code, C_)):
             exp = None                               # no such kernel for this dtype / C
         lse2 = grad = None
         if exp is not None:
@@ -207,7 +218,8 @@ class CrossEntropyFunction(torch.autograd.Function):
             # the logits), only when a gradient can be asked for
             lse2 = torch.empty((B, H, W), dtype=torch.float32, device=dev) \
                 if ctx.needs_input_grad[0] else None
-            L.check(L.lib().nmsa_loss_ce_fwd(
+            fwd = L.lib().nmsa_loss_ce_fwd_i16 if wide else L.lib().nmsa_loss_ce_fwd
+            L.check(fwd(
                 L.ptr(x), code, L.ptr(t), L.ptr(w), B, C_, H, W,
                 float(label_smoothing), L.ptr(s), L.ptr(n), L.ptr(wsum), L.ptr(lse2),
                 L.ptr(status), L.ptr(ws), nbytes, L.stream_ptr(dev)), 'nmsa_loss_ce_fwd')
@@ -239,7 +251,8 @@ class CrossEntropyFunction(torch.autograd.Function):
                 _counters_ptr(x.device), L.stream_ptr(x.device)), 'nmsa_loss_ce_bwd_unless')
             return grad, None, None, None, None
         grad = torch.empty_like(x)
-        L.check(L.lib().nmsa_loss_ce_bwd(
+        bwd = L.lib().nmsa_loss_ce_bwd_i16 if t.dtype == torch.int16 else L.lib().nmsa_loss_ce_bwd
+        L.check(bwd(
             L.ptr(x), L.float_dtype_code(x), L.ptr(t), L.ptr(w) if ctx.has_w else None,
             B, C_, H, W, ctx.ls, L.ptr(gs), L.ptr(lse2) if ctx.has_lse else None, L.ptr(grad),
             L.stream_ptr(x.device)), 'nmsa_loss_ce_bwd')

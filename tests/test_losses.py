@@ -328,12 +328,60 @@ def test_cos_emb_large_dims_vs_reference_golden(as_bf16):
     assert ran >= 3
 
 
-def test_ce_rejects_more_than_255_classes_and_flags_bad_labels():
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize('C,label_smoothing', [(256, 0.0), (549, 0.1), (1000, 0.0)])
+def test_ce_with_more_than_255_classes_vs_torch_fp64(dtype, C, label_smoothing):
+    """more classes than a uint8 label holds (the reference's CrossEntropyLoss takes any number,
+    ce.py:40-68; e.g. ScanNet's 549 classes): the labels travel as int16 through the two-kernel
+    path — sum, n, weight sum and gradient against torch's fp64 op, weighted reduction included"""
     from nicr_mt_scene_analysis_amd.loss import CrossEntropyLossSemantic, check_loss_status
-    x = torch.zeros((1, 300, 4, 4), device='cuda')
-    with pytest.raises(ValueError, match='uint8 labels'):
-        CrossEntropyLossSemantic()([x], [torch.zeros((1, 4, 4), dtype=torch.int64, device='cuda')])
+    g = torch.Generator(device='cuda').manual_seed(C)
+    B, H, W = 2, 9, 20
+    x = (torch.randn((B, C, H, W), device='cuda', generator=g) * 3).to(dtype)
+    t = torch.randint(0, C + 1, (B, H, W), device='cuda', generator=g)
+    t[0, 0, :4] = torch.tensor([C, C - 1, 256, 0], device='cuda')        # labels beyond uint8, and void
+    w = torch.rand(C, device='cuda', generator=g) + 0.5
+    xr = x.double().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(xr, t - 1, weight=w.double(), reduction='sum', ignore_index=-1,
+                                            label_smoothing=label_smoothing)
+    n_ref = int((t != 0).sum())
+    (ref / n_ref).backward()
+    for target in (t, t.to(torch.int16), t.to(torch.int32)):
+        xs = x.clone().requires_grad_(True)
+        (loss, n), = CrossEntropyLossSemantic(weights=w, label_smoothing=label_smoothing)([xs], [target])
+        (loss / n).backward()
+        assert int(n) == n_ref
+        np.testing.assert_allclose(float(loss), float(ref), rtol=1e-5)
+        tol = 2e-5 if dtype == torch.float32 else 2 ** -7
+        # (with label smoothing the target class' element (a + bsum) p_t - a - b_t cancels in fp32:
+        # a handful of elements are off by up to 5e-5 of the largest gradient entry)
+        np.testing.assert_allclose(xs.grad.double().cpu().numpy(), xr.grad.cpu().numpy(), rtol=tol,
+                                   atol=max(tol * 0.05, 5e-5) * float(xr.grad.abs().max()))
+    (lw, nw), = CrossEntropyLossSemantic(weights=w, weighted_reduction=True)([x], [t])
+    ref_w = torch.nn.functional.cross_entropy(x.double(), t - 1, weight=w.double(), reduction='mean', ignore_index=-1)
+    np.testing.assert_allclose(float(lw), float(ref_w), rtol=1e-5)
+    check_loss_status()
+
+
+def test_ce_rejects_more_than_4096_classes_and_flags_bad_labels():
+    from nicr_mt_scene_analysis_amd.loss import CrossEntropyLossSemantic, check_loss_status
+    x = torch.zeros((1, 4097, 2, 2), device='cuda')
+    with pytest.raises(ValueError, match='4096'):
+        CrossEntropyLossSemantic()([x], [torch.zeros((1, 2, 2), dtype=torch.int64, device='cuda')])
     check_loss_status()                                  # clean so far
+    # a label beyond C in the int16 path is flagged like in the uint8 path
+    x = torch.randn((1, 300, 4, 8), device='cuda')
+    t = torch.randint(0, 301, (1, 4, 8), device='cuda')
+    t[0, 2, 2] = 301
+    try:
+        CrossEntropyLossSemantic()([x], [t])
+        raised_at_call = False
+    except IndexError:
+        raised_at_call = True
+    if not raised_at_call:
+        with pytest.raises(IndexError, match='out of range'):
+            check_loss_status()
+    check_loss_status()
     x = torch.randn((1, 5, 4, 8), device='cuda')
     t = torch.randint(0, 6, (1, 4, 8), device='cuda')
     (l0, n0), = CrossEntropyLossSemantic()([x], [t])
