@@ -39,12 +39,17 @@ class LossBase(torch.nn.Module):
         loss/_functional.py `expected_scale`); losses that can write their gradient in the
         forward pass do so, the others ignore it"""
         pairs = []
+        # (the flag lives for the duration of this call only — also when a scale raises — and is
+        # restored, not cleared: a loss called from inside another loss's forward keeps its own)
+        before = self.__dict__.get('_several_scales', False)
         self.__dict__['_several_scales'] = len(input_tensors) > 1
-        for i, (prediction, target) in enumerate(zip(input_tensors, target_tensors)):
-            if expected_scales is None or expected_scales[i] is None:
-                pairs.append(self._compute_loss(prediction, target))
-            else:
-                pairs.append(self._compute_loss(prediction, target,
-                                                expected_scale=expected_scales[i]))
-        self.__dict__['_several_scales'] = False
+        try:
+            for i, (prediction, target) in enumerate(zip(input_tensors, target_tensors)):
+                if expected_scales is None or expected_scales[i] is None:
+                    pairs.append(self._compute_loss(prediction, target))
+                else:
+                    pairs.append(self._compute_loss(prediction, target,
+                                                    expected_scale=expected_scales[i]))
+        finally:
+            self.__dict__['_several_scales'] = before
         return tuple(pairs)

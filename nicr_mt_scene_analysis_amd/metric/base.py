@@ -110,6 +110,15 @@ class Metric(torch.nn.Module):
         pickles and `deepcopy` of a metric keep working: nothing is bound to an instance), the
         OUTERMOST call only: `super().compute()` inside a subclass must not sum a second time"""
         super().__init_subclass__(**kwargs)
+        for name, fn in list(cls.__dict__.items()):         # update*(): never on synced states
+            if name.startswith('update') and callable(fn) and not isinstance(fn, (staticmethod, classmethod)) \
+                    and not getattr(fn, '_nmsa_guarded', False):
+                def guarded(self, *args, _fn=fn, **kw):
+                    self._require_unsynced()
+                    return _fn(self, *args, **kw)
+                functools.update_wrapper(guarded, fn)
+                guarded._nmsa_guarded = True
+                setattr(cls, name, guarded)
         compute = cls.__dict__.get('compute')
         if compute is None or getattr(compute, '_nmsa_sync_wrapped', False):
             return
@@ -126,6 +135,13 @@ class Metric(torch.nn.Module):
                 self._compute_depth -= 1
         wrapped._nmsa_sync_wrapped = True
         cls.compute = wrapped
+
+    def _require_unsynced(self) -> None:
+        """an update between `sync()` and `unsync()` would land in the rank-SUMMED states and be
+        thrown away by `unsync()` (torchmetrics raises here too)"""
+        if self._is_synced:
+            raise RuntimeError(f"{type(self).__name__}: the states are synced over the ranks (sync() without "
+                               "unsync()); call unsync() or reset() before updating again")
 
     def _world_size(self, process_group=None) -> int:
         import torch.distributed as dist

@@ -46,6 +46,7 @@ class MeanIntersectionOverUnion(Metric):
         return self
 
     def _require_gpu(self):
+        self._require_unsynced()                # (also reached through PanopticQuality.update_with_miou)
         if self.device.type != 'cuda':
             raise L.NmsaError('MeanIntersectionOverUnion.update needs the MI355X '
                               '(states live on the GPU; no CPU fallback)')

@@ -16,7 +16,12 @@ DEFAULT_MAX_CENTERS = 256
 # persistent, always-zero vote tables (one per device / shape): nmsa_panoptic_assign clears
 # the rows it read, so the next step needs no memset.  Keyed by stream as well, so that
 # concurrent pipelines on different streams never share a table.
-_VOTE_TABLES: Dict[tuple, torch.Tensor] = {}
+# At most _VOTE_TABLES_MAX tables are kept (least recently used first out): a ragged last batch
+# or short-lived streams must not leave a table behind each.  A dropped table is freed through
+# torch's allocator, stream-ordered behind the kernels that used it; a table that a captured
+# hipGraph holds stays alive through the graph's private pool.
+_VOTE_TABLES: 'collections.OrderedDict[tuple, torch.Tensor]' = __import__('collections').OrderedDict()
+_VOTE_TABLES_MAX = 8
 
 
 def _vote_table(dev: torch.device, B: int, n_cols: int) -> torch.Tensor:
@@ -25,6 +30,10 @@ def _vote_table(dev: torch.device, B: int, n_cols: int) -> torch.Tensor:
     if t is None:
         t = torch.zeros((B, 256, n_cols), dtype=torch.int32, device=dev)
         _VOTE_TABLES[key] = t
+        while len(_VOTE_TABLES) > _VOTE_TABLES_MAX:
+            _VOTE_TABLES.popitem(last=False)
+    else:
+        _VOTE_TABLES.move_to_end(key)
     return t
 
 

@@ -641,8 +641,15 @@ def gen_argmax_ties(ref):
         am = torch.from_numpy(x).argmax(dim=1).numpy()
         print(f'  {name}: reference differs from argmax(x) on '
               f'{int((extra[f"{name}_ref_idx"] != am).sum())} of {am.size} px')
+    # which ATen build resolved these near-ties: its CPU softmax (Sleef expf_u10, vectorised
+    # summation order) is what csrc/argmax_state.hpp restates; another build (exp_u20, no FMA,
+    # a GPU softmax) may resolve columns inside the 2^-25 .. 2^-23 band differently
+    import platform
+    producer = {'torch': torch.__version__, 'cpu_capability': torch.backends.cpu.get_cpu_capability(),
+                'machine': platform.machine(), 'threads': torch.get_num_threads()}
     save('argmax_ties', logits=logits, ref_idx=ref_idx, c1=c1s, c2=c2s, delta=delta,
-         natural_blobby=np.array(nb, np.int64), natural_small=np.array(ns, np.int64), **extra)
+         natural_blobby=np.array(nb, np.int64), natural_small=np.array(ns, np.int64),
+         producer=jdump(producer), **extra)
 
 
 COS_LARGE_CASES = (

@@ -183,6 +183,37 @@ def test_task_helper_epoch_end_sums_the_ranks(tmp_path):
         got[1]['local_pq'] != got[1]['log_panoptic_all_deeplab_pq']
 
 
+def _synced_update_worker(rank, world, port, out_dir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion
+    miou = MeanIntersectionOverUnion(N_CAT, device='cpu')
+    miou.confmat += 1
+    miou.sync()
+    try:
+        miou.update(torch.zeros((1, 2, 2), dtype=torch.int64), torch.zeros((1, 2, 2), dtype=torch.int64))
+        outcome = 'no error'
+    except RuntimeError as e:
+        outcome = 'raised' if 'synced' in str(e) else f'other: {e}'
+    miou.unsync()
+    assert int(miou.confmat.sum()) == N_CAT * N_CAT           # the rank-local states are back
+    with open(os.path.join(out_dir, f'rank{rank}.txt'), 'w') as f:
+        f.write(outcome)
+    dist.destroy_process_group()
+
+
+def test_update_on_synced_states_raises(tmp_path):
+    """an update between sync() and unsync() would land in the rank-summed states and be discarded
+    by unsync(): it raises, like torchmetrics (checked before the device is even looked at)"""
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+    mp.spawn(_synced_update_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for rank in range(2):
+        assert (tmp_path / f'rank{rank}.txt').read_text() == 'raised'
+
+
 def test_sync_without_process_group_is_noop():
     from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion
     m = MeanIntersectionOverUnion(3, device='cpu')

@@ -360,30 +360,51 @@ def test_crop_and_resize_host_side():
                                                          mode='bicubic')
 
 
-def test_bench_self_launch_command_and_host_cores(monkeypatch):
-    """`python bench.py --gpus N` without a launcher: N fresh ranks through torch.distributed.run as
-    a CHILD process (no exec), the user's arguments forwarded, rendezvous on 127.0.0.1"""
+def test_bench_self_launch_command_and_host_cores(monkeypatch, capsys):
+    """`python bench.py --gpus N` without a launcher: N fresh ranks as CHILD processes (no exec) with
+    the environment a launcher gives them, the user's arguments forwarded, rendezvous on 127.0.0.1;
+    a rank that fails is named with the tail of its stderr and its code is returned"""
     import importlib
     import sys
     bench = importlib.import_module('bench')
-    seen = {}
+    started = []
 
-    def fake_call(cmd, env=None):
-        seen['cmd'], seen['env'] = cmd, env
-        return 7
-    monkeypatch.setattr(bench.subprocess, 'call', fake_call)
+    class FakeProc:
+        def __init__(self, cmd, env=None, stdout=None, stderr=None):
+            self.cmd, self.env, self.rank = cmd, env, int(env['RANK'])
+            self.code = 7 if self.rank == 2 else 0
+            if self.rank == 2:
+                stderr.write('Traceback ...\nRuntimeError: boom on rank 2\n')
+                stderr.flush()
+            self.killed = False
+            started.append(self)
+
+        def poll(self):
+            return self.code if self.rank in (0, 2) else None       # ranks 1 and 3 hang in a collective
+
+        def terminate(self):
+            self.killed = True
+
+        def wait(self, timeout=None):
+            return -15
+
+        def kill(self):
+            self.killed = True
+    monkeypatch.setattr(bench.subprocess, 'Popen', FakeProc)
     monkeypatch.setattr(sys, 'argv', ['bench.py', '--gpus', '4', '--steps', '9', '--warmup', '2'])
     monkeypatch.delenv('RANK', raising=False)
     args = bench.parse_args()
-    assert bench.launch_ranks(args) == 7                        # the child's return code
-    cmd = seen['cmd']
-    assert cmd[0] == sys.executable and cmd[1:3] == ['-m', 'torch.distributed.run']
-    assert '--nnodes=1' in cmd and '--nproc-per-node=4' in cmd
-    assert cmd[cmd.index('--master-addr') + 1] == '127.0.0.1'
-    assert 0 < int(cmd[cmd.index('--master-port') + 1]) < 65536
-    script = cmd.index(bench.os.path.abspath(bench.__file__))
-    assert cmd[script + 1:] == ['--gpus', '4', '--steps', '9', '--warmup', '2']
-    assert seen['env'].get('HSA_ENABLE_IPC_MODE_LEGACY') is not None
+    assert bench.launch_ranks(args) == 7                        # the failed rank's return code
+    assert [p.rank for p in started] == [0, 1, 2, 3]
+    for p in started:
+        assert p.cmd[0] == sys.executable and p.cmd[1] == bench.os.path.abspath(bench.__file__)
+        assert p.cmd[2:] == ['--gpus', '4', '--steps', '9', '--warmup', '2']
+        assert p.env['WORLD_SIZE'] == '4' and p.env['LOCAL_RANK'] == p.env['RANK']
+        assert p.env['MASTER_ADDR'] == '127.0.0.1' and 0 < int(p.env['MASTER_PORT']) < 65536
+        assert p.env.get('HSA_ENABLE_IPC_MODE_LEGACY') is not None and int(p.env['OMP_NUM_THREADS']) >= 1
+    assert started[1].killed and started[3].killed and not started[0].killed
+    err = capsys.readouterr().err
+    assert 'rank 2 of 4 exited with code 7' in err and 'boom on rank 2' in err
     cores = bench.host_cores()
     assert 1 <= cores['usable'] <= cores['affinity'] <= max(cores['nproc'], cores['affinity'])
     assert cores['cgroup_quota'] is None or cores['usable'] <= max(1, round(cores['cgroup_quota']))

@@ -240,8 +240,13 @@ def test_argmax_tie_band_boundary(oracle):
     with delta in (2^-25, 2^-23] included (38 of them return the lower index) —, two whole maps
     ('tiny': every class within 2^-25, 'small': 4 classes per pixel on a 2^-26 grid) and their
     full-resolution twins (the same rule on the bilinearly interpolated logits)."""
-    from _golden import aten_softmax_argmax
+    from _golden import aten_softmax_argmax, jload
     g = load('argmax_ties')
+    # the tie rule is that of ONE ATen build — the one that ran the reference for this fixture
+    # (recorded in it): its CPU softmax (Sleef expf_u10, vectorised fp32 summation).  Oracle and
+    # kernels restate that arithmetic; they do not call torch, so the check holds on any box
+    producer = jload(g['producer'])
+    assert producer['torch'].startswith('2.10') and producer['cpu_capability'] == 'AVX512', producer
     idx, _ = oracle.semantic_argmax(g['logits'])
     idx, ref = idx.reshape(-1), g['ref_idx'].reshape(-1)
     delta, c1, c2 = g['delta'], g['c1'], g['c2']
