@@ -373,8 +373,18 @@ __global__ __launch_bounds__(RZ_TW * RZ_TH) void k_argmax_resized(
 // the window itself with pitch P.  Two LDS buffers: chunk i+1 is in flight while chunk i is
 // interpolated, one barrier per chunk.  Lane = output x (conflict-free LDS reads), each
 // thread owns 4 consecutive output rows.
-constexpr int LT_TW = 64, LT_TH = 16, LT_THREADS = 256;
-constexpr int LT_CH = 4;                   // classes per chunk (x 2 LDS buffers)
+#ifndef NMSA_LT_TH
+#define NMSA_LT_TH 16
+#endif
+constexpr int LT_TW = 64, LT_TH = NMSA_LT_TH, LT_THREADS = 16 * NMSA_LT_TH;
+// classes per chunk and LDS buffers of the ring (k_resized_tile): 4 x 2 for the score mode
+// (groups of four classes), 2 x 4 otherwise — the same bytes of LDS either way
+#ifndef NMSA_LT_CH
+#define NMSA_LT_CH 4
+#define NMSA_LT_NB 2
+#endif
+__host__ __device__ constexpr int lt_ch(int mode) { return mode == 1 ? 4 : NMSA_LT_CH; }
+__host__ __device__ constexpr int lt_nb(int mode) { return mode == 1 ? 2 : NMSA_LT_NB; }
 constexpr int LT_MODE_ARGMAX = 0, LT_MODE_ARGMAX_SCORE = 1, LT_MODE_MATERIALISE = 2;
 
 __device__ __forceinline__ void glds_piece(const void* gsrc, void* lds_wave_base)
@@ -442,6 +452,12 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     void* __restrict__ dst)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    // a ring of LT_NB LDS buffers of LT_CH classes each: the chunks i+1 .. i+LT_NB-1 are in
+    // flight (LDS-DMA) while chunk i is interpolated.  Round 5: 2 classes x 4 buffers instead of
+    // 4 x 2 (the same 32 KB: occupancy unchanged) — three chunks = 6 classes ahead instead of
+    // one = 4, and a wave waits for the DMAs of chunk i only (counted vmcnt), not for everything
+    // it has issued; the score mode keeps groups of four classes (argmax_group4_score)
+    constexpr int LT_CH = lt_ch(MODE), LT_NB = lt_nb(MODE);
     constexpr int ESZ = (DTYPE == NMSA_F32) ? 4 : 2;   // bytes per element
     constexpr int EPP = 16 / ESZ;                      // elements per 16-byte piece
     constexpr int PLANE = K16 * LT_THREADS * EPP;      // elements per staged class plane
@@ -515,30 +531,42 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     unsigned char* wave_lds = lds_raw + (size_t)wv * 64 * 16;
     const int k_used = (n_pieces + LT_THREADS - 1) / LT_THREADS;
 
-    // two LDS buffers of LT_CH classes: chunk i+1 is in flight (LDS-DMA) while chunk i is
-    // interpolated; ONE barrier per chunk
+    // every thread issues exactly LT_CH * K16 DMA pieces per chunk (a class beyond the tile's
+    // planes or an unused slot re-loads a valid piece: the counted waits below rely on the count)
+    (void)k_used;
     auto stage = [&](int c0, int buf) {
-        const int nch = min(LT_CH, C - c0);
-        for (int cc = 0; cc < nch; ++cc) {
-            const size_t pb = base + (size_t)(c0 + cc) * plane_stride;
+#pragma unroll
+        for (int cc = 0; cc < LT_CH; ++cc) {
+            const size_t pb = base + (size_t)min(c0 + cc, C - 1) * plane_stride;
             unsigned char* L = wave_lds + (size_t)(buf * LT_CH + cc) * PLANE * ESZ;
 #pragma unroll
             for (int k = 0; k < K16; ++k)
-                if (k < k_used)
-                    glds_piece((const unsigned char*)src + (pb + goff[k]) * ESZ,
-                               L + (size_t)k * LT_THREADS * 16);
+                glds_piece((const unsigned char*)src + (pb + goff[k]) * ESZ,
+                           L + (size_t)k * LT_THREADS * 16);
         }
     };
     ArgmaxState st;
     argmax_init(st);
     // (three buffers — two chunks in flight — were tried: 48 KB of LDS per workgroup leave 3
     // instead of 5 workgroups per CU and the kernel lost 3-11 %)
-    stage(0, 0);
+    const int n_chunks = (C + LT_CH - 1) / LT_CH;
+#pragma unroll
+    for (int i = 0; i < LT_NB - 1; ++i) if (i < n_chunks) stage(i * LT_CH, i);
     int buf = 0;
-    for (int c0 = 0; c0 < C; c0 += LT_CH, buf ^= 1) {
+    for (int ci = 0; ci < n_chunks; ++ci, buf = (buf + 1 == LT_NB) ? 0 : buf + 1) {
+        const int c0 = ci * LT_CH;
         const int nch = min(LT_CH, C - c0);
-        __syncthreads();          // vmcnt(0) + barrier: chunk c0 has landed, the other buffer is free
-        if (c0 + LT_CH < C) stage(c0 + LT_CH, buf ^ 1);
+        // my DMAs of chunk ci have landed: all but the youngest (chunks in flight behind it) x
+        // (pieces per chunk and thread) of my vector-memory operations are done ...
+        const int behind = min(LT_NB - 2, n_chunks - 1 - ci);          // (wave-uniform)
+        if (behind >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * LT_CH * K16) : "memory");
+        else if (behind == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(1 * LT_CH * K16) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        // ... and so have everybody's; the buffer chunk ci + LT_NB - 1 goes to (read LT_NB - 1
+        // iterations ago... no: ONE iteration ago, chunk ci - 1) is free
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (ci + LT_NB - 1 < n_chunks) stage((ci + LT_NB - 1) * LT_CH, (buf + LT_NB - 1) % LT_NB);
         const void* L = lds_raw + (size_t)buf * LT_CH * PLANE * ESZ;
         // FULL: all LT_CH classes of the chunk exist (every chunk but possibly the last) — no
         // per-class bounds checks in the unrolled body
@@ -587,8 +615,7 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
                         }
                     }
                 } else if (MODE == LT_MODE_ARGMAX_SCORE) {
-                    static_assert(LT_CH == 4, "argmax_group4_score");
-                    argmax_group4_score(st, j, v, c0);
+                    if constexpr (LT_CH == 4) argmax_group4_score(st, j, v, c0);
                 } else {
 #pragma unroll
                     for (int cc = 0; cc < LT_CH; ++cc)
@@ -651,7 +678,7 @@ int launch_tile_k(const void* src, const CropResize& g, int planes, int group,
     const long long n_tiles = (long long)tiles_x * tiles_y * groups;
     const long long blocks = ((n_tiles + 7) / 8) * 8;       // see xcd_contiguous_tile
     if (blocks > 0x7fffffffLL) return NMSA_ERR_ARG;
-    const size_t lds_bytes = (size_t)K16 * LT_THREADS * 16 * LT_CH * 2;
+    const size_t lds_bytes = (size_t)K16 * LT_THREADS * 16 * lt_ch(MODE) * lt_nb(MODE);
     hipLaunchKernelGGL((k_resized_tile<DTYPE, MODE, K16>), dim3((unsigned)blocks), dim3(LT_THREADS),
                        lds_bytes, stream, src, g, planes, group, tiles_x, tiles_y, n_tiles,
                        idx_u8, idx_i64, score, dst);
