@@ -287,13 +287,16 @@ int nmsa_instance_orientation_wide(const float* orientation, const void* instanc
  *  status bits (OR-ed into *status): 1 too many distinct ids, 32 id out of range,
  *     64 semantic label outside [0, n_classes), 128 id table (max_segments) overflow.
  *  workspace: nmsa_targets_workspace_bytes(B, n_classes, max_instances), 8-byte aligned (16-byte
- *     aligned for the one-launch front end of the on-wire layout, see below).  A caller that
- *     allocates 16 bytes more and passes `status` = workspace + nmsa_targets_workspace_bytes(..)
- *     gets the status word zeroed by nmsa_instance_targets / nmsa_panoptic_targets themselves
- *     (one launch less); any other status word is the caller's to zero (bits are OR-ed).
+ *     aligned for the one-launch front end of the on-wire layout, see below).
+ *     workspace_is_clean (nmsa_instance_targets / nmsa_panoptic_targets): 1 = this very workspace
+ *     (same B, n_classes, max_instances) was last used by one of these two calls on the on-wire
+ *     layout and nothing else wrote to it since — they leave their tables zeroed, so the call
+ *     skips its memset; 0 = unknown contents (first use): the call zeroes what it needs.
+ *  status: on the on-wire layout the word is SET by the call (no need to zero it); on any other
+ *     layout the bits are OR-ed into it (zero it first).
  *  launches: the on-wire layout (semantic uint8, instance int32, 16-byte aligned rows of 4 pixels,
- *     W % 4 == 0, n_classes <= 16384) runs as memset + ONE scan launch (presence, statistics, rank,
- *     decide / naive ranks: k_tg_scan) + the paint launch; any other layout as memset + 5.
+ *     W % 4 == 0, n_classes <= 16384) runs as [memset +] ONE scan launch (presence, statistics,
+ *     rank, decide / naive ranks: k_tg_scan) + the paint launch; any other layout as memset + 5.
  *
  *  nmsa_instance_clear_stuff   InstanceClearStuffIDs._preprocess   data/preprocessing/instance.py:46-93
  *     instance[is_stuff_class[semantic]] = 0, in place (is_stuff_class includes void)
@@ -326,14 +329,14 @@ int nmsa_instance_targets(const void* semantic, int sem_dtype, const void* insta
                           float* center, void* offset, uint8_t* foreground, uint8_t* center_mask,
                           int32_t* encoded_ids, int32_t* n_encoded,
                           int32_t* skipped_ids, int32_t* n_skipped,
-                          int32_t* status, void* workspace, size_t workspace_bytes,
+                          int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
                           nmsa_stream_t stream);
 int nmsa_panoptic_targets(const void* semantic, int sem_dtype, const void* instance, int ins_dtype,
                           const uint8_t* is_thing_class, int B, int n_classes, int H, int W,
                           int64_t max_instances_per_category, int64_t void_label,
                           int max_instances, int max_segments,
                           int64_t* panoptic, int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
-                          int32_t* status, void* workspace, size_t workspace_bytes,
+                          int32_t* status, void* workspace, size_t workspace_bytes, int workspace_is_clean,
                           nmsa_stream_t stream);
 int nmsa_dve_targets(const int64_t* panoptic, const int64_t* keys, const int32_t* n_keys,
                      const float* embeddings, const float* image_embedding, float diff_factor,

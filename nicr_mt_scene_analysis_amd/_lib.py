@@ -79,9 +79,9 @@ _SIGNATURES = {
     'nmsa_targets_workspace_bytes': (_sz, [_i, _i, _i]),
     'nmsa_instance_clear_stuff': (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _vp]),
     'nmsa_instance_targets': (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _i, _i,
-                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     'nmsa_panoptic_targets': (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i64, _i64, _i, _i,
-                                   _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _sz, _i, _vp]),
     'nmsa_dve_targets': (_i, [_vp, _vp, _vp, _vp, _vp, _f, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
     'nmsa_instance_orientation_wide': (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp,
                                             _vp, _vp, _sz, _vp]),

@@ -435,6 +435,9 @@ __host__ __device__ inline int tg_hash_slots(int cap)
     return ht;
 }
 
+// behind the images' hash tables: [0] status bits of the running call, [1] tails that are done
+constexpr size_t TG_GLOBAL_BYTES = 256;
+
 __host__ __device__ inline size_t tg_hash_bytes(int cap, int NC)
 {
     const size_t ht = (size_t)tg_hash_slots(cap);
@@ -492,7 +495,8 @@ __device__ __forceinline__ void tg_rank_decide_tail(
     const uint8_t* __restrict__ is_thing_class, int32_t* __restrict__ encoded_ids,
     int32_t* __restrict__ n_encoded, int32_t* __restrict__ skipped_ids, int32_t* __restrict__ n_skipped,
     int pair_cap, int64_t max_inst, int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins,
-    int32_t* __restrict__ n_ids, int* __restrict__ status)
+    int32_t* __restrict__ n_ids, int* __restrict__ status /* the call's internal word */,
+    uint32_t* __restrict__ gblock, int n_images, int* __restrict__ user_status)
 {
     int* scratch = (int*)lds;                            // [32]
     uint32_t* s_bitmap = lds + 32;
@@ -736,6 +740,42 @@ __device__ __forceinline__ void tg_rank_decide_tail(
             if (totp > pair_cap) atomicOr(status, TG_ST_PAIR_OVERFLOW);
         }
     }
+    // ---- leave the image's hash tables as they were found: all zero.  The next call on this
+    // workspace then needs no memset (`workspace_is_clean`).  Every slot that holds a key is
+    // cleaned by the thread that loaded it, whatever the status bits say.
+    __syncthreads();                                     // (every read of the accumulators is done)
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) {
+        if (key[k] <= 0) continue;
+        const int sl = t + k * 256;
+        h.hkeys[sl] = 0;
+        h.hsum_y[sl] = 0ull;
+        h.hsum_x[sl] = 0ull;
+    }
+    if (n_dense == total) {                              // the usual case: rows by all threads
+        const int n_cells = n_dense * NC;
+        for (int i = t; i < n_cells; i += 256) {
+            const int d = i / NC;
+            h.hvotes[(size_t)s_slot[d] * NC + (i - d * NC)] = 0u;
+        }
+    } else {                                             // more ids than dense slots: by the key's owner
+#pragma unroll 1
+        for (int k = 0; k < KPT; ++k) {
+            if (key[k] <= 0) continue;
+            uint32_t* row = h.hvotes + (size_t)(t + k * 256) * NC;
+            for (int cc = 0; cc < NC; ++cc) row[cc] = 0u;
+        }
+    }
+    if (t == 0) h.ticket[0] = 0u;
+    // the call's status goes to the caller's word with the LAST tail of the batch (set, not OR-ed)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (t == 0) {
+        if (atomicAdd(&gblock[1], 1u) == (uint32_t)(n_images - 1)) {
+            *user_status = (int)atomicExch(&gblock[0], 0u);
+            gblock[1] = 0u;
+        }
+    }
 }
 
 // The on-wire layout only (uint8 semantic, int32 ids, 16-byte aligned rows of 4 pixels, W % 4 == 0,
@@ -747,7 +787,7 @@ __global__ __launch_bounds__(256) void k_tg_scan(
     const uint8_t* __restrict__ is_thing_class, int32_t* __restrict__ encoded_ids,
     int32_t* __restrict__ n_encoded, int32_t* __restrict__ skipped_ids, int32_t* __restrict__ n_skipped,
     int pair_cap, int64_t max_inst, int64_t* __restrict__ ids_pan, int64_t* __restrict__ ids_ins,
-    int32_t* __restrict__ n_ids, int* __restrict__ status)
+    int32_t* __restrict__ n_ids, int* __restrict__ user_status)
 {
     // all LDS is dynamic (no static variable in front of it: the base stays 16-byte aligned):
     // [ control word (16 B) | the scan table, then the tail's arrays ]
@@ -759,6 +799,10 @@ __global__ __launch_bounds__(256) void k_tg_scan(
     const int b = blockIdx.y;
     const int HT = tg_hash_slots(cap);
     TgHash h = tg_hash_view(hs, b, cap, NC);
+    // the call's status bits collect in the workspace (zero between calls) and reach the caller's
+    // word with the last tail of the batch
+    uint32_t* gblock = (uint32_t*)(hs + (size_t)gridDim.y * tg_hash_bytes(cap, NC));
+    int* status = (int*)gblock;
     const int p_begin = blockIdx.x * px_per_wg, p_end = min(P, p_begin + px_per_wg);   // px_per_wg % 1024 == 0
     const int n_rounds = (p_end - p_begin + 1023) / 1024;
     // the labels of the next TGS_AHEAD rounds are on their way while a round is worked on
@@ -851,7 +895,7 @@ __global__ __launch_bounds__(256) void k_tg_scan(
     if (!ctl[0]) return;
     tg_rank_decide_tail<WITH_MOMENTS>(tg_view(ws, b, cap, NC), h, b, cap, HT, NC, tgs_lds + 4, is_thing_class,
                                       encoded_ids, n_encoded, skipped_ids, n_skipped, pair_cap, max_inst,
-                                      ids_pan, ids_ins, n_ids, status);
+                                      ids_pan, ids_ins, n_ids, status, gblock, (int)gridDim.y, user_status);
 }
 
 // ---- paint: heat-map, offsets, foreground, center mask -------------------------------------------
@@ -1517,17 +1561,17 @@ int tg_common(const void* sem, int sem_dtype, const void* ins, int ins_dtype, in
               hipStream_t stream, const uint8_t* is_thing_class = nullptr, int32_t* encoded_ids = nullptr,
               int32_t* n_encoded = nullptr, int32_t* skipped_ids = nullptr, int32_t* n_skipped = nullptr,
               int pair_cap = 0, int64_t max_inst = 0, int64_t* ids_pan = nullptr, int64_t* ids_ins = nullptr,
-              int32_t* n_ids = nullptr, bool* did_tail = nullptr)
+              int32_t* n_ids = nullptr, bool* did_tail = nullptr, int workspace_is_clean = 0)
 {
     if (did_tail) *did_tail = false;
     if (tg_scan_ok(sem, sem_dtype, ins, ins_dtype, P, W, NC) && (uintptr_t)ws % 16 == 0) {
         // ONE launch behind a memset of the hash tables (k_tg_scan: scan + rank + decide / naive ranks)
         unsigned char* hs = ws + (size_t)B * tg_image_bytes(cap, NC);
-        // (a status word that sits right behind the workspace is zeroed by the same memset: the
-        // caller saves the launch that would zero it)
-        const size_t hbytes = (size_t)B * tg_hash_bytes(cap, NC);
-        int rc = check_hip(hipMemsetAsync(hs, 0, hbytes + ((unsigned char*)status == hs + hbytes ? 16 : 0), stream));
-        if (rc) return rc;
+        // a workspace the previous call left behind is all zero again (the tails clean what the
+        // scan dirtied): no memset then.  The status word is SET by the call's last tail.
+        const size_t hbytes = (size_t)B * tg_hash_bytes(cap, NC) + TG_GLOBAL_BYTES;
+        int rc = NMSA_OK;
+        if (!workspace_is_clean && (rc = check_hip(hipMemsetAsync(hs, 0, hbytes, stream)))) return rc;
         const size_t lds = tg_scan_lds_bytes(cap, moments);
         const int px = tg_scan_px_per_wg(B, P, lds);
         const dim3 grid((P + px - 1) / px, B);
@@ -1574,7 +1618,7 @@ extern "C" size_t nmsa_targets_workspace_bytes(int B, int n_classes, int max_ins
     if (B <= 0 || n_classes <= 0 || max_instances <= 0 || max_instances > 4096) return 0;
     // [ dense per-image tables (TgView) | per-image hash tables of the one-launch front end (TgHash) ]
     const int cap = tg_cap(max_instances);
-    return (size_t)B * (tg_image_bytes(cap, n_classes) + tg_hash_bytes(cap, n_classes));
+    return (size_t)B * (tg_image_bytes(cap, n_classes) + tg_hash_bytes(cap, n_classes)) + TG_GLOBAL_BYTES;
 }
 
 extern "C" int nmsa_instance_targets(const void* semantic, int sem_dtype, const void* instance,
@@ -1587,7 +1631,7 @@ extern "C" int nmsa_instance_targets(const void* semantic, int sem_dtype, const 
                                      int32_t* encoded_ids, int32_t* n_encoded,
                                      int32_t* skipped_ids, int32_t* n_skipped,
                                      int32_t* status, void* workspace, size_t workspace_bytes,
-                                     nmsa_stream_t stream_)
+                                     int workspace_is_clean, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!semantic || !instance || !gauss_lut || !center || !offset || !foreground || !status || !workspace)
@@ -1607,7 +1651,7 @@ extern "C" int nmsa_instance_targets(const void* semantic, int sem_dtype, const 
     bool decided = false;
     int rc = tg_common(semantic, sem_dtype, instance, ins_dtype, B, n_classes, P, W, cap, true, ws, need,
                        status, stream, is_thing_class, encoded_ids, n_encoded, skipped_ids, n_skipped, 0, 0,
-                       nullptr, nullptr, nullptr, &decided);
+                       nullptr, nullptr, nullptr, &decided, workspace_is_clean);
     if (rc) return rc;
     if (!decided) {
         hipLaunchKernelGGL(k_tg_decide, dim3(B), dim3(1024), 0, stream, ws, cap, n_classes, is_thing_class,
@@ -1655,7 +1699,7 @@ extern "C" int nmsa_panoptic_targets(const void* semantic, int sem_dtype, const 
                                      int max_instances, int max_segments,
                                      int64_t* panoptic, int64_t* ids_pan, int64_t* ids_ins, int32_t* n_ids,
                                      int32_t* status, void* workspace, size_t workspace_bytes,
-                                     nmsa_stream_t stream_)
+                                     int workspace_is_clean, nmsa_stream_t stream_)
 {
     hipStream_t stream = (hipStream_t)stream_;
     if (!semantic || !instance || !panoptic || !ids_pan || !ids_ins || !n_ids || !status || !workspace)
@@ -1674,7 +1718,7 @@ extern "C" int nmsa_panoptic_targets(const void* semantic, int sem_dtype, const 
     bool ranked = false;
     int rc = tg_common(semantic, sem_dtype, instance, ins_dtype, B, n_classes, P, W, cap, false, ws, need,
                        status, stream, nullptr, nullptr, nullptr, nullptr, nullptr, max_segments,
-                       max_instances_per_category, ids_pan, ids_ins, n_ids, &ranked);
+                       max_instances_per_category, ids_pan, ids_ins, n_ids, &ranked, workspace_is_clean);
     if (rc) return rc;
     if (!ranked) {
         hipLaunchKernelGGL(k_tg_naive_ranks, dim3(B), dim3(1024), 0, stream, ws, cap, n_classes, max_segments,

@@ -381,24 +381,36 @@ def _gauss_lut(sigma: int, dev: torch.device) -> torch.Tensor:
     return _GAUSS_LUTS[key]
 
 
-def _targets_workspace(B: int, n_classes: int, max_instances: int, dev, with_status: bool = False):
-    """(workspace, bytes) — with_status: (workspace, bytes, status): the int32 status word sits
-    right behind the workspace, where the target generators zero it with their own memset (no
-    launch of ours to zero it)"""
+# Persistent workspaces of the target generators, one per (device, stream, B, classes,
+# max_instances): on the on-wire layout a call leaves its hash tables zeroed, so the next call on
+# the same workspace skips the memset (`workspace_is_clean`).  LRU of 4.
+_TARGET_WORKSPACES: 'collections.OrderedDict[tuple, list]' = __import__('collections').OrderedDict()
+
+
+def _targets_workspace(B: int, n_classes: int, max_instances: int, dev, reusable: bool = False):
+    """(workspace, bytes, entry): entry = [tensor, clean]; `clean` = this workspace was last used
+    by a target-generator call on the on-wire layout that was enqueued successfully, and may skip
+    its memset (the caller sets entry[1] = 1 after its own call went through)"""
     nbytes = L.lib().nmsa_targets_workspace_bytes(B, n_classes, max_instances)
     if nbytes == 0:
         raise ValueError('max_instances must be in [1, 4096]')
-    if not with_status:
-        return torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev), nbytes
-    assert nbytes % 16 == 0
-    buf = torch.empty((nbytes // 8 + 2,), dtype=torch.int64, device=dev)
-    status = buf[nbytes // 8:].view(torch.int32)[:1]
-    return buf, nbytes, status
+    if not reusable:
+        t = torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev)
+        return t, nbytes, [t, 0]
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, B, n_classes, max_instances)
+    entry = _TARGET_WORKSPACES.get(key)
+    if entry is None:
+        entry = _TARGET_WORKSPACES[key] = [torch.empty(((nbytes + 7) // 8,), dtype=torch.int64, device=dev), 0]
+        while len(_TARGET_WORKSPACES) > 4:
+            _TARGET_WORKSPACES.popitem(last=False)
+    else:
+        _TARGET_WORKSPACES.move_to_end(key)
+    return entry[0], nbytes, entry
 
 
-def _targets_zero_their_status(sem: torch.Tensor, ins: torch.Tensor, H: int, W: int, n_classes: int) -> bool:
-    """the layouts the one-launch front end of csrc/targets.hip takes (it zeroes a status word that
-    sits behind its workspace): the on-wire dtypes, rows of 4 pixels"""
+def _targets_on_wire(sem: torch.Tensor, ins: torch.Tensor, H: int, W: int, n_classes: int) -> bool:
+    """the layouts the one-launch front end of csrc/targets.hip takes (it SETS the status word and
+    leaves its workspace clean): the on-wire dtypes, rows of 4 pixels"""
     import os
     return (os.environ.get('NMSA_TG_FUSED', '1') != '0' and sem.dtype == torch.uint8 and
             ins.dtype == torch.int32 and W % 4 == 0 and n_classes <= 16384 and
@@ -447,16 +459,19 @@ def instance_targets(
     skp = torch.empty((B, cap), dtype=torch.int32, device=dev)
     n_enc = torch.empty((B,), dtype=torch.int32, device=dev)
     n_skp = torch.empty((B,), dtype=torch.int32, device=dev)
-    ws, ws_bytes, status = _targets_workspace(B, int(n_classes), int(max_instances), dev, with_status=True)
-    if not _targets_zero_their_status(sem, ins, H, W, int(n_classes)):
-        status.zero_()
+    on_wire = _targets_on_wire(sem, ins, H, W, int(n_classes))
+    ws, ws_bytes, ws_entry = _targets_workspace(B, int(n_classes), int(max_instances), dev, reusable=on_wire)
+    clean, ws_entry[1] = ws_entry[1], 0
+    status = torch.empty((1,), dtype=torch.int32, device=dev) if on_wire else \
+        torch.zeros((1,), dtype=torch.int32, device=dev)
     L.check(L.lib().nmsa_instance_targets(
         L.ptr(sem), L.int_dtype_code(sem), L.ptr(ins), L.int_dtype_code(ins), L.ptr(th), L.ptr(st),
         B, int(n_classes), H, W, int(sigma), L.ptr(_gauss_lut(sigma, dev)),
         int(bool(normalized_offset)), int(max_instances),
         L.ptr(center), L.ptr(offset), L.ptr(fg), L.ptr(cm), L.ptr(enc), L.ptr(n_enc),
-        L.ptr(skp), L.ptr(n_skp), L.ptr(status), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+        L.ptr(skp), L.ptr(n_skp), L.ptr(status), L.ptr(ws), ws_bytes, int(clean), L.stream_ptr(dev)),
         'nmsa_instance_targets')
+    ws_entry[1] = int(on_wire)
     return {'center': center, 'offset': offset, 'foreground': fg.view(torch.bool),
             'center_mask': cm.view(torch.bool), 'encoded_ids': enc, 'n_encoded': n_enc,
             'skipped_ids': skp, 'n_skipped': n_skp, 'status': status}
@@ -483,15 +498,18 @@ def panoptic_targets(
     ids_pan = torch.empty((B, int(max_segments)), dtype=torch.int64, device=dev)
     ids_ins = torch.empty((B, int(max_segments)), dtype=torch.int64, device=dev)
     n_ids = torch.empty((B,), dtype=torch.int32, device=dev)
-    ws, ws_bytes, status = _targets_workspace(B, int(n_classes), int(max_instances), dev, with_status=True)
-    if not _targets_zero_their_status(sem, ins, H, W, int(n_classes)):
-        status.zero_()
+    on_wire = _targets_on_wire(sem, ins, H, W, int(n_classes))
+    ws, ws_bytes, ws_entry = _targets_workspace(B, int(n_classes), int(max_instances), dev, reusable=on_wire)
+    clean, ws_entry[1] = ws_entry[1], 0
+    status = torch.empty((1,), dtype=torch.int32, device=dev) if on_wire else \
+        torch.zeros((1,), dtype=torch.int32, device=dev)
     L.check(L.lib().nmsa_panoptic_targets(
         L.ptr(sem), L.int_dtype_code(sem), L.ptr(ins), L.int_dtype_code(ins), L.ptr(th),
         B, int(n_classes), H, W, int(max_instances_per_category), int(void_label),
         int(max_instances), int(max_segments), L.ptr(pan), L.ptr(ids_pan), L.ptr(ids_ins),
-        L.ptr(n_ids), L.ptr(status), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+        L.ptr(n_ids), L.ptr(status), L.ptr(ws), ws_bytes, int(clean), L.stream_ptr(dev)),
         'nmsa_panoptic_targets')
+    ws_entry[1] = int(on_wire)
     return {'panoptic': pan, 'ids_pan': ids_pan, 'ids_ins': ids_ins, 'n_ids': n_ids,
             'status': status}
 
@@ -636,7 +654,7 @@ def instance_orientation_sums_wide(
     sums = torch.empty((B, cap, 2), dtype=torch.float64, device=dev)
     count = torch.empty((B, cap), dtype=torch.int32, device=dev)
     status = torch.zeros((1,), dtype=torch.int32, device=dev)
-    ws, ws_bytes = _targets_workspace(B, 1, int(max_instances), dev)
+    ws, ws_bytes, _ = _targets_workspace(B, 1, int(max_instances), dev)
     L.check(L.lib().nmsa_instance_orientation_wide(
         L.ptr(o), L.ptr(ins), L.int_dtype_code(ins), L.ptr(_u8(mask)), B, H, W, int(max_instances),
         L.ptr(ids), L.ptr(n_ids), L.ptr(sums), L.ptr(count), L.ptr(status), L.ptr(ws), ws_bytes,
