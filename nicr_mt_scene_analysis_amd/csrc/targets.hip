@@ -542,15 +542,34 @@ __device__ __forceinline__ void tg_rank_decide_tail(
         if (total > cap) atomicOr(status, TG_ST_OVERFLOW);
     }
     // dense rank of every key: ascending id order = np.unique order
+    int rank_of_key[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
+        rank_of_key[k] = -1;
         if (key[k] <= 0) continue;
         const int d = (int)s_prefix[key[k] >> 5] + __popc(s_bitmap[key[k] >> 5] & ((1u << (key[k] & 31)) - 1u));
-        if (d < cap) { s_slot[d] = (uint16_t)(t + k * 256); v.id_of_dense[d] = key[k]; }
+        if (d < cap) { s_slot[d] = (uint16_t)(t + k * 256); v.id_of_dense[d] = key[k]; rank_of_key[k] = d; }
     }
     __syncthreads();                                     // (bitmap + prefix in LDS are dead from here)
+    // the ids by dense rank, kept in the dead prefix words (up to 2048 ranks; beyond: the table)
+    int* s_id = (int*)s_prefix;
+#pragma unroll
+    for (int k = 0; k < KPT; ++k) if (rank_of_key[k] >= 0 && rank_of_key[k] < MW_WORDS) s_id[rank_of_key[k]] = key[k];
+    auto id_of = [&](int d) -> int { return d < MW_WORDS ? s_id[d] : ld_shared(&h.hkeys[s_slot[d]]); };
+    bool handed_over = false;
     if (WITH_MOMENTS) {
-        uint32_t* s_center = s_bitmap;                   // [cap <= 4096]: (cy << 16) | cx
+        // every status bit of this image is known (the overflow bit above was this tail's last):
+        // the batch's last tail hands the call's status to the caller — requested here, so that the
+        // atomic's round trip hides behind the histogram loads below
+        uint32_t my_turn = 0;
+        if (t == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (my atomicOr above has been performed)
+            my_turn = atomicAdd(&gblock[1], 1u);                 // (looked at behind the loop below)
+        }
+        handed_over = true;
+        // [cap]: (cy << 16) | cx — in the dead bitmap words; with more than 2048 dense slots the
+        // centers beyond go behind the ids (both regions are 2048 words)
+        uint32_t* s_center = s_bitmap;                   // [min(cap, 2048)]
         // per instance: a group of 16 lanes per dense slot (lane = class, strided), four slots per
         // group in flight: with up to 64 instances every histogram load of the image is issued at
         // once (the loop is a chain of memory latencies, not work)
@@ -561,6 +580,13 @@ __device__ __forceinline__ void tg_rank_decide_tail(
             long long best[4] = {-1, -1, -1, -1};     // (count << 32) | ~class: max = larger count, lower class
 #pragma unroll
             for (int u = 0; u < 4; ++u) slot[u] = (d0 + 16 * u < n_dense) ? (int)s_slot[d0 + 16 * u] : -1;
+            // (lane u of the group will finish slot u: its coordinate sums are requested with the
+            // histogram loads, not after their reduction)
+            int my_slot = -1;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (l16 == u) my_slot = slot[u];
+            unsigned long long my_sy = 0, my_sx = 0;
+            if (l16 < 4 && my_slot >= 0) { my_sy = ld_shared(&h.hsum_y[my_slot]); my_sx = ld_shared(&h.hsum_x[my_slot]); }
             for (int cc = l16; cc < NC; cc += 16) {
                 uint32_t x[4];
 #pragma unroll
@@ -600,12 +626,16 @@ __device__ __forceinline__ void tg_rank_decide_tail(
                 v.enc[d] = e;
                 if (e) {
                     // int(np.mean(rows)), int(np.mean(cols)): exact integer floor (instance.py:210-211)
-                    const int cy = (int)(ld_shared(&h.hsum_y[su]) / tu), cx = (int)(ld_shared(&h.hsum_x[su]) / tu);
-                    v.center_yx[2 * d] = cy;
-                    v.center_yx[2 * d + 1] = cx;
-                    s_center[d] = ((uint32_t)cy << 16) | (uint32_t)cx;       // H, W < 32768
+                    const int cy = (int)(my_sy / tu), cx = (int)(my_sx / tu);
+                    st_shared(&v.center_yx[2 * d], cy);
+                    st_shared(&v.center_yx[2 * d + 1], cx);
+                    if (d < MW_WORDS) s_center[d] = ((uint32_t)cy << 16) | (uint32_t)cx;       // H, W < 32768
                 }
             }
+        }
+        if (t == 0 && my_turn == (uint32_t)(n_images - 1)) {
+            *user_status = (int)atomicExch(&gblock[0], 0u);
+            gblock[1] = 0u;
         }
         __syncthreads();
         // the ordered lists: encoded / skipped ids ascending, the encoded centers compacted
@@ -623,10 +653,15 @@ __device__ __forceinline__ void tg_rank_decide_tail(
         for (int j = 0; j < per; ++j) {
             const int d = t * per + j;
             if (d >= n_dense) break;
-            const int id = ld_shared(&h.hkeys[s_slot[d]]);
+            const int id = id_of(d);
             if (s_enc[d]) {
-                v.enc_list[2 * pe] = (int)(s_center[d] >> 16);
-                v.enc_list[2 * pe + 1] = (int)(s_center[d] & 0xffffu);
+                if (d < MW_WORDS) {
+                    v.enc_list[2 * pe] = (int)(s_center[d] >> 16);
+                    v.enc_list[2 * pe + 1] = (int)(s_center[d] & 0xffffu);
+                } else {                                  // (more than 2048 instances: through L2)
+                    v.enc_list[2 * pe] = ld_shared(&v.center_yx[2 * d]);
+                    v.enc_list[2 * pe + 1] = ld_shared(&v.center_yx[2 * d + 1]);
+                }
                 if (encoded_ids) encoded_ids[(size_t)b * cap + pe] = id;
                 ++pe;
             } else {
@@ -721,7 +756,7 @@ __device__ __forceinline__ void tg_rank_decide_tail(
         }
         __syncthreads();
         for (int d = t >> 6; d < n_dense; d += 4) {
-            const int id = ld_shared(&h.hkeys[s_slot[d]]);
+            const int id = id_of(d);
             int at = s_base[d];
             for (int c0 = 0; c0 < NC; c0 += 64) {
                 const int cc = c0 + lane_id();
@@ -767,6 +802,7 @@ __device__ __forceinline__ void tg_rank_decide_tail(
         }
     }
     if (t == 0) h.ticket[0] = 0u;
+    if (handed_over) return;
     // the call's status goes to the caller's word with the LAST tail of the batch (set, not OR-ed)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
