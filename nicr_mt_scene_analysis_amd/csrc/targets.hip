@@ -479,6 +479,17 @@ __device__ __forceinline__ T ld_shared(const T* p) { return __hip_atomic_load(p,
 struct TgScanTab { int key[TG_H2]; uint32_t cnt[TG_H2], sy[TG_H2], sx[TG_H2]; };
 constexpr int TGS_AHEAD = 2;                             // rounds of labels in flight per thread
 
+// Diagnosis build only (-DNMSA_TG_STAMPS, tools/diag_f4_stamps.py): thread 0 of every workgroup of
+// k_tg_scan stamps the 100 MHz wall clock at its phase boundaries into a buffer of the code object
+// that nothing else reads; the product build has no stamp.
+#ifdef NMSA_TG_STAMPS
+__device__ unsigned long long g_tg_stamps[8192 * 8];
+#define TG_STAMP(i) do { if (threadIdx.x == 0) { const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;          \
+        if (wg_ < 8192) g_tg_stamps[wg_ * 8 + (i)] = wall_clock64(); } } while (0)
+#else
+#define TG_STAMP(i) do { } while (0)
+#endif
+
 // ---- tail: what k_tg_rank + k_tg_decide (WITH_MOMENTS) or k_tg_rank + k_tg_naive_ranks did, by
 // the workgroup (256 threads) that drew the image's last ticket.  What the NEXT launch reads goes
 // out as plain stores (write-through sc1 stores left no copy behind and the paint kernels took
@@ -489,7 +500,7 @@ constexpr int TGS_AHEAD = 2;                             // rounds of labels in 
 // u16 rank cells of the naive merge (up to 8192 cells; beyond: the rows in global memory).
 constexpr int TGS_CELLS_LDS = 2 * MW_WORDS * 2;          // u16 cells in the bitmap + prefix region
 
-template <bool WITH_MOMENTS>
+template <bool WITH_MOMENTS, int KPT>                  // KPT: table slots per thread (HT <= 256 KPT)
 __device__ __forceinline__ void tg_rank_decide_tail(
     TgView v, TgHash h, int b, int cap, int HT, int NC, uint32_t* __restrict__ lds,
     const uint8_t* __restrict__ is_thing_class, int32_t* __restrict__ encoded_ids,
@@ -506,8 +517,8 @@ __device__ __forceinline__ void tg_rank_decide_tail(
     const int t = threadIdx.x;
     for (int i = t; i < MW_WORDS; i += 256) s_bitmap[i] = 0u;
     __syncthreads();
-    // the keys of the table: every thread keeps its share in registers (HT / 256 <= 16)
-    constexpr int KPT = 16;
+    // the keys of the table: every thread keeps its share in registers (HT / 256 = 4 for up to
+    // 1024 instances — the usual table —, 16 for the largest)
     int key[KPT];
 #pragma unroll
     for (int k = 0; k < KPT; ++k) {
@@ -551,6 +562,7 @@ __device__ __forceinline__ void tg_rank_decide_tail(
         if (d < cap) { s_slot[d] = (uint16_t)(t + k * 256); v.id_of_dense[d] = key[k]; rank_of_key[k] = d; }
     }
     __syncthreads();                                     // (bitmap + prefix in LDS are dead from here)
+    TG_STAMP(5);
     // the ids by dense rank, kept in the dead prefix words (up to 2048 ranks; beyond: the table)
     int* s_id = (int*)s_prefix;
 #pragma unroll
@@ -638,6 +650,7 @@ __device__ __forceinline__ void tg_rank_decide_tail(
             gblock[1] = 0u;
         }
         __syncthreads();
+        TG_STAMP(6);
         // the ordered lists: encoded / skipped ids ascending, the encoded centers compacted
         const int per = cap / 256;                       // cap is a multiple of 1024
         int n_enc = 0, n_skip = 0;
@@ -647,9 +660,11 @@ __device__ __forceinline__ void tg_rank_decide_tail(
             n_enc += s_enc[d];
             n_skip += !s_enc[d];
         }
-        int tot_enc, tot_skip;
-        int pe = mw_block_scan(n_enc, scratch, &tot_enc) - n_enc;
-        int ps = mw_block_scan(n_skip, scratch, &tot_skip) - n_skip;
+        // ONE block scan for both lists: (encoded << 16) | skipped (each at most cap <= 4096)
+        int tot_both;
+        const int both = mw_block_scan((n_enc << 16) | n_skip, scratch, &tot_both) - ((n_enc << 16) | n_skip);
+        int pe = both >> 16, ps = both & 0xffff;
+        const int tot_enc = tot_both >> 16, tot_skip = tot_both & 0xffff;
         for (int j = 0; j < per; ++j) {
             const int d = t * per + j;
             if (d >= n_dense) break;
@@ -775,6 +790,7 @@ __device__ __forceinline__ void tg_rank_decide_tail(
             if (totp > pair_cap) atomicOr(status, TG_ST_PAIR_OVERFLOW);
         }
     }
+    TG_STAMP(7);
     // ---- leave the image's hash tables as they were found: all zero.  The next call on this
     // workspace then needs no memset (`workspace_is_clean`).  Every slot that holds a key is
     // cleaned by the thread that loaded it, whatever the status bits say.
@@ -816,7 +832,7 @@ __device__ __forceinline__ void tg_rank_decide_tail(
 
 // The on-wire layout only (uint8 semantic, int32 ids, 16-byte aligned rows of 4 pixels, W % 4 == 0,
 // NC <= 16384): everything else keeps the launches of rounds 2-4.
-template <bool WITH_MOMENTS>
+template <bool WITH_MOMENTS, int KPT>
 __global__ __launch_bounds__(256) void k_tg_scan(
     const uint8_t* __restrict__ sem, const int32_t* __restrict__ ins, int P, int W, int cap, int NC,
     int px_per_wg, unsigned char* __restrict__ ws, unsigned char* __restrict__ hs,
@@ -841,6 +857,7 @@ __global__ __launch_bounds__(256) void k_tg_scan(
     int* status = (int*)gblock;
     const int p_begin = blockIdx.x * px_per_wg, p_end = min(P, p_begin + px_per_wg);   // px_per_wg % 1024 == 0
     const int n_rounds = (p_end - p_begin + 1023) / 1024;
+    TG_STAMP(0);
     // the labels of the next TGS_AHEAD rounds are on their way while a round is worked on
     i32x4_t id4[TGS_AHEAD];
     u8x4_t sm4[TGS_AHEAD];
@@ -913,12 +930,14 @@ __global__ __launch_bounds__(256) void k_tg_scan(
         }
     }
     __syncthreads();
+    TG_STAMP(1);
     if (T.key[threadIdx.x] >= 0)
         global_add(T.key[threadIdx.x], T.cnt[threadIdx.x], T.sy[threadIdx.x], T.sx[threadIdx.x]);
     if (st) atomicOr(status, st);
     // every atomic of this workgroup has been performed before its ticket is drawn
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    TG_STAMP(2);
     if (threadIdx.x == 0) {
         const bool last = atomicAdd(&h.ticket[0], 1u) == gridDim.x - 1;
         ctl[0] = last ? 1u : 0u;
@@ -928,10 +947,12 @@ __global__ __launch_bounds__(256) void k_tg_scan(
         }
     }
     __syncthreads();
+    TG_STAMP(3);
     if (!ctl[0]) return;
-    tg_rank_decide_tail<WITH_MOMENTS>(tg_view(ws, b, cap, NC), h, b, cap, HT, NC, tgs_lds + 4, is_thing_class,
+    tg_rank_decide_tail<WITH_MOMENTS, KPT>(tg_view(ws, b, cap, NC), h, b, cap, HT, NC, tgs_lds + 4, is_thing_class,
                                       encoded_ids, n_encoded, skipped_ids, n_skipped, pair_cap, max_inst,
                                       ids_pan, ids_ins, n_ids, status, gblock, (int)gridDim.y, user_status);
+    TG_STAMP(4);
 }
 
 // ---- paint: heat-map, offsets, foreground, center mask -------------------------------------------
@@ -1576,11 +1597,12 @@ size_t tg_scan_lds_bytes(int cap, bool moments)
 
 // pixels per workgroup: ONE round of resident workgroups over the batch (8 workgroups of 256
 // threads per CU, fewer when the LDS footprint says so), whole rounds of 1024 px, at most 2^17 px
-int tg_scan_px_per_wg(int B, int P, size_t lds)
+int tg_scan_px_per_wg(int B, int P, size_t lds, int resident_per_cu)
 {
     const DeviceGeometry g = device_geometry();
     long long per_cu = (long long)(g.lds_per_cu / lds);
     if (per_cu > 8) per_cu = 8;
+    if (resident_per_cu > 0 && per_cu > resident_per_cu) per_cu = resident_per_cu;   // (registers: the occupancy query)
     if (per_cu < 1) per_cu = 1;
     const char* e = getenv("NMSA_TG_WGS_PER_CU");       // (per call: tuning)
     if (e && atoi(e) > 0) per_cu = atoi(e);
@@ -1609,13 +1631,29 @@ int tg_common(const void* sem, int sem_dtype, const void* ins, int ins_dtype, in
         int rc = NMSA_OK;
         if (!workspace_is_clean && (rc = check_hip(hipMemsetAsync(hs, 0, hbytes, stream)))) return rc;
         const size_t lds = tg_scan_lds_bytes(cap, moments);
-        const int px = tg_scan_px_per_wg(B, P, lds);
+        const bool small = tg_hash_slots(cap) <= 1024;
+        // ONE round of resident workgroups: what the registers and the LDS of this instantiation admit
+        int resident = 0;
+        {
+            hipError_t e = hipErrorUnknown;
+            if (moments) e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_tg_scan<true, 4>, 256, lds)
+                                   : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_tg_scan<true, 16>, 256, lds);
+            else e = small ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_tg_scan<false, 4>, 256, lds)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&resident, k_tg_scan<false, 16>, 256, lds);
+            if (e != hipSuccess) { resident = 0; (void)hipGetLastError(); }
+            // (the occupancy query reads one workgroup per CU high for SGPR-heavy 256-thread kernels —
+            // 106 SGPRs here: 6 admitted, 7 reported, MI355X_MICROARCH.md "Residency"; a workgroup that
+            // is not resident starts 12 us late and the whole launch ends that much later)
+            if (resident > 2) resident -= 1;
+        }
+        const int px = tg_scan_px_per_wg(B, P, lds, resident);
         const dim3 grid((P + px - 1) / px, B);
-#define NMSA_LAUNCH_SCAN(M) do { rc = allow_dynamic_lds(k_tg_scan<M>, lds); if (rc) return rc;                  \
-        hipLaunchKernelGGL((k_tg_scan<M>), grid, dim3(256), lds, stream, (const uint8_t*)sem, (const int32_t*)ins, \
+#define NMSA_LAUNCH_SCAN(M, K) do { rc = allow_dynamic_lds(k_tg_scan<M, K>, lds); if (rc) return rc;            \
+        hipLaunchKernelGGL((k_tg_scan<M, K>), grid, dim3(256), lds, stream, (const uint8_t*)sem, (const int32_t*)ins, \
                            P, W, cap, NC, px, ws, hs, is_thing_class, encoded_ids, n_encoded, skipped_ids,       \
                            n_skipped, pair_cap, max_inst, ids_pan, ids_ins, n_ids, status); } while (0)
-        if (moments) NMSA_LAUNCH_SCAN(true); else NMSA_LAUNCH_SCAN(false);
+        if (moments) { if (small) NMSA_LAUNCH_SCAN(true, 4); else NMSA_LAUNCH_SCAN(true, 16); }
+        else { if (small) NMSA_LAUNCH_SCAN(false, 4); else NMSA_LAUNCH_SCAN(false, 16); }
 #undef NMSA_LAUNCH_SCAN
         if (did_tail) *did_tail = true;
         return check_launch();
@@ -1851,3 +1889,17 @@ extern "C" int nmsa_instance_orientation_wide(const float* orientation, const vo
     hipLaunchKernelGGL(k_ow_export, dim3(B), dim3(256), 0, stream, ws, cap, ids, n_ids);
     return check_launch();
 }
+
+#ifdef NMSA_TG_STAMPS
+extern "C" int nmsa_debug_tg_stamps(unsigned long long* host_dst, int n_words)
+{
+    return check_hip(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nmsa::g_tg_stamps),
+                                         (size_t)n_words * sizeof(unsigned long long)));
+}
+extern "C" int nmsa_debug_tg_stamps_clear(void)
+{
+    void* p = nullptr;
+    if (check_hip(hipGetSymbolAddress(&p, HIP_SYMBOL(nmsa::g_tg_stamps)))) return NMSA_ERR_LAUNCH;
+    return check_hip(hipMemset(p, 0, sizeof(unsigned long long) * 8192 * 8));
+}
+#endif
