@@ -155,7 +155,13 @@ class PanopticQuality(Metric):
         """`parts` (ops.panoptic_pipeline's semantic_idx_u8 / instance / pan_of_inst + the thing
         LUT, what the map `preds` was painted from) can stand in for `preds` in
         `update_with_miou`: `preds` IS the painted map of these parts"""
-        if not parts or parts.get('panoptic') is not preds:
+        painted = parts.get('panoptic') if parts else None
+        # the very map these parts were painted into: the tensor itself, or a view of ALL of it
+        # (the full-resolution entry of a prediction at dataset resolution is a full slice of it)
+        if not isinstance(painted, torch.Tensor) or not (
+                painted is preds or (preds.data_ptr() == painted.data_ptr() and preds.shape == painted.shape
+                                     and preds.stride() == painted.stride() and preds.dtype == painted.dtype
+                                     and preds.is_contiguous())):
             return False
         s, i, t, th = (parts.get(k) for k in ('semantic_idx_u8', 'instance', 'pan_of_inst', 'is_thing'))
         return (all(isinstance(x, torch.Tensor) and x.is_cuda and x.is_contiguous() for x in (s, i, t, th))

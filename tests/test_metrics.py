@@ -541,6 +541,8 @@ def test_pq_confmat_from_the_parts_of_the_prediction(shape, max_inst, offset):
         assert torch.equal(getattr(pq_a, name), getattr(pq_b, name)), name
     assert float(pq_a.tp_per_class.sum()) + float(pq_a.fp_per_class.sum()) > 0
     # parts of ANOTHER map (a clone is not the painted tensor itself) are not used
+    assert PanopticQuality.parts_usable(parts, pred[..., slice(0, H), slice(0, W)], max_inst)    # a full view of it
+    assert not PanopticQuality.parts_usable(parts, pred[:, 1:], max_inst)
     assert not PanopticQuality.parts_usable(dict(parts, panoptic=pred.clone()), pred, max_inst)
     assert not PanopticQuality.parts_usable(parts, pred, max_inst + 1)
 
