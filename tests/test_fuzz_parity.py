@@ -401,6 +401,56 @@ def test_fuzz_targets_vs_oracle(oracle, seed, B, H, W, NC, n_inst, sigma, normal
     assert [list(d.items()) for d in got] == [list(d.items()) for d in dicts]
 
 
+@settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(8, 96), W4=st.integers(1, 40),
+       NC=st.integers(2, 12), n_inst=st.integers(0, 60), sigma=st.integers(1, 4), clustered=st.booleans())
+def test_fuzz_targets_scan_launch_vs_oracle(oracle, seed, B, H, W4, NC, n_inst, sigma, clustered):
+    """the one-launch front end of the target generators (csrc/targets.hip k_tg_scan: rows of 4
+    pixels, several workgroups per image handing over through the per-image hash table and the
+    ticket tail): images of up to 96 x 160, up to 60 instances with sparse uint16 ids — or ids that
+    all fall on ONE slot of the table's hash (clustered: multiples of 2^20 apart after the multiply)
+    — against the oracle, twice on the same persistent workspace"""
+    from nicr_mt_scene_analysis_amd import ops
+    rng = np.random.default_rng(seed)
+    W = 4 * W4
+    sem = rng.integers(0, NC, (B, H, W)).astype(np.uint8)
+    ins = np.zeros((B, H, W), np.int32)
+    # (clustered: 63 ids whose home slot in the 1024-slot table is the same — a probe chain of 63)
+    all_ids = np.arange(1, 65536, dtype=np.uint64)
+    home = (((all_ids * np.uint64(2654435761)) & np.uint64(0xffffffff)) >> np.uint64(12)) & np.uint64(1023)
+    pool = all_ids[home == np.uint64(seed % 1024)][:63].astype(np.int64) if clustered else None
+    for b in range(B):
+        for _ in range(n_inst):
+            ya, xa = rng.integers(0, H), rng.integers(0, W)
+            yb, xb = rng.integers(ya, min(H, ya + 24)) + 1, rng.integers(xa, min(W, xa + 40)) + 1
+            ins[b, ya:yb, xa:xb] = rng.choice(pool) if clustered else rng.integers(1, 65536)
+            if rng.random() < 0.6:
+                sem[b, ya:yb, xa:xb] = rng.integers(0, NC)
+    is_thing = rng.random(NC) < 0.5
+    is_thing[0] = False
+    stuff = np.zeros((NC,), np.uint8)
+    stuff[np.where(~is_thing)[0][1:]] = 1
+    o = oracle.instance_targets(sem, ins, NC, is_thing, stuff, sigma, True)
+    pan, dicts = oracle.naive_merge(sem, ins, 1 << 16, np.where(is_thing)[0], 0)
+    for _ in range(2):
+        r = ops.instance_targets(dev(sem), dev(ins), NC, dev(is_thing.astype(np.uint8)), dev(stuff), sigma, True)
+        assert int(r['status'].item()) == 0
+        assert np.array_equal(r['center'].cpu().numpy(), o['center'])
+        assert np.array_equal(r['offset'].cpu().numpy(), o['offset'])
+        assert np.array_equal(r['foreground'].cpu().numpy(), o['foreground'])
+        assert np.array_equal(r['center_mask'].cpu().numpy(), o['center_mask'])
+        ne, ns = r['n_encoded'].cpu().numpy(), r['n_skipped'].cpu().numpy()
+        for b in range(B):
+            assert r['encoded_ids'][b, :ne[b]].cpu().tolist() == o['encoded'][b]
+            assert r['skipped_ids'][b, :ns[b]].cpu().tolist() == o['skipped'][b]
+        p = ops.panoptic_targets(dev(sem), dev(ins), NC, dev(is_thing.astype(np.uint8)), 1 << 16, 0)
+        assert int(p['status'].item()) == 0
+        assert np.array_equal(p['panoptic'].cpu().numpy(), pan)
+        got = ids_from_arrays(p['n_ids'].cpu().numpy(), p['ids_pan'].cpu().numpy(), p['ids_ins'].cpu().numpy())
+        assert [list(d.items()) for d in got] == [list(d.items()) for d in dicts]
+
+
 @settings(max_examples=_n(120), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(2, 30), W=st.integers(2, 41),
