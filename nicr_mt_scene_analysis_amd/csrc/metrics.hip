@@ -337,10 +337,9 @@ __device__ __forceinline__ longlong2 ld_i64x2_stream(const int64_t* p)
 // task_helper/panoptic.py:57-63): shifts, and every per-pixel range test as branch-free selects —
 // the early returns of the generic form are eight divergent branch diamonds per load, with an
 // inlined 64-bit division in each.
-// PARTS: the prediction is not read as its painted int64 map (8 B/px) but formed in registers from
-// what the merge painted it from — semantic class u8, instance id u8 and the per-image table
-// pan_of_inst (k_paint2's rule, panoptic.hip): 2 B/px.  The metric chain of a validation step then
-// reads 11 B/px instead of 17; the map itself is still written for the API.
+// The prediction as the PARTS the merge painted its int64 map from — semantic class u8, instance id
+// u8 and the per-image table pan_of_inst (k_paint2's rule, panoptic.hip): 2 B/px instead of 8, read
+// by k_pq_count_parts below.  The map itself is still written for the API.
 struct PqPredParts {
     const uint8_t* sem;                // [B,P] class index 0..C-1
     const uint8_t* inst;               // [B,P] instance id 0..255
@@ -350,29 +349,35 @@ struct PqPredParts {
     int64_t max_inst, void_label;
 };
 
-template <bool WITH_CM, bool POW2, bool PARTS>
+// Diagnosis build only (-DNMSA_PQ_STAMPS, tools/diag_pq_stamps.py): thread 0 of every workgroup
+// leaves the 100 MHz wall clock at the phase boundaries of k_pq_count.
+#ifdef NMSA_PQ_STAMPS
+__device__ unsigned long long g_pq_stamps[4096 * 8];
+#define PQ_STAMP(i) do { if (threadIdx.x == 0) { const int wg_ = blockIdx.y * gridDim.x + blockIdx.x;          \
+        if (wg_ < 4096) g_pq_stamps[wg_ * 8 + (i)] = wall_clock64(); } } while (0)
+#else
+#define PQ_STAMP(i) do { } while (0)
+#endif
+
+template <bool WITH_CM, bool POW2>
 __global__ __launch_bounds__(256) void k_pq_count(
     const int64_t* __restrict__ pred, const int64_t* __restrict__ target,
     int P, int64_t offset, int px_per_block,
     unsigned char* __restrict__ ws, int cap, int* __restrict__ status,
     const uint8_t* __restrict__ target_sem, int cm_n, int64_t cm_div, int cm_shift,
     uint32_t* __restrict__ cm_slab, int* __restrict__ cm_status, int ablate,
-    int* __restrict__ list_n_all, PqPredParts parts)
+    int* __restrict__ list_n_all)
 {
     __shared__ int64_t lkI[PQ_LI];
     __shared__ uint32_t lcI[PQ_LI];
-    __shared__ int64_t s_pinst[PARTS ? 256 : 1], s_pstuff[PARTS ? 256 : 1];
     extern __shared__ uint32_t cm_hist_pq[];
     const int b = blockIdx.y;
-    if (PARTS) {
-        const int t = threadIdx.x;
-        s_pinst[t] = parts.pan_of_inst[(size_t)b * 256 + t];
-        s_pstuff[t] = (t < parts.C && !parts.is_thing[t]) ? (int64_t)(t + 1) * parts.max_inst : parts.void_label;
-    }
+    PQ_STAMP(0);
     const int cm_bins = WITH_CM ? cm_n * cm_n : 0;
     for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) { lkI[i] = KEY_EMPTY; lcI[i] = 0; }
     if (WITH_CM) for (int i = threadIdx.x; i < cm_bins; i += blockDim.x) cm_hist_pq[i] = 0;
     __syncthreads();
+    PQ_STAMP(1);
     const uint8_t* ts = WITH_CM ? target_sem + (size_t)b * P : nullptr;
     bool cm_bad = false;
     auto cm_key = [&](int64_t t, int64_t p, bool valid) -> int {
@@ -407,11 +412,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
     int* list_n = list_n_all + b * PQ_LIST_STRIDE;     // one counter per image, each on a line of its own
     uint32_t* list_slots = (uint32_t*)(pq_list_keys(ws, b, cap) + cap / 2) + cap / 2;
     const int list_cap = cap / 2;
-    const int64_t* pr = PARTS ? nullptr : pred + (size_t)b * P;
-    const uint8_t* psem = PARTS ? parts.sem + (size_t)b * P : nullptr;
-    const uint8_t* pins = PARTS ? parts.inst + (size_t)b * P : nullptr;
-    // the painted value of a pixel (k_paint2): its instance's panoptic id, else its stuff class's
-    auto painted = [&](uint32_t sm, uint32_t in) -> int64_t { return in ? s_pinst[in] : s_pstuff[sm]; };
+    const int64_t* pr = pred + (size_t)b * P;
     const int64_t* tg = target + (size_t)b * P;
     const int start = blockIdx.x * px_per_block;
     const int end = min(start + px_per_block, P);
@@ -461,7 +462,6 @@ __global__ __launch_bounds__(256) void k_pq_count(
     // the image plane is consumed as 16-B (2 px) loads when the rows allow it
     const bool vec = ((P & 1) == 0) && ((start & 1) == 0) &&
                      ((((uintptr_t)pr | (uintptr_t)tg) & 15) == 0) &&
-                     (!PARTS || ((((uintptr_t)psem | (uintptr_t)pins) & 1) == 0)) &&
                      (!WITH_CM || (((uintptr_t)ts) & 1) == 0);
     if (vec) {
         const int tile = blockDim.x * 2 * PQ_UNROLL;            // px per block iteration
@@ -476,23 +476,8 @@ __global__ __launch_bounds__(256) void k_pq_count(
                 const int i = base + (u * blockDim.x + threadIdx.x) * 2;
                 ok[u] = i < end;                                // end is even on this path
                 tv[u] = ok[u] ? ld_i64x2_stream(tg + i) : make_longlong2(0, 0);
-                if (!PARTS) pv[u] = ok[u] ? ld_i64x2_stream(pr + i) : make_longlong2(0, 0);
-                else {
-                    // (the two label bytes of both pixels travel in the prediction's registers
-                    // until all loads of the tile are issued)
-                    pv[u].x = ok[u] ? (long long)(((uint32_t)*(const uint16_t*)(psem + i) << 16) | *(const uint16_t*)(pins + i)) : 0;
-                    pv[u].y = 0;
-                }
+                pv[u] = ok[u] ? ld_i64x2_stream(pr + i) : make_longlong2(0, 0);
                 sv[u] = (WITH_CM && ok[u]) ? (uint32_t)*(const uint16_t*)(ts + i) : 0u;
-            }
-            if (PARTS) {
-#pragma unroll
-                for (int u = 0; u < PQ_UNROLL; ++u) {
-                    const uint32_t w = (uint32_t)pv[u].x;
-                    const uint32_t sm = w >> 16, in = w & 0xFFFFu;
-                    pv[u].x = ok[u] ? painted(sm & 0xFFu, in & 0xFFu) : 0;
-                    pv[u].y = ok[u] ? painted(sm >> 8, in >> 8) : 0;
-                }
             }
             if (WITH_CM) {
 #pragma unroll
@@ -531,6 +516,7 @@ __global__ __launch_bounds__(256) void k_pq_count(
                     if (ok[u] && !same) add(i1, 1u);
                 }
             }
+            if (base == start) PQ_STAMP(2);
         }
     } else {
         const int span = end - start;
@@ -538,12 +524,14 @@ __global__ __launch_bounds__(256) void k_pq_count(
         for (int k = 0; k < trips; ++k) {
             const int i = start + k * blockDim.x + threadIdx.x;
             const bool valid = i < end;
-            const int64_t pi = !valid ? 0 : PARTS ? painted(psem[i], pins[i]) : pr[i];
+            const int64_t pi = valid ? pr[i] : 0;
             wave_runs(valid, iid_of(valid ? tg[i] : 0, pi, valid), 1u);
             if (WITH_CM) cm_runs(cm_key(valid ? ts[i] : 0, pi, valid), 1u);
         }
     }
+    PQ_STAMP(3);
     __syncthreads();
+    PQ_STAMP(4);
     if (WITH_CM) {
         uint32_t* mine = cm_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * cm_bins;
         if (!(ablate & 4)) for (int i = threadIdx.x; i < cm_bins; i += blockDim.x) mine[i] = cm_hist_pq[i];
@@ -555,6 +543,210 @@ __global__ __launch_bounds__(256) void k_pq_count(
         if (lkI[i] != KEY_EMPTY && !table_add_listed(gk, gc, cap - 1, lkI[i], lcI[i], 256, list_n, list_slots, list_cap))
             st |= ST_TABLE_OVERFLOW;
     if (st) atomicOr(status, st);
+    PQ_STAMP(5);
+}
+
+// ---- the same count for a prediction given as its PARTS (PqPredParts), compact keys ----------
+// k_pq_count's time is VALU issue (a wave64 instruction holds a 16-lane SIMD for four cycles:
+// 2430 per wave = 19 us of its 46), most of it 64-bit: forming t * offset + p, hashing and
+// comparing it, the class of p for the confusion matrix, range tests — per pixel.  With the parts
+// a pixel's prediction is one of 512 CODES (its instance id, else 256 + its class), so the block
+// counts (target id, code) pairs and decodes each DISTINCT pair once, at the flush: the
+// intersection id comes from a 512-entry LDS table there, and the confusion-matrix class of a
+// code from another one per pixel.  Per pixel that leaves a 24-bit multiplicative hash
+// (v_mul_u32_u24 is full rate, a 32-bit multiply is not), one 8-byte LDS read, one compare, one
+// LDS atomic, and for the matrix one 2-byte LDS read, one multiply-add, one LDS atomic.  Targets
+// that do not fit 32 bits (negative ids included) go straight to the decode, pixel by pixel —
+// exact, slow, and not what label maps hold.  Full tiles run without per-lane bounds; the ragged
+// rest one pixel per lane.
+constexpr unsigned long long PQP_EMPTY = ~0ull;
+constexpr uint32_t PQP_BAD_CLASS = 0x8000u;          // > any n * n (n <= PQ_CM_MAX_CLASSES = 64)
+
+__device__ __forceinline__ uint32_t pqp_slot(uint32_t tlo, uint32_t code)
+{
+    return ((uint32_t)__umul24(tlo, 0x9E3779u) + (uint32_t)__umul24(code, 0x85EBCBu)) >> 22;     // PQ_LI = 1024 slots
+}
+
+__global__ __launch_bounds__(256) void k_pq_count_parts(
+    const int64_t* __restrict__ target, int P, int64_t offset, int px_per_block,
+    unsigned char* __restrict__ ws, int cap, int* __restrict__ status,
+    const uint8_t* __restrict__ target_sem, int cm_n, int64_t cm_div, int cm_shift,
+    uint32_t* __restrict__ cm_slab, int* __restrict__ cm_status,
+    int* __restrict__ list_n_all, PqPredParts parts)
+{
+    static_assert(PQ_LI == 1024, "pqp_slot keeps the top ten bits of the hash");
+    __shared__ unsigned long long lk[PQ_LI];        // code << 32 | target id
+    __shared__ uint32_t lc[PQ_LI];
+    __shared__ int64_t s_pan[512];                  // code -> painted panoptic id (k_paint2's rule)
+    __shared__ uint16_t s_cls[512];                 // code -> confusion-matrix class of that id
+    extern __shared__ uint32_t cm_hist_pq[];
+    const int b = blockIdx.y;
+    PQ_STAMP(0);
+    const uint32_t cm_bins = (uint32_t)(cm_n * cm_n);
+    {
+        const int t = threadIdx.x;
+        const int64_t pi = parts.pan_of_inst[(size_t)b * 256 + t];
+        const int64_t ps = (t < parts.C && !parts.is_thing[t]) ? (int64_t)(t + 1) * parts.max_inst : parts.void_label;
+        auto cls_of = [&](int64_t p) -> uint16_t {          // miou.py:50 on the painted id
+            if (p < 0) return (uint16_t)PQP_BAD_CLASS;      // bincount rejects negatives
+            const int64_t pc = cm_shift >= 0 ? (p >> cm_shift) : (p / cm_div);
+            return pc >= cm_n ? (uint16_t)PQP_BAD_CLASS : (uint16_t)pc;
+        };
+        s_pan[t] = pi;       s_cls[t] = cls_of(pi);
+        s_pan[256 + t] = ps; s_cls[256 + t] = cls_of(ps);
+    }
+    for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) { lk[i] = PQP_EMPTY; lc[i] = 0; }
+    for (int i = threadIdx.x; i < (int)cm_bins; i += blockDim.x) cm_hist_pq[i] = 0;
+    __syncthreads();
+    PQ_STAMP(1);
+    int64_t* gk = pq_keys(ws, b, cap);
+    uint32_t* gc = pq_cnts(ws, b, cap);
+    int* list_n = list_n_all + b * PQ_LIST_STRIDE;
+    uint32_t* list_slots = (uint32_t*)(pq_list_keys(ws, b, cap) + cap / 2) + cap / 2;
+    const int list_cap = cap / 2;
+    const uint8_t* psem = parts.sem + (size_t)b * P;
+    const uint8_t* pins = parts.inst + (size_t)b * P;
+    const uint8_t* ts = target_sem + (size_t)b * P;
+    const int64_t* tg = target + (size_t)b * P;
+    const int start = blockIdx.x * px_per_block;
+    const int end = min(start + px_per_block, P);
+    const int off_shift = ((offset & (offset - 1)) == 0) ? (63 - __clzll((long long)offset)) : -1;
+    int st = 0;
+    bool cm_bad = false;
+
+    // one distinct (target id, code) with its pixel count: the decode
+    auto decode = [&](int64_t t, uint32_t code, uint32_t cnt) {
+        const int64_t p = s_pan[code];
+        if (t < 0 || p < 0 || p >= offset) st |= ST_MISSING_KEY;
+        // torch's int64 wrap-around arithmetic (pq.py:104)
+        const int64_t iid = off_shift >= 0 ? (int64_t)(((uint64_t)t << off_shift) + (uint64_t)p)
+                                           : (int64_t)((uint64_t)t * (uint64_t)offset + (uint64_t)p);
+        if (iid == KEY_EMPTY) { st |= ST_SENTINEL_KEY; return; }
+        if (!table_add_listed(gk, gc, cap - 1, iid, cnt, 256, list_n, list_slots, list_cap)) st |= ST_TABLE_OVERFLOW;
+    };
+    // off the fast path: a key not (yet) in its home slot, or a target id beyond 32 bits
+    auto slow = [&](int64_t t, uint32_t code, uint32_t cnt) {
+        bool placed = false;
+        if (((uint64_t)t >> 32) == 0) {
+            const unsigned long long key = ((unsigned long long)code << 32) | (uint32_t)t;
+            uint32_t slot = pqp_slot((uint32_t)t, code);
+#pragma unroll 1
+            for (int probe = 0; probe < 32 && !placed; ++probe) {
+                const unsigned long long cur = __hip_atomic_load(&lk[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (cur == key) placed = true;
+                else if (cur == PQP_EMPTY) {
+                    const unsigned long long prev = atomicCAS(&lk[slot], PQP_EMPTY, key);
+                    placed = prev == PQP_EMPTY || prev == key;
+                }
+                if (placed) atomicAdd(&lc[slot], cnt);
+                else slot = (slot + 1) & (PQ_LI - 1);
+            }
+        }
+        if (!placed) decode(t, code, cnt);
+    };
+    auto code_of = [](uint32_t sm, uint32_t in) -> uint32_t { return in ? in : (256u | sm); };
+    // confusion matrix (miou.py:50) of a lane's two pixels: bin = target class * n + class of the
+    // painted id; a bad class of either side lands beyond the bins
+    auto cm_pair = [&](uint32_t ts0, uint32_t ts1, uint32_t cls0, uint32_t cls1) {
+        const uint32_t k0 = ts0 * (uint32_t)cm_n + cls0, k1 = ts1 * (uint32_t)cm_n + cls1;
+        const bool in0 = k0 < cm_bins, in1 = k1 < cm_bins;
+        cm_bad = cm_bad || !in0 || !in1;
+        const bool ksame = in0 && k0 == k1;
+        const uint32_t kf = (uint32_t)__builtin_amdgcn_readfirstlane((int)k0);
+        if (__all(ksame && k0 == kf)) {                           // the wave sits on one bin
+            if (lane_id() == 0) atomicAdd(&cm_hist_pq[kf], 128u);
+        } else {
+            if (in0) atomicAdd(&cm_hist_pq[k0], ksame ? 2u : 1u);
+            if (in1 && !ksame) atomicAdd(&cm_hist_pq[k1], 1u);
+        }
+    };
+
+    const bool vec = ((P & 1) == 0) && ((start & 1) == 0) && ((((uintptr_t)tg) & 15) == 0) &&
+                     (((((uintptr_t)psem | (uintptr_t)pins | (uintptr_t)ts)) & 1) == 0);
+    int base = start;
+    if (vec) {
+        const int tile = blockDim.x * 2 * PQ_UNROLL;
+        auto step = [&](int64_t t0, int64_t t1, uint32_t c0, uint32_t c1, uint32_t ts0, uint32_t ts1) {
+            cm_pair(ts0, ts1, s_cls[c0], s_cls[c1]);
+            const uint32_t l0 = (uint32_t)t0, l1 = (uint32_t)t1;
+            const bool big = (((uint64_t)t0 | (uint64_t)t1) >> 32) != 0;
+            const bool same = l0 == l1 && c0 == c1;
+            const uint32_t fl = (uint32_t)__builtin_amdgcn_readfirstlane((int)l0);
+            const uint32_t fc = (uint32_t)__builtin_amdgcn_readfirstlane((int)c0);
+            const bool uni = __all(same && !big && l0 == fl && c0 == fc);
+            bool act0 = uni ? lane_id() == 0 : true;
+            bool act1 = !uni && (big || !same);
+            const uint32_t cnt0 = uni ? 128u : ((same && !big) ? 2u : 1u);
+            if (act0 && !big) {
+                const uint32_t slot = pqp_slot(l0, c0);
+                const unsigned long long key = ((unsigned long long)c0 << 32) | l0, cur = lk[slot];
+                if (cur == key) { atomicAdd(&lc[slot], cnt0); act0 = false; }
+                else if (cur == PQP_EMPTY) {
+                    const unsigned long long prev = atomicCAS(&lk[slot], PQP_EMPTY, key);
+                    if (prev == PQP_EMPTY || prev == key) { atomicAdd(&lc[slot], cnt0); act0 = false; }
+                }
+            }
+            if (act1 && !big) {
+                const uint32_t slot = pqp_slot(l1, c1);
+                const unsigned long long key = ((unsigned long long)c1 << 32) | l1, cur = lk[slot];
+                if (cur == key) { atomicAdd(&lc[slot], 1u); act1 = false; }
+                else if (cur == PQP_EMPTY) {
+                    const unsigned long long prev = atomicCAS(&lk[slot], PQP_EMPTY, key);
+                    if (prev == PQP_EMPTY || prev == key) { atomicAdd(&lc[slot], 1u); act1 = false; }
+                }
+            }
+            if (__any(act0 || act1)) {
+#pragma unroll 1
+                for (int k = 0; k < 2; ++k)
+                    if (k ? act1 : act0) slow(k ? t1 : t0, k ? c1 : c0, k ? 1u : cnt0);
+            }
+        };
+        for (; base + tile <= end; base += tile) {
+            longlong2 tv[PQ_UNROLL];
+            uint32_t ls[PQ_UNROLL], li[PQ_UNROLL], lt[PQ_UNROLL];
+#pragma unroll
+            for (int u = 0; u < PQ_UNROLL; ++u) {
+                const int i = base + (u * blockDim.x + threadIdx.x) * 2;
+                tv[u] = ld_i64x2_stream(tg + i);
+                ls[u] = *(const uint16_t*)(psem + i);
+                li[u] = *(const uint16_t*)(pins + i);
+                lt[u] = *(const uint16_t*)(ts + i);
+            }
+#pragma unroll
+            for (int u = 0; u < PQ_UNROLL; ++u)
+                step(tv[u].x, tv[u].y, code_of(ls[u] & 0xFFu, li[u] & 0xFFu), code_of(ls[u] >> 8, li[u] >> 8),
+                     lt[u] & 0xFFu, lt[u] >> 8);
+            if (base == start) PQ_STAMP(2);
+        }
+        for (; base + (int)blockDim.x * 2 <= end; base += blockDim.x * 2) {      // single steps up to the last full one
+            const int i = base + threadIdx.x * 2;
+            const longlong2 t = ld_i64x2_stream(tg + i);
+            const uint32_t s2 = *(const uint16_t*)(psem + i), i2 = *(const uint16_t*)(pins + i), t2 = *(const uint16_t*)(ts + i);
+            step(t.x, t.y, code_of(s2 & 0xFFu, i2 & 0xFFu), code_of(s2 >> 8, i2 >> 8), t2 & 0xFFu, t2 >> 8);
+        }
+    }
+    for (int i0 = base; i0 < end; i0 += blockDim.x) {          // the ragged rest, one pixel per lane
+        const int i = i0 + threadIdx.x;
+        if (i < end) {
+            const uint32_t code = code_of(psem[i], pins[i]);
+            const uint32_t k = (uint32_t)ts[i] * (uint32_t)cm_n + s_cls[code];
+            if (k < cm_bins) atomicAdd(&cm_hist_pq[k], 1u); else cm_bad = true;
+            slow(tg[i], code, 1u);
+        }
+    }
+    PQ_STAMP(3);
+    __syncthreads();
+    PQ_STAMP(4);
+    uint32_t* mine = cm_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * cm_bins;
+    for (int i = threadIdx.x; i < (int)cm_bins; i += blockDim.x) mine[i] = cm_hist_pq[i];
+    if (cm_bad) atomicOr(cm_status, ST_VALUE_RANGE);
+    // decode the block's distinct pairs into the image's table
+    for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) {
+        const unsigned long long key = lk[i];
+        if (key != PQP_EMPTY) decode((int64_t)(uint32_t)key, (uint32_t)(key >> 32), lc[i]);
+    }
+    if (st) atomicOr(status, st);
+    PQ_STAMP(5);
 }
 
 // ---- block helpers ------------------------------------------------------------------
@@ -958,20 +1150,23 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
         int shift = -1;
         if ((cm_div & (cm_div - 1)) == 0) shift = __builtin_ctzll((unsigned long long)cm_div);
         const bool p2 = off_pow2 && shift >= 0;
-        auto kern = parts ? (p2 ? k_pq_count<true, true, true> : k_pq_count<true, false, true>)
-                          : (p2 ? k_pq_count<true, true, false> : k_pq_count<true, false, false>);
-        hipLaunchKernelGGL(kern, grid, dim3(256),
-                           (size_t)cm_n * cm_n * sizeof(uint32_t),
-                           stream, pred, target, P, offset, px_per_block, ws, cap, status, target_sem, cm_n,
-                           cm_div, shift, (uint32_t*)cm_workspace, cm_status, ablate, list_n,
-                           parts ? *parts : PqPredParts{});
+        if (parts) {
+            hipLaunchKernelGGL(k_pq_count_parts, grid, dim3(256), (size_t)cm_n * cm_n * sizeof(uint32_t), stream,
+                               target, P, offset, px_per_block, ws, cap, status, target_sem, cm_n, cm_div, shift,
+                               (uint32_t*)cm_workspace, cm_status, list_n, *parts);
+        } else {
+            auto kern = p2 ? k_pq_count<true, true> : k_pq_count<true, false>;
+            hipLaunchKernelGGL(kern, grid, dim3(256), (size_t)cm_n * cm_n * sizeof(uint32_t),
+                               stream, pred, target, P, offset, px_per_block, ws, cap, status, target_sem, cm_n,
+                               cm_div, shift, (uint32_t*)cm_workspace, cm_status, ablate, list_n);
+        }
     } else {
-        auto kern = parts ? (off_pow2 ? k_pq_count<false, true, true> : k_pq_count<false, false, true>)
-                          : (off_pow2 ? k_pq_count<false, true, false> : k_pq_count<false, false, false>);
+        if (parts) return NMSA_ERR_ARG;            // the parts come with the confusion matrix (one entry point)
+        auto kern = off_pow2 ? k_pq_count<false, true> : k_pq_count<false, false>;
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream,
                            pred, target, P, offset,
                            px_per_block, ws, cap, status, (const uint8_t*)nullptr, 0, (int64_t)1, -1,
-                           (uint32_t*)nullptr, (int*)nullptr, ablate, list_n, parts ? *parts : PqPredParts{});
+                           (uint32_t*)nullptr, (int*)nullptr, ablate, list_n);
     }
     rc = check_launch();
     if (rc) return rc;
@@ -1072,3 +1267,16 @@ extern "C" int nmsa_pq_update_with_confmat_parts(
                           target_semantic, confmat_classes, pred_div, confmat, confmat_status,
                           confmat_workspace, (hipStream_t)stream_, &parts);
 }
+
+#ifdef NMSA_PQ_STAMPS
+extern "C" int nmsa_debug_pq_stamps(unsigned long long* host_dst, int n_words, int clear)
+{
+    if (clear) {
+        void* p = nullptr;
+        if (nmsa::check_hip(hipGetSymbolAddress(&p, HIP_SYMBOL(nmsa::g_pq_stamps)))) return NMSA_ERR_LAUNCH;
+        return nmsa::check_hip(hipMemset(p, 0, sizeof(unsigned long long) * 4096 * 8));
+    }
+    return nmsa::check_hip(hipMemcpyFromSymbol(host_dst, HIP_SYMBOL(nmsa::g_pq_stamps),
+                                               sizeof(unsigned long long) * (size_t)n_words));
+}
+#endif

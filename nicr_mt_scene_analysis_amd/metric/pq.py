@@ -174,7 +174,7 @@ class PanopticQuality(Metric):
                                target_semantic: torch.Tensor, pred_div: int) -> None:
         """`update_with_miou(parts['panoptic'], ...)` without reading the painted int64 map: the
         predicted id of every pixel is formed in registers from the parts the merge painted it
-        from (csrc/metrics.hip k_pq_count<.., PARTS>): bit-identical states, 11 instead of 17
+        from (csrc/metrics.hip k_pq_count_parts: compact keys): bit-identical states, 11 instead of 17
         bytes per pixel.  Falls back to `update_with_miou` when the parts do not apply."""
         preds = parts['panoptic']
         if not (self.parts_usable(parts, preds, self.max_instances_per_category)

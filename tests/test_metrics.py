@@ -548,6 +548,71 @@ def test_pq_confmat_from_the_parts_of_the_prediction(shape, max_inst, offset):
 
 
 @gpu
+@pytest.mark.parametrize('kind', ['noise', 'wide_ids', 'negative_ids', 'bad_classes', 'ragged'])
+def test_pq_parts_hard_inputs(kind):
+    """the compact-key count of the parts path (k_pq_count_parts) against the map path on what its
+    fast path does not hold: more distinct (target, prediction) pairs in a workgroup than its LDS
+    table has slots, target ids beyond 32 bits / negative ones (decoded pixel by pixel), classes the
+    confusion matrix rejects, and sizes whose rows end inside a tile — states, confusion matrix AND
+    both status words equal"""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
+    B, H, W = (2, 63, 130) if kind == 'ragged' else (2, 96, 512)
+    C, max_inst, offset = 8, 1 << 16, 256 ** 3
+    n = C + 1
+    g = torch.Generator(device='cuda').manual_seed(len(kind) * 1009)
+    is_thing_c = torch.tensor([False, True, True, False, True, True, False, True], device='cuda')
+
+    def blocky(hi, cell=8):
+        c = torch.randint(0, hi, (B, (H + cell - 1) // cell, (W + cell - 1) // cell), device='cuda', generator=g)
+        return c.repeat_interleave(cell, 1).repeat_interleave(cell, 2)[:, :H, :W].contiguous()
+    sem = blocky(C).to(torch.uint8)
+    inst = (blocky(6, 16) * is_thing_c[sem.long()]).to(torch.uint8)
+    pan_of_inst = torch.zeros((B, 256), dtype=torch.int64, device='cuda')
+    for b in range(B):
+        for i in range(1, 6):
+            pan_of_inst[b, i] = int(torch.randint(1, n, (1,), generator=g, device='cuda')) * max_inst + i
+    if kind == 'bad_classes':
+        pan_of_inst[0, 2] = (n + 3) * max_inst + 2          # a class beyond the matrix
+        pan_of_inst[1, 3] = -7                              # bincount's negative
+    thing_u8 = is_thing_c.to(torch.uint8)
+    pred = torch.empty((B, H, W), dtype=torch.int64, device='cuda')
+    L_ = ops.L
+    L_.check(L_.lib().nmsa_panoptic_paint(L_.ptr(sem), L_.ptr(inst), L_.ptr(pan_of_inst), L_.ptr(thing_u8), B, C, H, W,
+                                          max_inst, 0, L_.ptr(pred), None, L_.stream_ptr(pred.device)),
+             'nmsa_panoptic_paint')
+    tgt = blocky(n) * max_inst + blocky(3)
+    tsem = blocky(n).to(torch.uint8)
+    if kind == 'noise':           # 108 target ids pixel by pixel: ~1500 distinct triples per workgroup, 1024 slots
+        tgt = torch.randint(0, n, (B, H, W), device='cuda', generator=g) * max_inst + \
+            torch.randint(0, 12, (B, H, W), device='cuda', generator=g)
+    elif kind == 'wide_ids':
+        tgt[:, 10:30] += 1 << 33
+        tgt[:, 50:52, ::3] = (1 << 40) + 5
+    elif kind == 'negative_ids':
+        tgt[0, 5:9, 100:300] = -3
+        tgt[1, -1, -1] = -(1 << 35)
+    elif kind == 'bad_classes':
+        tsem[1, 40:44] = 200
+    parts = {'panoptic': pred, 'semantic_idx_u8': sem, 'instance': inst, 'pan_of_inst': pan_of_inst,
+             'is_thing': thing_u8, 'void_label': 0, 'max_instances_per_category': max_inst}
+    is_thing = [False] + is_thing_c.tolist()
+    pq_a, pq_b = (PanopticQuality(n, 0, max_inst, offset, is_thing, device='cuda') for _ in range(2))
+    mi_a, mi_b = (MeanIntersectionOverUnion(n, device='cuda') for _ in range(2))
+    assert PanopticQuality.parts_usable(parts, pred, max_inst)
+    for _ in range(2):
+        pq_a.update_with_miou(pred, tgt, mi_a, tsem, max_inst)
+        pq_b.update_with_miou_parts(parts, tgt, mi_b, tsem, max_inst)
+    torch.cuda.synchronize()
+    assert int(pq_a._status) == int(pq_b._status) and int(mi_a._status) == int(mi_b._status)
+    assert (int(pq_a._status) == 0) == (kind in ('noise', 'ragged'))      # (wide ids: categories out of range)
+    assert (int(mi_a._status) != 0) == (kind == 'bad_classes')
+    assert torch.equal(mi_a.confmat, mi_b.confmat) and int(mi_a.confmat.sum()) > 0
+    for name in ('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class'):
+        assert torch.equal(getattr(pq_a, name), getattr(pq_b, name)), name
+
+
+@gpu
 def test_compare_and_accumulate_function(oracle):
     """module-level compare_and_accumulate (reference pq.py:60-179 signature) on the HIP path"""
     from nicr_mt_scene_analysis_amd.metric.pq import compare_and_accumulate
