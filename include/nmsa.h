@@ -611,6 +611,42 @@ int nmsa_loss_cos_emb_bwd_unless(const void* pred, int dtype, const int32_t* ind
 int nmsa_loss_cos_emb_can_keep_dots(int D, int H, int W, int L);
 
 /* ---------------------------------------------------------------------------
+ * a7 / a9  the forms of the same loss classes that no task helper calls (csrc/losses_forms.hip)
+ * nmsa_loss_elementwise_none_*  MSELoss / L1Loss with reduction='none' (loss/mse.py:21-41 else
+ *     branch, loss/l1.py:21-41): out[i] = (pred[i] - target[i])^2 or |pred[i] - target[i]| over n
+ *     contiguous elements, op-math in fp32, rounded once to out_dtype (NMSA_F32 or `dtype` — the
+ *     type promotion of pred and target); kind 0 = MSE, 1 = L1.  _bwd: grad_pred[i] =
+ *     upstream[i] * d out[i] / d pred[i], upstream in upstream_dtype (NMSA_F32 or `dtype`).
+ *     The reference's 2-D [N, C] rows with 'sum' / 'mean' need no entry point of their own:
+ *     sum_n mean_c f = (1 / C) * nmsa_loss_masked_fwd over the n * C elements as one plane.
+ * nmsa_loss_cos_rows_*  CosineEmbeddingLoss on rows with labels (loss/cos_emb.py:21-56 with
+ *     `target_similarity`; torch.nn.CosineEmbeddingLoss, margin 0): input [n_rows, D] in `dtype`,
+ *     target f32 [n_rows, D], labels f32 [n_rows] (+1 similar: 1 - cos; -1 dissimilar:
+ *     max(0, cos - margin); anything else: 0) or NULL (all +1); loss_rows f32 [n_rows] — the
+ *     'none' reduction; 'sum' / 'mean' are the sum of that vector.  _bwd: grad_input =
+ *     upstream[row] * d loss_rows[row] / d input (upstream f32 [n_rows], or ONE f32 scalar when
+ *     upstream_is_scalar != 0). */
+int nmsa_loss_elementwise_none_fwd(const void* pred, int dtype, const float* target, int64_t n,
+                                   int kind, int out_dtype, void* out, nmsa_stream_t stream);
+int nmsa_loss_elementwise_none_bwd(const void* pred, int dtype, const float* target, int64_t n,
+                                   int kind, int upstream_dtype, const void* upstream,
+                                   void* grad_pred, nmsa_stream_t stream);
+int nmsa_loss_cos_rows_fwd(const void* input, int dtype, const float* target, const float* labels,
+                           int64_t n_rows, int D, float margin, float* loss_rows,
+                           nmsa_stream_t stream);
+int nmsa_loss_cos_rows_bwd(const void* input, int dtype, const float* target, const float* labels,
+                           int64_t n_rows, int D, float margin, const float* upstream,
+                           int upstream_is_scalar, void* grad_input, nmsa_stream_t stream);
+/* VonMisesLossBiternion with reduction='none' (loss/vonmises.py:27-51): input [n_rows, 2] in
+ * `dtype`, target f32 [n_rows, 2] -> loss_rows f32 [n_rows] = 1 - exp(kappa (x.y - 1));
+ * _bwd: grad_input = upstream[row] * d loss_rows[row] / d input, upstream f32 [n_rows] */
+int nmsa_loss_vonmises_rows_fwd(const void* input, int dtype, const float* target, int64_t n_rows,
+                                float kappa, float* loss_rows, nmsa_stream_t stream);
+int nmsa_loss_vonmises_rows_bwd(const void* input, int dtype, const float* target, int64_t n_rows,
+                                float kappa, const float* upstream, void* grad_input,
+                                nmsa_stream_t stream);
+
+/* ---------------------------------------------------------------------------
  * a10  the losses of a task helper in one call
  *      InstanceTaskHelper._compute_losses  task_helper/instance.py:92-269
  *      SemanticTaskHelper._compute_losses  task_helper/semantic.py:57-90

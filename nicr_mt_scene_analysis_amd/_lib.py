@@ -130,6 +130,12 @@ _SIGNATURES = {
     'nmsa_loss_cos_emb_fwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     'nmsa_loss_cos_emb_bwd': (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     'nmsa_loss_cos_emb_can_keep_dots': (_i, [_i, _i, _i, _i]),
+    'nmsa_loss_elementwise_none_fwd': (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _vp]),
+    'nmsa_loss_elementwise_none_bwd': (_i, [_vp, _i, _vp, _i64, _i, _i, _vp, _vp, _vp]),
+    'nmsa_loss_cos_rows_fwd': (_i, [_vp, _i, _vp, _vp, _i64, _i, _f, _vp, _vp]),
+    'nmsa_loss_cos_rows_bwd': (_i, [_vp, _i, _vp, _vp, _i64, _i, _f, _vp, _i, _vp, _vp]),
+    'nmsa_loss_vonmises_rows_fwd': (_i, [_vp, _i, _vp, _i64, _f, _vp, _vp]),
+    'nmsa_loss_vonmises_rows_bwd': (_i, [_vp, _i, _vp, _i64, _f, _vp, _vp, _vp]),
     'nmsa_pq_workspace_bytes': (_sz, [_i, _i, _i, _i]),
     'nmsa_pq_update': (_i, [_vp, _vp, _i, _i, _i, _i, _i64, _i64, _i64, _i64,
                             _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _vp, _sz, _i, _vp]),

@@ -3,8 +3,10 @@
 reduction='sum' (what every task helper uses) on [B,H,W] / [B,C,H,W] inputs runs
 in the HIP kernels k_elem_fwd / k_elem_bwd, optionally with the task helpers'
 `pred*mask` folded in (`masked_sum`); 'mean' is the same kernel's sum divided by the pixel
-count.  The 'none' reduction and 2-D [N,C] inputs are not on the hot path and use plain
-torch ops on the device.  Host tensors raise: there is no CPU path.
+count.  Inputs of any other rank go through the same kernels as ONE plane (2-D [N, C] rows:
+sum_n mean_c f = the plane's sum / C); reduction='none' is k_elem_none (csrc/losses_forms.hip).
+Only an empty input or a target that itself asks for a gradient is left to torch ops on the
+device.  Host tensors raise: there is no CPU path.
 """
 from typing import Optional, Tuple
 
@@ -53,8 +55,23 @@ class _ElementwiseLoss(LossBase):
             if self._reduction == 'mean':
                 return loss / n_px, 1           # mean over all elements == sum_px mean_c / n_px
             return loss, n_px
-        # per-element losses ('none') and 2-D [N, C] rows are off the hot path: plain torch ops
-        # ON THE DEVICE
+        plain = input_.numel() > 0 and not target.requires_grad and self._kind in ('mse', 'l1')
+        if plain and self._reduction in ('sum', 'mean'):
+            # any other rank: ONE plane of numel elements through the same kernels.  The reference
+            # averages a 2-D input over its feature axis first (mse.py:30-34): sum_n mean_c f =
+            # (sum over all elements) / C
+            numel = input_.numel()
+            flat = input_.reshape(1, numel, 1)
+            total, _ = F_.masked_elementwise_sum(flat, target.expand_as(input_).reshape(1, numel, 1), None,
+                                                 self._kind, None)
+            if self._reduction == 'mean':
+                return total / numel, 1
+            if input_.ndim == 2:
+                return total / input_.shape[1], input_.shape[0]
+            return total, numel
+        if plain and self._reduction == 'none':
+            return F_.elementwise_none(input_, target, self._kind), input_.numel()
+        # an empty input, or a target that itself asks for a gradient: plain torch ops ON THE DEVICE
         loss = self._pointwise(input_, target.to(input_.device))
         if self._reduction == 'sum':
             if loss.ndim in (2, 4):

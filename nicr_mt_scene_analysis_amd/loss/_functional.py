@@ -427,6 +427,116 @@ def cross_entropy_sum(logits, target, weights=None, label_smoothing=0.0, expecte
 _KINDS = {'mse': 0, 'l1': 1, 'focal': 2}
 
 
+class ElementwiseNoneFunction(torch.autograd.Function):
+    """per-element (pred - target)^2 / |pred - target| (reduction='none', reference
+    loss/mse.py:21-41, l1.py:21-41): csrc/losses_forms.hip k_elem_none"""
+
+    @staticmethod
+    def forward(ctx, pred, target, kind):
+        x = L.require_device_tensor(pred, 'input_')
+        dev = x.device
+        y = target.to(dev, torch.float32).contiguous()
+        if y.shape != x.shape:
+            y = y.expand_as(x).contiguous()
+        # the reference's result has the promoted type of its two operands
+        out_dtype = torch.result_type(pred, target)
+        if out_dtype not in (torch.float32, x.dtype):
+            out_dtype = torch.float32
+        out = torch.empty(x.shape, dtype=out_dtype, device=dev)
+        L.check(L.lib().nmsa_loss_elementwise_none_fwd(
+            L.ptr(x), L.float_dtype_code(x), L.ptr(y), x.numel(), int(kind), L.float_dtype_code(out),
+            L.ptr(out), L.stream_ptr(dev)), 'nmsa_loss_elementwise_none_fwd')
+        ctx.save_for_backward(x, y)
+        ctx.kind = int(kind)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = g.contiguous()
+        grad = torch.empty_like(x)
+        L.check(L.lib().nmsa_loss_elementwise_none_bwd(
+            L.ptr(x), L.float_dtype_code(x), L.ptr(y), x.numel(), ctx.kind, L.float_dtype_code(g),
+            L.ptr(g), L.ptr(grad), L.stream_ptr(x.device)), 'nmsa_loss_elementwise_none_bwd')
+        return grad, None, None
+
+
+class CosineRowsFunction(torch.autograd.Function):
+    """per-row cosine embedding loss of [N, D] rows with labels +1 / -1 (reference
+    loss/cos_emb.py:21-56 with `target_similarity`; margin 0): csrc/losses_forms.hip k_cos_rows"""
+
+    @staticmethod
+    def forward(ctx, input_, target, labels):
+        x = L.require_device_tensor(input_, 'input_')
+        dev = x.device
+        n, d = x.shape
+        y = target.to(dev, torch.float32).contiguous()
+        lab = None if labels is None else labels.to(dev, torch.float32).contiguous()
+        if lab is not None and lab.numel() != n:
+            raise ValueError(f'target_similarity holds {lab.numel()} labels for {n} rows')
+        rows = torch.empty((n,), dtype=torch.float32, device=dev)
+        L.check(L.lib().nmsa_loss_cos_rows_fwd(
+            L.ptr(x), L.float_dtype_code(x), L.ptr(y), None if lab is None else L.ptr(lab), n, d, 0.0,
+            L.ptr(rows), L.stream_ptr(dev)), 'nmsa_loss_cos_rows_fwd')
+        ctx.save_for_backward(x, y, lab if lab is not None else torch.empty(0, device=dev))
+        ctx.has_labels = lab is not None
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y, lab = ctx.saved_tensors
+        n, d = x.shape
+        # `rows.sum()` hands over one value for every row (a stride-0 view): passed as a scalar
+        scalar = g.numel() > 0 and g.stride(0) == 0
+        up = (g.reshape(-1)[:1] if scalar else g).to(torch.float32).contiguous()
+        grad = torch.empty_like(x)
+        L.check(L.lib().nmsa_loss_cos_rows_bwd(
+            L.ptr(x), L.float_dtype_code(x), L.ptr(y), L.ptr(lab) if ctx.has_labels else None, n, d, 0.0,
+            L.ptr(up), int(scalar), L.ptr(grad), L.stream_ptr(x.device)), 'nmsa_loss_cos_rows_bwd')
+        return grad, None, None
+
+
+class VonMisesRowsFunction(torch.autograd.Function):
+    """per-row 1 - exp(kappa (x.y - 1)) of biternion rows [N, 2] (reduction='none', reference
+    loss/vonmises.py:27-51): csrc/losses_forms.hip k_vm_rows"""
+
+    @staticmethod
+    def forward(ctx, input_, target, kappa):
+        x = L.require_device_tensor(input_, 'input_')
+        dev = x.device
+        n = x.shape[0]
+        y = target.to(dev, torch.float32).contiguous()
+        rows = torch.empty((n, 1), dtype=torch.float32, device=dev)
+        L.check(L.lib().nmsa_loss_vonmises_rows_fwd(
+            L.ptr(x), L.float_dtype_code(x), L.ptr(y), n, float(kappa), L.ptr(rows), L.stream_ptr(dev)),
+            'nmsa_loss_vonmises_rows_fwd')
+        ctx.save_for_backward(x, y)
+        ctx.kappa = float(kappa)
+        return rows
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        up = g.to(torch.float32).contiguous()
+        grad = torch.empty_like(x)
+        L.check(L.lib().nmsa_loss_vonmises_rows_bwd(
+            L.ptr(x), L.float_dtype_code(x), L.ptr(y), x.shape[0], ctx.kappa, L.ptr(up), L.ptr(grad),
+            L.stream_ptr(x.device)), 'nmsa_loss_vonmises_rows_bwd')
+        return grad, None, None
+
+
+def vonmises_rows(input_, target, kappa: float) -> torch.Tensor:
+    return VonMisesRowsFunction.apply(input_, target, kappa)
+
+
+def elementwise_none(pred, target, kind: str) -> torch.Tensor:
+    return ElementwiseNoneFunction.apply(pred, target, _KINDS[kind])
+
+
+def cosine_embedding_rows(input_, target, labels=None) -> torch.Tensor:
+    return CosineRowsFunction.apply(input_, target, labels)
+
+
 def masked_elementwise_sum(pred, target, mask, kind: str, expected_scale=None
                            ) -> Tuple[torch.Tensor, torch.Tensor]:
     return MaskedElementwiseFunction.apply(pred, target, mask, _KINDS[kind], expected_scale)

@@ -34,11 +34,12 @@ class CosineEmbeddingLoss(LossBase):
         # fit the registers; the backward kernel reads the saved dot products instead)
         L.require_device_tensor(input_, 'input_')        # no CPU path: raises for host tensors
         n, d = input_.shape
-        # the HIP kernel covers similar pairs (label +1) with 'sum' / 'mean' — what the task
-        # helper uses.  Explicit labels (dissimilar pairs), per-row losses ('none') and a target
-        # that itself asks for a gradient are off the hot path: ATen's op ON THE DEVICE.
+        # similar pairs (label +1) with 'sum' / 'mean' — what the task helper uses — run the LUT
+        # kernel below.  Explicit labels (dissimilar pairs) and per-row losses ('none') run the
+        # row kernel k_cos_rows (csrc/losses_forms.hip).  Only an empty input or a target that
+        # itself asks for a gradient is left to ATen's op ON THE DEVICE.
         labelled = target_similarity is not None
-        if labelled or self._reduction == 'none' or n == 0 or target.requires_grad:
+        if n == 0 or target.requires_grad:
             labels = target_similarity if labelled else torch.ones(n, device=input_.device)
             loss = torch.nn.functional.cosine_embedding_loss(
                 input_, target.to(input_.device), labels.to(input_.device), reduction='none')
@@ -47,6 +48,16 @@ class CosineEmbeddingLoss(LossBase):
             if self._reduction == 'mean':
                 return loss.mean(), 1
             return loss, input_.numel()
+        if labelled or self._reduction == 'none':
+            rows = F_.cosine_embedding_rows(input_, target, target_similarity)
+            out_dtype = torch.result_type(input_, target)
+            if rows.dtype != out_dtype and out_dtype in (torch.bfloat16, torch.float16):
+                rows = rows.to(out_dtype)
+            if self._reduction == 'sum':
+                return rows.sum(), rows.numel()
+            if self._reduction == 'mean':
+                return rows.mean(), 1
+            return rows, input_.numel()
         # rows (n, d): prediction planar (1, d, n, 1); the targets are their own LUT
         x = input_.t().contiguous().view(1, d, n, 1)
         idx = torch.arange(1, n + 1, dtype=torch.int32, device=input_.device).view(1, n, 1)

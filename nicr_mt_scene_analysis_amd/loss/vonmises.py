@@ -35,11 +35,17 @@ class VonMisesLossBiternion(LossBase):
                 "(b*h*w, 2) first, or call masked_sum() with the planar tensors")
         L.require_device_tensor(input_, 'input_')        # no CPU path: raises for host tensors
         n = input_.shape[0]
-        if self._reduction == 'none' or n == 0 or target.requires_grad:
-            # per-row losses are off the hot path: plain torch ops ON THE DEVICE
+        if n == 0 or target.requires_grad:
+            # an empty input, or a target that itself asks for a gradient: torch ops ON THE DEVICE
             cos = (input_ * target.to(input_.device)).sum(dim=1, keepdim=True)
             score = 1 - torch.exp(self._kappa * (cos - 1))
             return (score.sum() if self._reduction == 'sum' else score), score.numel()
+        if self._reduction == 'none':
+            if input_.shape[1] != 2:
+                raise ValueError(f'expected biternion rows of shape (n, 2), got {tuple(input_.shape)}')
+            rows = F_.vonmises_rows(input_, target, self._kappa)          # k_vm_rows: [n, 1] like the reference's
+            out_dtype = torch.result_type(input_, target)
+            return (rows.to(out_dtype) if out_dtype in (torch.bfloat16, torch.float16) else rows), n
         # rows (n, 2) -> planar (1, 2, n, 1) for the kernel (autograd carries the transpose)
         x = input_.t().contiguous().view(1, 2, n, 1)
         y = target.t().contiguous().view(1, 2, n, 1)

@@ -548,6 +548,49 @@ def gen_losses(ref):
     save('loss_cases', **out)
 
 
+def gen_loss_forms(ref):
+    """the forms of the loss classes no task helper calls: reduction none / sum / mean on 2-D, 3-D
+    and 4-D inputs (mse.py:21-41, l1.py:21-41) and labelled cosine pairs (cos_emb.py:21-56)"""
+    print('loss forms (reductions x ranks of MSE / L1, labelled cosine rows; with autograd grads)')
+    rng = np.random.default_rng(77)
+    out = {}
+    shapes = {'r2': (7, 5), 'r3': (2, 6, 8), 'r4': (2, 3, 6, 8)}
+    for rk, shp in shapes.items():
+        out[f'{rk}__x'] = rng.standard_normal(shp).astype(np.float32)
+        out[f'{rk}__t'] = rng.standard_normal(shp).astype(np.float32)
+        out[f'{rk}__w'] = rng.standard_normal(shp).astype(np.float32)      # upstream of the 'none' form
+    for kind, cls in (('mse', ref.loss_mse.MSELoss), ('l1', ref.loss_l1.L1Loss)):
+        for rk in shapes:
+            for red in ('none', 'sum', 'mean'):
+                x = torch.from_numpy(out[f'{rk}__x']).clone().requires_grad_(True)
+                t = torch.from_numpy(out[f'{rk}__t'])
+                (loss, n), = cls(reduction=red)([x], [t])
+                (loss * torch.from_numpy(out[f'{rk}__w'])).sum().backward() if red == 'none' else loss.backward()
+                out[f'{kind}_{rk}_{red}__loss'] = loss.detach().numpy().astype(np.float32)
+                out[f'{kind}_{rk}_{red}__n'] = np.int64(n)
+                out[f'{kind}_{rk}_{red}__grad'] = x.grad.numpy()
+    N, D = 11, 16
+    out['cos__x'] = rng.standard_normal((N, D)).astype(np.float32)
+    tgt = rng.standard_normal((N, D)).astype(np.float32)
+    tgt[:4] = out['cos__x'][:4] + 0.3 * tgt[:4]                # some similar pairs, some not
+    tgt[4:6] = -out['cos__x'][4:6] + 0.2 * tgt[4:6]            # opposite directions: the clamp is active
+    out['cos__t'] = tgt
+    out['cos__labels'] = np.array([1, -1, 1, -1, -1, 1, -1, 0, 1, -1, -1], dtype=np.float32)
+    out['cos__w'] = rng.standard_normal((N,)).astype(np.float32)
+    for lab in ('labelled', 'plain'):
+        for red in ('none', 'sum', 'mean'):
+            x = torch.from_numpy(out['cos__x']).clone().requires_grad_(True)
+            fn = ref.loss_cos_emb.CosineEmbeddingLoss(reduction=red)
+            args = (x, torch.from_numpy(out['cos__t'])) + \
+                ((torch.from_numpy(out['cos__labels']),) if lab == 'labelled' else ())
+            loss, n = fn._compute_loss(*args)
+            (loss * torch.from_numpy(out['cos__w'])).sum().backward() if red == 'none' else loss.backward()
+            out[f'cos_{lab}_{red}__loss'] = loss.detach().numpy().astype(np.float32)
+            out[f'cos_{lab}_{red}__n'] = np.int64(n)
+            out[f'cos_{lab}_{red}__grad'] = x.grad.numpy()
+    save('loss_forms', **out)
+
+
 def gen_argmax_ties(ref):
     """a1 boundary: the reference takes max(softmax(x)) (model/postprocessing/semantic.py:52-53),
     the kernels take argmax(x).  Adversarial columns: classes c1 < c2 with x[c2] = x[c1] + k ulp,
@@ -1187,6 +1230,8 @@ def main():
         gen_metrics(ref)
     if want('losses'):
         gen_losses(ref)
+    if want('loss_forms'):
+        gen_loss_forms(ref)
     if want('argmax_ties'):
         gen_argmax_ties(ref)
     if want('cos_emb_large'):

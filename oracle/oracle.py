@@ -286,6 +286,47 @@ def loss_cosine_embedding(pred, indices, lut, want_grad=False):
     return s.value, n.value, grad
 
 
+def loss_elementwise_form(pred, target, kind, reduction, upstream=None):
+    """MSELoss / L1Loss for every reduction and rank (reference loss/mse.py:21-41, l1.py:21-41):
+    per-element f = (pred - target)^2 | |pred - target|; 'sum': 2-D / 4-D inputs are averaged over
+    axis 1 first (mse.py:30-34), n = elements left; 'mean': mean of f, n = 1; 'none': f itself,
+    n = pred.size.  -> (loss, n, d(sum(loss * upstream)) / d pred); plain numpy in fp64."""
+    x = np.asarray(pred, np.float64)
+    d = x - np.asarray(target, np.float64)
+    f = d * d if kind == 'mse' else np.abs(d)
+    df = 2.0 * d if kind == 'mse' else np.sign(d)
+    if reduction == 'none':
+        return f, x.size, df * (1.0 if upstream is None else np.asarray(upstream, np.float64))
+    if reduction == 'mean':
+        return f.mean(), 1, df / x.size
+    if x.ndim in (2, 4):
+        return f.mean(axis=1).sum(), x.size // x.shape[1], df / x.shape[1]
+    return f.sum(), x.size, df
+
+
+def loss_cosine_rows(input_, target, labels, reduction, upstream=None):
+    """CosineEmbeddingLoss on [N, D] rows with labels (reference loss/cos_emb.py:21-56: the wrapped
+    torch.nn.CosineEmbeddingLoss(reduction='none'), margin 0): cos = x.y / sqrt((|x|^2 + 1e-12)
+    (|y|^2 + 1e-12)); +1: 1 - cos; -1: max(0, cos); labels None = all +1.
+    -> (loss, n, gradient w.r.t. input_ of sum(loss * upstream)); plain numpy in fp64."""
+    x = np.asarray(input_, np.float64)
+    y = np.asarray(target, np.float64)
+    lab = np.ones(x.shape[0]) if labels is None else np.asarray(labels, np.float64)
+    m1 = (x * x).sum(1) + 1e-12
+    m2 = (y * y).sum(1) + 1e-12
+    den = np.sqrt(m1 * m2)
+    c = (x * y).sum(1) / den
+    rows = np.where(lab == 1, 1.0 - c, 0.0) + np.where(lab == -1, np.maximum(c, 0.0), 0.0)
+    dc = y / den[:, None] - (c / m1)[:, None] * x
+    sgn = np.where(lab == 1, -1.0, np.where((lab == -1) & (c >= 0), 1.0, 0.0))
+    if reduction == 'none':
+        up = np.ones_like(rows) if upstream is None else np.asarray(upstream, np.float64)
+        return rows, x.size, (sgn * up)[:, None] * dc
+    if reduction == 'mean':
+        return rows.mean(), 1, (sgn / rows.size)[:, None] * dc
+    return rows.sum(), rows.size, sgn[:, None] * dc
+
+
 # -- f2: crop + resize (dense_base.py:15-58) -------------------------------------
 def _crop_args(shape, crop):
     Hs, Ws = shape[-2:]

@@ -397,3 +397,108 @@ def test_ce_rejects_more_than_4096_classes_and_flags_bad_labels():
         with pytest.raises(IndexError, match='out of range'):
             check_loss_status()
     check_loss_status()                                  # the word was cleared
+
+
+def test_loss_forms_vs_golden(oracle, monkeypatch):
+    """the forms of MSELoss / L1Loss / CosineEmbeddingLoss no task helper calls — reduction none /
+    sum / mean on 2-D, 3-D and 4-D inputs (reference mse.py:21-41, l1.py:21-41), labelled cosine
+    pairs (cos_emb.py:21-56) — against the reference-run fixture and the fp64 oracle, through the
+    library (ATen's cosine op and the torch subtraction of the old fallback are made to raise)"""
+    from nicr_mt_scene_analysis_amd import loss as L_
+    from nicr_mt_scene_analysis_amd.loss import _elementwise
+    g = load('loss_forms')
+
+    def no_torch(*a, **k):
+        raise AssertionError('this form must run in the library')
+    monkeypatch.setattr(torch.nn.functional, 'cosine_embedding_loss', no_torch)
+    monkeypatch.setattr(_elementwise._ElementwiseLoss, '_pointwise', no_torch)
+    for kind, cls in (('mse', L_.MSELoss), ('l1', L_.L1Loss)):
+        for rk in ('r2', 'r3', 'r4'):
+            for red in ('none', 'sum', 'mean'):
+                key = f'{kind}_{rk}_{red}'
+                x = dev(g[f'{rk}__x']).requires_grad_(True)
+                (loss, n), = cls(reduction=red)([x], [dev(g[f'{rk}__t'])])
+                ((loss * dev(g[f'{rk}__w'])).sum() if red == 'none' else loss).backward()
+                np.testing.assert_allclose(loss.detach().cpu().numpy(), g[key + '__loss'], rtol=1e-5,
+                                           atol=1e-7, err_msg=key)
+                assert int(n) == int(g[key + '__n']), key
+                np.testing.assert_allclose(x.grad.cpu().numpy(), g[key + '__grad'], rtol=1e-5, atol=1e-7,
+                                           err_msg=key)
+                o_loss, o_n, o_grad = oracle.loss_elementwise_form(g[f'{rk}__x'], g[f'{rk}__t'], kind, red,
+                                                                   g[f'{rk}__w'])
+                np.testing.assert_allclose(loss.detach().cpu().numpy(), o_loss, rtol=1e-5, atol=1e-7)
+                np.testing.assert_allclose(x.grad.cpu().numpy(), o_grad, rtol=1e-5, atol=1e-7)
+    for lab in ('labelled', 'plain'):
+        for red in ('none', 'sum', 'mean'):
+            key = f'cos_{lab}_{red}'
+            x = dev(g['cos__x']).requires_grad_(True)
+            fn = L_.CosineEmbeddingLoss(reduction=red)
+            args = (x, dev(g['cos__t'])) + ((dev(g['cos__labels']),) if lab == 'labelled' else ())
+            loss, n = fn._compute_loss(*args)
+            ((loss * dev(g['cos__w'])).sum() if red == 'none' else loss).backward()
+            np.testing.assert_allclose(loss.detach().cpu().numpy(), g[key + '__loss'], rtol=1e-5, atol=1e-6,
+                                       err_msg=key)
+            assert int(n) == int(g[key + '__n']), key
+            np.testing.assert_allclose(x.grad.cpu().numpy(), g[key + '__grad'], rtol=1e-4, atol=1e-6,
+                                       err_msg=key)
+
+
+@pytest.mark.parametrize('dtype', [torch.bfloat16, torch.float16])
+def test_loss_forms_16_bit_inputs(dtype):
+    """the same forms on 16-bit predictions: op-math in fp32, one rounding to the promoted type
+    (what ATen does), gradients in the prediction's type — against torch's own ops on the device"""
+    from nicr_mt_scene_analysis_amd import loss as L_
+    g = torch.Generator(device='cuda').manual_seed(3)
+    x0 = torch.randn((5, 3, 9, 7), device='cuda', generator=g).to(dtype)
+    for t_dtype in (torch.float32, dtype):
+        t = torch.randn((5, 3, 9, 7), device='cuda', generator=g).to(t_dtype)
+        w = torch.randn((5, 3, 9, 7), device='cuda', generator=g)
+        for kind, cls, ref in (('mse', L_.MSELoss, torch.nn.functional.mse_loss),
+                               ('l1', L_.L1Loss, torch.nn.functional.l1_loss)):
+            x = x0.clone().requires_grad_(True)
+            (loss, n), = cls(reduction='none')([x], [t])
+            xr = x0.clone().requires_grad_(True)
+            want = ref(xr, t, reduction='none') if t_dtype == dtype else ref(xr.float(), t, reduction='none')
+            assert loss.dtype == want.dtype and n == x0.numel()
+            # (ATen's 16-bit kernel rounds the difference before it squares it: two roundings)
+            torch.testing.assert_close(loss, want, rtol=2e-2 if t_dtype == dtype else 1e-6, atol=1e-3 if t_dtype == dtype else 1e-6)
+            (loss.float() * w).sum().backward()
+            (want.float() * w).sum().backward()
+            torch.testing.assert_close(x.grad.float(), xr.grad.float(), rtol=2e-2, atol=1e-3)
+    rows = torch.randn((33, 48), device='cuda', generator=g).to(dtype)
+    tgt = torch.randn((33, 48), device='cuda', generator=g)
+    lab = torch.where(torch.rand(33, device='cuda', generator=g) < 0.5, 1.0, -1.0)
+    x = rows.clone().requires_grad_(True)
+    loss, n = L_.CosineEmbeddingLoss(reduction='sum')._compute_loss(x, tgt, lab)
+    loss.backward()
+    xr = rows.float().clone().requires_grad_(True)
+    want = torch.nn.functional.cosine_embedding_loss(xr, tgt, lab, reduction='sum')
+    want.backward()
+    assert n == 33
+    torch.testing.assert_close(loss.float(), want, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(x.grad.float(), xr.grad, rtol=2e-2, atol=2e-3)
+
+
+@pytest.mark.parametrize('dtype', [torch.float32, torch.bfloat16])
+def test_vonmises_rows_none_vs_torch(dtype, monkeypatch):
+    """VonMisesLossBiternion(reduction='none') on biternion rows (reference vonmises.py:27-51): the
+    row kernel against the reference's three torch lines, loss [n, 1] and gradient"""
+    from nicr_mt_scene_analysis_amd.loss import VonMisesLossBiternion
+    g = torch.Generator(device='cuda').manual_seed(11)
+    ang = torch.rand((1000, 2), device='cuda', generator=g) * 6.28
+    rows = torch.stack([torch.cos(ang[:, 0]), torch.sin(ang[:, 0])], 1).to(dtype)
+    tgt = torch.stack([torch.cos(ang[:, 1]), torch.sin(ang[:, 1])], 1)
+    w = torch.randn((1000, 1), device='cuda', generator=g)
+    for kappa in (1.0, 2.5):
+        xr = rows.float().clone().requires_grad_(True)
+        want = 1 - torch.exp(kappa * ((xr * tgt).sum(dim=1, keepdim=True) - 1))
+        (want * w).sum().backward()
+        monkeypatch.setattr(torch, 'exp', None)          # the library's path calls no torch.exp
+        x = rows.clone().requires_grad_(True)
+        (loss, n), = VonMisesLossBiternion(kappa=kappa, reduction='none')([x], [tgt])
+        monkeypatch.undo()
+        assert loss.shape == (1000, 1) and n == 1000 and loss.dtype == torch.float32
+        (loss * w).sum().backward()
+        torch.testing.assert_close(loss, want.detach(), rtol=1e-5, atol=1e-6)
+        tol = dict(rtol=1e-5, atol=1e-6) if dtype == torch.float32 else dict(rtol=2e-2, atol=2e-3)
+        torch.testing.assert_close(x.grad.float(), xr.grad, **tol)

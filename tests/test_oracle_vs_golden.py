@@ -230,6 +230,30 @@ def test_losses(oracle):
     np.testing.assert_allclose(grad, g['cos_emb__grad'], rtol=1e-4, atol=1e-6)
 
 
+def test_loss_forms(oracle):
+    """the reductions / ranks / labelled pairs no task helper uses (reference-run fixture
+    loss_forms.npz: mse.py:21-41, l1.py:21-41, cos_emb.py:21-56)"""
+    g = load('loss_forms')
+    for kind in ('mse', 'l1'):
+        for rk in ('r2', 'r3', 'r4'):
+            for red in ('none', 'sum', 'mean'):
+                loss, n, grad = oracle.loss_elementwise_form(g[f'{rk}__x'], g[f'{rk}__t'], kind, red,
+                                                             g[f'{rk}__w'])
+                key = f'{kind}_{rk}_{red}'
+                np.testing.assert_allclose(loss, g[key + '__loss'], rtol=2e-6, atol=1e-7, err_msg=key)
+                assert n == g[key + '__n'], key
+                np.testing.assert_allclose(grad, g[key + '__grad'], rtol=1e-5, atol=1e-7, err_msg=key)
+    for lab in ('labelled', 'plain'):
+        for red in ('none', 'sum', 'mean'):
+            loss, n, grad = oracle.loss_cosine_rows(g['cos__x'], g['cos__t'],
+                                                    g['cos__labels'] if lab == 'labelled' else None,
+                                                    red, g['cos__w'])
+            key = f'cos_{lab}_{red}'
+            np.testing.assert_allclose(loss, g[key + '__loss'], rtol=1e-5, atol=1e-6, err_msg=key)
+            assert n == g[key + '__n'], key
+            np.testing.assert_allclose(grad, g[key + '__grad'], rtol=1e-4, atol=1e-6, err_msg=key)
+
+
 def test_argmax_tie_band_boundary(oracle):
     """a1: the reference takes max(softmax(x)) (semantic.py:52-53).  softmax is monotone, so that
     is argmax(x) with first-index ties — except where a lower-indexed class sits so close below
