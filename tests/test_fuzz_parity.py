@@ -284,6 +284,70 @@ def test_fuzz_metrics_vs_oracle(oracle, seed, B, H, W, n_cat, n_seg):
 
 @settings(max_examples=_n(120), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), B=st.integers(1, 3), H=st.integers(3, 70),
+       W=st.sampled_from([5, 16, 31, 64, 130, 256, 517]), C=st.integers(2, 12), n_seg=st.integers(1, 12),
+       max_inst=st.sampled_from([1 << 16, 1000]), noise=st.booleans())
+@example(seed=3, B=2, H=64, W=256, C=5, n_seg=9, max_inst=1 << 16, noise=True)     # > 1024 pairs in a workgroup
+def test_fuzz_pq_from_the_parts_vs_oracle(oracle, seed, B, H, W, C, n_seg, max_inst, noise):
+    """k_pq_count_parts (compact keys; full tiles, single steps, the ragged rest): the prediction
+    given as class u8 / instance u8 / pan_of_inst, PQ states and confusion matrix bit-exact vs the
+    oracle on the map the parts paint"""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
+    rng = np.random.default_rng(seed)
+    n = C + 1
+    offset = 256 ** 3 if max_inst == 1 << 16 else 10 ** 7
+    thing_c = rng.integers(0, 2, C).astype(bool)
+
+    def rects(hi, fill=None):
+        out = np.zeros((B, H, W), np.int64) if fill is None else fill.copy()
+        for b in range(B):
+            for _ in range(n_seg):
+                y0, x0 = rng.integers(0, H), rng.integers(0, W)
+                y1, x1 = rng.integers(y0, H) + 1, rng.integers(x0, W) + 1
+                out[b, y0:y1, x0:x1] = rng.integers(0, hi)
+        return out
+    sem = rects(C).astype(np.uint8)
+    inst = (rects(7) * thing_c[sem]).astype(np.uint8)                    # instances on thing classes only
+    pan_of_inst = np.zeros((B, 256), np.int64)
+    pan_of_inst[:, 1:7] = rng.integers(1, n, (B, 6)) * max_inst + np.arange(1, 7)
+    tgt = rects(n) * max_inst + rects(3)
+    tsem = rects(n).astype(np.uint8)
+    if noise:                                                            # incoherent pixels: many pairs, no runs
+        k = rng.random((B, H, W)) < 0.5
+        tgt[k] = (rng.integers(0, n, k.sum()) * max_inst + rng.integers(0, 9, k.sum()))
+        tsem[k] = rng.integers(0, n, k.sum())
+    pred = np.where(inst > 0, np.take_along_axis(pan_of_inst, inst.reshape(B, -1).astype(np.int64), 1).reshape(B, H, W),
+                    np.where(thing_c[sem], 0, (sem.astype(np.int64) + 1) * max_inst))       # nmsa_panoptic_paint's rule
+    d_pred = torch.empty((B, H, W), dtype=torch.int64, device='cuda')
+    L_ = ops.L
+    d_sem, d_inst, d_poi, d_thing = dev(sem), dev(inst), dev(pan_of_inst), dev(thing_c.astype(np.uint8))
+    L_.check(L_.lib().nmsa_panoptic_paint(L_.ptr(d_sem), L_.ptr(d_inst), L_.ptr(d_poi), L_.ptr(d_thing), B, C, H, W,
+                                          max_inst, 0, L_.ptr(d_pred), None, L_.stream_ptr(d_pred.device)),
+             'nmsa_panoptic_paint')
+    assert np.array_equal(d_pred.cpu().numpy(), pred)
+    parts = {'panoptic': d_pred, 'semantic_idx_u8': d_sem, 'instance': d_inst, 'pan_of_inst': d_poi,
+             'is_thing': d_thing, 'void_label': 0, 'max_instances_per_category': max_inst}
+    is_thing = [False] + thing_c.tolist()
+    pq = PanopticQuality(n, 0, max_inst, offset, is_thing, device='cuda')
+    miou = MeanIntersectionOverUnion(n, device='cuda')
+    assert PanopticQuality.parts_usable(parts, d_pred, max_inst)
+    pq.update_with_miou_parts(parts, dev(tgt), miou, dev(tsem), max_inst)
+    torch.cuda.synchronize()
+    if noise and H * W >= 4096 and int(pq._status):
+        pq._status.zero_()          # more distinct intersections than the image's table holds: reported, not counted
+        return
+    state = None
+    for b in range(B):
+        *state, _ = oracle.pq_compare_and_accumulate(pred[b], tgt[b], n, 0, max_inst, offset, state=state)
+    for g_, w in zip([pq.iou_per_class, pq.tp_per_class, pq.fn_per_class, pq.fp_per_class], state):
+        assert np.array_equal(g_.cpu().numpy(), np.asarray(w, dtype=np.float64)), (seed, B, H, W)
+    assert np.array_equal(miou.confmat.cpu().numpy(), oracle.confmat_update(pred // max_inst, tsem, n))
+    assert int(pq._status) == 0 and int(miou._status) == 0
+
+
+@settings(max_examples=_n(120), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), Hs=st.integers(1, 40), Ws=st.integers(1, 48),
        Ho=st.integers(1, 70), Wo=st.integers(1, 90), C=st.integers(1, 6))
 def test_fuzz_resize_vs_oracle(oracle, seed, Hs, Ws, Ho, Wo, C):
