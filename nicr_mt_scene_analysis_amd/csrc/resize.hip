@@ -376,7 +376,12 @@ __global__ __launch_bounds__(RZ_TW * RZ_TH) void k_argmax_resized(
 #ifndef NMSA_LT_TH
 #define NMSA_LT_TH 16
 #endif
-constexpr int LT_TW = 64, LT_TH = NMSA_LT_TH, LT_THREADS = 16 * NMSA_LT_TH;
+#ifndef NMSA_LT_TW
+#define NMSA_LT_TW 64
+#endif
+// a wave = 64 output columns x 4 output rows; a workgroup = (LT_TW / 64) x (LT_TH / 4) waves
+constexpr int LT_TW = NMSA_LT_TW, LT_TH = NMSA_LT_TH, LT_THREADS = NMSA_LT_TW * NMSA_LT_TH / 4;
+static_assert(LT_TW % 64 == 0 && LT_TH % 4 == 0 && LT_THREADS <= 1024, "tile of whole waves");
 // classes per chunk and LDS buffers of the ring (k_resized_tile): 4 x 2 for the score mode
 // (groups of four classes), 2 x 4 otherwise — the same bytes of LDS either way
 #ifndef NMSA_LT_CH
@@ -470,6 +475,7 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     const int p_begin = grp * group;
     const int C = min(group, planes - p_begin);        // planes (classes) of this tile
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int wvx = wv % (LT_TW / 64), wvy = wv / (LT_TW / 64);       // the wave's place in the tile
 
     // ---- tile footprint in the source (block-uniform) --------------------------------------
     int xs0, xs1, ys0, ys1, ti;
@@ -485,7 +491,7 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     const int n_pieces = PR * SHt;                     // <= K16 * 256 (host-checked bound)
 
     // ---- this thread's 4 output pixels ---------------------------------------------------------
-    const int x = tx * LT_TW + lane;
+    const int x = tx * LT_TW + wvx * 64 + lane;
     int ix0, ix1;
     float wx0, wx1;
     bilinear_src(g.sx, min(x, g.Wo - 1), g.w, ix0, ix1, wx0, wx1);
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     float wy0[4], wy1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        yy[j] = ty * LT_TH + wv * 4 + j;
+        yy[j] = ty * LT_TH + wvy * 4 + j;
         int iy0, iy1;
         bilinear_src(g.sy, min(yy[j], g.Ho - 1), g.h, iy0, iy1, wy0[j], wy1[j]);
         r0[j] = (iy0 - ys0) * P;
@@ -660,7 +666,7 @@ int plan_tiles(const CropResize& g, int elem_bytes)
 {
     if (getenv("NMSA_RESIZE_NO_LDS")) return 0;
     // ix1(last) - ix0(first) + 1 <= 63*sx + 3 (+1 slack for the float rounding of the indices)
-    const long long sw = (long long)(63.0f * g.sx) + 4, sh = (long long)((LT_TH - 1) * g.sy) + 4;
+    const long long sw = (long long)((float)(LT_TW - 1) * g.sx) + 4, sh = (long long)((LT_TH - 1) * g.sy) + 4;
     const int epp = 16 / elem_bytes;
     const long long pr = (sw + epp - 1) / epp;
     if (pr * sh > 2 * LT_THREADS) return 0;
