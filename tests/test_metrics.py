@@ -344,6 +344,52 @@ def test_own_miou_void_handling(n_classes_without_void):
 
 
 @gpu
+@pytest.mark.parametrize('mode', ['plain', 'masked_void'])
+@pytest.mark.parametrize('kind', ['coherent', 'noise', 'flat', 'ragged', 'bad'])
+def test_confmat_uint8_maps_vs_oracle(oracle, kind, mode):
+    """k_confmat_u8 (both maps uint8: 16 px per lane, runs merged in registers): equal to the
+    oracle and to the general kernel on int64 copies of the maps — coherent label maps, incoherent
+    pixels, a single bin (the wave-uniform shortcut), a size whose end falls inside a lane's 16
+    pixels, and a class beyond the matrix (status)"""
+    from nicr_mt_scene_analysis_amd import metric
+    n = 41
+    rng = np.random.default_rng(len(kind) * 7 + len(mode))
+    shape = (3, 97, 131) if kind == 'ragged' else (4, 96, 256)
+    if kind in ('coherent', 'ragged', 'bad'):
+        cell = rng.integers(0, n, (shape[0], (shape[1] + 15) // 16, (shape[2] + 31) // 32))
+        pred = np.repeat(np.repeat(cell, 16, 1), 32, 2)[:, :shape[1], :shape[2]]
+        cell = rng.integers(0, n, (shape[0], (shape[1] + 23) // 24, (shape[2] + 23) // 24))
+        tgt = np.repeat(np.repeat(cell, 24, 1), 24, 2)[:, :shape[1], :shape[2]]
+    elif kind == 'noise':
+        pred, tgt = rng.integers(0, n, shape), rng.integers(0, n, shape)
+    else:
+        pred, tgt = np.full(shape, 7), np.full(shape, 9)
+    pred, tgt = np.ascontiguousarray(pred).astype(np.uint8), np.ascontiguousarray(tgt).astype(np.uint8)
+    if kind == 'bad':
+        pred[1, 5, 77] = 250
+        tgt[2, 90, 3] = 99
+    a = metric.MeanIntersectionOverUnion(n)
+    b = metric.MeanIntersectionOverUnion(n)
+    upd = (lambda m, p, t: m.update_masked_void(p, t)) if mode == 'masked_void' else (lambda m, p, t: m.update(p, t))
+    for _ in range(2):
+        upd(a, T(pred), T(tgt))
+        upd(b, T(pred.astype(np.int64)), T(tgt.astype(np.int64)))
+    torch.cuda.synchronize()
+    assert torch.equal(a.confmat, b.confmat) and int(a._status) == int(b._status)
+    assert (int(a._status) != 0) == (kind == 'bad')
+    if kind != 'bad':
+        if mode == 'masked_void':
+            keep = tgt != 0
+            want = oracle.confmat_update(pred[keep], tgt[keep] - 1, n)
+        else:
+            want = oracle.confmat_update(pred, tgt, n)
+        assert np.array_equal(a.confmat.cpu().numpy(), 2 * want)
+        assert int(a.confmat.sum()) > 0
+    a._status.zero_()
+    b._status.zero_()
+
+
+@gpu
 def test_miou_out_of_range_raises():
     from nicr_mt_scene_analysis_amd import metric
     m = metric.MeanIntersectionOverUnion(4)
