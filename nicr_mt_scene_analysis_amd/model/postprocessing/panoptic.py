@@ -10,6 +10,7 @@ offset grouping + per-instance class votes), the per-instance class/rank
 assignment and the paint kernel; everything stays on the GPU and the Python
 dicts (`..._ids`, `..._instance_meta`) are built from one small D2H copy.
 """
+import os
 from typing import Dict, List, Tuple
 
 import numpy as np
@@ -40,6 +41,8 @@ class _HostTables:
             self._fetch = None
         return self._host
 
+
+_PACK_VIA_DEVICE = os.environ.get('NMSA_PACK_VIA_DEVICE', '0') == '1'
 
 class PanopticPostprocessing(DensePostprocessingBase):
     def __init__(
@@ -279,19 +282,26 @@ class PanopticPostprocessing(DensePostprocessingBase):
         ki = min(kc, p['ids_pan'].shape[1])
         ka = min(kc + 1, p['area'].shape[1])
         dev = p['center_scores'].device
-        flat_dev = torch.empty((B, 2 + 3 * kc + ka + 2 * ki), dtype=torch.float64, device=dev)
+        shape = (B, 2 + 3 * kc + ka + 2 * ki)
         L = ops.L
+        # pinned buffers come from a small ring owned by this object: allocating pinned memory per
+        # call is slow, and the caching host allocator cannot recycle a block while the host runs
+        # ahead of the GPU.  A slot that is reused while its previous result has not been read yet
+        # first hands that result a private copy.
+        slot = self._pinned_slot(shape)
+        flat_host = slot['buffer']
+        # The pack kernel stores the table STRAIGHT into the pinned host buffer (pinned memory is
+        # mapped into the device's address space at the same address): no device staging tensor and
+        # no copy kernel (5 us on the stream the host is waiting for).  NMSA_PACK_VIA_DEVICE=1: the
+        # staged form.
+        via_device = _PACK_VIA_DEVICE
+        flat_dev = torch.empty(shape, dtype=torch.float64, device=dev) if via_device else flat_host
         L.check(L.lib().nmsa_pack_tables(
             L.ptr(p['n_centers']), L.ptr(p['n_ids']), L.ptr(p['centers_yx']),
             L.ptr(p['center_scores']), L.ptr(p['area']), L.ptr(p['ids_pan']), L.ptr(p['ids_ins']),
             B, K, kc, L.ptr(flat_dev), L.stream_ptr(dev)), 'nmsa_pack_tables')
-        # pinned staging buffers come from a small ring owned by this object: allocating pinned
-        # memory per call is slow, and the caching host allocator cannot recycle a block while the
-        # host runs ahead of the GPU.  A slot that is reused while its previous result has not
-        # been read yet first hands that result a private copy.
-        slot = self._pinned_slot(tuple(flat_dev.shape))
-        flat_host = slot['buffer']
-        flat_host.copy_(flat_dev, non_blocking=True)
+        if via_device:
+            flat_host.copy_(flat_dev, non_blocking=True)
         done = slot['event']
         done.record(torch.cuda.current_stream(dev))
         max_centers = post._max_centers
