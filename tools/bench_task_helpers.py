@@ -94,3 +94,11 @@ if '--profile' in sys.argv:
     torch.cuda.synchronize()
     pr.disable()
     pstats.Stats(pr).sort_stats('tottime').print_stats(25)
+if '--torch-profile' in sys.argv:       # which ATen ops (with shapes) run inside a step
+    from torch.profiler import ProfilerActivity, profile
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize()
+    print(prof.key_averages(group_by_input_shape=True).table(sort_by='cuda_time_total', row_limit=40,
+                                                               max_name_column_width=50))
