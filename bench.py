@@ -227,19 +227,26 @@ def launch_ranks(args) -> int:
         return code
 
 
-def hip_timed(fn, reps, warm):
+def hip_timed(fn, reps, warm, min_region_ms=5.0, max_reps=400):
     """mean milliseconds per call, HIP events on the stream the kernels are launched on
-    (the ops enqueue on torch's current stream)"""
+    (the ops enqueue on torch's current stream).  The GPU idles between the start event and the
+    first kernel for as long as the host needs to enqueue one call (~35 us for the target
+    generators): a region shorter than `min_region_ms` is measured again with as many calls as
+    fill it (10 calls of a 65 us op read 72 us, 50 calls 64 us)."""
     for _ in range(warm):
         fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps
+    while True:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        total = e0.elapsed_time(e1)
+        if total >= min_region_ms or reps >= max_reps:
+            return total / reps
+        reps = min(max_reps, max(reps + 1, int(reps * min_region_ms / max(total, 1e-3) * 1.1)))
 
 
 def _leg(ms, n_px, bytes_px, **extra):
