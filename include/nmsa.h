@@ -405,6 +405,9 @@ int nmsa_pq_update(const int64_t* pred, const int64_t* target, int B, int H, int
  *     f64 row per image (exact: ids < 2^53, f32 scores) -> ONE device->host copy per batch.
  *     n_ids / ids_pan / ids_ins may be NULL together (instance-only postprocessing): the row
  *     then ends after the areas and its second entry is 0.
+ *     `out` may also be pinned host memory (hipHostMalloc: mapped into the device's address space
+ *     at the same address): the kernel then stores the rows where the host reads them — valid
+ *     once an event recorded behind the call has completed — and no copy is needed at all.
  * ------------------------------------------------------------------------- */
 int nmsa_pack_tables(const int32_t* n_centers, const int32_t* n_ids,
                      const int32_t* centers_yx, const float* scores,
