@@ -194,7 +194,10 @@ __global__ __launch_bounds__(256) void k_confmat_u8(
             const uint32_t b0 = bin_of(tv.x & 0xFFu, pv.x & 0xFFu);
             const uint32_t bf = (uint32_t)__builtin_amdgcn_readfirstlane((int)b0);
             if (__all(flat && b0 == bf)) {                            // the wave sits on one bin
-                if (lane_id() == 0 && bf != 0xFFFFFFFFu) atomicAdd(&cm_hist[bf], 1024u);
+                // (the lanes in here are those whose 16 pixels exist: a prefix of the wave in the
+                // image's last tile — lane 0 is one of them and speaks for all that are)
+                const uint32_t lanes = (uint32_t)__popcll(__ballot(true));
+                if (lane_id() == 0 && bf != 0xFFFFFFFFu) atomicAdd(&cm_hist[bf], 16u * lanes);
                 continue;
             }
             uint32_t prev = 0xFFFFFFFFu, run = 0;

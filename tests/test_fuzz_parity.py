@@ -346,6 +346,39 @@ def test_fuzz_pq_from_the_parts_vs_oracle(oracle, seed, B, H, W, C, n_seg, max_i
     assert int(pq._status) == 0 and int(miou._status) == 0
 
 
+@settings(max_examples=_n(150), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), n_px=st.integers(1, 40000), n=st.integers(1, 70),
+       cell=st.sampled_from([1, 3, 16, 64, 1000]), masked=st.booleans(), offset=st.sampled_from([0, 0, 16, 1, 7]))
+def test_fuzz_confmat_uint8_vs_oracle(oracle, seed, n_px, n, cell, masked, offset):
+    """two uint8 maps (k_confmat_u8 when both are 16-byte aligned, the general kernel otherwise —
+    `offset` shifts the views): confusion matrix bit-exact vs the oracle for runs of every
+    length, any size (the scalar tail of the last lane), both void treatments"""
+    from nicr_mt_scene_analysis_amd import metric
+    rng = np.random.default_rng(seed)
+    hi = n + 1 if masked else n
+
+    def runs(top):
+        v = np.repeat(rng.integers(0, top, n_px // cell + 2), cell)
+        return v[rng.integers(0, cell):][:n_px].astype(np.uint8)
+    pred, tgt = runs(n), runs(hi)
+    d_pred = torch.zeros(n_px + 64, dtype=torch.uint8, device='cuda')[offset:offset + n_px]
+    d_tgt = torch.zeros(n_px + 64, dtype=torch.uint8, device='cuda')[offset:offset + n_px]
+    d_pred.copy_(dev(pred))
+    d_tgt.copy_(dev(tgt))
+    m = metric.MeanIntersectionOverUnion(n)
+    if masked:
+        m.update_masked_void(d_pred, d_tgt)
+        keep = tgt != 0
+        want = oracle.confmat_update(pred[keep], tgt[keep] - 1, n)
+    else:
+        m.update(d_pred, d_tgt)
+        want = oracle.confmat_update(pred, tgt, n)
+    torch.cuda.synchronize()
+    assert int(m._status) == 0
+    assert np.array_equal(m.confmat.cpu().numpy(), want), (seed, n_px, n, cell, masked, offset)
+
+
 @settings(max_examples=_n(120), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), Hs=st.integers(1, 40), Ws=st.integers(1, 48),
