@@ -346,6 +346,42 @@ def test_fuzz_pq_from_the_parts_vs_oracle(oracle, seed, B, H, W, C, n_seg, max_i
     assert int(pq._status) == 0 and int(miou._status) == 0
 
 
+@settings(max_examples=_n(60), deadline=None, derandomize=_DERANDOMIZE,
+          suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
+@given(seed=st.integers(0, 2 ** 31 - 1), N=st.integers(1, 300), D=st.integers(2, 200),
+       red=st.sampled_from(['none', 'sum', 'mean']), labelled=st.booleans(),
+       kind=st.sampled_from(['mse', 'l1']), shape=st.sampled_from([(7,), (3, 5), (2, 3, 4), (2, 3, 4, 5), (2, 1, 3, 2, 2)]))
+def test_fuzz_loss_forms_vs_oracle(oracle, seed, N, D, red, labelled, kind, shape):
+    """the loss forms no task helper calls (csrc/losses_forms.hip): cosine rows of any [N, D] with
+    labels from {+1, -1, 0}, MSE / L1 of any rank with every reduction — values and gradients
+    against the fp64 oracle"""
+    from nicr_mt_scene_analysis_amd import loss as L_
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, D)).astype(np.float32)
+    y = rng.standard_normal((N, D)).astype(np.float32)
+    lab = rng.choice(np.array([1.0, -1.0, 0.0], np.float32), N, p=[0.45, 0.45, 0.1]) if labelled else None
+    w = rng.standard_normal(N).astype(np.float32)
+    dx = dev(x).requires_grad_(True)
+    fn = L_.CosineEmbeddingLoss(reduction=red)
+    loss, n = fn._compute_loss(dx, dev(y), *((dev(lab),) if labelled else ()))
+    ((loss * dev(w)).sum() if red == 'none' else loss).backward()
+    o_loss, o_n, o_grad = oracle.loss_cosine_rows(x, y, lab, red, w)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), o_loss, rtol=2e-5, atol=2e-6)
+    assert int(n) == int(o_n)
+    # (fp32 cancellation in y / den - cos x / |x|^2 when x is nearly parallel to y: absolute floor)
+    np.testing.assert_allclose(dx.grad.cpu().numpy(), o_grad, rtol=2e-4, atol=3e-5)
+    a = rng.standard_normal(shape).astype(np.float32)
+    b = rng.standard_normal(shape).astype(np.float32)
+    wa = rng.standard_normal(shape).astype(np.float32)
+    da = dev(a).requires_grad_(True)
+    (loss, n), = (L_.MSELoss if kind == 'mse' else L_.L1Loss)(reduction=red)([da], [dev(b)])
+    ((loss * dev(wa)).sum() if red == 'none' else loss).backward()
+    o_loss, o_n, o_grad = oracle.loss_elementwise_form(a, b, kind, red, wa)
+    np.testing.assert_allclose(loss.detach().cpu().numpy(), o_loss, rtol=2e-5, atol=1e-6)
+    assert int(n) == int(o_n)
+    np.testing.assert_allclose(da.grad.cpu().numpy(), o_grad, rtol=2e-5, atol=1e-6)
+
+
 @settings(max_examples=_n(150), deadline=None, derandomize=_DERANDOMIZE,
           suppress_health_check=[HealthCheck.too_slow, HealthCheck.function_scoped_fixture])
 @given(seed=st.integers(0, 2 ** 31 - 1), n_px=st.integers(1, 40000), n=st.integers(1, 70),
