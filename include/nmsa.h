@@ -441,7 +441,10 @@ int nmsa_pq_update_with_confmat(
  * 8 B/px; results are bit-identical to nmsa_pq_update_with_confmat on the painted map
  * (task_helper/panoptic.py:104-126 at network resolution; no match list).
  *   pred_semantic u8 [B,H,W] class index 0..n_sem_classes-1 (<= 255), pred_instance u8 [B,H,W],
- *   pan_of_inst i64 [B,256], is_thing_class u8 [n_sem_classes] */
+ *   pan_of_inst i64 [B,256], is_thing_class u8 [n_sem_classes].
+ *   confmat_classes = 0 with target_semantic = confmat = confmat_status = NULL: the PQ update
+ *   alone (nmsa_pq_update on the painted map, read as its parts) — for class counts beyond the
+ *   fused matrix (64) */
 int nmsa_pq_update_with_confmat_parts(
     const uint8_t* pred_semantic, const uint8_t* pred_instance, const int64_t* pan_of_inst,
     const uint8_t* is_thing_class, int n_sem_classes, int64_t void_label,

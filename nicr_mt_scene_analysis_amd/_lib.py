@@ -179,8 +179,14 @@ def device_geometry():
 
 
 def ptr(t: Optional[torch.Tensor]):
+    """Address of a tensor the kernels may touch: device memory, or pinned host memory (mapped
+    into the GPU's address space).  A pageable host tensor raises here — handed to a kernel it
+    would be a GPU memory fault, not a Python error."""
     if t is None:
         return None
+    if not t.is_cuda and not t.is_pinned():
+        raise ValueError(f'the C-ABI takes device (or pinned host) memory; got a pageable '
+                         f'{t.device} tensor of shape {tuple(t.shape)}')
     return C.c_void_p(t.data_ptr())
 
 

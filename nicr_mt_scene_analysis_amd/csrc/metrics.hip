@@ -646,6 +646,7 @@ __global__ __launch_bounds__(256) void k_pq_count_parts(
     const int b = blockIdx.y;
     PQ_STAMP(0);
     const uint32_t cm_bins = (uint32_t)(cm_n * cm_n);
+    const bool with_cm = cm_n > 0;                  // (block-uniform: the PQ-only form passes 0 classes)
     {
         const int t = threadIdx.x;
         const int64_t pi = parts.pan_of_inst[(size_t)b * 256 + t];
@@ -669,7 +670,7 @@ __global__ __launch_bounds__(256) void k_pq_count_parts(
     const int list_cap = cap / 2;
     const uint8_t* psem = parts.sem + (size_t)b * P;
     const uint8_t* pins = parts.inst + (size_t)b * P;
-    const uint8_t* ts = target_sem + (size_t)b * P;
+    const uint8_t* ts = with_cm ? target_sem + (size_t)b * P : nullptr;
     const int64_t* tg = target + (size_t)b * P;
     const int start = blockIdx.x * px_per_block;
     const int end = min(start + px_per_block, P);
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(256) void k_pq_count_parts(
     if (vec) {
         const int tile = blockDim.x * 2 * PQ_UNROLL;
         auto step = [&](int64_t t0, int64_t t1, uint32_t c0, uint32_t c1, uint32_t ts0, uint32_t ts1) {
-            cm_pair(ts0, ts1, s_cls[c0], s_cls[c1]);
+            if (with_cm) cm_pair(ts0, ts1, s_cls[c0], s_cls[c1]);
             const uint32_t l0 = (uint32_t)t0, l1 = (uint32_t)t1;
             const bool big = (((uint64_t)t0 | (uint64_t)t1) >> 32) != 0;
             const bool same = l0 == l1 && c0 == c1;
@@ -773,7 +774,7 @@ __global__ __launch_bounds__(256) void k_pq_count_parts(
                 tv[u] = ld_i64x2_stream(tg + i);
                 ls[u] = *(const uint16_t*)(psem + i);
                 li[u] = *(const uint16_t*)(pins + i);
-                lt[u] = *(const uint16_t*)(ts + i);
+                lt[u] = with_cm ? (uint32_t)*(const uint16_t*)(ts + i) : 0u;
             }
 #pragma unroll
             for (int u = 0; u < PQ_UNROLL; ++u)
@@ -784,7 +785,8 @@ __global__ __launch_bounds__(256) void k_pq_count_parts(
         for (; base + (int)blockDim.x * 2 <= end; base += blockDim.x * 2) {      // single steps up to the last full one
             const int i = base + threadIdx.x * 2;
             const longlong2 t = ld_i64x2_stream(tg + i);
-            const uint32_t s2 = *(const uint16_t*)(psem + i), i2 = *(const uint16_t*)(pins + i), t2 = *(const uint16_t*)(ts + i);
+            const uint32_t s2 = *(const uint16_t*)(psem + i), i2 = *(const uint16_t*)(pins + i);
+            const uint32_t t2 = with_cm ? (uint32_t)*(const uint16_t*)(ts + i) : 0u;
             step(t.x, t.y, code_of(s2 & 0xFFu, i2 & 0xFFu), code_of(s2 >> 8, i2 >> 8), t2 & 0xFFu, t2 >> 8);
         }
     }
@@ -792,17 +794,21 @@ __global__ __launch_bounds__(256) void k_pq_count_parts(
         const int i = i0 + threadIdx.x;
         if (i < end) {
             const uint32_t code = code_of(psem[i], pins[i]);
-            const uint32_t k = (uint32_t)ts[i] * (uint32_t)cm_n + s_cls[code];
-            if (k < cm_bins) atomicAdd(&cm_hist_pq[k], 1u); else cm_bad = true;
+            if (with_cm) {
+                const uint32_t k = (uint32_t)ts[i] * (uint32_t)cm_n + s_cls[code];
+                if (k < cm_bins) atomicAdd(&cm_hist_pq[k], 1u); else cm_bad = true;
+            }
             slow(tg[i], code, 1u);
         }
     }
     PQ_STAMP(3);
     __syncthreads();
     PQ_STAMP(4);
-    uint32_t* mine = cm_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * cm_bins;
-    for (int i = threadIdx.x; i < (int)cm_bins; i += blockDim.x) mine[i] = cm_hist_pq[i];
-    if (cm_bad) atomicOr(cm_status, ST_VALUE_RANGE);
+    if (with_cm) {
+        uint32_t* mine = cm_slab + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * cm_bins;
+        for (int i = threadIdx.x; i < (int)cm_bins; i += blockDim.x) mine[i] = cm_hist_pq[i];
+        if (cm_bad) atomicOr(cm_status, ST_VALUE_RANGE);
+    }
     // decode the block's distinct pairs into the image's table
     for (int i = threadIdx.x; i < PQ_LI; i += blockDim.x) {
         const unsigned long long key = lk[i];
@@ -1236,8 +1242,11 @@ int pq_update_impl(const int64_t* pred, const int64_t* target, int B, int H, int
                                stream, pred, target, P, offset, px_per_block, ws, cap, status, target_sem, cm_n,
                                cm_div, shift, (uint32_t*)cm_workspace, cm_status, ablate, list_n);
         }
+    } else if (parts) {                             // PQ only (more classes than the fused matrix holds)
+        hipLaunchKernelGGL(k_pq_count_parts, grid, dim3(256), 0, stream,
+                           target, P, offset, px_per_block, ws, cap, status, (const uint8_t*)nullptr, 0, (int64_t)1, -1,
+                           (uint32_t*)nullptr, (int*)nullptr, list_n, *parts);
     } else {
-        if (parts) return NMSA_ERR_ARG;            // the parts come with the confusion matrix (one entry point)
         auto kern = off_pow2 ? k_pq_count<false, true> : k_pq_count<false, false>;
         hipLaunchKernelGGL(kern, grid, dim3(256), 0, stream,
                            pred, target, P, offset,
@@ -1329,11 +1338,15 @@ extern "C" int nmsa_pq_update_with_confmat_parts(
 {
     if (!pred_semantic || !pred_instance || !pan_of_inst || !is_thing_class) return NMSA_ERR_ARG;
     if (n_sem_classes <= 0 || n_sem_classes > 255 || void_label < 0) return NMSA_ERR_ARG;
-    if (!target_semantic || !confmat || !confmat_status || !confmat_workspace) return NMSA_ERR_ARG;
-    if (confmat_classes <= 0 || confmat_classes > PQ_CM_MAX_CLASSES || pred_div <= 0) return NMSA_ERR_ARG;
-    const size_t need = nmsa_pq_confmat_workspace_bytes(B, H, W, confmat_classes);
-    if (need == 0) return NMSA_ERR_ARG;
-    if (confmat_workspace_bytes < need) return NMSA_ERR_WORKSPACE;
+    // confmat_classes == 0 with NULL target_semantic / confmat / confmat_status: the PQ update alone
+    const bool pq_only = confmat_classes == 0 && !target_semantic && !confmat && !confmat_status;
+    if (!pq_only) {
+        if (!target_semantic || !confmat || !confmat_status || !confmat_workspace) return NMSA_ERR_ARG;
+        if (confmat_classes <= 0 || confmat_classes > PQ_CM_MAX_CLASSES || pred_div <= 0) return NMSA_ERR_ARG;
+        const size_t need = nmsa_pq_confmat_workspace_bytes(B, H, W, confmat_classes);
+        if (need == 0) return NMSA_ERR_ARG;
+        if (confmat_workspace_bytes < need) return NMSA_ERR_WORKSPACE;
+    }
     const PqPredParts parts{pred_semantic, pred_instance, pan_of_inst, is_thing_class, n_sem_classes,
                             max_instances_per_category, void_label};
     return pq_update_impl(nullptr, target, B, H, W, num_categories, ignored_label,

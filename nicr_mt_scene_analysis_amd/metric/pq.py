@@ -102,6 +102,18 @@ class PanopticQuality(Metric):
                   L.ptr(self.iou_per_class), L.ptr(self.tp_per_class), L.ptr(self.fn_per_class),
                   L.ptr(self.fp_per_class), L.ptr(matches), self._match_capacity, L.ptr(n_matches),
                   L.ptr(self._status), L.ptr(ws), ws_bytes, int(clean))
+        if miou is None and parts is not None:
+            # PQ alone from the parts (more classes than the fused confusion matrix holds)
+            th = parts['is_thing']
+            L.check(lib.nmsa_pq_update_with_confmat_parts(
+                L.ptr(parts['semantic_idx_u8']), L.ptr(parts['instance']), L.ptr(parts['pan_of_inst']),
+                L.ptr(th), int(th.numel()), int(parts.get('void_label', 0)), L.ptr(t), None,
+                B, H, W, self.num_categories, int(self.ignored_label),
+                int(self.max_instances_per_category), int(self.offset), int(self.void_segment_id),
+                L.ptr(self.iou_per_class), L.ptr(self.tp_per_class), L.ptr(self.fn_per_class),
+                L.ptr(self.fp_per_class), L.ptr(self._status), L.ptr(ws), ws_bytes, int(clean),
+                0, 1, None, None, None, 0, L.stream_ptr(dev)), 'nmsa_pq_update_with_confmat_parts')
+            return None
         if miou is None:
             L.check(lib.nmsa_pq_update(L.ptr(p), L.ptr(t), *common, L.stream_ptr(dev)),
                     'nmsa_pq_update')
@@ -177,9 +189,14 @@ class PanopticQuality(Metric):
         from (csrc/metrics.hip k_pq_count_parts: compact keys): bit-identical states, 11 instead of 17
         bytes per pixel.  Falls back to `update_with_miou` when the parts do not apply."""
         preds = parts['panoptic']
-        if not (self.parts_usable(parts, preds, self.max_instances_per_category)
-                and self._can_fuse(preds, miou, target_semantic)):
+        if not self.parts_usable(parts, preds, self.max_instances_per_category):
             self.update_with_miou(preds, targets, miou, target_semantic, pred_div)
+            return
+        if not self._can_fuse(preds, miou, target_semantic):
+            # e.g. more than 64 classes: the confusion matrix in its own pass over the map, the PQ
+            # count still from the parts
+            miou.update_from_panoptic(preds, target_semantic, pred_div)
+            self._device_update(preds, targets, want_matches=False, parts=parts)
             return
         miou._require_gpu()
         self._device_update(preds, targets, want_matches=False, miou=miou,

@@ -52,6 +52,14 @@ def test_cpu_tensors_are_rejected_loudly():
         ops.semantic_argmax(torch.zeros((1, 3, 4, 4)))
 
 
+def test_raw_pointer_helper_refuses_pageable_host_memory():
+    """`_lib.ptr` is the one place a tensor becomes a kernel argument: a pageable host tensor
+    there would be a GPU memory fault (a test of round 5 did exactly that), so it raises"""
+    with pytest.raises(ValueError, match='pageable'):
+        L.ptr(torch.zeros(8))
+    assert L.ptr(None) is None
+
+
 def test_header_is_plain_c99():
     """include/nmsa.h is the FFI contract: it must compile as C (no C++ / HIP types)."""
     import os

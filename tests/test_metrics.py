@@ -659,6 +659,60 @@ def test_pq_parts_hard_inputs(kind):
 
 
 @gpu
+def test_pq_from_the_parts_with_more_classes_than_the_fused_matrix(oracle):
+    """100 classes: the confusion matrix cannot ride in the PQ count (64 at most), so
+    `update_with_miou_parts` runs the matrix over the map and the PQ count from the parts alone
+    (k_pq_count_parts without its histogram) — states and matrix equal to the map path and to
+    the oracle"""
+    from nicr_mt_scene_analysis_amd import ops
+    from nicr_mt_scene_analysis_amd.metric import MeanIntersectionOverUnion, PanopticQuality
+    B, H, W, C, max_inst, offset = 2, 96, 512, 100, 1 << 16, 256 ** 3
+
+    def D(a):                                   # numpy -> device (the raw C-ABI takes device pointers only)
+        return torch.as_tensor(np.ascontiguousarray(a)).cuda()
+    n = C + 1
+    rng = np.random.default_rng(5)
+    thing_c = rng.integers(0, 2, C).astype(bool)
+
+    def blocky(hi, cell):
+        c = rng.integers(0, hi, (B, (H + cell - 1) // cell, (W + cell - 1) // cell))
+        return np.repeat(np.repeat(c, cell, 1), cell, 2)[:, :H, :W]
+    sem = blocky(C, 8).astype(np.uint8)
+    inst = (blocky(9, 16) * thing_c[sem]).astype(np.uint8)
+    pan_of_inst = np.zeros((B, 256), np.int64)
+    pan_of_inst[:, 1:9] = rng.integers(1, n, (B, 8)) * max_inst + np.arange(1, 9)
+    tgt = blocky(n, 12) * max_inst + blocky(3, 12)
+    tsem = blocky(n, 12).astype(np.uint8)
+    d_sem, d_inst, d_poi, d_thing = D(sem), D(inst), D(pan_of_inst), D(thing_c.astype(np.uint8))
+    d_tgt, d_tsem = D(tgt), D(tsem)
+    d_pred = torch.empty((B, H, W), dtype=torch.int64, device='cuda')
+    L_ = ops.L
+    L_.check(L_.lib().nmsa_panoptic_paint(L_.ptr(d_sem), L_.ptr(d_inst), L_.ptr(d_poi), L_.ptr(d_thing), B, C, H, W,
+                                          max_inst, 0, L_.ptr(d_pred), None, L_.stream_ptr(d_pred.device)),
+             'nmsa_panoptic_paint')
+    parts = {'panoptic': d_pred, 'semantic_idx_u8': d_sem, 'instance': d_inst, 'pan_of_inst': d_poi,
+             'is_thing': d_thing, 'void_label': 0, 'max_instances_per_category': max_inst}
+    is_thing = [False] + thing_c.tolist()
+    pq_a, pq_b = (PanopticQuality(n, 0, max_inst, offset, is_thing, device='cuda') for _ in range(2))
+    mi_a, mi_b = (MeanIntersectionOverUnion(n, device='cuda') for _ in range(2))
+    assert not pq_b._can_fuse(d_pred, mi_b, d_tsem)
+    for _ in range(2):
+        pq_a.update_with_miou(d_pred, d_tgt, mi_a, d_tsem, max_inst)
+        pq_b.update_with_miou_parts(parts, d_tgt, mi_b, d_tsem, max_inst)
+    torch.cuda.synchronize()
+    assert int(pq_a._status) == 0 and int(pq_b._status) == 0 and int(mi_b._status) == 0
+    assert torch.equal(mi_a.confmat, mi_b.confmat)
+    pred = d_pred.cpu().numpy()
+    state = None
+    for _ in range(2):
+        for b in range(B):
+            *state, _ = oracle.pq_compare_and_accumulate(pred[b], tgt[b], n, 0, max_inst, offset, state=state)
+    for name, w in zip(('iou_per_class', 'tp_per_class', 'fn_per_class', 'fp_per_class'), state):
+        assert torch.equal(getattr(pq_a, name), getattr(pq_b, name)), name
+        assert np.array_equal(getattr(pq_b, name).cpu().numpy(), np.asarray(w, dtype=np.float64)), name
+
+
+@gpu
 def test_compare_and_accumulate_function(oracle):
     """module-level compare_and_accumulate (reference pq.py:60-179 signature) on the HIP path"""
     from nicr_mt_scene_analysis_amd.metric.pq import compare_and_accumulate
