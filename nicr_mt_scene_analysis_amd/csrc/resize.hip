@@ -26,6 +26,8 @@
 // the identity below 2^24 and reproduced above it.
 #include <stdlib.h>
 #include <type_traits>
+#include <algorithm>
+#include <cmath>
 #include "nmsa_common.hpp"
 #include "argmax_state.hpp"
 
@@ -392,11 +394,15 @@ __host__ __device__ constexpr int lt_ch(int mode) { return mode == 1 ? 4 : NMSA_
 __host__ __device__ constexpr int lt_nb(int mode) { return mode == 1 ? 2 : NMSA_LT_NB; }
 constexpr int LT_MODE_ARGMAX = 0, LT_MODE_ARGMAX_SCORE = 1, LT_MODE_MATERIALISE = 2;
 
+// cache policy of the staging DMAs (aux operand: 0 default, 2 = nt, non-temporal)
+#ifndef NMSA_LT_AUX
+#define NMSA_LT_AUX 0
+#endif
 __device__ __forceinline__ void glds_piece(const void* gsrc, void* lds_wave_base)
 {
     typedef const __attribute__((address_space(1))) void* gptr_t;
     typedef __attribute__((address_space(3))) void* lptr_t;
-    __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_wave_base, 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((gptr_t)gsrc, (lptr_t)lds_wave_base, 16, 0, NMSA_LT_AUX);
 }
 
 template <int DTYPE>
@@ -452,7 +458,7 @@ __device__ __noinline__ float2 resized_column_exact(
 template <int DTYPE, int MODE, int K16>
 __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     const void* __restrict__ src, CropResize g, int planes, int group, int tiles_x, int tiles_y,
-    long long n_tiles,
+    long long n_tiles, int pra_lg,
     uint8_t* __restrict__ idx_u8, int64_t* __restrict__ idx_i64, float* __restrict__ score,
     void* __restrict__ dst)
 {
@@ -485,9 +491,20 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     bilinear_src(g.sy, min(ty * LT_TH, g.Ho - 1), g.h, ys0, ti, tf0, tf1);
     bilinear_src(g.sy, min(ty * LT_TH + LT_TH - 1, g.Ho - 1), g.h, ti, ys1, tf0, tf1);
     const int SHt = ys1 - ys0 + 1;
-    const int PR = (xs1 - xs0 + EPP) / EPP;            // pieces per window row
+    // Two window shapes (plan_tiles decides, block-uniform):
+    //  * row-aligned (pra_lg > 0): 2^pra_lg lanes per window row, the window starts on a 16-byte
+    //    boundary of the source row — every wave DMA instruction is 64 / 2^pra_lg WHOLE row
+    //    segments of aligned 16-byte pieces (no piece straddles a 16-byte boundary, no row break
+    //    inside a segment of lanes), the LDS pitch is a power of two;
+    //  * packed (pra_lg == 0): the window starts at the first source column, pieces in row-major
+    //    order over ceil(width / EPP) pieces per row (sources whose rows are not 16-byte
+    //    multiples, windows wider than 16 pieces)
+    const int PR = pra_lg ? (1 << pra_lg) : (xs1 - xs0 + EPP) / EPP;      // pieces per window row
     const int P = PR * EPP;                            // window width = LDS pitch (elements)
-    const int xa = min(xs0, g.Ws - g.x0 - P);          // window start: never past the row end
+    // window start relative to the crop's first column (negative in the aligned shape when the
+    // crop itself starts off a 16-byte boundary); never past the row end
+    const int xa = pra_lg ? min(((g.x0 + xs0) / EPP) * EPP, g.Ws - P) - g.x0
+                          : min(xs0, g.Ws - g.x0 - P);
     const int n_pieces = PR * SHt;                     // <= K16 * 256 (host-checked bound)
 
     // ---- this thread's 4 output pixels ---------------------------------------------------------
@@ -529,11 +546,11 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
 #pragma unroll
     for (int k = 0; k < K16; ++k) {
         const int e = min((int)threadIdx.x + k * LT_THREADS, n_pieces - 1);
-        const int r = e / PR, q = e - r * PR;
+        const int r = pra_lg ? (e >> pra_lg) : e / PR, q = e - r * PR;
         goff[k] = r * g.Ws + q * EPP;
     }
     const size_t plane_stride = (size_t)g.Hs * g.Ws;
-    const size_t base = (size_t)p_begin * plane_stride + (size_t)(g.y0 + ys0) * g.Ws + g.x0 + xa;
+    const size_t base = (size_t)p_begin * plane_stride + (size_t)(g.y0 + ys0) * g.Ws + (size_t)(g.x0 + xa);
     unsigned char* wave_lds = lds_raw + (size_t)wv * 64 * 16;
     const int k_used = (n_pieces + LT_THREADS - 1) / LT_THREADS;
 
@@ -659,23 +676,60 @@ __global__ __launch_bounds__(LT_THREADS) void k_resized_tile(
     }
 }
 
-// Staging slots per thread and class (K16 = 1 or 2 pieces of 16 bytes) for this resize; 0 when
-// the gather kernels must be used (downscaling: the footprint of a tile does not fit the
-// staging slots; or a source row narrower than one window).
-int plan_tiles(const CropResize& g, int elem_bytes)
+// bilinear_src's source indices on the host: the same IEEE operations (fmaf / single adds), so
+// the host sees exactly the windows the kernel is going to compute
+void bilinear_src_host(float scale, int dst, int in, int& i0, int& i1)
 {
-    if (getenv("NMSA_RESIZE_NO_LDS")) return 0;
-    // ix1(last) - ix0(first) + 1 <= 63*sx + 3 (+1 slack for the float rounding of the indices)
-    const long long sw = (long long)((float)(LT_TW - 1) * g.sx) + 4, sh = (long long)((LT_TH - 1) * g.sy) + 4;
+    float s = fmaf(scale, (float)dst + 0.5f, -0.5f);
+    s = (s < 0.f) ? 0.f : s;
+    i0 = std::min((int)s, in - 1);
+    i1 = std::min(i0 + 1, in - 1);
+}
+
+// How k_resized_tile stages this resize: k16 = staging slots per thread and class (1 or 2 pieces
+// of 16 bytes; 0: the gather kernels must be used — downscaling: the footprint of a tile does not
+// fit the staging slots; or a source row narrower than one window), pra_lg = log2 of the lanes
+// per window row of the row-aligned shape (0: the packed shape).
+struct TilePlan { int k16, pra_lg; };
+
+TilePlan plan_tiles(const CropResize& g, int elem_bytes, const void* src)
+{
+    if (getenv("NMSA_RESIZE_NO_LDS")) return {0, 0};
     const int epp = 16 / elem_bytes;
+    // row-aligned shape: rows of whole 16-byte pieces from a 16-byte aligned base; the exact
+    // largest window of any tile (columns counted from the 16-byte boundary at or below its first
+    // source column) must fit 8 or 16 pieces, its rows the staging slots
+    if (!getenv("NMSA_RESIZE_PACKED_STAGING") && ((size_t)g.Ws * elem_bytes) % 16 == 0 &&
+        (uintptr_t)src % 16 == 0) {
+        const int tiles_x = (g.Wo + LT_TW - 1) / LT_TW, tiles_y = (g.Ho + LT_TH - 1) / LT_TH;
+        int wmax = 0, hmax = 0, a, b, t;
+        for (int tx = 0; tx < tiles_x; ++tx) {
+            bilinear_src_host(g.sx, std::min(tx * LT_TW, g.Wo - 1), g.w, a, t);
+            bilinear_src_host(g.sx, std::min(tx * LT_TW + LT_TW - 1, g.Wo - 1), g.w, t, b);
+            wmax = std::max(wmax, g.x0 + b - ((g.x0 + a) / epp) * epp + 1);
+        }
+        for (int ty = 0; ty < tiles_y; ++ty) {
+            bilinear_src_host(g.sy, std::min(ty * LT_TH, g.Ho - 1), g.h, a, t);
+            bilinear_src_host(g.sy, std::min(ty * LT_TH + LT_TH - 1, g.Ho - 1), g.h, t, b);
+            hmax = std::max(hmax, b - a + 1);
+        }
+        for (int lg = 3; lg <= 4; ++lg) {
+            const int pr = 1 << lg;
+            if (wmax > pr * epp || g.Ws < pr * epp) continue;
+            if (hmax * pr <= LT_THREADS) return {1, lg};
+            if (hmax * pr <= 2 * LT_THREADS) return {2, lg};
+        }
+    }
+    // packed shape: ix1(last) - ix0(first) + 1 <= 63*sx + 3 (+1 slack for the float rounding of the indices)
+    const long long sw = (long long)((float)(LT_TW - 1) * g.sx) + 4, sh = (long long)((LT_TH - 1) * g.sy) + 4;
     const long long pr = (sw + epp - 1) / epp;
-    if (pr * sh > 2 * LT_THREADS) return 0;
-    if ((long long)g.Ws - g.x0 < pr * epp) return 0;
-    return pr * sh > LT_THREADS ? 2 : 1;
+    if (pr * sh > 2 * LT_THREADS) return {0, 0};
+    if ((long long)g.Ws - g.x0 < pr * epp) return {0, 0};
+    return {pr * sh > LT_THREADS ? 2 : 1, 0};
 }
 
 template <int DTYPE, int MODE, int K16>
-int launch_tile_k(const void* src, const CropResize& g, int planes, int group,
+int launch_tile_k(const void* src, const CropResize& g, int pra_lg, int planes, int group,
                   uint8_t* idx_u8, int64_t* idx_i64, float* score, void* dst, hipStream_t stream)
 {
     const int tiles_x = (g.Wo + LT_TW - 1) / LT_TW;
@@ -686,18 +740,18 @@ int launch_tile_k(const void* src, const CropResize& g, int planes, int group,
     if (blocks > 0x7fffffffLL) return NMSA_ERR_ARG;
     const size_t lds_bytes = (size_t)K16 * LT_THREADS * 16 * lt_ch(MODE) * lt_nb(MODE);
     hipLaunchKernelGGL((k_resized_tile<DTYPE, MODE, K16>), dim3((unsigned)blocks), dim3(LT_THREADS),
-                       lds_bytes, stream, src, g, planes, group, tiles_x, tiles_y, n_tiles,
+                       lds_bytes, stream, src, g, planes, group, tiles_x, tiles_y, n_tiles, pra_lg,
                        idx_u8, idx_i64, score, dst);
     return check_launch();
 }
 
 template <int DTYPE, int MODE>
-int launch_tile(const void* src, const CropResize& g, int k16, int planes, int group,
+int launch_tile(const void* src, const CropResize& g, TilePlan plan, int planes, int group,
                 uint8_t* idx_u8, int64_t* idx_i64, float* score, void* dst, hipStream_t stream)
 {
-    if (k16 == 1)
-        return launch_tile_k<DTYPE, MODE, 1>(src, g, planes, group, idx_u8, idx_i64, score, dst, stream);
-    return launch_tile_k<DTYPE, MODE, 2>(src, g, planes, group, idx_u8, idx_i64, score, dst, stream);
+    if (plan.k16 == 1)
+        return launch_tile_k<DTYPE, MODE, 1>(src, g, plan.pra_lg, planes, group, idx_u8, idx_i64, score, dst, stream);
+    return launch_tile_k<DTYPE, MODE, 2>(src, g, plan.pra_lg, planes, group, idx_u8, idx_i64, score, dst, stream);
 }
 
 bool bad_geometry(int planes, int Hs, int Ws, int y0, int x0, int h, int w, int Ho, int Wo)
@@ -734,8 +788,8 @@ int launch_nearest(const void* src, void* dst, const CropResize& g, int planes, 
 template <int DTYPE>
 int launch_bilinear(const void* src, void* dst, const CropResize& g, int planes, hipStream_t stream)
 {
-    const int tile_k = plan_tiles(g, DTYPE == NMSA_F32 ? 4 : 2);
-    if (tile_k > 0)
+    const TilePlan tile_k = plan_tiles(g, DTYPE == NMSA_F32 ? 4 : 2, src);
+    if (tile_k.k16 > 0)
         return launch_tile<DTYPE, LT_MODE_MATERIALISE>(src, g, tile_k, planes, planes < 32 ? planes : 32,
                                                        nullptr, nullptr, nullptr, dst, stream);
     const long long groups = (planes + RB_PLANES - 1) / RB_PLANES;
@@ -758,8 +812,8 @@ template <int DTYPE>
 int launch_argmax_resized(const void* logits, const CropResize& g, int B, int C,
                           uint8_t* idx_u8, int64_t* idx_i64, float* score, hipStream_t stream)
 {
-    const int tile_k = plan_tiles(g, DTYPE == NMSA_F32 ? 4 : 2);
-    if (tile_k > 0) {
+    const TilePlan tile_k = plan_tiles(g, DTYPE == NMSA_F32 ? 4 : 2, logits);
+    if (tile_k.k16 > 0) {
         if (score) return launch_tile<DTYPE, LT_MODE_ARGMAX_SCORE>(logits, g, tile_k, B * C, C, idx_u8,
                                                                     idx_i64, score, nullptr, stream);
         return launch_tile<DTYPE, LT_MODE_ARGMAX>(logits, g, tile_k, B * C, C, idx_u8, idx_i64, score,

@@ -114,6 +114,42 @@ def test_argmax_resized_vs_oracle(ops, oracle, geom):
     np.testing.assert_allclose(rb['score'].cpu().numpy(), rb2['score'].cpu().numpy(), rtol=1e-5)
 
 
+@pytest.mark.parametrize('dtype', ['float32', 'bfloat16'])
+@pytest.mark.parametrize('geom', [
+    # (Hs, Ws, crop, size): rows of whole 16-byte pieces -> the row-aligned window shape
+    (60, 128, (slice(3, 57), slice(5, 123)), (97, 211)),      # crop starts off a 16-byte boundary
+    (48, 96, (slice(0, 48), slice(0, 96)), (55, 110)),        # last tile's window pulled back to the row end
+    (40, 256, (slice(1, 40), slice(130, 256)), (64, 300)),    # window start = the crop's first column, 2.4x
+])
+def test_upscaling_window_shapes_agree(ops, oracle, monkeypatch, geom, dtype):
+    """k_resized_tile stages a tile's source window either row-aligned (16-byte aligned rows of
+    8 / 16 pieces; plan_tiles picks it when the source rows allow it) or packed
+    (`NMSA_RESIZE_PACKED_STAGING=1`, read per call): same bits from both, equal to the oracle"""
+    Hs, Ws, crop, size = geom
+    rng = np.random.default_rng(Hs * Ws)
+    x = (rng.integers(-8, 9, (2, 9, Hs, Ws)) * 0.375).astype(np.float32)      # exact in bf16; ties
+    xd = dev(x).to(getattr(torch, dtype))
+    want = oracle.resize_bilinear(x, size, crop)
+    if dtype != 'float32':
+        want = torch.from_numpy(want).to(torch.bfloat16).float().numpy()
+    idx, score = oracle.semantic_argmax(want)
+    got = {}
+    for packed in ('', '1'):
+        if packed:
+            monkeypatch.setenv('NMSA_RESIZE_PACKED_STAGING', packed)
+        else:
+            monkeypatch.delenv('NMSA_RESIZE_PACKED_STAGING', raising=False)
+        lf = ops.resize_bilinear(xd, size, crop)
+        r = ops.semantic_argmax_resized(xd, size, crop, want_u8=True, want_i64=True, want_score=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(lf.float().cpu().numpy(), want)
+        assert np.array_equal(r['idx'].cpu().numpy(), idx)
+        np.testing.assert_allclose(r['score'].cpu().numpy(), score, rtol=1e-5, atol=1e-7)
+        got[packed] = (lf, r['idx'], r['idx_u8'], r['score'])
+    for a, b in zip(got[''], got['1']):
+        assert torch.equal(a, b)
+
+
 def test_panoptic_postprocess_fullres_vs_golden():
     """PanopticPostprocessing.postprocess with a real crop + upscale, every *_fullres entry
     against the reference's own output (oracle/gen_golden.py::gen_fullres)."""
