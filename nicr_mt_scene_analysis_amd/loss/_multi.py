@@ -80,6 +80,9 @@ class SpecState:
         """the learned upstream factors (host sync; tests, diagnostics)"""
         return self.records(dev).view(torch.float32)[:self.n_totals, 2].tolist()
 
+# where a forward-written gradient lives (tools/diag_cos_relalign.py swaps it to place the buffer)
+_alloc_grad = torch.empty_like
+
 
 def reset_all() -> None:
     """forget what every live SpecState has learned (new records on next use)"""
@@ -174,7 +177,7 @@ class MultiLossFunction(torch.autograd.Function):
                 msk = _u8(msk, dev)
             # (grad mode is always off inside forward(): desc['grad_enabled'] is the caller's grad
             # mode, needs_input_grad says which inputs autograd is going to ask a gradient for)
-            g = torch.empty_like(x) if want_grad and ctx.needs_input_grad[i + 1] else None
+            g = _alloc_grad(x) if want_grad and ctx.needs_input_grad[i + 1] else None
             a.pred, a.target = x.data_ptr(), (tgt.data_ptr() if tgt is not None else None)
             a.mask = msk.data_ptr() if msk is not None else None
             a.weights = wts.data_ptr() if wts is not None else None
