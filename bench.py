@@ -834,6 +834,7 @@ def main():
     dist = None
     backend = None
     rccl_ranks = None
+    rccl_error = None
     if launched:                                 # under a launcher also at N=1 (same code path)
         import torch.distributed as dist_
         dist = dist_
@@ -841,11 +842,28 @@ def main():
         # multi-rank path on a box with fewer GPUs than ranks (RCCL refuses shared devices).
         backend = os.environ.get('NMSA_BENCH_BACKEND', 'nccl')
         if backend == 'nccl':
-            dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
-            one = torch.ones((1,), dtype=torch.float64, device=dev)
-            dist.all_reduce(one, op=dist.ReduceOp.SUM)         # an actual RCCL all-reduce
-            rccl_ranks = int(one.item())
-            if rccl_ranks != world:
+            try:
+                if os.environ.get('NMSA_BENCH_FORCE_RCCL_FAIL'):            # test hook
+                    raise RuntimeError('NMSA_BENCH_FORCE_RCCL_FAIL: RCCL declared unavailable on request')
+                dist.init_process_group('nccl', rank=rank, world_size=world, device_id=dev)
+                one = torch.ones((1,), dtype=torch.float64, device=dev)
+                dist.all_reduce(one, op=dist.ReduceOp.SUM)     # an actual RCCL all-reduce
+                rccl_ranks = int(one.item())
+            except Exception as e:               # noqa: BLE001 — whatever the runtime raises
+                # A node whose RCCL cannot start (IPC, topology) still gets its scaling figures:
+                # the ONE ~15 KB accumulator all-reduce of the run goes through gloo (staged
+                # through the host), said so in the line (`collective.backend`, `rccl_error`).
+                # The data path never had a collective.
+                rccl_error = f'{type(e).__name__}: {e}'.replace('\n', ' ')[:400]
+                print(f'[bench] rank {rank}: RCCL unavailable ({rccl_error}); the accumulator '
+                      f'all-reduce falls back to gloo', file=sys.stderr, flush=True)
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                backend = 'gloo'
+                import datetime
+                dist.init_process_group('gloo', rank=rank, world_size=world,
+                                        timeout=datetime.timedelta(seconds=180))
+            if rccl_ranks is not None and rccl_ranks != world:
                 raise SystemExit(f'RCCL all-reduce saw {rccl_ranks} ranks, expected {world}')
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
@@ -1109,6 +1127,7 @@ def main():
                    'parallelism': f'dp{world} (images sharded, accumulators all-reduced '
                                   f'{"every step" if args.metric_sync == "step" else "once per run, timed"})'},
         'collective': {'backend': ('rccl' if backend == 'nccl' else backend), 'rccl_ranks': rccl_ranks,
+                       'rccl_error': rccl_error,
                        'payload_bytes': metrics.payload_bytes if metrics is not None else 0,
                        'calls': 'Metric.sync(): one all-reduce per state dtype (int64, float64)',
                        'totals_identical_on_all_ranks': totals_identical,

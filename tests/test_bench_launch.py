@@ -74,6 +74,23 @@ def test_bench_under_launcher_runs_the_rccl_leg():
     assert c['payload_bytes'] == (9 * 9 + 4 * 9) * 8 and c['totals_identical_on_all_ranks'] is True
 
 
+def test_bench_falls_back_to_gloo_when_rccl_cannot_start():
+    """a node whose RCCL does not come up (NMSA_BENCH_FORCE_RCCL_FAIL: the hook raises where
+    init_process_group('nccl') would) still yields the scaling figures: the accumulator all-reduce
+    goes through gloo, and the line says so"""
+    env = dict(os.environ, NMSA_BENCH_FORCE_RCCL_FAIL='1')
+    for k in ('NMSA_BENCH_BACKEND', 'RANK', 'WORLD_SIZE'):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL,
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = _json_line(r.stdout)
+    c = d['collective']
+    assert d['n_gpus'] == 2 and c['backend'] == 'gloo' and c['rccl_ranks'] is None
+    assert 'NMSA_BENCH_FORCE_RCCL_FAIL' in c['rccl_error']
+    assert c['totals_identical_on_all_ranks'] is True
+
+
 def test_bench_rejects_a_world_size_mismatch():
     env = dict(os.environ, RANK='0', WORLD_SIZE='1', LOCAL_RANK='0')
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2'] + SMALL,
